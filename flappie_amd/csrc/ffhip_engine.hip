@@ -1,0 +1,656 @@
+// ffhip_engine.hip -- host side of the C-ABI in include/ffhip.h: engine, resident model, batch.
+// One engine per GPU; weights are re-packed once into MFMA fragment order and stay in HBM; a batch
+// owns all of its workspace (sized for the whole pipeline, no allocation on the run path).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+
+#include "../../include/ffhip.h"
+#include "ffhip_internal.hpp"
+
+using namespace ffhip;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr, ret)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            set_err(FFHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ret;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+extern "C" const char *ffhip_last_error(void) { return g_err; }
+extern "C" const char *ffhip_version(void) { return "ffhip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------ engine
+struct ffhip_engine {
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t streams[2] = { nullptr, nullptr };
+    int next_stream = 0;
+    int profiling = 0;
+};
+
+extern "C" int ffhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" ffhip_engine *ffhip_engine_create(int device) {
+    int n = ffhip_device_count();
+    if (n <= 0 || device < 0 || device >= n) { set_err(FFHIP_ENODEV, "no HIP device %d (found %d)", device, n); return nullptr; }
+    ffhip_engine *e = new ffhip_engine();
+    e->device = device;
+    HIP_TRY(hipSetDevice(device), (delete e, nullptr));
+    HIP_TRY(hipGetDeviceProperties(&e->prop, device), (delete e, nullptr));
+    if (strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(FFHIP_ENODEV, "device %d is %s; this library is built for gfx950 only", device, e->prop.gcnArchName);
+        delete e;
+        return nullptr;
+    }
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
+    return e;
+}
+
+extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
+    if (!e) return;
+    for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
+    delete e;
+}
+
+extern "C" int ffhip_engine_synchronize(ffhip_engine *e) {
+    if (!e) return set_err(FFHIP_EINVAL, "null engine");
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(e->streams[i]), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_engine_info(const ffhip_engine *e, char *name, size_t name_len, int *ncu, int *clock_khz) {
+    if (!e) return set_err(FFHIP_EINVAL, "null engine");
+    if (name && name_len) { strncpy(name, e->prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (ncu) *ncu = e->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = e->prop.clockRate;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_engine_set_profiling(ffhip_engine *e, int on) {
+    if (!e) return set_err(FFHIP_EINVAL, "null engine");
+    e->profiling = on;
+    return FFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ model
+struct ConvDev {
+    int Fin = 0, Fout = 0, winlen = 0, stride = 1;
+    float *taps = nullptr;      // [Fout][winlen][Fin]   (VALU layers)
+    float *bias = nullptr;      // [Fout] or [Mpad] for the MFMA layer
+    float4 *Wp = nullptr;       // A-fragment order     (last layer)
+    int K16 = 0, Mpad = 0;
+};
+struct RnnDev {
+    float4 *iWp = nullptr, *sWp = nullptr;
+    float *bias = nullptr;      // [4*Hp] permuted rows
+    int Kin16 = 0;
+};
+
+struct ffhip_model {
+    ffhip_engine *eng = nullptr;
+    int kind = 0, nconv = 0, G = 4;
+    int H = 0, Hp = 0;          // hidden units, padded to a multiple of 16
+    int P = 0, Ps = 0, nbase = 0, nstate = 0;
+    int act = ACT_SWISH;
+    ConvDev conv[3];
+    RnnDev rnn[5];
+    float4 *FFp = nullptr;
+    float *FFb = nullptr;
+    std::vector<void *> owned;
+};
+
+static void *dev_upload(ffhip_model *m, const void *host, size_t bytes) {
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    m->owned.push_back(d);
+    return d;
+}
+
+// W(row m, k) accessor -> A-fragment order [Mt][K16][64 lanes][4]; rows/cols beyond the matrix are 0
+template <class F>
+static std::vector<float> pack_afrag(int Mt, int K16, F w) {
+    std::vector<float> out((size_t)Mt * K16 * 256, 0.0f);
+    for (int mt = 0; mt < Mt; mt++)
+        for (int k16 = 0; k16 < K16; k16++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int i = lane & 15, kq = lane >> 4;
+                for (int e = 0; e < 4; e++)
+                    out[(((size_t)mt * K16 + k16) * 64 + lane) * 4 + e] = w(mt * 16 + i, k16 * 16 + kq * 4 + e);
+            }
+    return out;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" void ffhip_model_free(ffhip_model *m) {
+    if (!m) return;
+    for (void *p : m->owned) hipFree(p);
+    delete m;
+}
+
+extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_desc *d) {
+    if (!eng || !d) { set_err(FFHIP_EINVAL, "null engine or descriptor"); return nullptr; }
+    if (d->kind != FFHIP_NET_LSTM5 && d->kind != FFHIP_NET_GRUMOD5) { set_err(FFHIP_EINVAL, "unknown network kind %d", d->kind); return nullptr; }
+    if (d->nconv < 1 || d->nconv > 3) { set_err(FFHIP_EINVAL, "nconv must be 1..3"); return nullptr; }
+    hipSetDevice(eng->device);
+    ffhip_model *m = new ffhip_model();
+    m->eng = eng;
+    m->kind = d->kind;
+    m->nconv = d->nconv;
+    m->G = (d->kind == FFHIP_NET_LSTM5) ? 4 : 3;
+    m->act = (d->kind == FFHIP_NET_LSTM5) ? ACT_SWISH : ACT_TANH;
+#define FAIL(...) do { set_err(FFHIP_EINVAL, __VA_ARGS__); ffhip_model_free(m); return nullptr; } while (0)
+    for (int l = 0; l < 5; l++)
+        if (!d->rnn_iW[l] || !d->rnn_sW[l] || !d->rnn_b[l]) FAIL("missing recurrent layer %d", l);
+    if (!d->FF_W || !d->FF_b) FAIL("missing output layer");
+    const int H = (int)d->rnn_sW[0]->nr, G = m->G;
+    if (H <= 0 || H % 4 != 0) FAIL("hidden size %d must be a positive multiple of 4 (layers.c:1012)", H);
+    m->H = H;
+    m->Hp = round_up(H, 16);
+    const int Hp = m->Hp;
+
+    // ---- convolutions
+    int Fin = 1;
+    for (int l = 0; l < d->nconv; l++) {
+        const_flappie_matrix W = d->conv_W[l], b = d->conv_b[l];
+        if (!W || !b) FAIL("missing convolution %d", l);
+        ConvDev &c = m->conv[l];
+        const int nf_pad = round_up(Fin, 4);
+        if ((int)W->nrq * 4 % nf_pad != 0) FAIL("conv %d: filter rows do not match %d input features", l, Fin);
+        c.Fin = Fin;
+        c.Fout = (int)W->nc;
+        c.winlen = (int)(W->nrq * 4) / nf_pad;                 // layers.c:199
+        c.stride = d->conv_stride[l];
+        if (c.stride < 1 || c.winlen < 1 || c.winlen > 48) FAIL("conv %d: unsupported winlen %d / stride %d", l, c.winlen, c.stride);
+        if (b->nr != W->nc) FAIL("conv %d: bias length", l);
+        auto tap = [&](int f, int t, int j) -> float {
+            const size_t row = (size_t)t * nf_pad + j;
+            return row < W->nr ? W->data.f[(size_t)f * W->stride + row] : 0.0f;
+        };
+        const bool last = (l == d->nconv - 1);
+        if (!last) {
+            if (c.Fout > 32) FAIL("conv %d: more than 32 filters in a front layer", l);
+            std::vector<float> taps((size_t)c.Fout * c.winlen * Fin);
+            for (int f = 0; f < c.Fout; f++)
+                for (int t = 0; t < c.winlen; t++)
+                    for (int j = 0; j < Fin; j++) taps[((size_t)f * c.winlen + t) * Fin + j] = tap(f, t, j);
+            c.taps = (float *)dev_upload(m, taps.data(), taps.size() * 4);
+            c.bias = (float *)dev_upload(m, b->data.f, (size_t)c.Fout * 4);
+            if (!c.taps || !c.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        } else {
+            if (c.Fout != H) FAIL("last convolution has %d filters, recurrent stack expects %d", c.Fout, H);
+            const int K = c.winlen * Fin;
+            c.K16 = (K + 15) / 16;
+            c.Mpad = Hp;
+            if (c.K16 * 16 > kSamplePad * Fin) FAIL("conv %d: window too long for the sample pad", l);
+            auto w = [&](int row, int k) -> float {
+                if (row >= c.Fout || k >= K) return 0.0f;
+                return tap(row, k / Fin, k % Fin);
+            };
+            std::vector<float> wp = pack_afrag(Hp / 16, c.K16, w);
+            std::vector<float> bias(Hp, 0.0f);
+            for (int f = 0; f < c.Fout; f++) bias[f] = b->data.f[f];
+            c.Wp = (float4 *)dev_upload(m, wp.data(), wp.size() * 4);
+            c.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
+            if (!c.Wp || !c.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        }
+        Fin = c.Fout;
+    }
+
+    // ---- recurrent layers: gate rows permuted unit-major (m = 4u + g), padded units are all-zero
+    for (int l = 0; l < 5; l++) {
+        const_flappie_matrix iW = d->rnn_iW[l], sW = d->rnn_sW[l], b = d->rnn_b[l];
+        if ((int)iW->nr != H || (int)iW->nc != G * H) FAIL("rnn %d: iW is %zux%zu, expected %dx%d", l, iW->nr, iW->nc, H, G * H);
+        if ((int)sW->nr != H || (int)sW->nc != G * H) FAIL("rnn %d: sW is %zux%zu, expected %dx%d", l, sW->nr, sW->nc, H, G * H);
+        if ((int)b->nr != G * H) FAIL("rnn %d: bias length %zu, expected %d", l, b->nr, G * H);
+        auto rowcol = [&](const_flappie_matrix Wm, int row, int k) -> float {
+            const int u = row / 4, g = row % 4;
+            if (u >= H || g >= G || k >= H) return 0.0f;
+            return Wm->data.f[(size_t)(g * H + u) * Wm->stride + k];      // column g*H+u of the [H x G*H] matrix
+        };
+        std::vector<float> ip = pack_afrag(Hp / 4, Hp / 16, [&](int r, int k) { return rowcol(iW, r, k); });
+        std::vector<float> sp = pack_afrag(Hp / 4, Hp / 16, [&](int r, int k) { return rowcol(sW, r, k); });
+        std::vector<float> bias((size_t)4 * Hp, 0.0f);
+        for (int u = 0; u < H; u++)
+            for (int g = 0; g < G; g++) bias[(size_t)4 * u + g] = b->data.f[g * H + u];
+        RnnDev &r = m->rnn[l];
+        r.Kin16 = Hp / 16;
+        r.iWp = (float4 *)dev_upload(m, ip.data(), ip.size() * 4);
+        r.sWp = (float4 *)dev_upload(m, sp.data(), sp.size() * 4);
+        r.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
+        if (!r.iWp || !r.sWp || !r.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+    }
+
+    // ---- output layer
+    {
+        const_flappie_matrix W = d->FF_W, b = d->FF_b;
+        if ((int)W->nr != H) FAIL("FF_W has %zu rows, expected %d", W->nr, H);
+        const int P = (int)W->nc;
+        const int nbase = (int)roundf((-1.0f + sqrtf(1 + 2 * P)) / 2.0f);        // layers.c:1029-1032
+        if (2 * nbase * (nbase + 1) != P || nbase < 1 || 2 * nbase > kMaxState || P > 64)
+            FAIL("output layer has %d rows: not a flip-flop parameterisation this engine supports", P);
+        if ((int)b->nr != P) FAIL("FF_b length");
+        m->P = P; m->Ps = round_up(P, 4); m->nbase = nbase; m->nstate = 2 * nbase;
+        const int Mt = (P + 15) / 16;
+        if (Mt > 4) FAIL("output layer too wide");
+        std::vector<float> wp = pack_afrag(Mt, Hp / 16, [&](int row, int k) -> float {
+            if (row >= P || k >= H) return 0.0f;
+            return W->data.f[(size_t)row * W->stride + k];
+        });
+        std::vector<float> bias((size_t)Mt * 16, 0.0f);
+        for (int p = 0; p < P; p++) bias[p] = b->data.f[p];
+        m->FFp = (float4 *)dev_upload(m, wp.data(), wp.size() * 4);
+        m->FFb = (float *)dev_upload(m, bias.data(), bias.size() * 4);
+        if (!m->FFp || !m->FFb) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+    }
+#undef FAIL
+    return m;
+}
+
+extern "C" size_t ffhip_model_hidden(const ffhip_model *m) { return m ? (size_t)m->H : 0; }
+extern "C" size_t ffhip_model_nparam(const ffhip_model *m) { return m ? (size_t)m->P : 0; }
+extern "C" size_t ffhip_model_nbase(const ffhip_model *m) { return m ? (size_t)m->nbase : 0; }
+extern "C" size_t ffhip_model_nblock(const ffhip_model *m, size_t nsample) {
+    if (!m) return 0;
+    size_t n = nsample;
+    for (int l = 0; l < m->nconv; l++) n = (n + m->conv[l].stride - 1) / m->conv[l].stride;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ batch
+struct ConvPlan { int Tin = 0, Tout = 0; int *x0a = nullptr, *x0b = nullptr; };
+
+struct ffhip_batch {
+    ffhip_engine *eng = nullptr;
+    const ffhip_model *mdl = nullptr;
+    hipStream_t stream = nullptr;
+    int nread = 0, B16 = 0, Bp = 0;
+    int T = 0, Tb = 0;
+    ConvPlan plan[3];
+    SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
+    float *act[2] = { nullptr, nullptr };
+    float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    float *xa = nullptr, *cstate = nullptr;
+    float *trans = nullptr, *post = nullptr, *fwd = nullptr;
+    uint8_t *tb = nullptr;
+    int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
+    char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
+    int32_t *trace = nullptr;
+    float *scratch = nullptr;           // dense [Tb][H] for debug taps
+    // pinned host mirrors of the small results
+    char *h_bases = nullptr, *h_quals = nullptr; int *h_lens = nullptr; float *h_score = nullptr;
+    std::vector<void *> owned;
+    unsigned last_flags = 0;
+    int ran = 0, finished = 0;
+    int final_act = 0;                  // which act[] holds the last recurrent layer's output
+    hipEvent_t ev[FFHIP_NGROUP + 1];
+    int have_ev = 0;
+    int launches[FFHIP_NGROUP];
+    float prof_inproj = 0.f, prof_rnn = 0.f;
+};
+
+static void *dalloc(ffhip_batch *b, size_t bytes, bool zero) {
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) { set_err(FFHIP_ENOMEM, "hipMalloc of %zu bytes failed", bytes); return nullptr; }
+    if (zero && hipMemset(d, 0, bytes) != hipSuccess) { hipFree(d); set_err(FFHIP_EHIP, "hipMemset failed"); return nullptr; }
+    b->owned.push_back(d);
+    return d;
+}
+
+// Column -> window-start table of one convolution: the reference's three regions (layers.c:220-271)
+// restated in index space.  With zero pads either side of the input a
+// partial edge window is a full window starting at x0 (possibly negative).
+static int build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<int> &bq) {
+    const int padL = (winlen - 1) / 2, padR = winlen / 2;
+    const int Tout = (T + s - 1) / s;
+    const int ncolsL = (padL + s - 1) / s, shiftX = ncolsL * s - padL;
+    const int nstepC = (winlen + s - 1) / s, nstepX = s * nstepC;
+    if (T < winlen || T - shiftX - (winlen - 1) < 0) return -1;
+    a.assign(Tout, kNoWindow);
+    bq.assign(Tout, kNoWindow);
+    bool overflow = false;
+    auto add = [&](int c, int x0) {
+        if (c < 0 || c >= Tout) return;
+        if (a[c] == kNoWindow) a[c] = x0;
+        else if (bq[c] == kNoWindow) bq[c] = x0;
+        else overflow = true;
+    };
+    for (int w = 0; w < padL; w += s) add(w / s, w - padL);
+    for (int w = 0; w < winlen; w += s) {
+        const int ncol = (T - shiftX - w) / nstepX, col0 = ncolsL + w / s;
+        for (int k = 0; k < ncol; k++) add(col0 + nstepC * k, shiftX + w + nstepX * k);
+    }
+    const int maxCol = (T - shiftX) / nstepX, rem = (T - shiftX) % nstepX;
+    const int colR = ncolsL + nstepC * (maxCol - 1) + rem / s + 1;
+    const int startR = s - (padL + T - winlen) % s - 1;
+    for (int w = startR; w < padR; w += s) add(colR + w / s, T - winlen + 1 + w);
+    return overflow ? -2 : Tout;
+}
+
+extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->eng->device);
+    hipStreamSynchronize(b->stream);
+    for (void *p : b->owned) hipFree(p);
+    if (b->h_bases) hipHostFree(b->h_bases);
+    if (b->h_quals) hipHostFree(b->h_quals);
+    if (b->h_lens) hipHostFree(b->h_lens);
+    if (b->h_score) hipHostFree(b->h_score);
+    if (b->have_ev) for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
+    delete b;
+}
+
+extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model *m, int nread, size_t nsample) {
+    if (!eng || !m || nread <= 0 || nsample == 0 || nsample > (1u << 30)) { set_err(FFHIP_EINVAL, "bad batch arguments"); return nullptr; }
+    hipSetDevice(eng->device);
+    ffhip_batch *b = new ffhip_batch();
+    b->eng = eng; b->mdl = m;
+    b->stream = eng->streams[eng->next_stream];
+    eng->next_stream ^= 1;
+    b->nread = nread; b->B16 = (nread + 15) / 16; b->Bp = b->B16 * 16;
+    b->T = (int)nsample;
+#define BFAIL() do { ffhip_batch_destroy(b); return nullptr; } while (0)
+    int Tin = b->T;
+    for (int l = 0; l < m->nconv; l++) {
+        std::vector<int> a, bq;
+        const int Tout = build_conv_plan(Tin, m->conv[l].winlen, m->conv[l].stride, a, bq);
+        if (Tout < 0) { set_err(FFHIP_EINVAL, "conv %d: %d samples is outside the domain of the reference's convolution (winlen %d, stride %d)", l, Tin, m->conv[l].winlen, m->conv[l].stride); BFAIL(); }
+        b->plan[l].Tin = Tin; b->plan[l].Tout = Tout;
+        b->plan[l].x0a = (int *)dalloc(b, (size_t)Tout * 4, false);
+        b->plan[l].x0b = (int *)dalloc(b, (size_t)Tout * 4, false);
+        if (!b->plan[l].x0a || !b->plan[l].x0b) BFAIL();
+        hipMemcpy(b->plan[l].x0a, a.data(), (size_t)Tout * 4, hipMemcpyHostToDevice);
+        hipMemcpy(b->plan[l].x0b, bq.data(), (size_t)Tout * 4, hipMemcpyHostToDevice);
+        // input buffer of this conv
+        SampleBuf &sb = b->sbuf[l];
+        sb.F = m->conv[l].Fin; sb.T = Tin;
+        sb.rs = (size_t)round_up((Tin + 2 * kSamplePad) * sb.F, 64);
+        sb.p = (float *)dalloc(b, (size_t)b->Bp * sb.rs * 4, true);
+        if (!sb.p) BFAIL();
+        Tin = Tout;
+    }
+    b->Tb = Tin;
+    const size_t Tb = b->Tb, Bp = b->Bp, Hp = m->Hp, Ps = m->Ps, ns = m->nstate;
+    for (int i = 0; i < 2; i++) if (!(b->act[i] = (float *)dalloc(b, Tb * Bp * Hp * 4, false))) BFAIL();
+    if (!(b->xa = (float *)dalloc(b, Tb * Bp * Hp * 4 * 4, false))) BFAIL();
+    if (!(b->cstate = (float *)dalloc(b, Bp * Hp * 4, true))) BFAIL();
+    if (!(b->trans = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
+    if (!(b->post = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
+    if (!(b->fwd = (float *)dalloc(b, (size_t)nread * (Tb + 1) * kMaxState * 4, false))) BFAIL();
+    if (!(b->tb = (uint8_t *)dalloc(b, (size_t)nread * Tb * kMaxState, false))) BFAIL();
+    if (!(b->path = (int *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
+    if (!(b->qpath = (float *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
+    if (!(b->score = (float *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
+    if (!(b->bases = (char *)dalloc(b, (size_t)nread * (Tb + 1), true))) BFAIL();
+    if (!(b->quals = (char *)dalloc(b, (size_t)nread * (Tb + 1), true))) BFAIL();
+    if (!(b->lens = (int *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
+    if (!(b->trace = (int32_t *)dalloc(b, (size_t)nread * (Tb + 1) * ns * 4, true))) BFAIL();
+    if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_quals, (size_t)nread * (Tb + 1)) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_lens, (size_t)nread * 4) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_score, (size_t)nread * 4) != hipSuccess) {
+        set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL();
+    }
+    for (int i = 0; i <= FFHIP_NGROUP; i++)
+        if (hipEventCreate(&b->ev[i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
+    b->have_ev = 1;
+#undef BFAIL
+    return b;
+}
+
+extern "C" size_t ffhip_batch_nblock(const ffhip_batch *b) { return b ? (size_t)b->Tb : 0; }
+
+extern "C" int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, size_t ld) {
+    if (!b || !signals || ld < (size_t)b->T) return set_err(FFHIP_EINVAL, "bad signal arguments");
+    hipSetDevice(b->eng->device);
+    SampleBuf &sb = b->sbuf[0];
+    HIP_TRY(hipMemcpy2DAsync((void *)(sb.p + kSamplePad), sb.rs * 4, signals, ld * 4, (size_t)b->T * 4, b->nread,
+                             hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
+    if (!b || !reads) return set_err(FFHIP_EINVAL, "bad read arguments");
+    hipSetDevice(b->eng->device);
+    SampleBuf &sb = b->sbuf[0];
+    for (int r = 0; r < b->nread; r++) {
+        const raw_table &rt = reads[r];
+        if (!rt.raw || rt.end <= rt.start || rt.end - rt.start != (size_t)b->T)
+            return set_err(FFHIP_EINVAL, "read %d: end-start must equal the batch's %d samples", r, b->T);
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), rt.raw + rt.start, (size_t)b->T * 4,
+                               hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
+static void mark(ffhip_batch *b, int i) {
+    if (b->eng->profiling) hipEventRecord(b->ev[i], b->stream);
+}
+
+extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags) {
+    if (!b) return set_err(FFHIP_EINVAL, "null batch");
+    const ffhip_model *m = b->mdl;
+    hipSetDevice(b->eng->device);
+    hipStream_t s = b->stream;
+    const int Tb = b->Tb, B16 = b->B16, Bp = b->Bp, Hp = m->Hp;
+    const bool keep = (flags & FFHIP_RUN_KEEP_ACTS) != 0;
+    memset(b->launches, 0, sizeof(b->launches));
+    auto keep_copy = [&](int slot, const float *src) -> int {
+        if (!keep) return FFHIP_OK;
+        if (!b->keep[slot] && !(b->keep[slot] = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4, false))) return FFHIP_ENOMEM;
+        HIP_TRY(hipMemcpyAsync(b->keep[slot], src, (size_t)Tb * Bp * Hp * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+        return FFHIP_OK;
+    };
+
+    mark(b, 0);
+    // ---- convolutions (layers.c:189-276, activations :24-49)
+    for (int l = 0; l < m->nconv; l++) {
+        const ConvDev &c = m->conv[l];
+        if (l < m->nconv - 1) {
+            launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->plan[l].x0a, b->plan[l].x0b, Bp,
+                              b->plan[l].Tout, c.winlen, m->act);
+        } else {
+            launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->plan[l].x0a, b->plan[l].x0b, B16, Tb, c.Mpad,
+                             c.K16, m->act);
+        }
+        b->launches[0]++;
+    }
+    if (int rc = keep_copy(0, b->act[0])) return rc;
+    mark(b, 1);
+    // ---- recurrent stack: B,F,B,F,B (networks.c:556-580 / :459-483)
+    // profiling groups 1 (in-projection) and 2 (recurrent) interleave; their events bracket the
+    // whole stack and the split is measured with per-layer events when profiling is on.
+    int cur = 0;
+    float ms_inproj = 0.f, ms_rnn = 0.f;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (b->eng->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); }
+    for (int l = 0; l < 5; l++) {
+        const RnnDev &r = m->rnn[l];
+        const bool backward = (l % 2 == 0);
+        float *in = b->act[cur], *out = b->act[cur ^ 1];
+        if (e0) hipEventRecord(e0, s);
+        launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
+        b->launches[1]++;
+        if (e1) hipEventRecord(e1, s);
+        const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
+        for (int i = 0; i < Tb; i++) {
+            const int t = backward ? Tb - 1 - i : i;
+            const int tp = backward ? t + 1 : t - 1;
+            const float *hp = (i == 0) ? nullptr : out + (size_t)tp * h_step;
+            if (m->kind == FFHIP_NET_LSTM5)
+                launch_lstm_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, b->cstate, B16, Hp, i == 0);
+            else
+                launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0);
+        }
+        b->launches[2] += Tb;
+        if (e2) {
+            hipEventRecord(e2, s);
+            hipEventSynchronize(e2);
+            float a = 0, c2 = 0;
+            hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&c2, e1, e2);
+            ms_inproj += a; ms_rnn += c2;
+        }
+        cur ^= 1;
+        if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
+    }
+    if (e0) { hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); }
+    b->final_act = cur;
+    b->prof_inproj = ms_inproj; b->prof_rnn = ms_rnn;
+    mark(b, 3);
+    // ---- globalnorm_flipflop (layers.c:1082-1106)
+    launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
+    launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps);
+    b->launches[3] += 2;
+    mark(b, 4);
+    b->last_flags = flags;
+    if (!(flags & FFHIP_RUN_NO_DECODE)) {
+        const float *scores = b->trans;
+        if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
+            launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);
+            scores = b->post;
+            b->launches[4]++;
+        }
+        mark(b, 5);
+        launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
+        launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase);
+        b->launches[5] += 2;
+        if (!(flags & FFHIP_RUN_NO_TRACE)) {
+            launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps);
+            b->launches[5]++;
+        }
+    } else {
+        mark(b, 5);
+    }
+    mark(b, 6);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    b->ran = 1; b->finished = 0;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_batch_finish(ffhip_batch *b) {
+    if (!b) return set_err(FFHIP_EINVAL, "null batch");
+    if (!b->ran) return set_err(FFHIP_EINVAL, "ffhip_batch_run has not been called");
+    hipSetDevice(b->eng->device);
+    const size_t n = (size_t)b->nread, L = (size_t)b->Tb + 1;
+    if (!(b->last_flags & FFHIP_RUN_NO_DECODE)) {
+        HIP_TRY(hipMemcpyAsync(b->h_bases, b->bases, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->h_quals, b->quals, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->h_lens, b->lens, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->h_score, b->score, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    b->finished = 1;
+    return FFHIP_OK;
+}
+
+static bool results_ok(const ffhip_batch *b, int read) {
+    if (!b || !b->finished || read < 0 || read >= b->nread) { set_err(FFHIP_EINVAL, "results not available (finish the batch, check the read index)"); return false; }
+    return true;
+}
+
+extern "C" const char *ffhip_batch_basecall(const ffhip_batch *b, int read, size_t *length) {
+    if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return nullptr;
+    if (length) *length = (size_t)b->h_lens[read];
+    return b->h_bases + (size_t)read * (b->Tb + 1);
+}
+extern "C" const char *ffhip_batch_quality(const ffhip_batch *b, int read) {
+    if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return nullptr;
+    return b->h_quals + (size_t)read * (b->Tb + 1);
+}
+extern "C" float ffhip_batch_score(const ffhip_batch *b, int read) {
+    if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return NAN;
+    return b->h_score[read];
+}
+
+static int d2h(ffhip_batch *b, void *dst, const void *src, size_t bytes) {
+    hipSetDevice(b->eng->device);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_batch_get_path(ffhip_batch *b, int read, int *path, float *qpath) {
+    if (!results_ok(b, read)) return FFHIP_EINVAL;
+    const size_t L = (size_t)b->Tb + 1;
+    if (path) if (int rc = d2h(b, path, b->path + (size_t)read * L, L * 4)) return rc;
+    if (qpath) if (int rc = d2h(b, qpath, b->qpath + (size_t)read * L, L * 4)) return rc;
+    return FFHIP_OK;
+}
+
+static int get_scores(ffhip_batch *b, const float *src, int read, float *out) {
+    if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
+    const ffhip_model *m = b->mdl;
+    const size_t Tb = b->Tb;
+    if (m->Ps == m->P) return d2h(b, out, src + (size_t)read * Tb * m->Ps, Tb * m->P * 4);
+    std::vector<float> tmp(Tb * m->Ps);
+    if (int rc = d2h(b, tmp.data(), src + (size_t)read * Tb * m->Ps, tmp.size() * 4)) return rc;
+    for (size_t c = 0; c < Tb; c++) memcpy(out + c * m->P, tmp.data() + c * m->Ps, (size_t)m->P * 4);
+    return FFHIP_OK;
+}
+extern "C" int ffhip_batch_get_transitions(ffhip_batch *b, int read, float *out) { return b ? get_scores(b, b->trans, read, out) : FFHIP_EINVAL; }
+extern "C" int ffhip_batch_get_posterior(ffhip_batch *b, int read, float *out) {
+    if (b && (b->last_flags & (FFHIP_RUN_VITERBI_ONLY | FFHIP_RUN_NO_DECODE))) return set_err(FFHIP_EINVAL, "posterior was not computed in this run");
+    return b ? get_scores(b, b->post, read, out) : FFHIP_EINVAL;
+}
+extern "C" int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out) {
+    if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
+    if (b->last_flags & (FFHIP_RUN_NO_TRACE | FFHIP_RUN_NO_DECODE)) return set_err(FFHIP_EINVAL, "trace was not computed in this run");
+    const size_t n = ((size_t)b->Tb + 1) * b->mdl->nstate;
+    return d2h(b, out, b->trace + (size_t)read * n, n * 4);
+}
+
+extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out) {
+    if (!results_ok(b, read) || !out || layer < -1 || layer > 4) return FFHIP_EINVAL;
+    const ffhip_model *m = b->mdl;
+    const float *src = b->keep[layer + 1];
+    if (!src) {
+        if (layer == 4) src = b->act[b->final_act];
+        else return set_err(FFHIP_EINVAL, "activation of layer %d was not kept (run with flag 16)", layer);
+    }
+    hipSetDevice(b->eng->device);
+    if (!b->scratch && !(b->scratch = (float *)dalloc(b, (size_t)b->Tb * m->Hp * 4, false))) return FFHIP_ENOMEM;
+    launch_untile(b->stream, src, b->scratch, read, b->Tb, b->B16, m->Hp);
+    std::vector<float> tmp((size_t)b->Tb * m->Hp);
+    if (int rc = d2h(b, tmp.data(), b->scratch, tmp.size() * 4)) return rc;
+    for (int t = 0; t < b->Tb; t++) memcpy(out + (size_t)t * m->H, tmp.data() + (size_t)t * m->Hp, (size_t)m->H * 4);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launches[FFHIP_NGROUP]) {
+    if (!b || !b->eng->profiling || !b->finished) return set_err(FFHIP_EINVAL, "profiling is off or the batch is not finished");
+    float t01 = 0, t34 = 0, t45 = 0, t56 = 0;
+    hipEventElapsedTime(&t01, b->ev[0], b->ev[1]);
+    hipEventElapsedTime(&t34, b->ev[3], b->ev[4]);
+    hipEventElapsedTime(&t45, b->ev[4], b->ev[5]);
+    hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
+    ms[0] = t01; ms[1] = b->prof_inproj; ms[2] = b->prof_rnn; ms[3] = t34; ms[4] = t45; ms[5] = t56;
+    for (int i = 0; i < FFHIP_NGROUP; i++) launches[i] = b->launches[i];
+    return FFHIP_OK;
+}

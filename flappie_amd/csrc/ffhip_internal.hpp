@@ -1,0 +1,89 @@
+// ffhip_internal.hpp -- shared declarations between the HIP kernels and the host engine.
+// gfx950 (MI355X) only.  Not part of the public boundary (include/ffhip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ffhip {
+
+// ---------------------------------------------------------------------------------------------
+// Data layouts in HBM (all fp32 unless noted).  B16 = ceil(nread/16) read tiles, Bp = 16*B16.
+//
+//  sample-major  S[r][pad + t][F]        conv inputs; `pad` zero rows before and after the T real
+//                                        rows, read stride rs floats.  A window of `winlen` samples
+//                                        is one contiguous vector of winlen*F floats.
+//  tile-interleaved  A[t][rt][k/4][r16][k%4]
+//                                        recurrent-stack activations (H features).  For one
+//                                        (t, read tile) the 16 reads x 16 consecutive features are
+//                                        1 KiB in exactly the lane order of an MFMA 16x16x4 f32
+//                                        B-fragment quad: lane l=(kq=l>>4, r=l&15) holds float4
+//                                        {k = 16*k16 + 4*kq + 0..3}.
+//  D-fragment  X[t][rt][mt][lane][4]     gate pre-activations (Wi x + b).  Rows are permuted
+//                                        unit-major/gate-minor (m = 4*u + g), so an MFMA output tile
+//                                        (lane l: rows 4*(l>>4)+0..3, column l&15) gives every lane
+//                                        the 4 gates of ONE hidden unit of ONE read.
+//  weights  W[mt][k16][lane] float4      A-fragment order, lane l=(i=l&15, kq=l>>4) holds
+//                                        W[16*mt + i][16*k16 + 4*kq + 0..3].
+//  trans/post  T[r][blk][Ps]             Ps = 4*ceil(P/4): byte-identical to the reference's
+//                                        flappie_matrix image of one read (column = block).
+// ---------------------------------------------------------------------------------------------
+
+constexpr int kSamplePad = 64;     // zero rows either side of a sample-major buffer
+constexpr int kMaxState = 16;      // nstate <= 16 (nbase <= 8)
+constexpr int kNoWindow = INT32_MIN;
+
+struct SampleBuf {                 // sample-major activation buffer
+    float *p;
+    int F;                         // features per sample (exact, no padding)
+    int T;                         // real samples
+    size_t rs;                     // read stride in floats
+    __host__ __device__ const float *row(int r, int t) const { return p + (size_t)r * rs + (size_t)(kSamplePad + t) * F; }
+};
+
+enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_TANH = 2 };
+
+// ---- kernel launchers (ffhip_kernels.hip) ----------------------------------------------------
+void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf dst, int nread);
+
+// VALU convolution for the thin front layers; W dense taps [Fout][winlen][Fin]
+void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act);
+
+// MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
+void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act);
+
+// Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
+void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
+                   int ntile /*Tb*B16*/, int M /*rows, mult of 16*/, int K16);
+
+// one recurrent step for all reads (launch-per-step path)
+void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
+                      float *cstate, int B16, int H, int first);
+void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
+                     int B16, int H, int first);
+
+// persistent recurrent layer (ffhip_rnn_persist.hip); returns false if the shape is unsupported
+struct PersistPlan;
+bool persist_supported(int kind, int H, int B16, int ncu);
+
+// head: trans = tanh(W^T h + b) / (temperature/5)
+void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
+                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale);
+// CRF partition function (fp64) + subtraction of (float)(logZ/Tb)
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps);
+// forward/backward transition posteriors, log-normalised per block
+void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
+// Viterbi + traceback + qpath
+void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
+                    int nread, int Tb, int nbase, int Ps);
+// change positions -> base / quality strings
+void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
+                     int nread, int Tb, int nbase);
+// exp + trace_from_posterior
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps);
+// tile-interleaved -> dense [Tb][H] of one read (debug tap)
+void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H);
+
+}  // namespace ffhip

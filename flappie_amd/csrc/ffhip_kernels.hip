@@ -1,0 +1,718 @@
+// ffhip_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the flip-flop basecalling hot path.
+//
+// Every contraction runs on the matrix cores with the fp32-input MFMA v_mfma_f32_16x16x4_f32
+// (exact f32, 64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak): the parity bar (1e-4 on transition
+// scores through five recurrent layers, bit-exact base strings) rules out bf16/fp8 inputs.
+// Operands live in HBM in MFMA *fragment order* (see ffhip_internal.hpp), so every operand fetch
+// is one fully coalesced 1 KiB wave load of float4 that feeds four MFMAs.
+//
+// Reference functions replaced (paths relative to /root/reference/src):
+//   conv_small / conv_mfma   convolution()            layers.c:189-276 (+ swish/tanh :24-49)
+//   inproj                   feedforward_linear()     layers.c:279-283 -> affine_map flappie_matrix.c:361
+//   lstm_step / gru_step     lstm_step / grumod_step  layers.c:979-1026 / :664-715
+//   head + crf_norm          globalnorm_flipflop()    layers.c:1082-1106, partition fn :1035-1079
+//   transpost                transpost_crf_flipflop() decode.c:377-497 + log_row_normalise flappie_matrix.c:450
+//   viterbi                  decode_crf_flipflop()    decode.c:119-204
+//   assemble                 change_positions + calculate_post loop   decode.c:66-79, flappie.c:284-292
+//   trace                    exp_activation_inplace + trace_from_posterior   layers.c:56, decode.c:499-543
+#include "ffhip_internal.hpp"
+#include "ffhip_math.hpp"
+
+namespace ffhip {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f mfma4(v4f a, v4f b, v4f c) {
+    // four k-steps of 16x16x4: k = 16*k16 + 4*kq + {0,1,2,3}; the k order inside the 16 is free as
+    // long as A and B agree, and both fragments use the same (kq, component) -> k map.
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// XCD-aware bijective remap of a 1-D grid: hardware places block b on XCD b%8; give each XCD a
+// contiguous range of logical ids so that neighbours (which share operand panels) share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// VALU convolution for the thin front layers (1->4, 4->16 features): one thread per output
+// column, all filters.  `x0a/x0b[c]` are the first input samples of the (up to two) windows the
+// reference accumulates into column c -- this is how the right-edge behaviour of layers.c:257-271
+// is reproduced in index space; kNoWindow = none.  Input pads are zero, so partial windows at
+// either edge are plain full-length windows here.
+// ------------------------------------------------------------------------------------------
+template <int MAXF>
+__global__ void __launch_bounds__(256)
+k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
+             const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act) {
+    extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
+    const int Fin = in.F, Fout = out.F, K = winlen * Fin;
+    for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
+    for (int i = threadIdx.x; i < Fout; i += blockDim.x) w_lds[Fout * K + i] = bias[i];
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= Tout) return;
+    float acc[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; f++) acc[f] = (f < Fout) ? w_lds[Fout * K + f] : 0.0f;
+    const int xs[2] = { x0a[c], x0b[c] };
+#pragma unroll
+    for (int wdw = 0; wdw < 2; wdw++) {
+        if (xs[wdw] == kNoWindow) continue;
+        const float *x = in.row(r, xs[wdw]);
+        for (int k = 0; k < K; k++) {
+            const float xv = x[k];
+#pragma unroll
+            for (int f = 0; f < MAXF; f++)
+                if (f < Fout) acc[f] = acc[f] + w_lds[f * K + k] * xv;
+        }
+    }
+    float *o = out.p + (size_t)r * out.rs + (size_t)(kSamplePad + c) * Fout;
+#pragma unroll
+    for (int f = 0; f < MAXF; f++)
+        if (f < Fout) o[f] = apply_act(acc[f], act);
+}
+
+void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act) {
+    dim3 grid((Tout + 255) / 256, Bp), block(256);
+    const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
+    if (out.F <= 4)
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+    else if (out.F <= 16)
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+    else
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA tile engine shared by the last convolution, the input projections and the CRF head.
+// A workgroup = 4 waves arranged 2 (M) x 2 (N); each wave owns TM x TN tiles of 16x16.
+// A fragments: packed weights, `Wp + (mt*K16 + k16)*64 + lane`.
+// B fragments: per-lane pointer + k16 * bstep floats (tile-interleaved activations: contiguous
+// 1 KiB per k16; convolution windows: 16 consecutive floats of the window per k16).
+// Loads are register double-buffered; the f32 MFMA is slow enough (32 cycles per instruction)
+// that 8 coalesced 1 KiB loads per 64 MFMAs hide behind the matrix pipe.
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, bool BVEC>
+__device__ __forceinline__ void mma_tiles(const v4f *(&ap)[TM], const float *(&bp)[TN], size_t bstep, int K16,
+                                          v4f (&acc)[TM][TN]) {
+    v4f a0[TM], b0[TN], a1[TM], b1[TN];
+    auto loadA = [&](v4f(&a)[TM], int k16) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) a[i] = ap[i][(size_t)k16 * 64];
+    };
+    auto loadB = [&](v4f(&b)[TN], int k16) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const float *p = bp[j] + (size_t)k16 * bstep;
+            if (BVEC) b[j] = *(const v4f *)p;
+            else { b[j].x = p[0]; b[j].y = p[1]; b[j].z = p[2]; b[j].w = p[3]; }
+        }
+    };
+    auto mma = [&](v4f(&a)[TM], v4f(&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+    };
+    loadA(a0, 0); loadB(b0, 0);
+    int k16 = 0;
+    for (; k16 + 2 <= K16; k16 += 2) {
+        loadA(a1, k16 + 1); loadB(b1, k16 + 1);
+        mma(a0, b0);
+        if (k16 + 2 < K16) { loadA(a0, k16 + 2); loadB(b0, k16 + 2); }
+        mma(a1, b1);
+    }
+    if (k16 < K16) mma(a0, b0);
+}
+
+// ---- last convolution (implicit GEMM over the window) -------------------------------------
+// N tile = (output column c, read tile rt); all 16 reads share the window start.  Columns with a
+// second window (or none) are irregular and rare: handled by re-running the loop for window b.
+template <bool BVEC>
+__global__ void __launch_bounds__(256)
+k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, const float *__restrict__ bias,
+            const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act) {
+    constexpr int TM = 4, TN = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
+    const int ntile = Tout * B16;
+    const int nNblk = (ntile + 2 * TN - 1) / (2 * TN);
+    const int L = xcd_remap(blockIdx.x, nMblk * nNblk);
+    const int mblk = L % nMblk, nblk = L / nMblk;
+    const int mt0 = (mblk * 2 + wm) * TM, nt0 = (nblk * 2 + wn) * TN;
+    const int kq = lane >> 4, rl = lane & 15;
+
+    v4f acc[TM][TN];
+    const v4f *ap[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(mt0 + i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * K16 * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        const float *bp[TN];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = min(nt0 + j, ntile - 1);
+            const int c = nt / B16, rt = nt % B16;
+            int x0 = pass == 0 ? x0a[c] : x0b[c];
+            // a missing window contributes zero: point it at the leading zero pad
+            const bool have = (x0 != kNoWindow);
+            any |= have;
+            if (!have) x0 = -kSamplePad;
+            bp[j] = in.p + (size_t)(rt * 16 + rl) * in.rs + (size_t)(kSamplePad + x0) * in.F + kq * 4;
+        }
+        // `any` is uniform per wave (x0 depends on c only): skip the whole pass when nothing is there
+        if (pass == 1 && !__builtin_amdgcn_readfirstlane(any)) break;
+        mma_tiles<TM, TN, BVEC>(ap, bp, 16, K16, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = mt0 + i;
+        if (mt >= Mt) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            v4f v = acc[i][j];
+            v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
+            v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+            *(v4f *)(out + ((size_t)nt * Mt + mt) * 256 + lane * 4) = v;
+        }
+    }
+}
+
+void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act) {
+    const int Mt = M / 16;
+    const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
+    const bool vec = (in.F % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_conv_mfma<true>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
+                           x0a, x0b, B16, Tout, Mt, K16, act);
+    else
+        hipLaunchKernelGGL(k_conv_mfma<false>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
+                           x0a, x0b, B16, Tout, Mt, K16, act);
+}
+
+// ---- input projection: Xa[nt][mt] = Wp[mt] . act[nt] + b ----------------------------------
+__global__ void __launch_bounds__(256)
+k_inproj(const float *__restrict__ in, float *__restrict__ xa, const v4f *__restrict__ Wp,
+         const float *__restrict__ bias, int ntile, int Mt, int K16) {
+    constexpr int TM = 4, TN = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
+    const int nNblk = (ntile + 2 * TN - 1) / (2 * TN);
+    const int L = xcd_remap(blockIdx.x, nMblk * nNblk);
+    const int mblk = L % nMblk, nblk = L / nMblk;
+    const int mt0 = (mblk * 2 + wm) * TM, nt0 = (nblk * 2 + wn) * TN;
+    const int kq = lane >> 4;
+
+    v4f acc[TM][TN];
+    const v4f *ap[TM];
+    const float *bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(mt0 + i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * K16 * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int nt = min(nt0 + j, ntile - 1);
+        bp[j] = in + (size_t)nt * K16 * 256 + lane * 4;
+    }
+    mma_tiles<TM, TN, true>(ap, bp, 256, K16, acc);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = mt0 + i;
+        if (mt >= Mt) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            *(v4f *)(xa + ((size_t)nt * Mt + mt) * 256 + lane * 4) = acc[i][j];
+        }
+    }
+}
+
+void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
+                   int ntile, int M, int K16) {
+    const int Mt = M / 16;
+    const int nMblk = (Mt + 7) / 8, nNblk = (ntile + 7) / 8;
+    hipLaunchKernelGGL(k_inproj, dim3(nMblk * nNblk), dim3(256), 0, s, in, xa, (const v4f *)Wp, bias, ntile, Mt, K16);
+}
+
+
+// ---- recurrent steps, launch-per-step path --------------------------------------------------
+// Ut = H/4 unit tiles, K16 = H/16.  One wave = one unit tile (4 hidden units x 4 gate rows) x one
+// read tile.  After the MFMA chain lane l = (q = l>>4, r = l&15) holds the four gate
+// pre-activations of hidden unit 4*ut+q for read r: the gate math is lane-local and the cell
+// state never leaves its lane's slot.
+__global__ void __launch_bounds__(256)
+k_lstm_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const float *__restrict__ h_prev,
+            float *__restrict__ h_out, float *__restrict__ cstate, int Ut, int K16, int first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = blockIdx.x * 4 + wave, rt = blockIdx.y;
+    if (ut >= Ut) return;
+    v4f acc = xa_t[((size_t)rt * Ut + ut) * 64 + lane];
+    float c = 0.0f;
+    if (!first) {
+        const v4f *a = sWp + (size_t)ut * K16 * 64 + lane;
+        const v4f *b = (const v4f *)h_prev + (size_t)rt * K16 * 64 + lane;
+        v4f acc2 = { 0.f, 0.f, 0.f, 0.f };   // two chains hide the 40-cycle dependent MFMA latency
+        int k = 0;
+        for (; k + 2 <= K16; k += 2) {
+            acc = mfma4(a[(size_t)k * 64], b[(size_t)k * 64], acc);
+            acc2 = mfma4(a[(size_t)(k + 1) * 64], b[(size_t)(k + 1) * 64], acc2);
+        }
+        if (k < K16) acc = mfma4(a[(size_t)k * 64], b[(size_t)k * 64], acc);
+        acc = acc + acc2;
+        c = cstate[((size_t)rt * Ut + ut) * 64 + lane];
+    }
+    // layers.c:1014-1025, gate rows i,f,g,o
+    const float forget = logistic_ref(acc.y) * c;
+    const float update = logistic_ref(acc.x) * tanh_ref(acc.z);
+    c = forget + update;
+    const float h = logistic_ref(acc.w) * tanh_ref(c);
+    cstate[((size_t)rt * Ut + ut) * 64 + lane] = c;
+    const int q = lane >> 4, rl = lane & 15;
+    h_out[((size_t)rt * Ut + ut) * 64 + rl * 4 + q] = h;
+}
+
+void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
+                      float *cstate, int B16, int H, int first) {
+    const int Ut = H / 4, K16 = H / 16;
+    hipLaunchKernelGGL(k_lstm_step, dim3((Ut + 3) / 4, B16), dim3(256), 0, s, (const v4f *)sWp, (const v4f *)xa_t,
+                       h_prev, h_out, cstate, Ut, K16, first);
+}
+
+// grumod_step, layers.c:664-715.  Gate rows per unit: z, r, candidate, (unused).  The recurrent
+// weights of row 3 are zero; Xa row 2 (candidate input) is kept out of the accumulator because
+// the reference zeroes that chunk before the GEMV (:691) and adds x afterwards (:705).
+__global__ void __launch_bounds__(256)
+k_gru_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const float *__restrict__ h_prev,
+           float *__restrict__ h_out, int Ut, int K16, int first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = blockIdx.x * 4 + wave, rt = blockIdx.y;
+    if (ut >= Ut) return;
+    const int q = lane >> 4, rl = lane & 15;
+    const v4f x = xa_t[((size_t)rt * Ut + ut) * 64 + lane];
+    v4f acc = { x.x, x.y, 0.f, 0.f };
+    float hp = 0.0f;
+    if (!first) {
+        const v4f *a = sWp + (size_t)ut * K16 * 64 + lane;
+        const v4f *b = (const v4f *)h_prev + (size_t)rt * K16 * 64 + lane;
+        v4f acc2 = { 0.f, 0.f, 0.f, 0.f };
+        int k = 0;
+        for (; k + 2 <= K16; k += 2) {
+            acc = mfma4(a[(size_t)k * 64], b[(size_t)k * 64], acc);
+            acc2 = mfma4(a[(size_t)(k + 1) * 64], b[(size_t)(k + 1) * 64], acc2);
+        }
+        if (k < K16) acc = mfma4(a[(size_t)k * 64], b[(size_t)k * 64], acc);
+        acc = acc + acc2;
+        hp = h_prev[((size_t)rt * Ut + ut) * 64 + rl * 4 + q];
+    }
+    const float z = logistic_ref(acc.x);
+    const float r = logistic_ref(acc.y);
+    float hbar = r * acc.z + x.z;
+    hbar = tanh_ref(hbar);
+    const float h = z * hp + (1.0f - z) * hbar;
+    h_out[((size_t)rt * Ut + ut) * 64 + rl * 4 + q] = h;
+}
+
+void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
+                     int B16, int H, int first) {
+    const int Ut = H / 4, K16 = H / 16;
+    hipLaunchKernelGGL(k_gru_step, dim3((Ut + 3) / 4, B16), dim3(256), 0, s, (const v4f *)sWp, (const v4f *)xa_t,
+                       h_prev, h_out, Ut, K16, first);
+}
+
+// ---- CRF head: trans[r][blk][p] = tanh(W^T h + b) / (temperature/5) --------------------------
+// layers.c:1084-1087 (+ shift_scale_matrix_inplace flappie_matrix.c:625-633: a true division).
+__global__ void __launch_bounds__(256)
+k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__restrict__ Wp,
+       const float *__restrict__ bias, int Tb, int B16, int nread, int P, int Ps, int Mt, int K16, float scale) {
+    constexpr int TM = 4, TN = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntile = Tb * B16;
+    const int nt0 = (blockIdx.x * 4 + wave) * TN;
+    if (nt0 >= ntile) return;
+    const int q = lane >> 4, rl = lane & 15;
+    v4f acc[TM][TN];
+    const v4f *ap[TM];
+    const float *bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * K16 * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + q * 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int nt = min(nt0 + j, ntile - 1);
+        bp[j] = in + (size_t)nt * K16 * 256 + lane * 4;
+    }
+    mma_tiles<TM, TN, true>(ap, bp, 256, K16, acc);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int p = i * 16 + q * 4;
+        if (i >= Mt || p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            const int blk = nt / B16, read = (nt % B16) * 16 + rl;
+            if (read >= nread) continue;
+            v4f v = acc[i][j];
+            float *o = trans + ((size_t)read * Tb + blk) * Ps + p;
+            const float vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (p + e < P) o[e] = (tanh_ref(vv[e]) - 0.0f) / scale;
+        }
+    }
+}
+
+void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
+                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale) {
+    const int Mt = (P + 15) / 16;
+    const int ntile = Tb * B16;
+    hipLaunchKernelGGL(k_head, dim3((ntile + 15) / 16), dim3(256), 0, s, in, trans, (const v4f *)Wp, bias, Tb, B16,
+                       nread, P, Ps, Mt, K16, scale);
+}
+
+// ---- CRF partition function + global normalisation -------------------------------------------
+// layers.c:1035-1096.  One wavefront per read walks the blocks; the fp64 forward vector lives in
+// lanes 0..nstate-1.  Each of the P transition scores of a block is combined with its source
+// state's value in parallel, the per-destination logsumexp is evaluated as max + log(sum exp),
+// i.e. the same quantity as the reference's pairwise chain up to fp64 rounding (the result is
+// rounded to fp32 after the division by the block count, layers.c:1089).
+__global__ void __launch_bounds__(64)
+k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps) {
+    __shared__ double term[64];
+    __shared__ double smax[kMaxState];
+    const int lane = threadIdx.x;
+    const int ns = 2 * nbase, off = nbase * ns;
+    float *S = trans + (size_t)blockIdx.x * Tb * Ps;
+    // destination state of transition entry `lane`, and its source state
+    const int src = lane % ns;
+    int dst;
+    if (lane < off) dst = lane / ns;
+    else { const int idx = lane - off; dst = (idx < nbase) ? idx + nbase : idx; }
+    double prev = 0.0;
+    float s_next = (lane < P) ? S[lane] : 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = s_next;
+        if (blk + 1 < Tb) s_next = (lane < P) ? S[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+        const double pf = __shfl(prev, src);
+        term[lane] = (lane < P) ? pf + (double)s : -INFINITY;
+        __syncthreads();
+        if (lane < ns) {
+            double m;
+            if (lane < nbase) {
+                m = term[lane * ns];
+                for (int f = 1; f < ns; f++) m = fmax(m, term[lane * ns + f]);
+            } else {
+                m = fmax(term[off + lane], term[off + lane - nbase]);
+            }
+            smax[lane] = m;
+        }
+        __syncthreads();
+        const double e = (lane < P) ? exp(term[lane] - smax[dst]) : 0.0;
+        __syncthreads();
+        term[lane] = e;
+        __syncthreads();
+        if (lane < ns) {
+            double sum;
+            if (lane < nbase) {
+                sum = term[lane * ns];
+                for (int f = 1; f < ns; f++) sum += term[lane * ns + f];
+            } else {
+                sum = term[off + lane] + term[off + lane - nbase];
+            }
+            prev = smax[lane] + log(sum);
+        }
+        __syncthreads();
+    }
+    // logZ = logsumexp over final states (pairwise, layers.c:1071-1074)
+    double logZ = __shfl(prev, 0);
+    for (int st = 1; st < ns; st++) {
+        const double v = __shfl(prev, st);
+        logZ = fmax(logZ, v) + log1p(exp(-fabs(logZ - v)));
+    }
+    const float logZf = (float)(logZ / (double)Tb);
+    const size_t n = (size_t)Tb * Ps;
+    for (size_t i = lane; i < n; i += 64)
+        if ((int)(i % Ps) < P) S[i] -= logZf;
+}
+
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps) {
+    const int P = 2 * nbase * (nbase + 1);
+    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps);
+}
+
+// ---- forward/backward transition posteriors ---------------------------------------------------
+// decode.c:377-497.  One wavefront per read; lanes 0..nstate-1 carry the fwd / bwd vectors, lanes
+// 0..P-1 carry the block's transition scores.  The logsumexpf chains keep the reference's order.
+__global__ void __launch_bounds__(64)
+k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf,
+            int Tb, int nbase, int P, int Ps) {
+    const int lane = threadIdx.x;
+    const int ns = 2 * nbase, off = nbase * ns;
+    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
+    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const bool is_state = lane < ns, is_flip = lane < nbase;
+
+    // forwards (:396-423)
+    float prev = 0.0f;
+    if (is_state) F[lane] = 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = (lane < P) ? T[(size_t)blk * Ps + lane] : 0.0f;
+        float acc;
+        if (true) {
+            // flip candidate chain (valid for lanes < nbase)
+            const int base = is_flip ? lane * ns : 0;
+            acc = __shfl(s, base) + __shfl(prev, 0);
+            for (int f = 1; f < ns; f++) {
+                const float sc = __shfl(s, base + f) + __shfl(prev, f);
+                acc = logsumexpf_ref(acc, sc);
+            }
+            // flop: stay, then move from the flip state of the same base
+            const int b2 = (is_state && !is_flip) ? lane : nbase;
+            const float stay = __shfl(prev, b2) + __shfl(s, off + b2);
+            const float move = __shfl(prev, b2 - nbase) + __shfl(s, off + b2 - nbase);
+            const float flop = logsumexpf_ref(stay, move);
+            if (!is_flip) acc = flop;
+        }
+        prev = acc;
+        if (is_state) F[(size_t)(blk + 1) * kMaxState + lane] = acc;
+    }
+
+    // backwards (:434-484); `prev` is the backward vector of block blk
+    // source state (st) and destination state (to) of transition entry `lane`
+    const int st = lane % ns;
+    int to;
+    if (lane < off) to = lane / ns;
+    else { const int idx = lane - off; to = (idx < nbase) ? idx + nbase : idx; }
+    prev = 0.0f;
+    for (int blk = Tb; blk > 0; blk--) {
+        const float s = (lane < P) ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
+        const float f = is_state ? F[(size_t)(blk - 1) * kMaxState + lane] : 0.0f;
+        // tpost = fwd[st] + bwd[to] + trans   (left to right, :451-461)
+        const float tp = (__shfl(f, st) + __shfl(prev, to)) + s;
+        if (lane < P) Pp[(size_t)(blk - 1) * Ps + lane] = tp;
+        // update of the backward vector for source state `lane`
+        const int me = is_state ? lane : 0;
+        const int b2 = (me < nbase) ? me + nbase : me;               // flop state reached from `me`
+        float curr = __shfl(prev, b2) + __shfl(s, off + me);          // :466-472
+        for (int b1 = 0; b1 < nbase; b1++) {                          // :475-483
+            const float sc = __shfl(s, b1 * ns + me) + __shfl(prev, b1);
+            curr = logsumexpf_ref(curr, sc);
+        }
+        prev = curr;
+    }
+    __syncthreads();
+    // log_row_normalise_inplace (flappie_matrix.c:450-467): sequential chain over the P rows of a
+    // block; blocks are independent -> one block per lane.
+    for (int blk = lane; blk < Tb; blk += 64) {
+        float *x = Pp + (size_t)blk * Ps;
+        float row_logsum = x[0];
+        for (int r = 1; r < P; r++) row_logsum = logsumexpf_ref(row_logsum, x[r]);
+        for (int r = 0; r < P; r++) x[r] -= row_logsum;
+    }
+}
+
+void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
+    const int P = 2 * nbase * (nbase + 1);
+    hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
+}
+
+// ---- Viterbi ---------------------------------------------------------------------------------
+// decode.c:119-204 with its tie rules: a flop state keeps "stay" unless "move" is strictly
+// greater; a flip state scans from-states in ascending order and replaces only on strictly
+// greater (lowest index wins ties); the final state is the first maximum (util.c:17-31).
+// Traceback pointers are bytes; the traceback walks them through LDS in chunks.
+constexpr int kTbChunk = 2048;
+__global__ void __launch_bounds__(64)
+k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path,
+          float *__restrict__ qpath, float *__restrict__ score_out, int Tb, int nbase, int P, int Ps) {
+    __shared__ uint8_t tb_lds[kTbChunk * kMaxState];
+    __shared__ int path_lds[kTbChunk + 1];
+    const int lane = threadIdx.x;
+    const int ns = 2 * nbase, off = nbase * ns;
+    const float *T = M + (size_t)blockIdx.x * Tb * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    const bool is_state = lane < ns, is_flip = lane < nbase;
+
+    float prev = 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = (lane < P) ? T[(size_t)blk * Ps + lane] : 0.0f;
+        const int base = is_flip ? lane * ns : 0;
+        float best = __shfl(s, base) + __shfl(prev, 0);
+        int arg = 0;
+        for (int f = 1; f < ns; f++) {
+            const float sc = __shfl(s, base + f) + __shfl(prev, f);
+            if (sc > best) { best = sc; arg = f; }
+        }
+        const int b2 = (is_state && !is_flip) ? lane : nbase;
+        const float stay = __shfl(prev, b2) + __shfl(s, off + b2);
+        const float move = __shfl(prev, b2 - nbase) + __shfl(s, off + b2 - nbase);
+        if (!is_flip) {
+            best = stay; arg = b2;
+            if (move > stay) { best = move; arg = b2 - nbase; }
+        }
+        prev = best;
+        if (is_state) tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg;
+    }
+    // final score and state: first maximum
+    float score = __shfl(prev, 0);
+    int last = 0;
+    for (int st = 1; st < ns; st++) {
+        const float v = __shfl(prev, st);
+        if (v > score) { score = v; last = st; }
+    }
+    if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
+    __syncthreads();     // this wave's tb stores are complete and visible to its own loads below
+
+    // traceback, chunk by chunk from the end; `last` = path[c1]
+    for (int c1 = Tb; c1 > 0; c1 -= kTbChunk) {
+        const int c0 = max(0, c1 - kTbChunk), n = c1 - c0;
+        for (int i = lane; i < n * (kMaxState / 4); i += 64)
+            ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
+        __syncthreads();
+        if (lane == 0) {
+            int p = last;
+            path_lds[n] = p;
+            for (int i = n; i > 0; i--) { p = tb_lds[(i - 1) * kMaxState + p]; path_lds[i - 1] = p; }
+        }
+        __syncthreads();
+        if (c1 == Tb && lane == 0) pth[Tb] = path_lds[n];
+        for (int i = lane; i < n; i += 64) {
+            const int from = path_lds[i], to = path_lds[i + 1];
+            pth[c0 + i] = from;
+            // trans_lookup, decode.c:104-114
+            const int idx = (to < nbase) ? (to * ns + from) : (off + from);
+            qp[c0 + i + 1] = T[(size_t)(c0 + i) * Ps + idx];
+        }
+        last = path_lds[0];
+        last = __shfl(last, 0);
+        __syncthreads();
+    }
+}
+
+void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
+                    int nread, int Tb, int nbase, int Ps) {
+    const int P = 2 * nbase * (nbase + 1);
+    hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps);
+}
+
+// ---- change positions -> base and quality strings ---------------------------------------------
+// decode.c:66-79 + flappie.c:284-292 + phredf/qscoref (util.h:284-305).  pos runs over [1, nblock):
+// path[nblock] and the base of path[0] are never emitted, as in the reference.
+__global__ void __launch_bounds__(64)
+k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *__restrict__ bases,
+           char *__restrict__ quals, int *__restrict__ lens, int Tb, int nbase) {
+    const int lane = threadIdx.x;
+    const int *pth = path + (size_t)blockIdx.x * (Tb + 1);
+    const float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    char *bs = bases + (size_t)blockIdx.x * (Tb + 1);
+    char *qs = quals + (size_t)blockIdx.x * (Tb + 1);
+    int count = 0;
+    for (int p0 = 1; p0 < Tb; p0 += 64) {
+        const int pos = p0 + lane;
+        bool change = false;
+        int st = 0;
+        if (pos < Tb) { st = pth[pos]; change = (st != pth[pos - 1]); }
+        const unsigned long long mask = __ballot(change);
+        if (change) {
+            const int idx = count + __popcll(mask & ((1ull << lane) - 1ull));
+            const char lut[5] = { 'A', 'C', 'G', 'T', 'Z' };          // decode.h:16
+            bs[idx] = lut[st % nbase];
+            const float p = expf(qp[pos]);
+            const float p_clip = (p < 0.99999) ? p : 0.99999;
+            const float q = -(10.0f * 0.43429448190325182765) * log1pf(-p_clip);
+            char ph = (char)roundf(33.0f + q);
+            qs[idx] = (ph < 126) ? ph : 126;
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) { bs[count] = 0; qs[count] = 0; lens[blockIdx.x] = count; }
+}
+
+void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
+                     int nread, int Tb, int nbase) {
+    hipLaunchKernelGGL(k_assemble, dim3(nread), dim3(64), 0, s, path, qpath, bases, quals, lens, Tb, nbase);
+}
+
+// ---- trace --------------------------------------------------------------------------------------
+// exp_activation_inplace (layers.c:56-66, cephes exp) followed by trace_from_posterior
+// (decode.c:499-543): column 0 sums block 0 by from-state, column blk+1 sums block blk by to-state.
+// The posterior buffer is left in log space (the reference's in-place exp is folded in here).
+__global__ void __launch_bounds__(256)
+k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int Tb, int nbase, int P, int Ps) {
+    const int ns = 2 * nbase, off = nbase * ns;
+    const float *Pp = post + (size_t)blockIdx.y * Tb * Ps;
+    int32_t *tr = trace + (size_t)blockIdx.y * (Tb + 1) * ns;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (column, state)
+    if (i >= (Tb + 1) * ns) return;
+    const int col = i / ns, stt = i % ns;
+    float sum;
+    if (col == 0) {
+        sum = 0.0f;
+        for (int to = 0; to < nbase; to++) sum += exp_cephes(Pp[to * ns + stt]);
+        sum += exp_cephes(Pp[off + stt]);
+    } else {
+        const float *x = Pp + (size_t)(col - 1) * Ps;
+        if (stt < nbase) {
+            sum = exp_cephes(x[stt * ns]);
+            for (int f = 1; f < ns; f++) sum += exp_cephes(x[stt * ns + f]);
+        } else {
+            sum = exp_cephes(x[off + stt - nbase]) + exp_cephes(x[off + stt]);
+        }
+    }
+    tr[i] = (int32_t)roundf(255.0f * sum);
+}
+
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps) {
+    const int P = 2 * nbase * (nbase + 1);
+    const int n = (Tb + 1) * 2 * nbase;
+    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps);
+}
+
+// ---- debug tap: tile-interleaved -> dense [Tb][H] of one read --------------------------------
+__global__ void k_untile(const float *__restrict__ act, float *__restrict__ dense, int read, int Tb, int B16, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Tb * H) return;
+    const int t = i / H, f = i % H;
+    const int rt = read / 16, r = read % 16;
+    dense[i] = act[((size_t)t * B16 + rt) * H * 16 + (size_t)(f / 4) * 64 + r * 4 + (f % 4)];
+}
+
+void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H) {
+    hipLaunchKernelGGL(k_untile, dim3((Tb * H + 255) / 256), dim3(256), 0, s, act, dense, read, Tb, B16, H);
+}
+
+}  // namespace ffhip

@@ -1,0 +1,134 @@
+/*  ffhip.h -- the C-ABI between flappie's C host code and the MI355X (gfx950) HIP engine.
+ *
+ *  This is the thin shim the north-star asks for: plain C, plain pointers and sizes, no C++ or
+ *  torch types.  It is what the reference's host code would bind instead of calling into
+ *  layers.c/decode.c one read at a time.  Each entry point names the reference interface it
+ *  replaces (paths relative to /root/reference/src).
+ *
+ *  The reference has no batching (flappie.c:364-385 loops over files; one read = one forward
+ *  pass).  A GPU cannot be filled one read at a time, so the unit of work here is a BATCH of reads
+ *  that share one trimmed length (SURVEY.md section 8b "what the replacement must add").  Reads are
+ *  never split or padded in time: the CRF normaliser and the recurrent state are whole-read
+ *  quantities (layers.c:1089, :902-916), so results are identical to per-read evaluation.
+ *
+ *  Error convention (flappie_stdlib.h:37-45 RETURN_NULL_IF): functions returning pointers return
+ *  NULL on failure; functions returning int return 0 on success and a negative FFHIP_E* code
+ *  otherwise; nothing throws, nothing aborts.  ffhip_last_error() gives a static message.
+ *
+ *  Threading: an engine and everything created from it belong to one host thread (the reference
+ *  is single threaded).  Use one engine per GPU.
+ */
+#ifndef FFHIP_H
+#define FFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "flappie_matrix.h"
+#include "flappie_structures.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFHIP_OK          0
+#define FFHIP_EINVAL     -1   /* bad argument / unsupported model shape */
+#define FFHIP_ENOMEM     -2   /* host or device allocation failed      */
+#define FFHIP_EHIP       -3   /* a HIP runtime call failed             */
+#define FFHIP_ENODEV     -4   /* no usable gfx950 device               */
+#define FFHIP_ETIMEOUT   -5   /* an in-kernel wait gave up (persistent recurrent kernel) */
+
+typedef struct ffhip_engine ffhip_engine;
+typedef struct ffhip_model ffhip_model;
+typedef struct ffhip_batch ffhip_batch;
+
+enum ffhip_net_kind {
+    FFHIP_NET_LSTM5 = 0,    /* flipflop5_guppy_transitions, networks.c:539-586 */
+    FFHIP_NET_GRUMOD5 = 1   /* flipflop_guppy_transitions,  networks.c:450-489 */
+};
+
+/* Host-side weight bundle.  Mirrors `guppy_stride5_model` (networks.c:181-215) and `guppy_model`
+ * (networks.c:150-178): pointers to matrices in the .mdl layout, never owned by the engine. */
+typedef struct {
+    int kind;                         /* enum ffhip_net_kind */
+    int nconv;                        /* 3 (LSTM5: swish after each) or 1 (GRUMOD5: tanh) */
+    const_flappie_matrix conv_W[3];
+    const_flappie_matrix conv_b[3];
+    int conv_stride[3];
+    const_flappie_matrix rnn_iW[5];   /* layer order B1,F2,B3,F4,B5 */
+    const_flappie_matrix rnn_sW[5];
+    const_flappie_matrix rnn_b[5];
+    const_flappie_matrix FF_W;
+    const_flappie_matrix FF_b;
+} ffhip_model_desc;
+
+/* flags for ffhip_batch_run */
+#define FFHIP_RUN_VITERBI_ONLY   1u   /* `--viterbi`: decode the transitions, skip fwd/bwd (flappie.c:277-282) */
+#define FFHIP_RUN_NO_TRACE       2u   /* skip exp + trace_from_posterior (flappie.c:299-300)                  */
+#define FFHIP_RUN_NO_DECODE      4u   /* stop after calculate_transitions (networks.c:108-111)                */
+#define FFHIP_RUN_STEPWISE_RNN   8u   /* force the launch-per-step recurrent kernels (debug / cross-check)    */
+#define FFHIP_RUN_KEEP_ACTS     16u   /* keep every layer's activations for ffhip_batch_get_activation        */
+
+const char *ffhip_last_error(void);
+const char *ffhip_version(void);
+
+/* ---- engine: one per GPU ------------------------------------------------------------------ */
+int ffhip_device_count(void);
+ffhip_engine *ffhip_engine_create(int device);
+void ffhip_engine_destroy(ffhip_engine *eng);
+int ffhip_engine_synchronize(ffhip_engine *eng);
+/* name, CU count, clock in kHz of the engine's device */
+int ffhip_engine_info(const ffhip_engine *eng, char *name, size_t name_len, int *ncu, int *clock_khz);
+
+/* ---- model: weights re-packed into MFMA fragment order and kept resident in HBM ------------ */
+/* replaces the static model instances of networks.c:218-399 */
+ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_desc *desc);
+void ffhip_model_free(ffhip_model *mdl);
+size_t ffhip_model_hidden(const ffhip_model *mdl);
+size_t ffhip_model_nparam(const ffhip_model *mdl);       /* nstate * (nbase + 1), rows of `trans` */
+size_t ffhip_model_nbase(const ffhip_model *mdl);
+size_t ffhip_model_nblock(const ffhip_model *mdl, size_t nsample);   /* iceil chain, layers.c:204 */
+
+/* ---- batch: `nread` reads of `nsample` samples each, workspace resident in HBM -------------- */
+ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model *mdl, int nread, size_t nsample);
+void ffhip_batch_destroy(ffhip_batch *b);
+size_t ffhip_batch_nblock(const ffhip_batch *b);
+
+/* replaces features_from_raw (nnfeatures.c:15-28): copies raw[start..end) of every read to HBM.
+ * `reads[i].end - reads[i].start` must equal nsample. */
+int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads);
+/* same from a packed host array signals[nread][ld] */
+int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, size_t ld);
+
+/* replaces calculate_transitions (networks.c:108) + transpost_crf_flipflop (decode.c:377) +
+ * decode_crf_flipflop (decode.c:119) + change_positions / base+quality assembly
+ * (flappie.c:284-292) + exp_activation_inplace / trace_from_posterior (flappie.c:299-300)
+ * for the whole batch.  Asynchronous on the batch's stream; results stay in HBM. */
+int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags);
+/* copy the small results (calls, qualities, lengths, scores) to pinned host memory and wait */
+int ffhip_batch_finish(ffhip_batch *b);
+
+/* ---- results (valid after ffhip_batch_finish) ------------------------------------------------ */
+/* basecall/quality: NUL-terminated, at most nblock chars.  Returned pointers stay owned by the batch. */
+const char *ffhip_batch_basecall(const ffhip_batch *b, int read, size_t *length);
+const char *ffhip_batch_quality(const ffhip_batch *b, int read);
+float ffhip_batch_score(const ffhip_batch *b, int read);             /* decode_crf_flipflop return value */
+/* on-demand device-to-host copies; out buffers are caller owned */
+int ffhip_batch_get_path(ffhip_batch *b, int read, int *path /*[nblock+1]*/, float *qpath /*[nblock+1]*/);
+int ffhip_batch_get_transitions(ffhip_batch *b, int read, float *out /*[nblock][nparam] packed*/);
+int ffhip_batch_get_posterior(ffhip_batch *b, int read, float *out /*[nblock][nparam] packed, log*/);
+int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][nstate] packed*/);
+/* debug taps used by the parity tests: activations after conv stack (layer -1) or after RNN layer l
+ * (0..4) as dense [nblock][hidden] */
+int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* HIP-event timing of the kernel groups of one batch_run, on the stream they are launched on.
+ * groups: 0 conv, 1 in-projection GEMMs, 2 recurrent, 3 head+CRF norm, 4 posterior, 5 viterbi+assembly */
+#define FFHIP_NGROUP 6
+int ffhip_engine_set_profiling(ffhip_engine *eng, int on);
+int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launches[FFHIP_NGROUP]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

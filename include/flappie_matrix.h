@@ -1,0 +1,70 @@
+/*  flappie_matrix.h -- matrix type of the drop-in boundary.
+ *
+ *  Replaces /root/reference/src/flappie_matrix.h:18-83.  The first five members of `_Mat`
+ *  (nr, nrq, nc, stride, data) keep the reference's order, meaning and the `.data.f` spelling, so
+ *  that `.mdl` model headers -- which are C designated initialisers
+ *  `_Mat _NAME = { .nr=, .nrq=, .nc=, .stride=, .data.f = __NAME };`
+ *  (misc/taiyaki_flipflop5_guppy.py:52-54) -- compile unchanged against this header.
+ *  The reference declares `data.v` as `__m128 *`; here it is `void *` (no x86 intrinsics on this
+ *  side of the boundary).  Two members are appended: a device mirror and its state.
+ *
+ *  Layout: column-major fp32, each column padded with zeros to a multiple of 4 rows
+ *  (stride = 4 * nrq), 16-byte aligned, zero-filled on creation (flappie_matrix.c:20-51).
+ */
+#ifndef FFHIP_FLAPPIE_MATRIX_H
+#define FFHIP_FLAPPIE_MATRIX_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    size_t nr, nrq, nc, stride;
+    union {
+        void *v;
+        float *f;
+    } data;
+    /* -- extension (zero in static .mdl initialisers) -- */
+    void *dev;            /* HIP device buffer holding the same [nc][stride] image, or NULL */
+    int dev_state;        /* 0 = host only, 1 = host and device in sync, 2 = device newer   */
+} _Mat;
+
+typedef struct {
+    size_t nr, nrq, nc, stride;
+    union {
+        void *v;
+        int32_t *f;
+    } data;
+} _iMat;
+
+typedef _Mat *flappie_matrix;
+typedef _iMat *flappie_imatrix;
+typedef _Mat const *const_flappie_matrix;
+typedef _iMat const *const_flappie_imatrix;
+
+/* flappie_matrix.h:39-43 / flappie_matrix.c:20-148.  NULL on allocation failure;
+ * free_* returns NULL for the `x = free_flappie_matrix(x)` idiom. */
+flappie_matrix make_flappie_matrix(size_t nr, size_t nc);
+flappie_matrix remake_flappie_matrix(flappie_matrix M, size_t nr, size_t nc);
+flappie_matrix copy_flappie_matrix(const_flappie_matrix mat);
+flappie_matrix free_flappie_matrix(flappie_matrix mat);
+void zero_flappie_matrix(flappie_matrix M);
+flappie_matrix mat_from_array(const float *x, size_t nr, size_t nc);
+float *array_from_flappie_matrix(const_flappie_matrix mat);
+bool equality_flappie_matrix(const_flappie_matrix mat1, const_flappie_matrix mat2, const float tol);
+
+/* flappie_matrix.h:56-61 */
+flappie_imatrix make_flappie_imatrix(size_t nr, size_t nc);
+flappie_imatrix remake_flappie_imatrix(flappie_imatrix M, size_t nr, size_t nc);
+flappie_imatrix free_flappie_imatrix(flappie_imatrix mat);
+int32_t *array_from_flappie_imatrix(const_flappie_imatrix mat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
