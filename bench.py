@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s basecalled, r941_native shape, 256 reads x 4000 samples.
+
+One "step" = one pass of the whole hot path (signal already resident in HBM -> convolutions ->
+5 recurrent layers -> global-norm flip-flop scores -> forward/backward posterior -> Viterbi ->
+base + quality strings + trace, plus the copy of the called strings back to the host) over one batch
+of BASELINE.json's configs[1].  Reads are independent units: with N GPUs every rank runs the same
+per-GPU workload on its own reads (weak scaling), with no data-path collective.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size inferred from the model's size
+NREAD, NSAMPLE = 256, 4000
+
+
+def cpu_baseline(mdl, sig, budget_s=12.0, max_reads=6):
+    """The oracle (a scalar C port of the reference's algorithm, NOT the OpenBLAS reference itself,
+    which cannot be built in this image) timed on one host core over a bounded sample."""
+    from oracle import ffo
+    om = ffo.OracleModel(mdl)
+    t0 = time.time()
+    n = 0
+    while n < max_reads and (n == 0 or time.time() - t0 < budget_s):
+        om.basecall(sig[n], want_trans=False)
+        n += 1
+    dt = time.time() - t0
+    return dict(value=round(n * sig.shape[1] / dt / 1e6, 6), unit="Msamples/s", cores=1, kind="port",
+                sample="%d of the %d synthetic reads (%d samples each), whole path, 1 thread, %.1f s" % (n, sig.shape[0], sig.shape[1], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FFHIP_INFLIGHT", "1")),
+                    help="batches in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hidden", type=int, default=HIDDEN)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+
+    from flappie_amd import binding as B
+    from flappie_amd import model as M
+
+    eng = B.Engine(local_rank)
+    mdl = M.synthetic_model(M.NET_LSTM5, args.hidden, seed=1, ident="r941native")
+    dm = B.DeviceModel(eng, mdl)
+    rng = np.random.default_rng(20260928 + rank)
+    sig = rng.standard_normal((NREAD, NSAMPLE)).astype(np.float32)
+    nfl = max(1, min(args.inflight, 2))
+    batches = [B.Batch(dm, NREAD, NSAMPLE) for _ in range(nfl)]
+    for b in batches:
+        b.set_signals(sig)               # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def run_steps(n):
+        pending = []
+        for i in range(n):
+            b = batches[i % nfl]
+            if len(pending) == nfl:
+                pending.pop(0).finish()
+            b.run(1.0, 0)
+            pending.append(b)
+        for b in pending:
+            b.finish()
+
+    run_steps(args.warmup)
+    eng.set_profiling(True)              # HIP events on the kernels' own stream; no host synchronisation added
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = [b.profile() for b in batches]
+    eng.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        nblock = batches[0].nblock
+        value = world * args.steps * NREAD * NSAMPLE / dt / 1e6
+        # dominant kernel: the recurrent layer.  Algorithmic work: 2*H*4H FLOP per read per block
+        # (SURVEY.md section 8d), nblock blocks, NREAD reads per launch group; 5 layers per step.
+        rec = prof[-1]["recurrent"]
+        flop_layer = 2.0 * args.hidden * 4 * args.hidden * NREAD * nblock
+        launches_per_layer = rec["launches"] / 5.0
+        ms_layer = rec["ms"] / 5.0
+        achieved = flop_layer / (ms_layer * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/s basecalled (r941_native, 4k-sample chunks)",
+            "value": round(value, 4), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the r941_native architecture)",
+            "config": {"workload": "r941_native-shape LSTM5 H=%d, batch=256 synthetic 4000-sample reads per GPU, "
+                                   "posterior decode + trace (BASELINE.json configs[1])" % args.hidden,
+                       "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
+                       "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "recurrent layer (lstm step x %d)" % nblock,
+                         "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_launch": flop_layer / launches_per_layer,
+                         "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
+                         "launches_per_layer": launches_per_layer},
+            "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in prof[-1].items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mdl, sig)
+        print(json.dumps(out), flush=True)
+
+    for b in batches:
+        b.close()
+    dm.close()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

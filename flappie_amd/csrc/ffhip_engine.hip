@@ -308,7 +308,8 @@ struct ffhip_batch {
     hipEvent_t ev[FFHIP_NGROUP + 1];
     int have_ev = 0;
     int launches[FFHIP_NGROUP];
-    float prof_inproj = 0.f, prof_rnn = 0.f;
+    hipEvent_t lev[5][3];
+    int profiled = 0;
 };
 
 static void *dalloc(ffhip_batch *b, size_t bytes, bool zero) {
@@ -358,7 +359,10 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->h_quals) hipHostFree(b->h_quals);
     if (b->h_lens) hipHostFree(b->h_lens);
     if (b->h_score) hipHostFree(b->h_score);
-    if (b->have_ev) for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
+    if (b->have_ev) {
+        for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
+        for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
+    }
     delete b;
 }
 
@@ -415,6 +419,9 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     }
     for (int i = 0; i <= FFHIP_NGROUP; i++)
         if (hipEventCreate(&b->ev[i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
+    for (int l = 0; l < 5; l++)
+        for (int i = 0; i < 3; i++)
+            if (hipEventCreate(&b->lev[l][i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
     b->have_ev = 1;
 #undef BFAIL
     return b;
@@ -487,17 +494,15 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // profiling groups 1 (in-projection) and 2 (recurrent) interleave; their events bracket the
     // whole stack and the split is measured with per-layer events when profiling is on.
     int cur = 0;
-    float ms_inproj = 0.f, ms_rnn = 0.f;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (b->eng->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); }
+    const bool prof = b->eng->profiling != 0;
     for (int l = 0; l < 5; l++) {
         const RnnDev &r = m->rnn[l];
         const bool backward = (l % 2 == 0);
         float *in = b->act[cur], *out = b->act[cur ^ 1];
-        if (e0) hipEventRecord(e0, s);
+        if (prof) hipEventRecord(b->lev[l][0], s);
         launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
         b->launches[1]++;
-        if (e1) hipEventRecord(e1, s);
+        if (prof) hipEventRecord(b->lev[l][1], s);
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
         for (int i = 0; i < Tb; i++) {
             const int t = backward ? Tb - 1 - i : i;
@@ -509,19 +514,12 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0);
         }
         b->launches[2] += Tb;
-        if (e2) {
-            hipEventRecord(e2, s);
-            hipEventSynchronize(e2);
-            float a = 0, c2 = 0;
-            hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&c2, e1, e2);
-            ms_inproj += a; ms_rnn += c2;
-        }
+        if (prof) hipEventRecord(b->lev[l][2], s);
         cur ^= 1;
         if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
     }
-    if (e0) { hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); }
+    b->profiled = prof;
     b->final_act = cur;
-    b->prof_inproj = ms_inproj; b->prof_rnn = ms_rnn;
     mark(b, 3);
     // ---- globalnorm_flipflop (layers.c:1082-1106)
     launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
@@ -644,13 +642,20 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
 }
 
 extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launches[FFHIP_NGROUP]) {
-    if (!b || !b->eng->profiling || !b->finished) return set_err(FFHIP_EINVAL, "profiling is off or the batch is not finished");
+    if (!b || !b->profiled || !b->finished) return set_err(FFHIP_EINVAL, "the last run was not profiled or the batch is not finished");
     float t01 = 0, t34 = 0, t45 = 0, t56 = 0;
     hipEventElapsedTime(&t01, b->ev[0], b->ev[1]);
     hipEventElapsedTime(&t34, b->ev[3], b->ev[4]);
     hipEventElapsedTime(&t45, b->ev[4], b->ev[5]);
     hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
-    ms[0] = t01; ms[1] = b->prof_inproj; ms[2] = b->prof_rnn; ms[3] = t34; ms[4] = t45; ms[5] = t56;
+    float ms_inproj = 0.f, ms_rnn = 0.f;
+    for (int l = 0; l < 5; l++) {
+        float a = 0.f, c = 0.f;
+        hipEventElapsedTime(&a, b->lev[l][0], b->lev[l][1]);
+        hipEventElapsedTime(&c, b->lev[l][1], b->lev[l][2]);
+        ms_inproj += a; ms_rnn += c;
+    }
+    ms[0] = t01; ms[1] = ms_inproj; ms[2] = ms_rnn; ms[3] = t34; ms[4] = t45; ms[5] = t56;
     for (int i = 0; i < FFHIP_NGROUP; i++) launches[i] = b->launches[i];
     return FFHIP_OK;
 }

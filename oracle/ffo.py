@@ -142,7 +142,9 @@ class HostMat:
 
     @property
     def ptr(self):
-        return C.pointer(self.c)
+        p = C.pointer(self.c)
+        p._hostmat = self          # keep the numpy buffer alive for as long as the pointer object lives
+        return p
 
 
 def take(pmat, free: bool = True) -> np.ndarray:

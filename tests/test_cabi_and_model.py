@@ -1,0 +1,92 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/ffhip.h
+declares (no compute is called without a GPU), the .mdl text format round-trips, and the product
+package never touches the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if not n.startswith("__")))
+
+
+def test_library_exports_every_declared_symbol():
+    from flappie_amd import binding as B
+    path = B.library_path()
+    assert os.path.exists(path), "libffhip.so not built: run python -c 'import __graft_entry__ as g; g.build()'"
+    L = C.CDLL(path)
+    declared = _declared_functions("ffhip.h")
+    assert len(declared) >= 25
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, "symbols declared in include/ffhip.h but not exported: %s" % missing
+    assert b"gfx950" in C.cast(L.ffhip_version, C.CFUNCTYPE(C.c_char_p))()
+
+
+def test_host_library_exports_reference_api():
+    """The C host layer keeps the reference's names (networks.h:31-42, decode.h:21-38, flappie_matrix.h:39-61)."""
+    path = os.path.join(ROOT, "flappie_amd", "libflappie_host.so")
+    if not os.path.exists(path):
+        pytest.skip("host layer not built yet")
+    L = C.CDLL(path)
+    for hdr in ("flappie_matrix.h", "flappie_structures.h", "networks.h", "decode.h"):
+        if not os.path.exists(os.path.join(ROOT, "include", hdr)):
+            continue
+        missing = [n for n in _declared_functions(hdr) if not hasattr(L, n)]
+        assert not missing, "%s: not exported: %s" % (hdr, missing)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a gfx950 device the engine must refuse to exist -- there is no CPU path in the product."""
+    from flappie_amd import binding as B
+    if B.lib().ffhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(B.FFHipError):
+        B.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "flappie_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".c", ".h", ".hip", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "ff_oracle" not in text and "import ffo" not in text and "from oracle" not in text, fn
+
+
+@pytest.mark.parametrize("kind,hidden", [(M.NET_LSTM5, 32), (M.NET_GRUMOD5, 48)])
+def test_mdl_roundtrip(tmp_path, kind, hidden):
+    mdl = M.synthetic_model(kind, hidden, seed=3, ident="r941native" if kind == M.NET_LSTM5 else "r941native5mC")
+    path = str(tmp_path / "model.mdl")
+    M.write_mdl(path, mdl)
+    text = open(path).read()
+    # the grammar networks.c:218-323 relies on
+    prefix = "conv1_rnnrf_flipflop5_r941native_" if kind == M.NET_LSTM5 else "conv_rnnrf_flipflop_r941native5mC_"
+    assert "_Mat _%sW = {" % prefix in text
+    assert "#define %sstride  " % prefix in text
+    assert "const flappie_matrix %sW = &_%sW;" % (prefix, prefix) in text
+    back = M.load_mdl(path, kind, mdl.ident)
+    assert back.hidden == hidden and back.nparam == mdl.nparam
+    for a, b in zip(mdl.convs, back.convs):
+        assert (a.stride, a.winlen, a.nf) == (b.stride, b.winlen, b.nf)
+        assert np.array_equal(a.W.data, b.W.data) and np.array_equal(a.b.data, b.b.data)
+    for a, b in zip(mdl.rnns, back.rnns):
+        assert np.array_equal(a.iW.data, b.iW.data) and np.array_equal(a.sW.data, b.sW.data)
+        assert np.array_equal(a.b.data, b.b.data)
+    assert np.array_equal(mdl.FF_W.data, back.FF_W.data)
+
+
+def test_flop_count_matches_baseline_formula():
+    # 80 H^2 + 688 H + 3400 per block for the LSTM5 architecture
+    for H in (256, 384, 512):
+        mdl = M.synthetic_model(M.NET_LSTM5, H, seed=1)
+        assert mdl.flop_per_block() == 80 * H * H + 688 * H + 3400

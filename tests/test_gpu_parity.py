@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs, against the committed vectors, and -- at BASELINE.json's full size -- through
+size-independent properties.
+
+Tolerances (BASELINE.json north_star): transition scores within 1e-4 (absolute, fp32), called base
+string bit-exact.  Integer outputs (path, trace) are compared exactly except `trace`, whose
+round(255 p) may differ by one count where p sits on a rounding boundary."""
+import os
+
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCORE = 1e-4
+
+
+@pytest.fixture(scope="module")
+def B():
+    from flappie_amd import binding
+    return binding
+
+
+@pytest.fixture(scope="module")
+def ffo():
+    from oracle import ffo as _ffo
+    return _ffo
+
+
+def run_batch(B, engine, mdl, sig, flags=0, temperature=1.0):
+    dm = B.DeviceModel(engine, mdl)
+    b = B.Batch(dm, sig.shape[0], sig.shape[1])
+    b.set_signals(sig)
+    b.run(temperature, flags)
+    b.finish()
+    return dm, b
+
+
+def compare_read(b, r, ref, viterbi=False):
+    tr = b.transitions(r)
+    assert np.isfinite(tr).all()
+    assert np.abs(tr - ref["trans"]).max() <= TOL_SCORE
+    path, qpath = b.path(r)
+    assert np.array_equal(path, ref["path"])
+    assert np.isnan(qpath[0])
+    assert np.abs(qpath[1:] - ref["qpath"][1:]).max() <= TOL_SCORE
+    assert b.basecall(r) == ref["basecall"]
+    assert b.quality(r) == ref["quality"]
+    assert abs(b.score(r) - ref["score"]) <= 2e-3 * max(1.0, abs(ref["score"]) * 1e-2)
+    if not viterbi:
+        assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
+        assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
+
+
+CASES = [
+    # kind, hidden, T, nread
+    (M.NET_LSTM5, 64, 4000, 3),       # T % 5 == 0: the reference's right-edge column shift fires
+    (M.NET_LSTM5, 64, 4003, 2),       # T % 5 != 0
+    (M.NET_LSTM5, 96, 1237, 17),      # ragged: more than one read tile, partially filled
+    (M.NET_LSTM5, 36, 601, 2),        # hidden size not a multiple of 16 (zero-padded units)
+    (M.NET_GRUMOD5, 64, 2000, 3),     # modified-base model family: GRU, stride 2 (even T quirk), ACGTZ
+    (M.NET_GRUMOD5, 48, 1501, 2),
+]
+
+
+@pytest.mark.parametrize("kind,hidden,T,nread", CASES)
+def test_basecall_matches_oracle(B, ffo, engine, kind, hidden, T, nread):
+    mdl = M.synthetic_model(kind, hidden, seed=7)
+    om = ffo.OracleModel(mdl)
+    sig = np.random.default_rng(1000 + T).standard_normal((nread, T)).astype(np.float32)
+    dm, b = run_batch(B, engine, mdl, sig)
+    try:
+        for r in range(nread):
+            compare_read(b, r, om.basecall(sig[r]))
+    finally:
+        b.close(); dm.close()
+
+
+def test_viterbi_only_and_temperature(B, ffo, engine):
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=9)
+    om = ffo.OracleModel(mdl)
+    sig = np.random.default_rng(5).standard_normal((2, 1500)).astype(np.float32)
+    dm, b = run_batch(B, engine, mdl, sig, flags=B.RUN_VITERBI_ONLY, temperature=0.7)
+    try:
+        for r in range(2):
+            compare_read(b, r, om.basecall(sig[r], temperature=0.7, viterbi_only=True), viterbi=True)
+        with pytest.raises(B.FFHipError):
+            b.posterior(0)
+    finally:
+        b.close(); dm.close()
+
+
+def test_layer_by_layer_activations(B, ffo, engine):
+    """Every stage against the oracle's stage, so that a whole-network tolerance cannot hide a wrong layer."""
+    import ctypes as C
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=11)
+    sig = np.random.default_rng(6).standard_normal((1, 2000)).astype(np.float32)
+    dm, b = run_batch(B, engine, mdl, sig, flags=B.RUN_KEEP_ACTS)
+    try:
+        L = ffo.lib()
+        x = ffo.HostMat.from_dense(sig[0].reshape(-1, 1))
+        cur = x.ptr
+        for cv in mdl.convs:
+            nxt = L.fo_convolution(cur, ffo.HostMat.from_model_mat(cv.W).ptr, ffo.HostMat.from_model_mat(cv.b).ptr, cv.stride)
+            L.fo_swish_inplace(nxt)
+            cur = nxt
+        ref = ffo.take(cur, free=False)
+        assert np.abs(b.activation(-1, 0) - ref).max() <= 1e-5
+        for l, r in enumerate(mdl.rnns):
+            xa = L.fo_affine_map(cur, ffo.HostMat.from_model_mat(r.iW).ptr, ffo.HostMat.from_model_mat(r.b).ptr)
+            cur = L.fo_lstm(xa, ffo.HostMat.from_model_mat(r.sW).ptr, int(l % 2 == 0))
+            ref = ffo.take(cur, free=False)
+            assert np.abs(b.activation(l, 0) - ref).max() <= 5e-5, "layer %d" % l
+    finally:
+        b.close(); dm.close()
+
+
+@pytest.mark.parametrize("tag", ["lstm5_h64", "grumod5_h64", "lstm5_h96_t1237"])
+def test_against_committed_vectors(B, engine, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "oracle_net_%s.npz" % tag))
+    mdl = M.synthetic_model(int(g["kind"]), int(g["hidden"]), seed=int(g["seed"]))
+    sig = np.stack([g["signal0"], g["signal1"]])
+    dm, b = run_batch(B, engine, mdl, sig)
+    try:
+        for i in (0, 1):
+            assert np.abs(b.transitions(i) - g["trans%d" % i]).max() <= TOL_SCORE
+            assert b.basecall(i).encode() == g["basecall%d" % i].tobytes()
+            assert b.quality(i).encode() == g["quality%d" % i].tobytes()
+            assert np.array_equal(b.path(i)[0], g["path%d" % i])
+            assert np.abs(b.trace(i) - g["trace%d" % i].astype(np.int32)).max() <= 1
+    finally:
+        b.close(); dm.close()
+
+
+def test_raw_table_entry_point_and_batch_independence(B, ffo, engine):
+    """set_reads (raw_table, start/end honoured) == set_signals; a read's result does not depend on
+    which other reads share its batch (reads are independent units, flappie.c:364-385)."""
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=7)
+    rng = np.random.default_rng(8)
+    T = 1000
+    raws = [rng.standard_normal(T + 300).astype(np.float32) for _ in range(3)]
+    starts = [0, 123, 300]
+    sig = np.stack([r[s:s + T] for r, s in zip(raws, starts)])
+    dm = B.DeviceModel(engine, mdl)
+    b1 = B.Batch(dm, 3, T)
+    b1.set_reads(raws, starts)
+    b1.run(); b1.finish()
+    b2 = B.Batch(dm, 1, T)
+    b2.set_signals(sig[2:3])
+    b2.run(); b2.finish()
+    try:
+        assert np.array_equal(b1.transitions(2), b2.transitions(0))
+        assert b1.basecall(2) == b2.basecall(0)
+        om = ffo.OracleModel(mdl)
+        compare_read(b1, 1, om.basecall(sig[1]))
+    finally:
+        b1.close(); b2.close(); dm.close()
+
+
+def test_error_paths(B, engine):
+    mdl = M.synthetic_model(M.NET_LSTM5, 32, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    try:
+        with pytest.raises(B.FFHipError):
+            B.Batch(dm, 1, 10)            # shorter than the convolution window: outside the reference's domain
+        with pytest.raises(B.FFHipError):
+            B.Batch(dm, 0, 1000)          # empty batch
+        b = B.Batch(dm, 1, 1000)
+        with pytest.raises(B.FFHipError):
+            b.finish()                    # run() not called
+        b.close()
+    finally:
+        dm.close()
+
+
+def test_full_size_properties(B, engine):
+    """BASELINE.json config 2 (r941_native shape, 256 reads x 4000 samples).  The oracle needs seconds
+    per read at this size, so parity is checked through size-independent properties:
+      * duplicated reads give identical results wherever they sit in the batch;
+      * the transition scores are globally normalised: the CRF partition function of the
+        returned matrix is zero per block (logZ/nblock was subtracted, layers.c:1089-1096);
+      * log-posteriors normalise to one per block; Viterbi qpath sums to the path score;
+      * a handful of reads are checked against the oracle itself."""
+    from oracle import ffo
+    H, nread, T = 384, 256, 4000
+    mdl = M.synthetic_model(M.NET_LSTM5, H, seed=1)
+    rng = np.random.default_rng(20260928)
+    sig = rng.standard_normal((nread, T)).astype(np.float32)
+    sig[200] = sig[3]
+    sig[255] = sig[17]
+    dm, b = run_batch(B, engine, mdl, sig)
+    try:
+        assert b.nblock == 800
+        assert np.array_equal(b.transitions(200), b.transitions(3))
+        assert b.basecall(255) == b.basecall(17) and b.quality(255) == b.quality(17)
+        for r in (0, 100, 255):
+            tr = b.transitions(r)
+            logZ = ffo.lib().fo_partition_function(ffo.HostMat.from_dense(tr).ptr)
+            assert abs(logZ) / 800 <= 2e-6
+            post = b.posterior(r)
+            assert np.abs(np.exp(post.astype(np.float64)).sum(axis=1) - 1.0).max() <= 1e-4
+            path, qpath = b.path(r)
+            assert abs(float(qpath[1:].astype(np.float64).sum()) - b.score(r)) <= 1e-2
+            assert path.min() >= 0 and path.max() < 8
+            trc = b.trace(r)
+            assert trc.min() >= 0 and trc.max() <= 255
+            assert np.abs(trc[1:].sum(axis=1) - 255).max() <= 4
+        om = ffo.OracleModel(mdl)
+        for r in (0, 131):
+            compare_read(b, r, om.basecall(sig[r]))
+    finally:
+        b.close(); dm.close()
