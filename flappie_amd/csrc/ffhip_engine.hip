@@ -298,6 +298,7 @@ struct ffhip_batch {
     int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
     char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
     int32_t *trace = nullptr;
+    unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel step counters / abort word
     float *scratch = nullptr;           // dense [Tb][H] for debug taps
     // pinned host mirrors of the small results
     char *h_bases = nullptr, *h_quals = nullptr; int *h_lens = nullptr; float *h_score = nullptr;
@@ -359,6 +360,7 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->h_quals) hipHostFree(b->h_quals);
     if (b->h_lens) hipHostFree(b->h_lens);
     if (b->h_score) hipHostFree(b->h_score);
+    if (b->h_abort) hipHostFree(b->h_abort);
     if (b->have_ev) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
@@ -411,6 +413,10 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->quals = (char *)dalloc(b, (size_t)nread * (Tb + 1), true))) BFAIL();
     if (!(b->lens = (int *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
     if (!(b->trace = (int32_t *)dalloc(b, (size_t)nread * (Tb + 1) * ns * 4, true))) BFAIL();
+    if (!(b->pflags = (unsigned *)dalloc(b, persist_flag_words((int)Hp, b->B16) * sizeof(unsigned), true))) BFAIL();
+    if (!(b->pabort = (unsigned *)dalloc(b, sizeof(unsigned), true))) BFAIL();
+    if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
+    *b->h_abort = 0;
     if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
         hipHostMalloc((void **)&b->h_quals, (size_t)nread * (Tb + 1)) != hipSuccess ||
         hipHostMalloc((void **)&b->h_lens, (size_t)nread * 4) != hipSuccess ||
@@ -495,6 +501,10 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // whole stack and the split is measured with per-layer events when profiling is on.
     int cur = 0;
     const bool prof = b->eng->profiling != 0;
+    const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->kind, Hp, b->eng->prop.multiProcessorCount);
+    if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
+    const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
+    const int persist_mode = pm_env ? atoi(pm_env) : 0;
     for (int l = 0; l < 5; l++) {
         const RnnDev &r = m->rnn[l];
         const bool backward = (l % 2 == 0);
@@ -504,6 +514,19 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         b->launches[1]++;
         if (prof) hipEventRecord(b->lev[l][1], s);
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
+        if (use_persist) {
+            // one launch per layer (and per chunk of read tiles that fits co-resident on the chip)
+            const int maxt = persist_max_tiles(Hp, b->eng->prop.multiProcessorCount);
+            // the output doubles as the hand-off flag: pre-fill with the NaN sentinel
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFFFFFFFF, (size_t)Tb * Bp * Hp, s), FFHIP_EHIP);
+            for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
+                const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
+                HIP_TRY(hipMemsetAsync(b->pflags, 0, persist_flag_words(Hp, nrt) * sizeof(unsigned), s), FFHIP_EHIP);
+                if (!launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode))
+                    return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
+                b->launches[2]++;
+            }
+        } else
         for (int i = 0; i < Tb; i++) {
             const int t = backward ? Tb - 1 - i : i;
             const int tp = backward ? t + 1 : t - 1;
@@ -513,7 +536,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             else
                 launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0);
         }
-        b->launches[2] += Tb;
+        if (!use_persist) b->launches[2] += Tb;
         if (prof) hipEventRecord(b->lev[l][2], s);
         cur ^= 1;
         if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
@@ -562,8 +585,10 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         HIP_TRY(hipMemcpyAsync(b->h_lens, b->lens, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
         HIP_TRY(hipMemcpyAsync(b->h_score, b->score, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     }
+    HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    if (*b->h_abort != 0) return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
     b->finished = 1;
     return FFHIP_OK;
 }

@@ -64,9 +64,12 @@ void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const
 void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
                      int B16, int H, int first);
 
-// persistent recurrent layer (ffhip_rnn_persist.hip); returns false if the shape is unsupported
-struct PersistPlan;
-bool persist_supported(int kind, int H, int B16, int ncu);
+// persistent recurrent layer (ffhip_rnn_persist.hip): one launch per layer and chunk of read tiles
+bool persist_supported(int kind, int H, int ncu);
+int persist_max_tiles(int H, int ncu);      // read tiles one launch can take (all workgroups co-resident)
+bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
+                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
+size_t persist_flag_words(int H, int nrt);
 
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,

@@ -1,0 +1,291 @@
+// ffhip_rnn_persist.hip -- persistent recurrent layer for gfx950: one launch per layer.
+//
+// Replaces lstm_forward/lstm_backward + lstm_step (layers.c:877-1026) and
+// grumod_forward/grumod_backward + grumod_step (layers.c:571-715) for a whole batch.
+//
+// Why persistent.  A layer is Tb strictly dependent steps; per step the work is the small GEMM
+// [16*B16 reads x H] . [H x 4H].  Launch-per-step re-streams the whole recurrent matrix from L2
+// every step (8.5 us per step measured, 22 % of the f32 MFMA peak).  Here the recurrent matrix is
+// loaded ONCE per layer into VGPRs and stays there for all Tb steps:
+//
+//   * one GROUP of G workgroups per read tile (16 reads); member m owns UPC unit tiles
+//     (4 hidden units x 4 gate rows each), i.e. 16*UPC rows of sW^T;
+//   * inside a workgroup the 4 waves split K: wave w holds the [16*UPC x 16*KPW] slice of its rows
+//     as UPC*KPW float4 MFMA A-fragments in registers (72 VGPRs at H = 384);
+//   * per step a wave waits for the producers of ITS K slice only, loads that slice of h(t-1)
+//     straight from L2 in B-fragment order (KPW coalesced 1 KiB loads), issues UPC*KPW*4 MFMAs,
+//     and drops its partial tile sums in LDS; after one barrier wave j (j < UPC) adds the four
+//     partials to Xa(t), does the gate math lane-locally (cell state lives in a register for the
+//     whole layer), stores its 4 units x 16 reads of h(t) and publishes a per-unit-tile step counter.
+//
+// Two workgroups are resident per CU (<= 256 VGPRs, 24 KiB LDS each): while one waits for its
+// group's hand-off the other one's MFMAs own the matrix pipes, so the hand-off latency is hidden
+// by occupancy rather than by hand-written ping-pong code.
+//
+// Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility", cdna_hip_programming.md G16 form R2 "the data is the flag").
+// The payload is the layer's output h(t) itself.  The host pre-fills the output buffer with a NaN
+// sentinel; a producer lane publishes one aligned dword per (unit, read); a consumer wave re-reads
+// the 16-byte fragments of its K slice with sc1 loads (served by L2, never by the stale per-CU L1)
+// until no dword equals the sentinel.  |h| < 1 always, so a valid h can never be mistaken for the
+// sentinel; a NaN produced by NaN inputs shows up as FFHIP_ETIMEOUT instead of garbage.
+//   - placement-independent form: stores are write-through (sc1) -> visible to every XCD;
+//   - when the G members of a group verify at run time (hardware XCC id, exchanged with the
+//     write-through form) that they all sit on ONE XCD they share one L2, and plain stores
+//     (which stay in that L2) are sufficient and ~2x faster per hop.
+// Nothing depends on dispatch order or on an assumed block -> XCD map.  Every spin is bounded: on
+// timeout the workgroup raises the abort word, leaves through its barriers and the host reports
+// FFHIP_ETIMEOUT instead of hanging the GPU.
+#include "ffhip_internal.hpp"
+#include "ffhip_math.hpp"
+
+namespace ffhip {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+struct PersistArgs {
+    const v4f *sWp;        // [Ut][K16][64] float4, A-fragment order
+    const v4f *xa;         // [Tb][B16][Ut][64] float4, D-fragment order
+    float *hout;           // [Tb][B16][Ut*64] tile-interleaved
+    unsigned *flags;       // [nrt][G] XCC ids (zeroed before launch)
+    unsigned *abort_word;  // != 0 -> a wait timed out
+    int Tb, B16, Ut, K16, G, rt0, nrt, backward;
+    int mode;              // 0 = verify placement, use the L2-local hand-off when a group shares an XCD; 1 = always write-through
+};
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned kSentinel = 0xFFFFFFFFu;   // a NaN; never a value of h
+
+__device__ __forceinline__ v4f mfma4p(v4f a, v4f b, v4f c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// KIND 0 = LSTM (gate rows i,f,g,o), 1 = GRUmod (gate rows z,r,candidate,-)
+template <int KIND, int UPC, int KPW>
+__global__ void __launch_bounds__(256, 2)
+k_rnn_persist(PersistArgs a) {
+    __shared__ v4f part[2][4][UPC][64];
+    __shared__ int lds_abort;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = a.G, Ut = a.Ut, K16 = a.K16, Tb = a.Tb;
+    // block -> (group g, member m).  Hardware places block b on XCD b % 8: when the group count
+    // is a multiple of 8 give every XCD whole groups (speed only, never correctness).
+    int g, m;
+    {
+        const int b = blockIdx.x;
+        if ((a.nrt & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
+        else { g = b / G; m = b % G; }
+    }
+    const int rt = a.rt0 + g;
+    const int ut0 = m * UPC;
+    if (threadIdx.x == 0) lds_abort = 0;
+
+    // ---- placement check.  The write-through (sc1) hand-off is correct for any placement but every
+    // hop goes through the fabric.  CUs of ONE XCD share one L2, so when all G members of this group
+    // report the same XCC id (read from hardware, exchanged with the write-through protocol) the
+    // group may hand off through that L2: stores that stay in L2 (plain / sc0) + L1-bypassing loads.
+    __shared__ int lds_fast;
+    if (threadIdx.x < 64) {
+        int fast_l = 0;
+        if (a.mode == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc = (xcc & 0xfu) + 1u;
+            unsigned *ids = a.flags + (size_t)g * G;
+            if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
+            unsigned v = xcc;
+            for (unsigned spin = 0; spin < 2000000u; spin++) {
+                v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
+                if (__all(v != 0u)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            fast_l = __all(v == xcc) ? 1 : 0;      // a timeout leaves zeros -> not equal -> safe path
+        }
+        if (lane == 0) lds_fast = fast_l;
+    }
+
+    // ---- resident weights: rows of my UPC unit tiles, K slice of my wave
+    v4f wreg[UPC][KPW];
+#pragma unroll
+    for (int j = 0; j < UPC; j++)
+#pragma unroll
+        for (int kk = 0; kk < KPW; kk++) {
+            const int k16 = wave * KPW + kk;
+            const int ut = ut0 + j;
+            wreg[j][kk] = (k16 < K16 && ut < Ut) ? a.sWp[((size_t)ut * K16 + k16) * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
+        }
+    const int my_tile = (wave < UPC && ut0 + wave < Ut) ? wave : -1;   // gate role
+    float c = 0.0f, hprev_own = 0.0f;
+    const int q = lane >> 4, rl = lane & 15;
+    const size_t tile_floats = (size_t)Ut * 64;
+    __syncthreads();
+    const bool fast = lds_fast != 0;
+
+    for (int i = 0; i < Tb; i++) {
+        const int t = a.backward ? Tb - 1 - i : i;
+        const int tp = a.backward ? t + 1 : t - 1;
+        v4f x = { 0.f, 0.f, 0.f, 0.f };
+        if (my_tile >= 0) x = a.xa[(((size_t)t * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
+        if (i > 0) {
+            v4f acc[UPC];
+#pragma unroll
+            for (int j = 0; j < UPC; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            if (wave * KPW < K16) {
+                // B fragments of my K slice of h(t-1), straight from L2 (sc1 loads never hit this CU's
+                // L1).  The payload is its own flag: the layer output was pre-filled with a NaN
+                // sentinel, every h is a single aligned dword store and |h| < 1, so "no sentinel in my
+                // slice" == "every producer of my slice has published step i-1".  No separate counter,
+                // no extra round trip.
+                const float *hp = a.hout + ((size_t)tp * a.B16 + rt) * tile_floats;
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(tile_floats * 4), 0x00020000);
+                v4u raw[KPW];
+                bool timed_out = false;
+                for (unsigned spin = 0;; spin++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int kk = 0; kk < KPW; kk++) {
+                        const int k16 = wave * KPW + kk;
+                        raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KPW; kk++)
+                        ok = ok && raw[kk].x != kSentinel && raw[kk].y != kSentinel && raw[kk].z != kSentinel && raw[kk].w != kSentinel;
+                    if (__all(ok)) break;
+                    if (spin > 3000000u || (spin & 255u) == 255u) {
+                        const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                        if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (timed_out) {
+                    if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KPW; kk++) {
+                        const v4f bf = __builtin_bit_cast(v4f, raw[kk]);      // k16 beyond K16 reads 0 (buffer bounds)
+#pragma unroll
+                        for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wreg[j][kk], bf, acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
+            __syncthreads();
+            if (lds_abort) return;
+        }
+        if (my_tile >= 0) {
+            v4f s = { 0.f, 0.f, 0.f, 0.f };
+            if (i > 0) {
+#pragma unroll
+                for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
+            }
+            float h;
+            if (KIND == 0) {
+                s = s + x;
+                // layers.c:1014-1025
+                const float forget = logistic_ref(s.y) * c;
+                const float update = logistic_ref(s.x) * tanh_ref(s.z);
+                c = forget + update;
+                h = logistic_ref(s.w) * tanh_ref(c);
+            } else {
+                // layers.c:690-714: x added to z,r before the logistic; candidate = tanh(r*u + x_c)
+                const float z = logistic_ref(s.x + x.x);
+                const float r = logistic_ref(s.y + x.y);
+                float hbar = r * s.z + x.z;
+                hbar = tanh_ref(hbar);
+                h = z * hprev_own + (1.0f - z) * hbar;
+                hprev_own = h;
+            }
+            float *ho = a.hout + ((size_t)t * a.B16 + rt) * tile_floats + (size_t)(ut0 + my_tile) * 64 + rl * 4 + q;
+            if (fast) *ho = h;                                        // one dword, stays in the group's shared L2
+            else __hip_atomic_store(ho, h, RLX_AGENT);                // one dword, write-through (sc1)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int KIND, int UPC, int KPW>
+static void launch_one(hipStream_t s, const PersistArgs &a) {
+    hipLaunchKernelGGL((k_rnn_persist<KIND, UPC, KPW>), dim3(a.nrt * a.G), dim3(256), 0, s, a);
+}
+
+template <int KIND, int UPC>
+static bool dispatch_kpw(hipStream_t s, const PersistArgs &a, int kpw) {
+    switch (kpw) {
+    case 1: launch_one<KIND, UPC, 1>(s, a); return true;
+    case 2: launch_one<KIND, UPC, 2>(s, a); return true;
+    case 3: launch_one<KIND, UPC, 3>(s, a); return true;
+    case 4: launch_one<KIND, UPC, 4>(s, a); return true;
+    case 6: launch_one<KIND, UPC, 6>(s, a); return true;
+    case 8: launch_one<KIND, UPC, 8>(s, a); return true;
+    default: return false;
+    }
+}
+
+// group size: the largest divisor of Ut that is <= 32 (one XCD's worth of CUs)
+static int pick_group(int Ut) {
+    for (int g = 32; g >= 1; g--) if (Ut % g == 0) return g;
+    return 1;
+}
+
+static int pick_kpw(int K16) {
+    int kpw = (K16 + 3) / 4;
+    if (kpw == 5) kpw = 6;
+    if (kpw == 7) kpw = 8;
+    return kpw;
+}
+
+bool persist_supported(int kind, int H, int ncu) {
+    if (kind != 0 && kind != 1) return false;
+    if (H % 16 != 0) return false;
+    const int Ut = H / 4, K16 = H / 16;
+    const int G = pick_group(Ut), UPC = Ut / G, kpw = pick_kpw(K16);
+    if (UPC > 4 || kpw > 8) return false;
+    if (G > 2 * ncu) return false;
+    return true;
+}
+
+// words of the per-launch flag area: XCC ids [nrt][G]
+size_t persist_flag_words(int H, int nrt) { return (size_t)nrt * pick_group(H / 4); }
+
+int persist_max_tiles(int H, int ncu) {
+    const int G = pick_group(H / 4);
+    // two workgroups per CU are guaranteed resident (launch_bounds(256,2), 24.5 KiB LDS); every
+    // workgroup of a launch must be co-resident because groups spin on each other.
+    return (2 * ncu) / G;
+}
+
+// One recurrent layer over read tiles [rt0, rt0+nrt).  nrt <= persist_max_tiles().
+bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
+                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
+    PersistArgs a;
+    a.sWp = (const v4f *)sWp; a.xa = (const v4f *)xa; a.hout = hout; a.flags = flags; a.abort_word = abort_word;
+    a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
+    a.backward = backward;
+    a.mode = mode;
+    const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
+    if (kind == 0) {
+        switch (UPC) {
+        case 1: return dispatch_kpw<0, 1>(s, a, kpw);
+        case 2: return dispatch_kpw<0, 2>(s, a, kpw);
+        case 3: return dispatch_kpw<0, 3>(s, a, kpw);
+        case 4: return dispatch_kpw<0, 4>(s, a, kpw);
+        }
+    } else {
+        switch (UPC) {
+        case 1: return dispatch_kpw<1, 1>(s, a, kpw);
+        case 2: return dispatch_kpw<1, 2>(s, a, kpw);
+        case 3: return dispatch_kpw<1, 3>(s, a, kpw);
+        case 4: return dispatch_kpw<1, 4>(s, a, kpw);
+        }
+    }
+    return false;
+}
+
+}  // namespace ffhip
