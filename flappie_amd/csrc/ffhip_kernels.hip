@@ -17,6 +17,7 @@
 //   trace                    exp_activation_inplace + trace_from_posterior   layers.c:56, decode.c:499-543
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
+#include <stdlib.h>
 
 namespace ffhip {
 
@@ -543,9 +544,92 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
     }
 }
 
+
+// ---- fast path for nstate == 8 (ACGT models) ---------------------------------------------------
+// Lane l < 40 owns transition entry l: flip entries l = 8*to + from (l < 32), flop entries
+// l = 32 + idx (idx >= 4: stay in flop idx; idx < 4: move flip idx -> flop idx+4).  The source state
+// of entry l is always l & 7, so the state vector is kept replicated by (l & 7) and needs no
+// shuffle on the operand side.  Every per-destination logsumexp is evaluated as max + log(sum exp)
+// with wave butterflies instead of the reference's sequential pairwise chain (decode.c:417-421,
+// :478-482): same value up to fp32 rounding of the association, 7x shorter dependent chain.
+__device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 + s; }
+
+__global__ void __launch_bounds__(64)
+k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, int Tb) {
+    constexpr int P = 40, Ps = 40, ns = 8;
+    const int lane = threadIdx.x;
+    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
+    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const bool valid = lane < P, flip = lane < 32;
+    const int st = lane & 7;
+    const float NEG = -INFINITY;
+
+    // forwards: pv = fwd[blk][lane & 7]
+    float pv = 0.0f;
+    if (lane < ns) F[lane] = 0.0f;
+    float s_next = valid ? T[lane] : 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = s_next;
+        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+        const float term = valid ? s + pv : NEG;
+        float m = fmaxf(term, __shfl_xor(term, 4));
+        if (flip) { m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); }
+        float e = valid ? expf(term - m) : 0.0f;
+        e += __shfl_xor(e, 4);
+        if (flip) { e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); }
+        const float val = m + logf(e);
+        pv = __shfl(val, ff8_src_lane(st));
+        if (lane < ns) F[(size_t)(blk + 1) * kMaxState + lane] = pv;
+    }
+
+    // backwards: pb = bwd[blk][lane & 7]
+    int to;
+    if (lane < 32) to = lane >> 3;
+    else { const int idx = lane - 32; to = (idx < 4) ? idx + 4 : idx; }
+    float pb = 0.0f;
+    for (int blk = Tb; blk > 0; blk--) {
+        const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
+        const float f = F[(size_t)(blk - 1) * kMaxState + st];
+        const float pb_to = __shfl(pb, to & 7);
+        if (valid) Pp[(size_t)(blk - 1) * Ps + lane] = (f + pb_to) + s;          // decode.c:451-461
+        const float t2 = valid ? s + pb_to : NEG;
+        // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
+        const float f5 = __shfl(t2, 32 + st);
+        float m = fmaxf(t2, __shfl_xor(t2, 8));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, f5);
+        float e = flip ? expf(t2 - m) : 0.0f;
+        e += __shfl_xor(e, 8);
+        e += __shfl_xor(e, 16);
+        e += expf(f5 - m);
+        const float cur = m + logf(e);
+        pb = __shfl(cur, st);
+    }
+    __syncthreads();
+    // per-block log-normalisation over the 40 entries (flappie_matrix.c:450-467), one block per lane
+    for (int blk = lane; blk < Tb; blk += 64) {
+        float *x = Pp + (size_t)blk * Ps;
+        float v[P];
+        float m = NEG;
+#pragma unroll
+        for (int r = 0; r < P; r++) { v[r] = x[r]; m = fmaxf(m, v[r]); }
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < P; r++) sum += expf(v[r] - m);
+        const float lse = m + logf(sum);
+#pragma unroll
+        for (int r = 0; r < P; r++) x[r] = v[r] - lse;
+    }
+}
+
+
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
+    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
+        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb);
+    else
+        hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
 }
 
 // ---- Viterbi ---------------------------------------------------------------------------------
@@ -623,10 +707,87 @@ k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restr
     }
 }
 
+// Viterbi for nstate == 8: same lane layout; bit-identical to the sequential scan because max is
+// exact and the tie rules are reproduced (flip: lowest from-state wins; flop: stay unless move is
+// strictly greater).
+__global__ void __launch_bounds__(64)
+k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path,
+           float *__restrict__ qpath, float *__restrict__ score_out, int Tb) {
+    constexpr int P = 40, Ps = 40, ns = 8, nbase = 4, off = 32;
+    __shared__ uint8_t tb_lds[kTbChunk * kMaxState];
+    __shared__ int path_lds[kTbChunk + 1];
+    const int lane = threadIdx.x;
+    const float *T = M + (size_t)blockIdx.x * Tb * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    const bool valid = lane < P, flip = lane < 32;
+    const int st = lane & 7;
+    const float NEG = -INFINITY;
+
+    float pv = 0.0f;
+    float s_next = valid ? T[lane] : 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = s_next;
+        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+        float v = valid ? s + pv : NEG;
+        int a = st;
+        // flop pair (lanes 32..39): partner = lane ^ 4; stay = idx >= 4
+        const float o4 = __shfl_xor(v, 4);
+        if (!flip) {
+            const bool i_am_stay = (lane & 4) != 0;
+            const float stay = i_am_stay ? v : o4, move = i_am_stay ? o4 : v;
+            const int b2 = 4 + (lane & 3);
+            if (move > stay) { v = move; a = b2 - nbase; } else { v = stay; a = b2; }
+        } else {
+            // flip groups: argmax over from-state, lowest index on ties
+            { const int oa = a ^ 4; if (o4 > v || (o4 == v && oa < a)) { v = o4; a = oa; } }
+            { const float ov = __shfl_xor(v, 1); const int oa = __shfl_xor(a, 1); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+            { const float ov = __shfl_xor(v, 2); const int oa = __shfl_xor(a, 2); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+        }
+        const int src = ff8_src_lane(st);
+        pv = __shfl(v, src);
+        const int arg = __shfl(a, src);
+        if (lane < ns) tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg;
+    }
+    float score = __shfl(pv, 0);
+    int last = 0;
+    for (int s2 = 1; s2 < ns; s2++) {
+        const float v = __shfl(pv, s2);
+        if (v > score) { score = v; last = s2; }
+    }
+    if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
+    __syncthreads();
+    for (int c1 = Tb; c1 > 0; c1 -= kTbChunk) {
+        const int c0 = max(0, c1 - kTbChunk), n = c1 - c0;
+        for (int i = lane; i < n * (kMaxState / 4); i += 64)
+            ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
+        __syncthreads();
+        if (lane == 0) {
+            int p = last;
+            path_lds[n] = p;
+            for (int i = n; i > 0; i--) { p = tb_lds[(i - 1) * kMaxState + p]; path_lds[i - 1] = p; }
+        }
+        __syncthreads();
+        if (c1 == Tb && lane == 0) pth[Tb] = path_lds[n];
+        for (int i = lane; i < n; i += 64) {
+            const int from = path_lds[i], to = path_lds[i + 1];
+            pth[c0 + i] = from;
+            const int idx = (to < nbase) ? (to * ns + from) : (off + from);
+            qp[c0 + i + 1] = T[(size_t)(c0 + i) * Ps + idx];
+        }
+        last = path_lds[0];
+        __syncthreads();
+    }
+}
+
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
                     int nread, int Tb, int nbase, int Ps) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps);
+    if (nbase == 4 && Ps == 40)
+        hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb);
+    else
+        hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps);
 }
 
 // ---- change positions -> base and quality strings ---------------------------------------------

@@ -51,6 +51,7 @@ struct PersistArgs {
     unsigned *flags;       // [nrt][G] XCC ids (zeroed before launch)
     unsigned *abort_word;  // != 0 -> a wait timed out
     int Tb, B16, Ut, K16, G, rt0, nrt, backward;
+    unsigned long long *dbg; // optional phase timestamps [Tb][4 waves][6]
     int mode;              // 0 = verify placement, use the L2-local hand-off when a group shares an XCD; 1 = always write-through
 };
 
@@ -130,6 +131,12 @@ k_rnn_persist(PersistArgs a) {
     for (int i = 0; i < Tb; i++) {
         const int t = a.backward ? Tb - 1 - i : i;
         const int tp = a.backward ? t + 1 : t - 1;
+#ifdef FFHIP_PERSIST_TIMING
+#define STAMP(k) do { if (a.dbg && blockIdx.x == 8 && lane == 0) a.dbg[((size_t)i * 4 + wave) * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+        STAMP(0);
         v4f x = { 0.f, 0.f, 0.f, 0.f };
         if (my_tile >= 0) x = a.xa[(((size_t)t * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
         if (i > 0) {
@@ -163,6 +170,7 @@ k_rnn_persist(PersistArgs a) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                STAMP(1);
                 if (timed_out) {
                     if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
                 } else {
@@ -170,13 +178,22 @@ k_rnn_persist(PersistArgs a) {
                     for (int kk = 0; kk < KPW; kk++) {
                         const v4f bf = __builtin_bit_cast(v4f, raw[kk]);      // k16 beyond K16 reads 0 (buffer bounds)
 #pragma unroll
+#ifdef FFHIP_ABL_NOMFMA
+                        for (int j = 0; j < UPC; j++) acc[j] = acc[j] + bf * wreg[j][kk].x;
+#else
                         for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wreg[j][kk], bf, acc[j]);
+#endif
                     }
                 }
             }
+#ifdef FFHIP_PERSIST_TIMING
+            asm volatile("s_nop 0" :: "v"(acc[0].x));
+#endif
+            STAMP(2);
 #pragma unroll
             for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
             __syncthreads();
+            STAMP(3);
             if (lds_abort) return;
         }
         if (my_tile >= 0) {
@@ -186,6 +203,9 @@ k_rnn_persist(PersistArgs a) {
                 for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
             }
             float h;
+#ifdef FFHIP_ABL_NOGATE
+            s = s + x; c = c + s.y; h = s.x * 0.001f + s.z * 0.001f + s.w * 0.001f + c * 1e-9f; if (false)
+#endif
             if (KIND == 0) {
                 s = s + x;
                 // layers.c:1014-1025
@@ -202,12 +222,28 @@ k_rnn_persist(PersistArgs a) {
                 h = z * hprev_own + (1.0f - z) * hbar;
                 hprev_own = h;
             }
-            float *ho = a.hout + ((size_t)t * a.B16 + rt) * tile_floats + (size_t)(ut0 + my_tile) * 64 + rl * 4 + q;
-            if (fast) *ho = h;                                        // one dword, stays in the group's shared L2
-            else __hip_atomic_store(ho, h, RLX_AGENT);                // one dword, write-through (sc1)
+            // gather the 4 units of a read into one lane: lanes 0..15 then hold 16 contiguous bytes
+            // each, and the wave writes its 256 B (two whole 128-B lines) with ONE store instruction,
+            // so a consumer never finds a half-written line that L2 would have to complete from HBM.
+            v4f hv;
+            hv.x = __shfl(h, rl);
+            hv.y = __shfl(h, rl + 16);
+            hv.z = __shfl(h, rl + 32);
+            hv.w = __shfl(h, rl + 48);
+            float *ho = a.hout + ((size_t)t * a.B16 + rt) * tile_floats + (size_t)(ut0 + my_tile) * 64 + rl * 4;
+            STAMP(4);
+            if (lane < 16) {
+                if (fast) *(v4f *)ho = hv;                            // stays in the group's shared L2
+                else {
+                    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hout + ((size_t)t * a.B16 + rt) * tile_floats), 0, (int)(tile_floats * 4), 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, ((ut0 + my_tile) * 64 + rl * 4) * 4, 0, 16 /*sc1: write-through*/);
+                }
+            }
         }
     }
 }
+
+unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING builds)
 
 // ------------------------------------------------------------------------------------------
 template <int KIND, int UPC, int KPW>
@@ -269,6 +305,7 @@ bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float 
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward;
     a.mode = mode;
+    a.dbg = g_persist_dbg;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
         switch (UPC) {
