@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size inferred from the model's size
-NREAD, NSAMPLE = 256, 4000
+NREAD, NSAMPLE = int(os.environ.get('FFHIP_BENCH_NREAD', '256')), 4000
 
 
 def cpu_baseline(mdl, sig, budget_s=12.0, max_reads=6):

@@ -43,6 +43,11 @@ struct ffhip_engine {
     hipStream_t streams[2] = { nullptr, nullptr };
     int next_stream = 0;
     int profiling = 0;
+    // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.
+    // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
+    // launches are chained through this event.
+    hipEvent_t persist_done = nullptr;
+    int persist_chained = 0;
 };
 
 extern "C" int ffhip_device_count(void) {
@@ -64,12 +69,14 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
         return nullptr;
     }
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
+    HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
     return e;
 }
 
 extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     if (!e) return;
     for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
+    if (e->persist_done) hipEventDestroy(e->persist_done);
     delete e;
 }
 
@@ -298,7 +305,8 @@ struct ffhip_batch {
     int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
     char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
     int32_t *trace = nullptr;
-    unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel step counters / abort word
+    unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel XCC ids / abort word
+    int persist_concurrent_ok = 0;      // two such batches fit on the chip at once
     float *scratch = nullptr;           // dense [Tb][H] for debug taps
     // pinned host mirrors of the small results
     char *h_bases = nullptr, *h_quals = nullptr; int *h_lens = nullptr; float *h_score = nullptr;
@@ -417,6 +425,10 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->pabort = (unsigned *)dalloc(b, sizeof(unsigned), true))) BFAIL();
     if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
     *b->h_abort = 0;
+    if (persist_supported(m->kind, (int)Hp, eng->prop.multiProcessorCount)) {
+        const int maxt = persist_max_tiles(m->kind, (int)Hp, eng->prop.multiProcessorCount);
+        b->persist_concurrent_ok = 2 * b->B16 <= maxt;      // two such launches fit on the chip together
+    }
     if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
         hipHostMalloc((void **)&b->h_quals, (size_t)nread * (Tb + 1)) != hipSuccess ||
         hipHostMalloc((void **)&b->h_lens, (size_t)nread * 4) != hipSuccess ||
@@ -516,14 +528,17 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
         if (use_persist) {
             // one launch per layer (and per chunk of read tiles that fits co-resident on the chip)
-            const int maxt = persist_max_tiles(Hp, b->eng->prop.multiProcessorCount);
+            const int maxt = persist_max_tiles(m->kind, Hp, b->eng->prop.multiProcessorCount);
             // the output doubles as the hand-off flag: pre-fill with the NaN sentinel
             HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFFFFFFFF, (size_t)Tb * Bp * Hp, s), FFHIP_EHIP);
             for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
                 const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
                 HIP_TRY(hipMemsetAsync(b->pflags, 0, persist_flag_words(Hp, nrt) * sizeof(unsigned), s), FFHIP_EHIP);
+                const bool chain = !b->persist_concurrent_ok;
+                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (!launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode))
                     return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
+                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
             }
         } else

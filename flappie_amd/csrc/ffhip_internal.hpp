@@ -66,10 +66,11 @@ void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const 
 
 // persistent recurrent layer (ffhip_rnn_persist.hip): one launch per layer and chunk of read tiles
 bool persist_supported(int kind, int H, int ncu);
-int persist_max_tiles(int H, int ncu);      // read tiles one launch can take (all workgroups co-resident)
+int persist_max_tiles(int kind, int H, int ncu);      // read tiles one launch can take (all workgroups co-resident)
 bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
                         unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
 size_t persist_flag_words(int H, int nrt);
+int persist_blocks_per_cu(int kind, int H);
 
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,

@@ -51,6 +51,54 @@ __device__ __forceinline__ float logsumexpf_ref(float x, float y) {
     return fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
 }
 
+// Four independent logistic evaluations written as one straight-line vector computation: the same
+// operations in the same order per component as logistic_ref (bit-identical results), but the
+// four dependency chains are interleaved by construction, which is what a single wave on the
+// recurrent critical path needs (latency-bound, one element per lane).
+typedef float ffv4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ ffv4 exp_cephes4(ffv4 x) {
+    const ffv4 hi = { 88.3762626647949f, 88.3762626647949f, 88.3762626647949f, 88.3762626647949f };
+    x = __builtin_elementwise_min(x, hi);
+    x = __builtin_elementwise_max(x, -hi);
+    ffv4 fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    ffv4 tmp;
+    tmp.x = (float)__float2int_rz(fx.x); tmp.y = (float)__float2int_rz(fx.y);
+    tmp.z = (float)__float2int_rz(fx.z); tmp.w = (float)__float2int_rz(fx.w);
+    ffv4 one_if_gt;
+    one_if_gt.x = (tmp.x > fx.x) ? 1.0f : 0.0f; one_if_gt.y = (tmp.y > fx.y) ? 1.0f : 0.0f;
+    one_if_gt.z = (tmp.z > fx.z) ? 1.0f : 0.0f; one_if_gt.w = (tmp.w > fx.w) ? 1.0f : 0.0f;
+    fx = tmp - one_if_gt;
+    tmp = fx * 0.693359375f;
+    ffv4 z = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - z;
+    z = x * x;
+    ffv4 y = { 1.9875691500E-4f, 1.9875691500E-4f, 1.9875691500E-4f, 1.9875691500E-4f };
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z;
+    y = y + x;
+    y = y + 1.0f;
+    ffv4 p2;
+    p2.x = __int_as_float((__float2int_rz(fx.x) + 0x7f) << 23);
+    p2.y = __int_as_float((__float2int_rz(fx.y) + 0x7f) << 23);
+    p2.z = __int_as_float((__float2int_rz(fx.z) + 0x7f) << 23);
+    p2.w = __int_as_float((__float2int_rz(fx.w) + 0x7f) << 23);
+    return y * p2;
+}
+
+__device__ __forceinline__ ffv4 logistic_ref4(ffv4 x) {
+    const ffv4 e = exp_cephes4(-x);
+    ffv4 r;
+    r.x = 1.0f / (1.0f + e.x); r.y = 1.0f / (1.0f + e.y); r.z = 1.0f / (1.0f + e.z); r.w = 1.0f / (1.0f + e.w);
+    return r;
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? swish_ref(x) : (act == 2 ? tanh_ref(x) : x);
 }

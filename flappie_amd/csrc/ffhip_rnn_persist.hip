@@ -38,6 +38,7 @@
 // FFHIP_ETIMEOUT instead of hanging the GPU.
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
+#include <stdlib.h>
 
 namespace ffhip {
 
@@ -127,6 +128,16 @@ k_rnn_persist(PersistArgs a) {
     const size_t tile_floats = (size_t)Ut * 64;
     __syncthreads();
     const bool fast = lds_fast != 0;
+    // This kernel is latency-bound (a dependent chain of Tb hand-offs) and leaves the matrix pipes
+    // idle about half of the time; throughput kernels of another stream (input projections of the
+    // next batch) are meant to fill those slots.  Raise the wave priority so that they never
+    // lengthen the chain.
+    __builtin_amdgcn_s_setprio(3);
+    v4f x_next = { 0.f, 0.f, 0.f, 0.f };
+    if (my_tile >= 0) {
+        const int t0 = a.backward ? Tb - 1 : 0;
+        x_next = a.xa[(((size_t)t0 * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
+    }
 
     for (int i = 0; i < Tb; i++) {
         const int t = a.backward ? Tb - 1 - i : i;
@@ -137,8 +148,13 @@ k_rnn_persist(PersistArgs a) {
 #define STAMP(k) do { } while (0)
 #endif
         STAMP(0);
-        v4f x = { 0.f, 0.f, 0.f, 0.f };
-        if (my_tile >= 0) x = a.xa[(((size_t)t * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
+        const v4f x = x_next;
+#ifndef FFHIP_ABL_NOXA
+        if (my_tile >= 0 && i + 1 < Tb) {      // Xa streams from HBM: fetch one step ahead
+            const int tn = a.backward ? t - 1 : t + 1;
+            x_next = a.xa[(((size_t)tn * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
+        }
+#endif
         if (i > 0) {
             v4f acc[UPC];
 #pragma unroll
@@ -192,7 +208,11 @@ k_rnn_persist(PersistArgs a) {
             STAMP(2);
 #pragma unroll
             for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() would also drain vmcnt and put the HBM latency of the
+            // Xa prefetch on the critical path of every step.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             STAMP(3);
             if (lds_abort) return;
         }
@@ -208,11 +228,26 @@ k_rnn_persist(PersistArgs a) {
 #endif
             if (KIND == 0) {
                 s = s + x;
-                // layers.c:1014-1025
+                // layers.c:1014-1025.  sigma(i), sigma(f), sigma(o) and tanh(g) = 2 sigma(2g) - 1 are
+                // four independent logistic evaluations: do them as one interleaved vector call.
+#if defined(FFHIP_ABL_FASTGATE)
+                auto sg = [](float v) { return __frcp_rn(1.0f + __expf(-v)); };
+                const float si = sg(s.x), sf = sg(s.y), so = sg(s.w), tg = 2.0f * sg(2.0f * s.z) - 1.0f;
+                c = sf * c + si * tg;
+                h = so * (2.0f * sg(2.0f * c) - 1.0f);
+#elif defined(FFHIP_GATE_OLD)
                 const float forget = logistic_ref(s.y) * c;
                 const float update = logistic_ref(s.x) * tanh_ref(s.z);
                 c = forget + update;
                 h = logistic_ref(s.w) * tanh_ref(c);
+#else
+                const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const float tanh_g = (L.z + L.z) - 1.0f;
+                const float forget = L.y * c;
+                const float update = L.x * tanh_g;
+                c = forget + update;
+                h = L.w * tanh_ref(c);
+#endif
             } else {
                 // layers.c:690-714: x added to z,r before the logistic; candidate = tanh(r*u + x_c)
                 const float z = logistic_ref(s.x + x.x);
@@ -246,8 +281,16 @@ k_rnn_persist(PersistArgs a) {
 unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING builds)
 
 // ------------------------------------------------------------------------------------------
+static int g_query_blocks = -1;      // >= 0: dispatch answers the occupancy query instead of launching
+
 template <int KIND, int UPC, int KPW>
 static void launch_one(hipStream_t s, const PersistArgs &a) {
+    if (g_query_blocks >= 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rnn_persist<KIND, UPC, KPW>, 256, 0) != hipSuccess) n = 0;
+        g_query_blocks = n;
+        return;
+    }
     hipLaunchKernelGGL((k_rnn_persist<KIND, UPC, KPW>), dim3(a.nrt * a.G), dim3(256), 0, s, a);
 }
 
@@ -265,6 +308,7 @@ static bool dispatch_kpw(hipStream_t s, const PersistArgs &a, int kpw) {
 }
 
 // group size: the largest divisor of Ut that is <= 32 (one XCD's worth of CUs)
+int persist_blocks_per_cu(int kind, int H);
 static int pick_group(int Ut) {
     for (int g = 32; g >= 1; g--) if (Ut % g == 0) return g;
     return 1;
@@ -290,11 +334,24 @@ bool persist_supported(int kind, int H, int ncu) {
 // words of the per-launch flag area: XCC ids [nrt][G]
 size_t persist_flag_words(int H, int nrt) { return (size_t)nrt * pick_group(H / 4); }
 
-int persist_max_tiles(int H, int ncu) {
+// resident workgroups per CU of the kernel instantiation this shape selects (occupancy API; the
+// kernels use <= 64 SGPRs, outside the band where the API over-reports -- MI355X_MICROARCH.md)
+int persist_blocks_per_cu(int kind, int H) {
+    g_query_blocks = 0;
+    launch_rnn_persist(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1);
+    const int n = g_query_blocks;
+    g_query_blocks = -1;
+    return n;
+}
+
+int persist_max_tiles(int kind, int H, int ncu) {
     const int G = pick_group(H / 4);
-    // two workgroups per CU are guaranteed resident (launch_bounds(256,2), 24.5 KiB LDS); every
-    // workgroup of a launch must be co-resident because groups spin on each other.
-    return (2 * ncu) / G;
+    // every workgroup of a launch must be co-resident because groups spin on each other: at least two
+    // per CU are guaranteed (launch_bounds(256,2), <= 33 KiB LDS); use what the occupancy query admits.
+    int per_cu = persist_blocks_per_cu(kind, H);
+    if (per_cu < 2) per_cu = 2;
+    if (per_cu > 4) per_cu = 4;
+    return (per_cu * ncu) / G;
 }
 
 // One recurrent layer over read tiles [rt0, rt0+nrt).  nrt <= persist_max_tiles().

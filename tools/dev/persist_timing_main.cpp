@@ -7,8 +7,8 @@
 #include "ffhip_internal.hpp"
 namespace ffhip { extern unsigned long long *g_persist_dbg; }
 using namespace ffhip;
-int main() {
-    const int H = 384, B16 = 16, Tb = 800, Bp = 256;
+int main(int argc, char** argv) {
+    const int H = 384, B16 = argc > 1 ? atoi(argv[1]) : 16, Tb = 800, Bp = 16 * B16;
     float4 *sWp; float *xa, *hout; unsigned *flags, *ab; unsigned long long *dbg;
     hipMalloc(&sWp, (size_t)4*H*H*4); hipMemset(sWp, 0, (size_t)4*H*H*4);
     hipMalloc(&xa, (size_t)Tb*Bp*H*4*4); hipMemset(xa, 0, (size_t)Tb*Bp*H*4*4);
@@ -21,7 +21,7 @@ int main() {
         hipMemset(flags, 0, 4096*4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        launch_rnn_persist(0, 0, sWp, xa, hout, flags, ab, Tb, B16, H, 0, 16, 1, 0);
+        launch_rnn_persist(0, 0, sWp, xa, hout, flags, ab, Tb, B16, H, 0, B16, 1, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("layer %.3f ms = %.3f us/step\n", ms, ms*1e3/Tb);
