@@ -577,7 +577,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase);
         b->launches[5] += 2;
         if (!(flags & FFHIP_RUN_NO_TRACE)) {
-            launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps);
+            launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1);
             b->launches[5]++;
         }
     } else {
@@ -697,5 +697,89 @@ extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP],
     }
     ms[0] = t01; ms[1] = ms_inproj; ms[2] = ms_rnn; ms[3] = t34; ms[4] = t45; ms[5] = t56;
     for (int i = 0; i < FFHIP_NGROUP; i++) launches[i] = b->launches[i];
+    return FFHIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ single-matrix decode
+namespace {
+struct TmpDev {
+    std::vector<void *> p;
+    ~TmpDev() { for (void *q : p) hipFree(q); }
+    void *get(size_t bytes) {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        p.push_back(d);
+        return d;
+    }
+};
+bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
+    const int nb = (int)roundf((-1.0f + sqrtf(1.0f + 2.0f * (float)nparam)) / 2.0f);
+    if (nb < 1 || (size_t)(2 * nb * (nb + 1)) != nparam || 2 * nb > kMaxState || nparam > 64 || stride < nparam) return false;
+    *nbase = nb;
+    return true;
+}
+}  // namespace
+
+extern "C" int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nblock, size_t nparam, size_t stride,
+                               int return_log, float *post_out) {
+    int nbase;
+    if (!eng || !trans || !post_out || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad transpost arguments");
+    hipSetDevice(eng->device);
+    hipStream_t s = eng->streams[0];
+    TmpDev t;
+    const size_t n = nblock * stride;
+    float *d_tr = (float *)t.get(n * 4), *d_po = (float *)t.get(n * 4), *d_fw = (float *)t.get((nblock + 1) * kMaxState * 4);
+    if (!d_tr || !d_po || !d_fw) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(d_tr, trans, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(d_po, 0, n * 4, s), FFHIP_EHIP);
+    launch_transpost(s, d_tr, d_po, d_fw, 1, (int)nblock, nbase, (int)stride);
+    if (!return_log) launch_exp_inplace(s, d_po, n);
+    HIP_TRY(hipMemcpyAsync(post_out, d_po, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    if (!return_log && stride != nparam)      // the reference's exp touches pad lanes too: exp(0) = 1
+        for (size_t c = 0; c < nblock; c++) for (size_t r = nparam; r < stride; r++) post_out[c * stride + r] = 1.0f;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblock, size_t nparam, size_t stride,
+                             int combine_stays, int *path, float *qpath, float *score) {
+    int nbase;
+    if (!eng || !scores || !path || !qpath || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad viterbi arguments");
+    hipSetDevice(eng->device);
+    hipStream_t s = eng->streams[0];
+    TmpDev t;
+    const size_t n = nblock * stride;
+    float *d_sc = (float *)t.get(n * 4), *d_q = (float *)t.get((nblock + 1) * 4), *d_s = (float *)t.get(4);
+    uint8_t *d_tb = (uint8_t *)t.get(nblock * kMaxState);
+    int *d_p = (int *)t.get((nblock + 1) * 4);
+    if (!d_sc || !d_q || !d_s || !d_tb || !d_p) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(d_sc, scores, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
+    launch_viterbi(s, d_sc, d_tb, d_p, d_q, d_s, 1, (int)nblock, nbase, (int)stride);
+    HIP_TRY(hipMemcpyAsync(path, d_p, (nblock + 1) * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(qpath, d_q, (nblock + 1) * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    float sc = NAN;
+    HIP_TRY(hipMemcpyAsync(&sc, d_s, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    if (score) *score = sc;
+    if (combine_stays)          // decode.c:194-198
+        for (size_t b = 0; b <= nblock; b++) path[b] = (path[b] < nbase) ? path[b] : -1;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t nparam, size_t stride, int32_t *out) {
+    int nbase;
+    if (!eng || !post || !out || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad trace arguments");
+    hipSetDevice(eng->device);
+    hipStream_t s = eng->streams[0];
+    TmpDev t;
+    const size_t n = nblock * stride, nt = (nblock + 1) * 2 * nbase;
+    float *d_po = (float *)t.get(n * 4);
+    int32_t *d_tr = (int32_t *)t.get(nt * 4);
+    if (!d_po || !d_tr) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(d_po, post, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
+    launch_trace(s, d_po, d_tr, 1, (int)nblock, nbase, (int)stride, 0);
+    HIP_TRY(hipMemcpyAsync(out, d_tr, nt * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }

@@ -86,7 +86,8 @@ void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *pat
 void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
                      int nread, int Tb, int nbase);
 // exp + trace_from_posterior
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps);
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log);
+void launch_exp_inplace(hipStream_t s, float *x, size_t n);
 // tile-interleaved -> dense [Tb][H] of one read (debug tap)
 void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H);
 

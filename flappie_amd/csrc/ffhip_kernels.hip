@@ -833,34 +833,44 @@ void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *b
 // (decode.c:499-543): column 0 sums block 0 by from-state, column blk+1 sums block blk by to-state.
 // The posterior buffer is left in log space (the reference's in-place exp is folded in here).
 __global__ void __launch_bounds__(256)
-k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int Tb, int nbase, int P, int Ps) {
+k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int Tb, int nbase, int P, int Ps, int is_log) {
     const int ns = 2 * nbase, off = nbase * ns;
     const float *Pp = post + (size_t)blockIdx.y * Tb * Ps;
     int32_t *tr = trace + (size_t)blockIdx.y * (Tb + 1) * ns;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (column, state)
     if (i >= (Tb + 1) * ns) return;
     const int col = i / ns, stt = i % ns;
+    auto pr = [&](float v) { return is_log ? exp_cephes(v) : v; };
     float sum;
     if (col == 0) {
         sum = 0.0f;
-        for (int to = 0; to < nbase; to++) sum += exp_cephes(Pp[to * ns + stt]);
-        sum += exp_cephes(Pp[off + stt]);
+        for (int to = 0; to < nbase; to++) sum += pr(Pp[to * ns + stt]);
+        sum += pr(Pp[off + stt]);
     } else {
         const float *x = Pp + (size_t)(col - 1) * Ps;
         if (stt < nbase) {
-            sum = exp_cephes(x[stt * ns]);
-            for (int f = 1; f < ns; f++) sum += exp_cephes(x[stt * ns + f]);
+            sum = pr(x[stt * ns]);
+            for (int f = 1; f < ns; f++) sum += pr(x[stt * ns + f]);
         } else {
-            sum = exp_cephes(x[off + stt - nbase]) + exp_cephes(x[off + stt]);
+            sum = pr(x[off + stt - nbase]) + pr(x[off + stt]);
         }
     }
     tr[i] = (int32_t)roundf(255.0f * sum);
 }
 
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps) {
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log) {
     const int P = 2 * nbase * (nbase + 1);
     const int n = (Tb + 1) * 2 * nbase;
-    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps);
+    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps, is_log);
+}
+
+// exp_activation_inplace (layers.c:56-66) on the meaningful rows
+__global__ void k_exp_inplace(float *x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = exp_cephes(x[i]);
+}
+void launch_exp_inplace(hipStream_t s, float *x, size_t n) {
+    hipLaunchKernelGGL(k_exp_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n);
 }
 
 // ---- debug tap: tile-interleaved -> dense [Tb][H] of one read --------------------------------

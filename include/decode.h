@@ -1,0 +1,40 @@
+/*  decode.h -- flip-flop decoding entry points of the drop-in boundary.
+ *  Same signatures and semantics as /root/reference/src/decode.h:16-38 for the flip-flop functions
+ *  (the run-length half belongs to runnie and is out of scope).
+ */
+#ifndef FFHIP_DECODE_H
+#define FFHIP_DECODE_H
+#include <stdbool.h>
+#include "flappie_matrix.h"
+#include "flappie_structures.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* decode.h:16-19 */
+static const char base_lookup[5] = { 'A', 'C', 'G', 'T', 'Z' };
+static inline char basechar(int b) { return base_lookup[b]; }
+
+/* decode.c:39-63: NUL-terminated string owned by the caller, NULL on failure */
+char *collapse_repeats(int const *path, size_t npos, int modbase);
+/* decode.c:66-79: positions pos in [1, npos) with path[pos] != path[pos-1]; 0 if an argument is NULL */
+size_t change_positions(int const *path, size_t npos, int *chpos);
+
+/* decode.c:119-204: Viterbi; path needs nblock+1 ints, qpath nblock+1 floats (qpath[0] = NAN);
+ * returns the best score or NAN on failure */
+float decode_crf_flipflop(const_flappie_matrix trans, bool combine_stays, int *path, float *qpath);
+/* decode.c:377-497: forward/backward transition posteriors, log-normalised per block */
+flappie_matrix transpost_crf_flipflop(const_flappie_matrix trans, bool return_log);
+/* decode.c:499-543: tpost holds probabilities; returns [nstate x nblock+1] int32 */
+flappie_imatrix trace_from_posterior(flappie_matrix tpost);
+
+/* layers.c:56-66 (declared in layers.h in the reference; needed between the two calls above,
+ * flappie.c:299-300) and layers.c:1029-1032 */
+void exp_activation_inplace(flappie_matrix C);
+size_t nbase_from_flipflop_nparam(size_t nparam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

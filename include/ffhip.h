@@ -121,6 +121,19 @@ int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][ns
  * (0..4) as dense [nblock][hidden] */
 int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
 
+/* ---- single-matrix decode entry points -------------------------------------------------------
+ * Used by the reference-compatible wrappers in include/decode.h.  `trans` / `scores` / `post` are
+ * host arrays in the reference's flappie_matrix image: `nblock` columns of `stride` floats, the
+ * first `nparam` = nstate*(nbase+1) of each column meaningful. */
+/* transpost_crf_flipflop (decode.c:377-497): log posterior (return_log != 0) or probabilities */
+int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nblock, size_t nparam, size_t stride,
+                    int return_log, float *post_out);
+/* decode_crf_flipflop (decode.c:119-204): path[nblock+1], qpath[nblock+1] (qpath[0] = NAN) */
+int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblock, size_t nparam, size_t stride,
+                  int combine_stays, int *path, float *qpath, float *score);
+/* trace_from_posterior (decode.c:499-543): `post` holds PROBABILITIES; out[nblock+1][nstate] packed */
+int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t nparam, size_t stride, int32_t *out);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* HIP-event timing of the kernel groups of one batch_run, on the stream they are launched on.
  * groups: 0 conv, 1 in-projection GEMMs, 2 recurrent, 3 head+CRF norm, 4 posterior, 5 viterbi+assembly */

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(HERE)
 def _declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"typedef[^;{]*;", "", text)            # function-pointer typedefs are not symbols
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if not n.startswith("__")))
 
@@ -39,7 +40,7 @@ def test_host_library_exports_reference_api():
     if not os.path.exists(path):
         pytest.skip("host layer not built yet")
     L = C.CDLL(path)
-    for hdr in ("flappie_matrix.h", "flappie_structures.h", "networks.h", "decode.h"):
+    for hdr in ("flappie_matrix.h", "flappie_structures.h", "networks.h", "decode.h", "flappie_common.h"):
         if not os.path.exists(os.path.join(ROOT, "include", hdr)):
             continue
         missing = [n for n in _declared_functions(hdr) if not hasattr(L, n)]
