@@ -42,6 +42,22 @@ def cpu_baseline(mdl, sig, budget_s=12.0, max_reads=6):
                 sample="%d of the %d synthetic reads (%d samples each), whole path, 1 thread, %.1f s" % (n, sig.shape[0], sig.shape[1], dt))
 
 
+def measured_traffic(hidden):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus
+    WRITE_SIZE, separate passes).  Counters cannot be read inside this process, so the value is the
+    profile's, keyed by shape; null when no profile of this shape is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("hidden") == hidden and t.get("nread") == NREAD and t.get("nsample") == NSAMPLE:
+            return t.get("recurrent_layer_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,10 +120,8 @@ def main():
     prof = [b.profile() for b in batches]
     eng.set_profiling(False)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from flappie_amd import shard
+    dt = shard.max_over_ranks(dt, device="cuda" if world > 1 else None)
 
     if rank == 0:
         nblock = batches[0].nblock
@@ -129,9 +143,9 @@ def main():
                                    "posterior decode + trace (BASELINE.json configs[1])" % args.hidden,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "recurrent layer (lstm step x %d)" % nblock,
+            "roofline": {"bound": "mfma", "kernel": "k_rnn_persist (one recurrent layer, %d dependent steps)" % nblock,
                          "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.hidden),
                          "flop_per_launch": flop_layer / launches_per_layer,
                          "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
                          "launches_per_layer": launches_per_layer},
