@@ -426,7 +426,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
     *b->h_abort = 0;
     if (persist_supported(m->kind, (int)Hp, eng->prop.multiProcessorCount)) {
-        const int maxt = persist_max_tiles(m->kind, (int)Hp, eng->prop.multiProcessorCount);
+        const int maxt = persist_max_tiles(m->kind, (int)Hp, eng->prop.multiProcessorCount, fused_supported(m->kind, (int)Hp));
         b->persist_concurrent_ok = 2 * b->B16 <= maxt;      // two such launches fit on the chip together
     }
     if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
@@ -515,20 +515,24 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const bool prof = b->eng->profiling != 0;
     const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->kind, Hp, b->eng->prop.multiProcessorCount);
     if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
+    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->kind, Hp);
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     for (int l = 0; l < 5; l++) {
         const RnnDev &r = m->rnn[l];
         const bool backward = (l % 2 == 0);
         float *in = b->act[cur], *out = b->act[cur ^ 1];
+        const bool fuse = use_persist && use_fused;
         if (prof) hipEventRecord(b->lev[l][0], s);
-        launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
-        b->launches[1]++;
+        if (!fuse) {
+            launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
+            b->launches[1]++;
+        }
         if (prof) hipEventRecord(b->lev[l][1], s);
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
         if (use_persist) {
             // one launch per layer (and per chunk of read tiles that fits co-resident on the chip)
-            const int maxt = persist_max_tiles(m->kind, Hp, b->eng->prop.multiProcessorCount);
+            const int maxt = persist_max_tiles(m->kind, Hp, b->eng->prop.multiProcessorCount, fuse);
             // the output doubles as the hand-off flag: pre-fill with the NaN sentinel
             HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFFFFFFFF, (size_t)Tb * Bp * Hp, s), FFHIP_EHIP);
             for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
@@ -536,8 +540,10 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 HIP_TRY(hipMemsetAsync(b->pflags, 0, persist_flag_words(Hp, nrt) * sizeof(unsigned), s), FFHIP_EHIP);
                 const bool chain = !b->persist_concurrent_ok;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
-                if (!launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode))
-                    return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
+                const bool okl = fuse
+                    ? launch_lstm_fused(s, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
+                    : launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode);
+                if (!okl) return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
             }

@@ -66,10 +66,13 @@ void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const 
 
 // persistent recurrent layer (ffhip_rnn_persist.hip): one launch per layer and chunk of read tiles
 bool persist_supported(int kind, int H, int ncu);
-int persist_max_tiles(int kind, int H, int ncu);      // read tiles one launch can take (all workgroups co-resident)
+int persist_max_tiles(int kind, int H, int ncu, int fused);      // read tiles one launch can take (all workgroups co-resident)
 bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
                         unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
 size_t persist_flag_words(int H, int nrt);
+bool fused_supported(int kind, int H);
+bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
 int persist_blocks_per_cu(int kind, int H);
 
 // head: trans = tanh(W^T h + b) / (temperature/5)

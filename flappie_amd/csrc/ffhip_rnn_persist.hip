@@ -47,6 +47,9 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 struct PersistArgs {
     const v4f *sWp;        // [Ut][K16][64] float4, A-fragment order
+    const v4f *iWp;        // fused layers: input weights, same packing
+    const float *xin;      // fused layers: layer input, tile-interleaved [Tb][B16][Ut*64]
+    const float *bias;     // fused layers: permuted bias [16*Ut]
     const v4f *xa;         // [Tb][B16][Ut][64] float4, D-fragment order
     float *hout;           // [Tb][B16][Ut*64] tile-interleaved
     unsigned *flags;       // [nrt][G] XCC ids (zeroed before launch)
@@ -278,6 +281,178 @@ k_rnn_persist(PersistArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused LSTM layer: input projection + recurrence in ONE persistent kernel.
+//
+// The recurrent chain above leaves the matrix pipes idle more than half of the time (the hand-off
+// between steps is pure latency).  The input projection Wi x(t) + b has the same FLOP count as the
+// recurrence and does not depend on it, so each wave also keeps ITS slice of Wi in registers and
+// computes the Wi x(t) half of the gate pre-activations for step i while the producers of h(i-1)
+// are still finishing: the projection disappears from the critical path, the separate GEMM kernel
+// and the 1.26 GB Xa round trip through HBM disappear altogether.
+// Per wave and step: KPW coalesced 1 KiB loads of x(t) (issued one step ahead), UPC*KPW*4 MFMAs on
+// x, then the h sweep and another UPC*KPW*4 MFMAs on h; the rest is identical to k_rnn_persist.
+template <int UPC, int KPW>
+__global__ void __launch_bounds__(256, 2)
+k_lstm_fused(PersistArgs a) {
+    __shared__ v4f part[2][4][UPC][64];
+    __shared__ int lds_abort;
+    __shared__ int lds_fast;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = a.G, Ut = a.Ut, K16 = a.K16, Tb = a.Tb;
+    int g, m;
+    {
+        const int b = blockIdx.x;
+        if ((a.nrt & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
+        else { g = b / G; m = b % G; }
+    }
+    const int rt = a.rt0 + g;
+    const int ut0 = m * UPC;
+    if (threadIdx.x == 0) lds_abort = 0;
+    if (threadIdx.x < 64) {
+        int fast_l = 0;
+        if (a.mode == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc = (xcc & 0xfu) + 1u;
+            unsigned *ids = a.flags + (size_t)g * G;
+            if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
+            unsigned v = xcc;
+            for (unsigned spin = 0; spin < 2000000u; spin++) {
+                v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
+                if (__all(v != 0u)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            fast_l = __all(v == xcc) ? 1 : 0;
+        }
+        if (lane == 0) lds_fast = fast_l;
+    }
+    // resident weights: recurrent and input slices of my rows / my K range
+    v4f wreg[UPC][KPW], wi[UPC][KPW];
+#pragma unroll
+    for (int j = 0; j < UPC; j++)
+#pragma unroll
+        for (int kk = 0; kk < KPW; kk++) {
+            const int k16 = wave * KPW + kk;
+            const int ut = ut0 + j;
+            const bool ok = (k16 < K16 && ut < Ut);
+            wreg[j][kk] = ok ? a.sWp[((size_t)ut * K16 + k16) * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
+            wi[j][kk] = ok ? a.iWp[((size_t)ut * K16 + k16) * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
+        }
+    const int my_tile = (wave < UPC && ut0 + wave < Ut) ? wave : -1;
+    const int q = lane >> 4, rl = lane & 15;
+    const size_t tile_floats = (size_t)Ut * 64;
+    v4f bias = { 0.f, 0.f, 0.f, 0.f };
+    if (my_tile >= 0) bias = *(const v4f *)(a.bias + (size_t)(ut0 + my_tile) * 16 + q * 4);
+    float c = 0.0f;
+    __syncthreads();
+    const bool fast = lds_fast != 0;
+    __builtin_amdgcn_s_setprio(3);
+    const bool have_k = wave * KPW < K16;
+
+    // x(t) slices are plain data from the previous kernel: ordinary coalesced loads, one step ahead
+    v4f xf[KPW];
+    {
+        const int t0 = a.backward ? Tb - 1 : 0;
+        const v4f *xp = (const v4f *)(a.xin + ((size_t)t0 * a.B16 + rt) * tile_floats);
+#pragma unroll
+        for (int kk = 0; kk < KPW; kk++) {
+            const int k16 = wave * KPW + kk;
+            xf[kk] = (k16 < K16) ? xp[(size_t)k16 * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
+        }
+    }
+
+    for (int i = 0; i < Tb; i++) {
+        const int t = a.backward ? Tb - 1 - i : i;
+        const int tp = a.backward ? t + 1 : t - 1;
+        v4f acc[UPC];
+#pragma unroll
+        for (int j = 0; j < UPC; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        // ---- projection half: independent of the recurrence, runs under the hand-off latency
+        if (have_k) {
+#pragma unroll
+            for (int kk = 0; kk < KPW; kk++)
+#pragma unroll
+                for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wi[j][kk], xf[kk], acc[j]);
+            if (i + 1 < Tb) {
+                const int tn = a.backward ? t - 1 : t + 1;
+                const v4f *xp = (const v4f *)(a.xin + ((size_t)tn * a.B16 + rt) * tile_floats);
+#pragma unroll
+                for (int kk = 0; kk < KPW; kk++) {
+                    const int k16 = wave * KPW + kk;
+                    if (k16 < K16) xf[kk] = xp[(size_t)k16 * 64 + lane];
+                }
+            }
+        }
+        // ---- recurrent half
+        if (i > 0 && have_k) {
+            const float *hp = a.hout + ((size_t)tp * a.B16 + rt) * tile_floats;
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(tile_floats * 4), 0x00020000);
+            v4u raw[KPW];
+            bool timed_out = false;
+            for (unsigned spin = 0;; spin++) {
+                bool ok = true;
+#pragma unroll
+                for (int kk = 0; kk < KPW; kk++) {
+                    const int k16 = wave * KPW + kk;
+                    raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
+                }
+#pragma unroll
+                for (int kk = 0; kk < KPW; kk++)
+                    ok = ok && raw[kk].x != kSentinel && raw[kk].y != kSentinel && raw[kk].z != kSentinel && raw[kk].w != kSentinel;
+                if (__all(ok)) break;
+                if (spin > 3000000u || (spin & 255u) == 255u) {
+                    const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                    if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (timed_out) {
+                if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KPW; kk++) {
+                    const v4f bf = __builtin_bit_cast(v4f, raw[kk]);
+#pragma unroll
+                    for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wreg[j][kk], bf, acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (lds_abort) return;
+        if (my_tile >= 0) {
+            v4f s = bias;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
+            const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+            const float tanh_g = (L.z + L.z) - 1.0f;
+            const float forget = L.y * c;
+            const float update = L.x * tanh_g;
+            c = forget + update;
+            const float h = L.w * tanh_ref(c);
+            v4f hv;
+            hv.x = __shfl(h, rl);
+            hv.y = __shfl(h, rl + 16);
+            hv.z = __shfl(h, rl + 32);
+            hv.w = __shfl(h, rl + 48);
+            float *ho = a.hout + ((size_t)t * a.B16 + rt) * tile_floats + (size_t)(ut0 + my_tile) * 64 + rl * 4;
+            if (lane < 16) {
+                if (fast) *(v4f *)ho = hv;
+                else {
+                    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hout + ((size_t)t * a.B16 + rt) * tile_floats), 0, (int)(tile_floats * 4), 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, ((ut0 + my_tile) * 64 + rl * 4) * 4, 0, 16 /*sc1*/);
+                }
+            }
+        }
+    }
+}
+
 unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING builds)
 
 // ------------------------------------------------------------------------------------------
@@ -344,8 +519,9 @@ int persist_blocks_per_cu(int kind, int H) {
     return n;
 }
 
-int persist_max_tiles(int kind, int H, int ncu) {
+int persist_max_tiles(int kind, int H, int ncu, int fused) {
     const int G = pick_group(H / 4);
+    if (fused) return (2 * ncu) / G;          // k_lstm_fused: launch_bounds(256,2), 240 VGPRs at H = 384
     // every workgroup of a launch must be co-resident because groups spin on each other: at least two
     // per CU are guaranteed (launch_bounds(256,2), <= 33 KiB LDS); use what the occupancy query admits.
     int per_cu = persist_blocks_per_cu(kind, H);
@@ -354,11 +530,48 @@ int persist_max_tiles(int kind, int H, int ncu) {
     return (per_cu * ncu) / G;
 }
 
+// fused projection+recurrence needs 2*UPC*KPW weight fragments per lane in VGPRs next to the working
+// set; beyond 18 fragment pairs (H = 384) two workgroups per CU no longer fit in 256 VGPRs.
+bool fused_supported(int kind, int H) {
+    if (kind != 0 || H % 16 != 0) return false;
+    const int Ut = H / 4, K16 = H / 16;
+    const int G = pick_group(Ut), UPC = Ut / G, kpw = pick_kpw(K16);
+    return UPC <= 4 && kpw <= 8 && UPC * kpw <= 18;
+}
+
+template <int UPC>
+static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
+#define FUSED_CASE(K) case K: if (UPC * K <= 18) { hipLaunchKernelGGL((k_lstm_fused<UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
+    switch (kpw) {
+    FUSED_CASE(1) FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(6) FUSED_CASE(8)
+    default: return false;
+    }
+#undef FUSED_CASE
+}
+
+bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
+    PersistArgs a;
+    a.sWp = (const v4f *)sWp; a.iWp = (const v4f *)iWp; a.bias = bias; a.xin = xin; a.xa = nullptr; a.hout = hout;
+    a.flags = flags; a.abort_word = abort_word;
+    a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
+    a.backward = backward; a.mode = mode; a.dbg = nullptr;
+    const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
+    switch (UPC) {
+    case 1: return dispatch_fused<1>(s, a, kpw);
+    case 2: return dispatch_fused<2>(s, a, kpw);
+    case 3: return dispatch_fused<3>(s, a, kpw);
+    case 4: return dispatch_fused<4>(s, a, kpw);
+    }
+    return false;
+}
+
 // One recurrent layer over read tiles [rt0, rt0+nrt).  nrt <= persist_max_tiles().
 bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
                         unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
     PersistArgs a;
-    a.sWp = (const v4f *)sWp; a.xa = (const v4f *)xa; a.hout = hout; a.flags = flags; a.abort_word = abort_word;
+    a.sWp = (const v4f *)sWp; a.iWp = nullptr; a.xin = nullptr; a.bias = nullptr;
+    a.xa = (const v4f *)xa; a.hout = hout; a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward;
     a.mode = mode;
