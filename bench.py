@@ -42,7 +42,7 @@ def cpu_baseline(mdl, sig, budget_s=12.0, max_reads=6):
                 sample="%d of the %d synthetic reads (%d samples each), whole path, 1 thread, %.1f s" % (n, sig.shape[0], sig.shape[1], dt))
 
 
-def measured_traffic(hidden):
+def measured_traffic(hidden, fused):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus
     WRITE_SIZE, separate passes).  Counters cannot be read inside this process, so the value is the
@@ -51,7 +51,7 @@ def measured_traffic(hidden):
     try:
         with open(path) as fh:
             t = json.load(fh)
-        if t.get("hidden") == hidden and t.get("nread") == NREAD and t.get("nsample") == NSAMPLE:
+        if t.get("hidden") == hidden and t.get("nread") == NREAD and t.get("nsample") == NSAMPLE and bool(t.get("fused")) == fused:
             return t.get("recurrent_layer_hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
@@ -126,13 +126,17 @@ def main():
     if rank == 0:
         nblock = batches[0].nblock
         value = world * args.steps * NREAD * NSAMPLE / dt / 1e6
-        # dominant kernel: the recurrent layer.  Algorithmic work: 2*H*4H FLOP per read per block
-        # (SURVEY.md section 8d), nblock blocks, NREAD reads per launch group; 5 layers per step.
+        # dominant kernel: one recurrent layer.  Algorithmic work per read per block:
+        # 2*H*4H FLOP for the recurrence, and the same again for the input projection when the layer
+        # runs fused (projection and recurrence in one persistent launch; `inproj` then has 0 launches).
         rec = prof[-1]["recurrent"]
-        flop_layer = 2.0 * args.hidden * 4 * args.hidden * NREAD * nblock
+        fused = prof[-1]["inproj"]["launches"] == 0
+        flop_layer = (2.0 if fused else 1.0) * 2.0 * args.hidden * 4 * args.hidden * NREAD * nblock
         launches_per_layer = rec["launches"] / 5.0
         ms_layer = rec["ms"] / 5.0
         achieved = flop_layer / (ms_layer * 1e-3) / 1e12
+        kname = ("k_lstm_fused (input projection + recurrence of one layer, %d dependent steps)" if fused
+                 else "k_rnn_persist (recurrence of one layer, %d dependent steps)") % nblock
         out = {
             "metric": "Msamples/s basecalled (r941_native, 4k-sample chunks)",
             "value": round(value, 4), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -143,9 +147,9 @@ def main():
                                    "posterior decode + trace (BASELINE.json configs[1])" % args.hidden,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "k_rnn_persist (one recurrent layer, %d dependent steps)" % nblock,
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.hidden),
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.hidden, fused),
                          "flop_per_launch": flop_layer / launches_per_layer,
                          "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
                          "launches_per_layer": launches_per_layer},

@@ -56,6 +56,7 @@ struct PersistArgs {
     unsigned *abort_word;  // != 0 -> a wait timed out
     int Tb, B16, Ut, K16, G, rt0, nrt, backward;
     unsigned long long *dbg; // optional phase timestamps [Tb][4 waves][6]
+    int fast_gates;        // opt-in (FFHIP_FAST_GATES=1): hardware exp2/rcp gate math, NOT bit-compatible with the reference's exp_ps
     int mode;              // 0 = verify placement, use the L2-local hand-off when a group shares an XCD; 1 = always write-through
 };
 
@@ -430,12 +431,22 @@ k_lstm_fused(PersistArgs a) {
             v4f s = bias;
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
-            const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
-            const float tanh_g = (L.z + L.z) - 1.0f;
-            const float forget = L.y * c;
-            const float update = L.x * tanh_g;
-            c = forget + update;
-            const float h = L.w * tanh_ref(c);
+            float h;
+            if (a.fast_gates) {
+                // hardware exp2/rcp (1 ulp each): ~6x fewer VALU instructions than the cephes-exact path
+                auto sg = [](float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); };
+                const float si = sg(s.x), sf = sg(s.y), so = sg(s.w);
+                const float tg = 2.0f * sg(s.z + s.z) - 1.0f;
+                c = sf * c + si * tg;
+                h = so * (2.0f * sg(c + c) - 1.0f);
+            } else {
+                const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const float tanh_g = (L.z + L.z) - 1.0f;
+                const float forget = L.y * c;
+                const float update = L.x * tanh_g;
+                c = forget + update;
+                h = L.w * tanh_ref(c);
+            }
             v4f hv;
             hv.x = __shfl(h, rl);
             hv.y = __shfl(h, rl + 16);
@@ -556,6 +567,7 @@ bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, cons
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward; a.mode = mode; a.dbg = nullptr;
+    a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     switch (UPC) {
     case 1: return dispatch_fused<1>(s, a, kpw);
@@ -575,6 +587,7 @@ bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float 
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward;
     a.mode = mode;
+    a.fast_gates = 0;
     a.dbg = g_persist_dbg;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
