@@ -82,5 +82,14 @@ if __name__ == "__main__":
         parity(M.NET_GRUMOD5, 64, 2000, 4, eng)
         parity(M.NET_LSTM5, 64, 1003, 2, eng, flags=B.RUN_VITERBI_ONLY)
         parity(M.NET_LSTM5, 36, 601, 17, eng)
+    if "nread" in what:
+        for nr in (64, 128, 256):
+            timing(eng, 384, nr, 4000, steps=2)
     if "timing" in what:
         timing(eng, 384, 256, 4000)
+
+
+def timing_nread():
+    eng = B.Engine(0)
+    for nread in (64, 128, 256):
+        timing(eng, 384, nread, 4000, steps=2)
