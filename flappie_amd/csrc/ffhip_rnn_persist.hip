@@ -56,7 +56,6 @@ struct PersistArgs {
     unsigned *abort_word;  // != 0 -> a wait timed out
     int Tb, B16, Ut, K16, G, rt0, nrt, backward;
     unsigned long long *dbg; // optional phase timestamps [Tb][4 waves][6]
-    int variant;           // fused kernels: 1 = two workgroups per CU, 2 = wave-specialised, two read tiles per workgroup
     int fast_gates;        // opt-in (FFHIP_FAST_GATES=1): hardware exp2/rcp gate math, NOT bit-compatible with the reference's exp_ps
     int mode;              // 0 = verify placement, use the L2-local hand-off when a group shares an XCD; 1 = always write-through
 };
@@ -466,239 +465,6 @@ k_lstm_fused(PersistArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Fused LSTM layer, wave-specialised: ONE 8-wave workgroup per CU drives TWO read tiles.
-//
-// k_lstm_fused above relies on two independent workgroups per CU to hide each other's hand-off
-// latency; measured, the two run nearly in phase (1 WG/CU: 3.7 us per step, 2 WG/CU: 5.96 us for
-// both, matrix pipes 66 % busy) and on gfx950 the f32 MFMA never co-executes with VALU work of the
-// other wave (SQ_VALU_MFMA_COEXEC_CYCLES = 0).  Here the overlap is explicit:
-//   waves 0..3  MATRIX waves.  Hold their K slice of Wi and sW for the workgroup's rows in VGPRs and do
-//               nothing but: x-part(A) h-part(A) x-part(B) h-part(B) x-part(A) ...  Between the
-//               h-part of a tile at step i and its h-part at step i+1 lie three other MFMA blocks
-//               (~6900 cycles): the tile's gate math and its hand-off through L2 happen underneath.
-//   waves 4..6  GATE waves, one per unit tile, on the SIMDs' second wave slot: wait (LDS counter) for
-//               the four partial sums of a tile, add bias, gate math, cell state in registers for both
-//               read tiles, publish h.
-// Synchronisation inside the workgroup is by monotonic LDS counters only (no s_barrier in the loop);
-// between workgroups it is the same payload-as-flag protocol as above.
-template <int UPC, int KPW>
-__global__ void __launch_bounds__(512, 2)
-k_lstm_fused2(PersistArgs a) {
-    __shared__ v4f part[2][2][4][UPC][64];       // [slot][parity][matrix wave][unit tile][lane]
-    __shared__ unsigned cnt_part[2][4];          // per matrix wave: steps whose partial sums are in LDS (a wave
-                                                 // without a K slice may run ahead, so one shared counter would lie)
-    __shared__ unsigned cnt_gate[2];             // partial sets consumed, +1 per gate wave per step
-    __shared__ int lds_abort;
-    __shared__ int lds_fast;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int G = a.G, Ut = a.Ut, K16 = a.K16, Tb = a.Tb;
-    const int ngrp = (a.nrt + 1) >> 1;
-    int g, m;
-    {
-        const int b = blockIdx.x;
-        if ((ngrp & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
-        else { g = b / G; m = b % G; }
-    }
-    const int nslot = (2 * g + 1 < a.nrt) ? 2 : 1;
-    const int rt0 = a.rt0 + 2 * g;
-    const int ut0 = m * UPC;
-    if (threadIdx.x < 8) cnt_part[threadIdx.x >> 2][threadIdx.x & 3] = 0;
-    if (threadIdx.x == 0) { lds_abort = 0; cnt_gate[0] = cnt_gate[1] = 0; }
-    if (threadIdx.x < 64) {
-        int fast_l = 0;
-        if (a.mode == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc = (xcc & 0xfu) + 1u;
-            unsigned *ids = a.flags + (size_t)g * G;
-            if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
-            unsigned v = xcc;
-            for (unsigned spin = 0; spin < 2000000u; spin++) {
-                v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
-                if (__all(v != 0u)) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            fast_l = __all(v == xcc) ? 1 : 0;
-        }
-        if (lane == 0) lds_fast = fast_l;
-    }
-    __syncthreads();
-    const bool fast = lds_fast != 0;
-    const size_t tile_floats = (size_t)Ut * 64;
-    const int ngate = min(UPC, Ut - ut0);        // gate waves in use (unit tiles this member really owns)
-    volatile unsigned *vcnt_part = &cnt_part[0][0];
-    volatile unsigned *vcnt_gate = cnt_gate;
-    volatile int *vabort = &lds_abort;
-
-    if (wave < 4) {
-        // =============================== matrix wave ===============================
-        const bool have_k = wave * KPW < K16;
-        v4f wreg[UPC][KPW], wi[UPC][KPW];
-#pragma unroll
-        for (int j = 0; j < UPC; j++)
-#pragma unroll
-            for (int kk = 0; kk < KPW; kk++) {
-                const int k16 = wave * KPW + kk;
-                const int ut = ut0 + j;
-                const bool ok = (k16 < K16 && ut < Ut);
-                wreg[j][kk] = ok ? a.sWp[((size_t)ut * K16 + k16) * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
-                wi[j][kk] = ok ? a.iWp[((size_t)ut * K16 + k16) * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
-            }
-        __builtin_amdgcn_s_setprio(1);
-        // x(t) fragments are fetched one MFMA block ahead (blocks run (i,A) (i,B) (i+1,A) ...)
-        v4f xf_next[KPW];
-        auto load_x = [&](int step, int slot) {
-            const int tt = a.backward ? Tb - 1 - step : step;
-            const v4f *xp = (const v4f *)(a.xin + ((size_t)tt * a.B16 + rt0 + slot) * tile_floats);
-#pragma unroll
-            for (int kk = 0; kk < KPW; kk++) {
-                const int k16 = wave * KPW + kk;
-                xf_next[kk] = (k16 < K16) ? xp[(size_t)k16 * 64 + lane] : (v4f){ 0.f, 0.f, 0.f, 0.f };
-            }
-        };
-        if (have_k) load_x(0, 0);
-        for (int i = 0; i < Tb; i++) {
-            const int t = a.backward ? Tb - 1 - i : i;
-            const int tp = a.backward ? t + 1 : t - 1;
-            for (int slot = 0; slot < nslot; slot++) {
-                const int rt = rt0 + slot;
-                v4f acc[UPC];
-#pragma unroll
-                for (int j = 0; j < UPC; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-                if (have_k) {
-                    // ---- speculative first sweep of h(t-1): issued BEFORE the projection MFMAs so that its
-                    // L2 round trip is covered by them (the data was published several thousand cycles ago)
-                    v4u raw[KPW];
-                    __amdgpu_buffer_rsrc_t rsrc;
-                    if (i > 0) {
-                        const float *hp = a.hout + ((size_t)tp * a.B16 + rt) * tile_floats;
-                        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(tile_floats * 4), 0x00020000);
-#pragma unroll
-                        for (int kk = 0; kk < KPW; kk++) {
-                            const int k16 = wave * KPW + kk;
-                            raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
-                        }
-                    }
-                    // ---- projection half (x is plain data of the previous kernel, fetched one block ahead)
-                    v4f xf[KPW];
-#pragma unroll
-                    for (int kk = 0; kk < KPW; kk++) xf[kk] = xf_next[kk];
-                    {
-                        const int ns = (slot + 1 < nslot) ? slot + 1 : 0;
-                        const int ni = (slot + 1 < nslot) ? i : i + 1;
-                        if (ni < Tb) load_x(ni, ns);
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < KPW; kk++)
-#pragma unroll
-                        for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wi[j][kk], xf[kk], acc[j]);
-                    // ---- recurrent half
-                    if (i > 0) {
-                        bool timed_out = false;
-                        for (unsigned spin = 0;; spin++) {
-                            bool ok = true;
-#pragma unroll
-                            for (int kk = 0; kk < KPW; kk++)
-                                ok = ok && raw[kk].x != kSentinel && raw[kk].y != kSentinel && raw[kk].z != kSentinel && raw[kk].w != kSentinel;
-                            if (__all(ok)) break;
-                            if (spin > 3000000u || (spin & 255u) == 255u) {
-                                const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
-                                if (ab != 0u || spin > 3000000u || *vabort) { timed_out = true; break; }
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                            for (int kk = 0; kk < KPW; kk++) {
-                                const int k16 = wave * KPW + kk;
-                                raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
-                            }
-                        }
-                        if (timed_out) {
-                            if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); *vabort = 1; }
-                            return;
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < KPW; kk++) {
-                            const v4f bf = __builtin_bit_cast(v4f, raw[kk]);
-#pragma unroll
-                            for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wreg[j][kk], bf, acc[j]);
-                        }
-                    }
-                }
-                // WAR on the parity buffer: the gate waves must have consumed step i-2 of this slot
-                if (i >= 2) {
-                    const unsigned need = (unsigned)ngate * (unsigned)(i - 1);
-                    for (unsigned spin = 0; vcnt_gate[slot] < need; spin++) {
-                        if (*vabort || spin > 50000000u) { if (lane == 0) *vabort = 1; return; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < UPC; j++) part[slot][i & 1][wave][j][lane] = acc[j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) vcnt_part[slot * 4 + wave] = (unsigned)(i + 1);
-            }
-        }
-    } else {
-        // =============================== gate wave ===============================
-        const int j = wave - 4;
-        if (j >= ngate) return;
-        const int q = lane >> 4, rl = lane & 15;
-        const v4f bias = *(const v4f *)(a.bias + (size_t)(ut0 + j) * 16 + q * 4);
-        float c[2] = { 0.0f, 0.0f };
-        __builtin_amdgcn_s_setprio(3);
-        for (int i = 0; i < Tb; i++) {
-            const int t = a.backward ? Tb - 1 - i : i;
-#pragma unroll
-            for (int slot = 0; slot < 2; slot++) {
-                if (slot >= nslot) continue;
-                const int rt = rt0 + slot;
-                const unsigned need = (unsigned)(i + 1);
-                for (unsigned spin = 0;; spin++) {
-                    const unsigned f = vcnt_part[slot * 4 + (lane & 3)];
-                    if (__all(f >= need)) break;
-                    if (*vabort || spin > 50000000u) { if (lane == 0) *vabort = 1; return; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                v4f s = bias;
-#pragma unroll
-                for (int w2 = 0; w2 < 4; w2++) s = s + part[slot][i & 1][w2][j][lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) atomicAdd(&cnt_gate[slot], 1u);
-                float h;
-                if (a.fast_gates) {
-                    auto sg = [](float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); };
-                    const float si = sg(s.x), sf = sg(s.y), so = sg(s.w);
-                    const float tg = 2.0f * sg(s.z + s.z) - 1.0f;
-                    c[slot] = sf * c[slot] + si * tg;
-                    h = so * (2.0f * sg(c[slot] + c[slot]) - 1.0f);
-                } else {
-                    const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
-                    const float tanh_g = (L.z + L.z) - 1.0f;
-                    const float forget = L.y * c[slot];
-                    const float update = L.x * tanh_g;
-                    c[slot] = forget + update;
-                    h = L.w * tanh_ref(c[slot]);
-                }
-                v4f hv;
-                hv.x = __shfl(h, rl);
-                hv.y = __shfl(h, rl + 16);
-                hv.z = __shfl(h, rl + 32);
-                hv.w = __shfl(h, rl + 48);
-                float *hbase = a.hout + ((size_t)t * a.B16 + rt) * tile_floats;
-                if (lane < 16) {
-                    if (fast) *(v4f *)(hbase + (size_t)(ut0 + j) * 64 + rl * 4) = hv;
-                    else {
-                        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)hbase, 0, (int)(tile_floats * 4), 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, ((ut0 + j) * 64 + rl * 4) * 4, 0, 16 /*sc1*/);
-                    }
-                }
-            }
-        }
-    }
-}
-
 unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING builds)
 
 // ------------------------------------------------------------------------------------------
@@ -787,10 +553,7 @@ bool fused_supported(int kind, int H) {
 
 template <int UPC>
 static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
-#define FUSED_CASE(K) case K: if (UPC * K <= 18) { \
-        if (a.variant == 2) hipLaunchKernelGGL((k_lstm_fused2<UPC, (UPC * K <= 18 ? K : 1)>), dim3(((a.nrt + 1) / 2) * a.G), dim3(512), 0, s, a); \
-        else hipLaunchKernelGGL((k_lstm_fused<UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); \
-        return true; } return false;
+#define FUSED_CASE(K) case K: if (UPC * K <= 18) { hipLaunchKernelGGL((k_lstm_fused<UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
     switch (kpw) {
     FUSED_CASE(1) FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(6) FUSED_CASE(8)
     default: return false;
@@ -806,7 +569,6 @@ bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, cons
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward; a.mode = mode; a.dbg = nullptr;
     a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
-    a.variant = getenv("FFHIP_FUSED_VARIANT") ? atoi(getenv("FFHIP_FUSED_VARIANT")) : 2;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     switch (UPC) {
     case 1: return dispatch_fused<1>(s, a, kpw);
@@ -827,7 +589,6 @@ bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float 
     a.backward = backward;
     a.mode = mode;
     a.fast_gates = 0;
-    a.variant = 0;
     a.dbg = g_persist_dbg;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
