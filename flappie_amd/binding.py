@@ -21,6 +21,7 @@ RUN_NO_TRACE = 2
 RUN_NO_DECODE = 4
 RUN_STEPWISE_RNN = 8
 RUN_KEEP_ACTS = 16
+RUN_UNFUSED_RNN = 32
 NGROUP = 6
 GROUP_NAMES = ("conv", "inproj", "recurrent", "head_crf", "posterior", "viterbi_assembly")
 

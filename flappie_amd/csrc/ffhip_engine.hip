@@ -541,7 +541,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = !b->persist_concurrent_ok;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 const bool okl = fuse
-                    ? launch_lstm_fused(s, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
+                    ? launch_lstm_fused(s, m->kind, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
                     : launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode);
                 if (!okl) return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }

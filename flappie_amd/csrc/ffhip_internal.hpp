@@ -71,7 +71,7 @@ bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float 
                         unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
 size_t persist_flag_words(int H, int nrt);
 bool fused_supported(int kind, int H);
-bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
+bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
 int persist_blocks_per_cu(int kind, int H);
 

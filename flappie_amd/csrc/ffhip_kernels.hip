@@ -624,10 +624,95 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
 }
 
 
+
+// ---- any nstate: same max + log(sum exp) formulation with the segmented reductions through LDS ----
+// Used for the 5-base (ACGTZ, nstate 10) models where the 8-lane butterflies above do not apply.
+// State lanes (lane < nstate) own one state each; entry lanes (lane < P) own one transition score.
+__global__ void __launch_bounds__(64)
+k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf,
+                int Tb, int nbase, int P, int Ps) {
+    __shared__ float term[64];
+    __shared__ float svec[kMaxState];
+    const int lane = threadIdx.x;
+    const int ns = 2 * nbase, off = nbase * ns;
+    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
+    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const bool valid = lane < P, is_state = lane < ns, is_flip = lane < nbase;
+    const int src = lane % ns;                  // source state of entry `lane` (off is a multiple of ns)
+    int dst;                                    // destination state of entry `lane`
+    if (lane < off) dst = lane / ns;
+    else { const int idx = lane - off; dst = (idx < nbase) ? idx + nbase : idx; }
+    if (!valid) dst = 0;
+
+    // forwards
+    if (is_state) { F[lane] = 0.0f; svec[lane] = 0.0f; }
+    __syncthreads();
+    float s_next = valid ? T[lane] : 0.0f;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float s = s_next;
+        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+        term[lane] = valid ? s + svec[src] : -INFINITY;
+        __syncthreads();
+        float val = 0.0f;
+        if (is_state) {
+            if (is_flip) {
+                float m = term[lane * ns];
+                for (int f = 1; f < ns; f++) m = fmaxf(m, term[lane * ns + f]);
+                float e = 0.0f;
+                for (int f = 0; f < ns; f++) e += expf(term[lane * ns + f] - m);
+                val = m + logf(e);
+            } else {
+                const float a = term[off + lane], b = term[off + lane - nbase];
+                const float m = fmaxf(a, b);
+                val = m + logf(expf(a - m) + expf(b - m));
+            }
+            F[(size_t)(blk + 1) * kMaxState + lane] = val;
+        }
+        __syncthreads();
+        if (is_state) svec[lane] = val;
+        __syncthreads();
+    }
+
+    // backwards
+    if (is_state) svec[lane] = 0.0f;
+    __syncthreads();
+    for (int blk = Tb; blk > 0; blk--) {
+        const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
+        const float f = valid ? F[(size_t)(blk - 1) * kMaxState + src] : 0.0f;
+        const float pb_to = svec[dst];
+        if (valid) Pp[(size_t)(blk - 1) * Ps + lane] = (f + pb_to) + s;
+        term[lane] = valid ? s + pb_to : -INFINITY;
+        __syncthreads();
+        float cur = 0.0f;
+        if (is_state) {
+            float m = term[off + lane];
+            for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, term[b1 * ns + lane]);
+            float e = expf(term[off + lane] - m);
+            for (int b1 = 0; b1 < nbase; b1++) e += expf(term[b1 * ns + lane] - m);
+            cur = m + logf(e);
+        }
+        __syncthreads();
+        if (is_state) svec[lane] = cur;
+        __syncthreads();
+    }
+    for (int blk = lane; blk < Tb; blk += 64) {
+        float *x = Pp + (size_t)blk * Ps;
+        float m = x[0];
+        for (int r = 1; r < P; r++) m = fmaxf(m, x[r]);
+        float sum = 0.0f;
+        for (int r = 0; r < P; r++) sum += expf(x[r] - m);
+        const float lse = m + logf(sum);
+        for (int r = 0; r < P; r++) x[r] -= lse;
+    }
+}
+
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb);
+    else if (!getenv("FFHIP_EXACT_ORDER"))
+        hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
     else
         hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
 }

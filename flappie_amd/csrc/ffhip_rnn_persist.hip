@@ -294,7 +294,7 @@ k_rnn_persist(PersistArgs a) {
 // and the 1.26 GB Xa round trip through HBM disappear altogether.
 // Per wave and step: KPW coalesced 1 KiB loads of x(t) (issued one step ahead), UPC*KPW*4 MFMAs on
 // x, then the h sweep and another UPC*KPW*4 MFMAs on h; the rest is identical to k_rnn_persist.
-template <int UPC, int KPW>
+template <int KIND, int UPC, int KPW>
 __global__ void __launch_bounds__(256, 2)
 k_lstm_fused(PersistArgs a) {
     __shared__ v4f part[2][4][UPC][64];
@@ -347,7 +347,7 @@ k_lstm_fused(PersistArgs a) {
     const size_t tile_floats = (size_t)Ut * 64;
     v4f bias = { 0.f, 0.f, 0.f, 0.f };
     if (my_tile >= 0) bias = *(const v4f *)(a.bias + (size_t)(ut0 + my_tile) * 16 + q * 4);
-    float c = 0.0f;
+    float c = 0.0f, hprev_own = 0.0f;
     __syncthreads();
     const bool fast = lds_fast != 0;
     __builtin_amdgcn_s_setprio(3);
@@ -369,14 +369,22 @@ k_lstm_fused(PersistArgs a) {
         const int t = a.backward ? Tb - 1 - i : i;
         const int tp = a.backward ? t + 1 : t - 1;
         v4f acc[UPC];
+        v4f accx[KIND == 1 ? UPC : 1];       // GRUmod keeps the projection apart: its candidate row must not mix with sW h
 #pragma unroll
         for (int j = 0; j < UPC; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        if (KIND == 1) {
+#pragma unroll
+            for (int j = 0; j < UPC; j++) accx[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        }
         // ---- projection half: independent of the recurrence, runs under the hand-off latency
         if (have_k) {
 #pragma unroll
             for (int kk = 0; kk < KPW; kk++)
 #pragma unroll
-                for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wi[j][kk], xf[kk], acc[j]);
+                for (int j = 0; j < UPC; j++) {
+                    if (KIND == 1) accx[j] = mfma4p(wi[j][kk], xf[kk], accx[j]);
+                    else acc[j] = mfma4p(wi[j][kk], xf[kk], acc[j]);
+                }
             if (i + 1 < Tb) {
                 const int tn = a.backward ? t - 1 : t + 1;
                 const v4f *xp = (const v4f *)(a.xin + ((size_t)tn * a.B16 + rt) * tile_floats);
@@ -421,6 +429,11 @@ k_lstm_fused(PersistArgs a) {
                 }
             }
         }
+        if (KIND == 1) {
+            // rows (z, r, candidate, -): pack {z: x+h, r: x+h, u = (sW h)_c, x_c = (Wi x)_c}; row 3 is free
+#pragma unroll
+            for (int j = 0; j < UPC; j++) acc[j] = (v4f){ acc[j].x + accx[j].x, acc[j].y + accx[j].y, acc[j].z, accx[j].z };
+        }
 #pragma unroll
         for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -428,11 +441,20 @@ k_lstm_fused(PersistArgs a) {
         asm volatile("" ::: "memory");
         if (lds_abort) return;
         if (my_tile >= 0) {
-            v4f s = bias;
+            v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
             float h;
-            if (a.fast_gates) {
+            if (KIND == 1) {
+                // layers.c:690-714 with the bias rows (z, r, candidate)
+                const float z = logistic_ref(s.x + bias.x);
+                const float r = logistic_ref(s.y + bias.y);
+                float hbar = r * s.z + (s.w + bias.z);
+                hbar = tanh_ref(hbar);
+                h = z * hprev_own + (1.0f - z) * hbar;
+                hprev_own = h;
+            } else if (a.fast_gates) {
+                s = s + bias;
                 // hardware exp2/rcp (1 ulp each): ~6x fewer VALU instructions than the cephes-exact path
                 auto sg = [](float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); };
                 const float si = sg(s.x), sf = sg(s.y), so = sg(s.w);
@@ -440,6 +462,7 @@ k_lstm_fused(PersistArgs a) {
                 c = sf * c + si * tg;
                 h = so * (2.0f * sg(c + c) - 1.0f);
             } else {
+                s = s + bias;
                 const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
                 const float tanh_g = (L.z + L.z) - 1.0f;
                 const float forget = L.y * c;
@@ -545,15 +568,15 @@ int persist_max_tiles(int kind, int H, int ncu, int fused) {
 // fused projection+recurrence needs 2*UPC*KPW weight fragments per lane in VGPRs next to the working
 // set; beyond 18 fragment pairs (H = 384) two workgroups per CU no longer fit in 256 VGPRs.
 bool fused_supported(int kind, int H) {
-    if (kind != 0 || H % 16 != 0) return false;
+    if ((kind != 0 && kind != 1) || H % 16 != 0) return false;
     const int Ut = H / 4, K16 = H / 16;
     const int G = pick_group(Ut), UPC = Ut / G, kpw = pick_kpw(K16);
     return UPC <= 4 && kpw <= 8 && UPC * kpw <= 18;
 }
 
-template <int UPC>
+template <int KIND, int UPC>
 static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
-#define FUSED_CASE(K) case K: if (UPC * K <= 18) { hipLaunchKernelGGL((k_lstm_fused<UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
+#define FUSED_CASE(K) case K: if (UPC * K <= 18) { hipLaunchKernelGGL((k_lstm_fused<KIND, UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
     switch (kpw) {
     FUSED_CASE(1) FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(6) FUSED_CASE(8)
     default: return false;
@@ -561,7 +584,7 @@ static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
 #undef FUSED_CASE
 }
 
-bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
+bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
     PersistArgs a;
     a.sWp = (const v4f *)sWp; a.iWp = (const v4f *)iWp; a.bias = bias; a.xin = xin; a.xa = nullptr; a.hout = hout;
@@ -570,11 +593,20 @@ bool launch_lstm_fused(hipStream_t s, const float4 *sWp, const float4 *iWp, cons
     a.backward = backward; a.mode = mode; a.dbg = nullptr;
     a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
-    switch (UPC) {
-    case 1: return dispatch_fused<1>(s, a, kpw);
-    case 2: return dispatch_fused<2>(s, a, kpw);
-    case 3: return dispatch_fused<3>(s, a, kpw);
-    case 4: return dispatch_fused<4>(s, a, kpw);
+    if (kind == 0) {
+        switch (UPC) {
+        case 1: return dispatch_fused<0, 1>(s, a, kpw);
+        case 2: return dispatch_fused<0, 2>(s, a, kpw);
+        case 3: return dispatch_fused<0, 3>(s, a, kpw);
+        case 4: return dispatch_fused<0, 4>(s, a, kpw);
+        }
+    } else {
+        switch (UPC) {
+        case 1: return dispatch_fused<1, 1>(s, a, kpw);
+        case 2: return dispatch_fused<1, 2>(s, a, kpw);
+        case 3: return dispatch_fused<1, 3>(s, a, kpw);
+        case 4: return dispatch_fused<1, 4>(s, a, kpw);
+        }
     }
     return false;
 }

@@ -134,6 +134,25 @@ def test_against_committed_vectors(B, engine, golden_dir, tag):
         b.close(); dm.close()
 
 
+@pytest.mark.parametrize("kind,hidden", [(M.NET_LSTM5, 96), (M.NET_GRUMOD5, 64)])
+def test_recurrent_kernel_variants_agree(B, engine, kind, hidden):
+    """Three implementations of the recurrent stack must agree to rounding: the fused persistent
+    layer (projection + recurrence in one launch), the persistent recurrence behind a separate
+    projection GEMM, and the launch-per-step kernels.  Each is also the others' cross-check on
+    shapes the oracle is too slow for."""
+    mdl = M.synthetic_model(kind, hidden, seed=13)
+    sig = np.random.default_rng(77).standard_normal((18, 1500)).astype(np.float32)
+    outs = []
+    for flags in (0, B.RUN_UNFUSED_RNN, B.RUN_STEPWISE_RNN):
+        dm, b = run_batch(B, engine, mdl, sig, flags=flags)
+        outs.append(([b.transitions(r) for r in (0, 9, 17)], [b.basecall(r) for r in range(18)]))
+        b.close(); dm.close()
+    for tr, calls in outs[1:]:
+        for a, c in zip(outs[0][0], tr):
+            assert np.abs(a - c).max() <= 2e-5
+        assert calls == outs[0][1]
+
+
 def test_raw_table_entry_point_and_batch_independence(B, ffo, engine):
     """set_reads (raw_table, start/end honoured) == set_signals; a read's result does not depend on
     which other reads share its batch (reads are independent units, flappie.c:364-385)."""
