@@ -45,6 +45,8 @@ namespace ffhip {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING / FFHIP_TIMELINE builds)
+
 struct PersistArgs {
     const v4f *sWp;        // [Ut][K16][64] float4, A-fragment order
     const v4f *iWp;        // fused layers: input weights, same packing
@@ -351,6 +353,9 @@ k_lstm_fused(PersistArgs a) {
     __syncthreads();
     const bool fast = lds_fast != 0;
     __builtin_amdgcn_s_setprio(3);
+#ifdef FFHIP_TIMELINE
+    if (a.mode >= 100 && g >= 8) { const unsigned long long t0 = __builtin_readcyclecounter(); while (__builtin_readcyclecounter() - t0 < (unsigned long long)(a.mode - 100) * 100ull) __builtin_amdgcn_s_sleep(8); }
+#endif
     const bool have_k = wave * KPW < K16;
 
     // x(t) slices are plain data from the previous kernel: ordinary coalesced loads, one step ahead
@@ -365,9 +370,21 @@ k_lstm_fused(PersistArgs a) {
         }
     }
 
+#ifdef FFHIP_TIMELINE
+#define TL(k) do { if (a.dbg && i >= 100 && i < 132 && lane == 0) a.dbg[64 * 512 + (((size_t)blockIdx.x * 4 + wave) * 32 + (i - 100)) * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
+    if (a.dbg && threadIdx.x == 0) {
+        unsigned hw, xc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));
+        a.dbg[blockIdx.x] = ((unsigned long long)xc << 32) | hw;
+    }
+#else
+#define TL(k) do { } while (0)
+#endif
     for (int i = 0; i < Tb; i++) {
         const int t = a.backward ? Tb - 1 - i : i;
         const int tp = a.backward ? t + 1 : t - 1;
+        TL(0);
         v4f acc[UPC];
         v4f accx[KIND == 1 ? UPC : 1];       // GRUmod keeps the projection apart: its candidate row must not mix with sW h
 #pragma unroll
@@ -376,15 +393,34 @@ k_lstm_fused(PersistArgs a) {
 #pragma unroll
             for (int j = 0; j < UPC; j++) accx[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
         }
+        // ---- speculative first sweep of h(t-1): issued BEFORE the projection MFMAs so that its L2 round
+        // trip (~1200 cycles even when the data is already there) is covered by them
+        v4u raw[KPW];
+        __amdgpu_buffer_rsrc_t rsrc;
+        const bool do_h = (i > 0 && have_k);
+        if (do_h) {
+            const float *hp = a.hout + ((size_t)tp * a.B16 + rt) * tile_floats;
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(tile_floats * 4), 0x00020000);
+        }
         // ---- projection half: independent of the recurrence, runs under the hand-off latency
         if (have_k) {
 #pragma unroll
-            for (int kk = 0; kk < KPW; kk++)
+            for (int kk = 0; kk < KPW; kk++) {
+                if (kk == (KPW * 2) / 3 && do_h) {
+                    // the sweep's round trip overlaps the last third of the projection MFMAs; issued
+                    // earlier it would mostly find the sentinel and cost a second round trip
+#pragma unroll
+                    for (int k2 = 0; k2 < KPW; k2++) {
+                        const int k16 = wave * KPW + k2;
+                        raw[k2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < UPC; j++) {
                     if (KIND == 1) accx[j] = mfma4p(wi[j][kk], xf[kk], accx[j]);
                     else acc[j] = mfma4p(wi[j][kk], xf[kk], acc[j]);
                 }
+            }
             if (i + 1 < Tb) {
                 const int tn = a.backward ? t - 1 : t + 1;
                 const v4f *xp = (const v4f *)(a.xin + ((size_t)tn * a.B16 + rt) * tile_floats);
@@ -395,19 +431,12 @@ k_lstm_fused(PersistArgs a) {
                 }
             }
         }
+        TL(1);
         // ---- recurrent half
-        if (i > 0 && have_k) {
-            const float *hp = a.hout + ((size_t)tp * a.B16 + rt) * tile_floats;
-            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(tile_floats * 4), 0x00020000);
-            v4u raw[KPW];
+        if (do_h) {
             bool timed_out = false;
             for (unsigned spin = 0;; spin++) {
                 bool ok = true;
-#pragma unroll
-                for (int kk = 0; kk < KPW; kk++) {
-                    const int k16 = wave * KPW + kk;
-                    raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
-                }
 #pragma unroll
                 for (int kk = 0; kk < KPW; kk++)
                     ok = ok && raw[kk].x != kSentinel && raw[kk].y != kSentinel && raw[kk].z != kSentinel && raw[kk].w != kSentinel;
@@ -417,7 +446,13 @@ k_lstm_fused(PersistArgs a) {
                     if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                 }
                 __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int kk = 0; kk < KPW; kk++) {
+                    const int k16 = wave * KPW + kk;
+                    raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
+                }
             }
+            TL(2);
             if (timed_out) {
                 if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
             } else {
@@ -429,6 +464,10 @@ k_lstm_fused(PersistArgs a) {
                 }
             }
         }
+#ifdef FFHIP_TIMELINE
+        asm volatile("s_nop 0" :: "v"(acc[0].x), "v"(acc[UPC - 1].w));
+#endif
+        TL(3);
         if (KIND == 1) {
             // rows (z, r, candidate, -): pack {z: x+h, r: x+h, u = (sW h)_c, x_c = (Wi x)_c}; row 3 is free
 #pragma unroll
@@ -440,6 +479,7 @@ k_lstm_fused(PersistArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (lds_abort) return;
+        TL(4);
         if (my_tile >= 0) {
             v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
@@ -483,12 +523,12 @@ k_lstm_fused(PersistArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, ((ut0 + my_tile) * 64 + rl * 4) * 4, 0, 16 /*sc1*/);
                 }
             }
+            TL(5);
         }
     }
 }
 
 
-unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING builds)
 
 // ------------------------------------------------------------------------------------------
 static int g_query_blocks = -1;      // >= 0: dispatch answers the occupancy query instead of launching
@@ -590,7 +630,7 @@ bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 
     a.sWp = (const v4f *)sWp; a.iWp = (const v4f *)iWp; a.bias = bias; a.xin = xin; a.xa = nullptr; a.hout = hout;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
-    a.backward = backward; a.mode = mode; a.dbg = nullptr;
+    a.backward = backward; a.mode = mode; a.dbg = g_persist_dbg;
     a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
