@@ -1,0 +1,307 @@
+/*  flappie -- command line of the MI355X flip-flop basecaller.
+ *
+ *  Same option table, defaults, file/directory globbing and per-read output as the reference's
+ *  src/flappie.c (options :42-67, defaults :93-112, parse :127-239, main :319-399).  The body differs where
+ *  it has to: the reference calls calculate_post() per file (flappie.c:371); here files are read and
+ *  prepared on the host, grouped by trimmed length (the network never pads or splits a read) and sent to
+ *  the HIP engine in batches; records are written in input order.
+ */
+#include <argp.h>
+#include <assert.h>
+#include <dirent.h>
+#include <err.h>
+#include <glob.h>
+#include <libgen.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "../../include/decode.h"
+#include "../../include/fast5_interface.h"
+#include "../../include/ffhip.h"
+#include "../../include/flappie_common.h"
+#include "../../include/flappie_output.h"
+#include "../../include/networks.h"
+
+const char *argp_program_version = "flappie (MI355X/HIP) 0.1, interface of flappie 2.1.3";
+const char *argp_program_bug_address = "<this repository>";
+static char doc[] = "Flappie basecaller -- basecall from raw signal";
+static char args_doc[] = "fast5 [fast5 ...]";
+static struct argp_option options[] = {
+    {"delta", 'd', "factor", 0, "Using delta samples model with scaling factor"},
+    {"format", 'f', "format", 0, "Format to output reads (FASTA or SAM)"},
+    {"limit", 'l', "nreads", 0, "Maximum number of reads to call (0 is unlimited)"},
+    {"model", 'm', "name", 0, "Model to use (\"help\" to list)"},
+    {"output", 'o', "filename", 0, "Write to file rather than stdout"},
+    {"prefix", 'p', "string", 0, "Prefix to append to name of each read"},
+    {"reverse", 'r', 0, 0, "Reverse output base calls"},
+    {"no-reverse", 6, 0, OPTION_ALIAS, "Don't reverse output base calls"},
+    {"temperature", 7, "factor", 0, "Temperature for weights"},
+    {"trim", 't', "start:end", 0, "Number of samples to trim, as start:end"},
+    {"trace", 'T', "filename", 0, "Dump trace to HDF5 file"},
+    {"licence", 10, 0, 0, "Print licensing information"},
+    {"license", 11, 0, OPTION_ALIAS, "Print licensing information"},
+    {"segmentation", 3, "chunk:percentile", 0, "Chunk size and percentile for variance based segmentation"},
+    {"viterbi", 'v', 0, 0, "Use viterbi decoding only"},
+    {"no-viterbi", 8, 0, OPTION_ALIAS, "Use forward-backward followed by viterbi"},
+    {"fb", 9, 0, OPTION_ALIAS, "Use forward-backward followed by viterbi"},
+    {"hdf5-compression", 12, "level", 0, "Gzip compression level for HDF5 output (0:off, 1: quickest, 9: best)"},
+    {"hdf5-chunk", 13, "size", 0, "Chunk size for HDF5 output"},
+    {"uuid", 14, 0, 0, "Output UUID"},
+    {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
+    {"batch", 16, "nreads", 0, "Reads per GPU batch (default 256)"},
+    {0}
+};
+
+#define DEFAULT_MODEL FLAPPIE_MODEL_R941_NATIVE
+
+static struct {
+    int compression_level, compression_chunk_size;
+    float delta;
+    char *trace;
+    enum flappie_outformat_type outformat;
+    int limit;
+    enum model_type model;
+    FILE *output;
+    char *prefix;
+    bool reverse;
+    float temperature;
+    int trim_start, trim_end, varseg_chunk;
+    float varseg_thresh;
+    bool viterbi_only;
+    char **files;
+    bool uuid;
+    int batch;
+} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 256 };
+
+static void print_models(FILE *fh) {
+    for (int mdl = 0; mdl < (int)flappie_nmodel; mdl++)
+        fprintf(fh, "%10s : %s  %s\n", flappie_model_string(mdl), flappie_model_description(mdl), (DEFAULT_MODEL == mdl) ? "(default)" : "");
+}
+
+static error_t parse_arg(int key, char *arg, struct argp_state *state) {
+    char *next_tok = NULL;
+    switch (key) {
+    case 'd': args.delta = atof(arg); break;
+    case 'f':
+        args.outformat = get_outformat(arg);
+        if (FLAPPIE_OUTFORMAT_INVALID == args.outformat) errx(EXIT_FAILURE, "Unrecognised output format \"%s\".", arg);
+        break;
+    case 'l': args.limit = atoi(arg); break;
+    case 'm':
+        if (0 == strcasecmp(arg, "help")) { print_models(stdout); exit(EXIT_SUCCESS); }
+        args.model = get_flappie_model_type(arg);
+        if (FLAPPIE_MODEL_INVALID == args.model || args.model > FLAPPIE_MODEL_INVALID) {
+            fprintf(stdout, "Invalid Flappie model \"%s\".\n", arg);
+            print_models(stdout);
+            exit(EXIT_FAILURE);
+        }
+        break;
+    case 'o':
+        args.output = fopen(arg, "w");
+        if (NULL == args.output) errx(EXIT_FAILURE, "Failed to open \"%s\" for output.", arg);
+        break;
+    case 'p': args.prefix = arg; break;
+    case 'r': args.reverse = true; break;
+    case 't':
+        args.trim_start = atoi(strtok(arg, ":"));
+        next_tok = strtok(NULL, ":");
+        args.trim_end = (NULL != next_tok) ? atoi(next_tok) : args.trim_start;
+        if (args.trim_start < 0 || args.trim_end < 0) errx(EXIT_FAILURE, "--trim values must be non-negative");
+        break;
+    case 'T': args.trace = arg; break;
+    case 'v': args.viterbi_only = true; break;
+    case 3:
+        args.varseg_chunk = atoi(strtok(arg, ":"));
+        next_tok = strtok(NULL, ":");
+        if (NULL == next_tok) errx(EXIT_FAILURE, "--segmentation should be of form chunk:percentile");
+        args.varseg_thresh = atof(next_tok) / 100.0;
+        if (args.varseg_chunk < 2 || !(args.varseg_thresh >= 0.0f && args.varseg_thresh < 1.0f)) errx(EXIT_FAILURE, "--segmentation out of range");
+        break;
+    case 6: args.reverse = false; break;
+    case 7:
+        args.temperature = atof(arg);
+        if (!(isfinite(args.temperature) && args.temperature > 0.0f)) errx(EXIT_FAILURE, "--temperature must be positive");
+        break;
+    case 8:
+    case 9: args.viterbi_only = false; break;
+    case 10:
+    case 11:
+        /* The reference prints Oxford Nanopore's licence text (flappie_licence.h).  This program is an
+         * independent implementation of the same interface; it points at the respective licence files. */
+        puts("This MI355X/HIP basecaller is an independent implementation of the flappie command line interface.\n"
+             "The flappie reference implementation and its models are (c) Oxford Nanopore Technologies, Ltd. and are\n"
+             "distributed under the Oxford Nanopore Technologies, Ltd. Public License v1.0 (see LICENCE.txt of\n"
+             "https://github.com/nanoporetech/flappie); models loaded by this program remain under that licence.");
+        exit(EXIT_SUCCESS);
+    case 12:
+        args.compression_level = atoi(arg);
+        if (args.compression_level < 0 || args.compression_level > 9) errx(EXIT_FAILURE, "--hdf5-compression must be 0..9");
+        break;
+    case 13:
+        args.compression_chunk_size = atoi(arg);
+        if (args.compression_chunk_size <= 0) errx(EXIT_FAILURE, "--hdf5-chunk must be positive");
+        break;
+    case 14: args.uuid = true; break;
+    case 15: args.uuid = false; break;
+    case 16:
+        args.batch = atoi(arg);
+        if (args.batch <= 0) errx(EXIT_FAILURE, "--batch must be positive");
+        break;
+    case ARGP_KEY_NO_ARGS: argp_usage(state); break;
+    case ARGP_KEY_ARG:
+        args.files = &state->argv[state->next - 1];
+        state->next = state->argc;
+        break;
+    default: return ARGP_ERR_UNKNOWN;
+    }
+    return 0;
+}
+
+static struct argp argp = { options, parse_arg, args_doc, doc };
+
+typedef struct {
+    char *filename;                     /* owned */
+    struct _raw_basecall_info res;      /* rt filled by preparation; basecall == NULL until called */
+    int prepared;
+} item;
+
+/* flappie.c:248-262: read, trim/segment, normalise */
+static void prepare(item *it) {
+    raw_table rt = read_raw(it->filename, true);
+    if (NULL == rt.raw) return;
+    char *uuid = rt.uuid;
+    rt = trim_and_segment_raw(rt, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh);
+    if (NULL == rt.raw) { free(uuid); return; }
+    if (args.delta == 0.0f) {
+        medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
+    } else {
+        difference_array(rt.raw + rt.start, rt.end - rt.start);
+        shift_scale_array(rt.raw + rt.start, rt.end - rt.start, 0.0, args.delta);
+    }
+    it->res.rt = rt;
+    it->prepared = 1;
+}
+
+/* one batch of equal-length reads through the engine: the rest of calculate_post (flappie.c:264-316) */
+static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, item **its, int n) {
+    raw_table *rts = calloc(n, sizeof(raw_table));
+    for (int i = 0; i < n; i++) rts[i] = its[i]->res.rt;
+    const size_t len = rts[0].end - rts[0].start;
+    ffhip_batch *b = ffhip_batch_create(eng, mdl, n, len);
+    unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
+    if (NULL == b || 0 != ffhip_batch_set_reads(b, rts) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
+        warnx("%s", ffhip_last_error());
+        if (b) ffhip_batch_destroy(b);
+        free(rts);
+        return;
+    }
+    const size_t nblock = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
+    for (int i = 0; i < n; i++) {
+        struct _raw_basecall_info *r = &its[i]->res;
+        size_t blen = 0;
+        const char *bases = ffhip_batch_basecall(b, i, &blen);
+        r->basecall = strdup(bases);
+        r->quality = strdup(ffhip_batch_quality(b, i));
+        r->basecall_length = blen;
+        r->score = ffhip_batch_score(b, i);
+        r->nblock = nblock;
+        r->pos = calloc(nblock + 1, sizeof(int));
+        if (args.reverse) {                                    /* flappie.c:294-297 */
+            reverse_char_array(r->basecall, blen);
+            reverse_char_array(r->quality, blen);
+        }
+        if (args.trace) {
+            int32_t *tmp = malloc((nblock + 1) * nstate * sizeof(int32_t));
+            r->trace = make_flappie_imatrix(nstate, nblock + 1);
+            if (tmp && r->trace && 0 == ffhip_batch_get_trace(b, i, tmp)) {
+                for (size_t c = 0; c <= nblock; c++) memcpy(r->trace->data.f + c * r->trace->stride, tmp + c * nstate, nstate * sizeof(int32_t));
+            } else {
+                r->trace = free_flappie_imatrix(r->trace);
+            }
+            free(tmp);
+        }
+    }
+    ffhip_batch_destroy(b);
+    free(rts);
+}
+
+static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, hid_t hdf5out) {
+    item **group = calloc(n > 0 ? n : 1, sizeof(item *));
+    char *done = calloc(n > 0 ? n : 1, 1);
+    for (int i = 0; i < n; i++) {
+        if (done[i] || !items[i].prepared) continue;
+        const size_t len = items[i].res.rt.end - items[i].res.rt.start;
+        int m = 0;
+        for (int j = i; j < n && m < args.batch; j++)
+            if (!done[j] && items[j].prepared && items[j].res.rt.end - items[j].res.rt.start == len) { group[m++] = &items[j]; done[j] = 1; }
+        call_batch(eng, mdl, group, m);
+    }
+    for (int i = 0; i < n; i++) {                               /* flappie.c:371-384, in input order */
+        item *it = &items[i];
+        if (NULL == it->res.basecall) {
+            warnx("No basecall returned for %s", it->filename);
+        } else {
+            char *fn = strdup(it->filename);
+            const char *base = basename(fn);
+            const char *uuid = it->res.rt.uuid ? it->res.rt.uuid : "";
+            fprintf_format(args.outformat, args.output, uuid, base, args.uuid, args.prefix, it->res);
+            write_summary(hdf5out, args.uuid ? uuid : base, it->res, args.compression_chunk_size, args.compression_level);
+            free(fn);
+        }
+        free_raw_basecall_info(&it->res);
+        free(it->filename);
+    }
+    free(group);
+    free(done);
+}
+
+int main(int argc, char *argv[]) {
+    argp_parse(&argp, argc, argv, 0, 0, NULL);
+    if (NULL == args.output) args.output = stdout;
+    const struct ffhip_model *mdl = flappie_hip_model(args.model);
+    if (NULL == mdl) errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model));
+    struct ffhip_engine *eng = flappie_hip_engine();
+    hid_t hdf5out = open_or_create_hdf5(args.trace);
+
+    const int chunk_cap = 4 * args.batch;
+    item *items = calloc(chunk_cap, sizeof(item));
+    int nitem = 0, reads_started = 0;
+    const int reads_limit = args.limit;
+    for (int fn = 0; args.files && args.files[fn]; fn++) {
+        if (reads_limit > 0 && reads_started >= reads_limit) continue;
+        glob_t globbuf;
+        {   /* a directory means every .fast5 file inside it (flappie.c:341-353) */
+            const size_t rootlen = strlen(args.files[fn]);
+            char *globpath = calloc(rootlen + 9, sizeof(char));
+            memcpy(globpath, args.files[fn], rootlen);
+            DIR *dirp = opendir(args.files[fn]);
+            if (NULL != dirp) { memcpy(globpath + rootlen, "/*.fast5", 8); closedir(dirp); }
+            const int globret = glob(globpath, GLOB_NOSORT, NULL, &globbuf);
+            free(globpath);
+            if (0 != globret) {
+                if (GLOB_NOMATCH == globret) warnx("File or directory \"%s\" does not exist or no fast5 files found.", args.files[fn]);
+                globfree(&globbuf);
+                continue;
+            }
+        }
+        for (size_t f2 = 0; f2 < globbuf.gl_pathc; f2++) {
+            if (reads_limit > 0 && reads_started >= reads_limit) continue;
+            reads_started += 1;
+            item *it = &items[nitem++];
+            memset(it, 0, sizeof(*it));
+            it->filename = strdup(globbuf.gl_pathv[f2]);
+            prepare(it);
+            if (nitem == chunk_cap) { flush_chunk(eng, mdl, items, nitem, hdf5out); nitem = 0; }
+        }
+        globfree(&globbuf);
+    }
+    flush_chunk(eng, mdl, items, nitem, hdf5out);
+    free(items);
+    if (hdf5out >= 0) H5Fclose(hdf5out);
+    if (stdout != args.output) fclose(args.output);
+    flappie_hip_shutdown();
+    return EXIT_SUCCESS;
+}

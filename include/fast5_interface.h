@@ -1,0 +1,28 @@
+/*  fast5_interface.h -- single-read fast5 input and `--trace` HDF5 output.
+ *  Same signatures as /root/reference/src/fast5_interface.h:17-23.  Built only when libhdf5 is available
+ *  (FLAPPIE_HAVE_HDF5); the HIP engine does not depend on it.
+ */
+#ifndef FFHIP_FAST5_INTERFACE_H
+#define FFHIP_FAST5_INTERFACE_H
+#include <hdf5.h>
+#include <stdbool.h>
+#include "flappie_structures.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fast5_interface.c:231-318: /Raw/Reads/<first entry>/Signal + its `read_id`, optionally scaled to pA with
+ * /UniqueGlobalKey/channel_id {digitisation, offset, range}.  raw == NULL on failure. */
+raw_table read_raw(const char *filename, bool scale_to_pA);
+/* fast5_interface.c:59-74: -1 if filename is NULL; opens an existing file read-write, else creates it */
+hid_t open_or_create_hdf5(const char *filename);
+/* fast5_interface.c:321-349: group `readname` with `signal` (f32, trimmed normalised signal) and `trace`
+ * (u8 [nblock+1 x nstate]), shuffle + deflate when compression_level > 0 */
+void write_summary(hid_t hdf5file, const char *readname, const struct _raw_basecall_info res, hsize_t chunk_size,
+                   int compression_level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

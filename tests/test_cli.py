@@ -1,0 +1,285 @@
+"""The `flappie` command line (host/flappie_cli.c) and its I/O helpers: FASTA/FASTQ/SAM record layout
+(flappie_output.c:16-132), single-read fast5 input and --trace HDF5 output (fast5_interface.c:231-349),
+option handling (flappie.c:42-235).  Needs libhdf5 to have been found at build time; skipped otherwise
+(the HIP engine itself does not depend on HDF5)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+from test_host_layer import CIMat, RawTable, ROOT, _f
+
+FLAPPIE = os.path.join(ROOT, "flappie_amd", "flappie")
+TOOL = os.path.join(ROOT, "flappie_amd", "fast5_tool")
+FAST5LIB = os.path.join(ROOT, "flappie_amd", "libflappie_fast5.so")
+HOSTLIB = os.path.join(ROOT, "flappie_amd", "libflappie_host.so")
+
+needs_hdf5 = pytest.mark.skipif(not (os.path.exists(FLAPPIE) and os.path.exists(TOOL) and os.path.exists(FAST5LIB)),
+                                reason="libhdf5 not found when the host layer was built")
+
+
+class BasecallInfo(C.Structure):
+    _fields_ = [("score", C.c_float), ("rt", RawTable), ("basecall", C.c_char_p), ("quality", C.c_char_p),
+                ("basecall_length", C.c_size_t), ("trace", C.POINTER(CIMat)), ("pos", C.POINTER(C.c_int)),
+                ("nblock", C.c_size_t)]
+
+
+def write_fast5(path, read_id, raw_i16, digitisation=8192.0, offset=10.0, rng=1400.0, rate=4000.0):
+    tmp = str(path) + ".i16"
+    np.asarray(raw_i16, dtype="<i2").tofile(tmp)
+    subprocess.run([TOOL, "write", str(path), read_id, repr(digitisation), repr(offset), repr(rng), repr(rate), tmp], check=True)
+    os.unlink(tmp)
+
+
+def dump_trace(path, group):
+    out = subprocess.run([TOOL, "dump", str(path), group], capture_output=True, text=True, check=True).stdout.split("\n")
+    n = int(out[0].split()[1])
+    sig = np.array([float.fromhex(v) for v in out[1:1 + n]], dtype=np.float32)
+    _, r, c = out[1 + n].split()
+    tr = np.array([int(v) for v in out[2 + n:2 + n + int(r) * int(c)]], dtype=np.int32).reshape(int(r), int(c))
+    return sig, tr
+
+
+def synth_raw(rng, n):
+    """int16 DAC values with a noisy head (so that trimming by MAD has something to find)"""
+    x = rng.normal(500, 60, n)
+    x[:300] = rng.normal(520, 4, 300)
+    return np.clip(np.rint(x), 0, 8191).astype("<i2")
+
+
+# ------------------------------------------------------------------------------------ CPU
+def _cfile(libc, path, mode=b"w"):
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    return libc.fopen(str(path).encode(), mode)
+
+
+def _cfloat(v):
+    return "%f" % float(np.float32(v))
+
+
+@pytest.mark.parametrize("uuid_primary", [True, False])
+def test_record_layout(tmp_path, uuid_primary):
+    L = C.CDLL(HOSTLIB)
+    libc = C.CDLL(None)
+    L.get_outformat.restype = C.c_int
+    L.get_outformat.argtypes = [C.c_char_p]
+    L.flappie_outformat_string.restype = C.c_char_p
+    L.fprintf_format.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_bool, C.c_char_p, BasecallInfo]
+    assert [L.get_outformat(s) for s in (b"fasta", b"fastq", b"sam", b"bam", b"FASTA")] == [0, 1, 2, 3, 3]
+    assert L.get_outformat(None) == 3
+    assert [L.flappie_outformat_string(i) for i in range(3)] == [b"fasta", b"fastq", b"sam"]
+    res = BasecallInfo(score=np.float32(-123.5), basecall=b"ACGTTGCA", quality=b"!#%+5?IJ", basecall_length=8, nblock=37)
+    res.rt = RawTable(uuid=b"u-1", n=4000, start=200, end=3990, raw=None)
+    name = "u-1" if uuid_primary else "a.fast5"
+    hdr = ('%sPRE_%s  { "filename" : "a.fast5", "uuid" : "u-1", "normalised_score" : %s,  "nblock" : 37,  "sequence_length" : 8,'
+           '  "blocks_per_base" : %s, "nsample" : 4000, "trim" : [ 200, 3990 ] }\n')
+    ns, bpb = _cfloat(np.float32(123.5) / np.float32(37)), _cfloat(np.float32(37) / np.float32(8))
+    want = {0: hdr % (">", name, ns, bpb) + "ACGTTGCA\n",
+            1: hdr % ("@", name, ns, bpb) + "ACGTTGCA\n+\n!#%+5?IJ\n",
+            2: "PRE_%s\t4\t*\t0\t0\t*\t*\t0\t0\tACGTTGCA\t!#%%+5?IJ\nACGTTGCA\t!#%%+5?IJ\n" % name}
+    for fmt in range(3):
+        p = tmp_path / ("o%d" % fmt)
+        fp = _cfile(libc, p)
+        L.fprintf_format(fmt, fp, b"u-1", b"a.fast5", uuid_primary, b"PRE_", res)
+        libc.fclose(fp)
+        assert p.read_text() == want[fmt]
+    # FASTQ without qualities: nothing written (flappie_output.c:107-110)
+    res.quality = None
+    p = tmp_path / "noq"
+    fp = _cfile(libc, p)
+    L.fprintf_format(1, fp, b"u-1", b"a.fast5", uuid_primary, b"", res)
+    libc.fclose(fp)
+    assert p.read_text() == ""
+
+
+@pytest.fixture(scope="module")
+def f5lib():
+    L = C.CDLL(FAST5LIB)
+    L.read_raw.restype = RawTable
+    L.read_raw.argtypes = [C.c_char_p, C.c_bool]
+    L.open_or_create_hdf5.restype = C.c_int64
+    L.open_or_create_hdf5.argtypes = [C.c_char_p]
+    L.write_summary.argtypes = [C.c_int64, C.c_char_p, BasecallInfo, C.c_uint64, C.c_int]
+    L.H5Fclose.argtypes = [C.c_int64]                          # resolved through the library's libhdf5 dependency
+    return L
+
+
+@needs_hdf5
+def test_read_raw(tmp_path, f5lib):
+    rng = np.random.default_rng(3)
+    raw = synth_raw(rng, 5000)
+    p = tmp_path / "r.fast5"
+    write_fast5(p, "0a1b2c3d-read", raw, 8192.0, 7.0, 1437.5)
+    for scale in (False, True):
+        rt = f5lib.read_raw(str(p).encode(), scale)
+        assert rt.raw and rt.n == 5000 and (rt.start, rt.end) == (0, 5000) and rt.uuid == b"0a1b2c3d-read"
+        got = np.ctypeslib.as_array(rt.raw, shape=(5000,)).copy()
+        want = raw.astype(np.float32)
+        if scale:
+            want = (want + np.float32(7.0)) * (np.float32(1437.5) / np.float32(8192.0))
+        np.testing.assert_array_equal(got, want)
+    # failures: raw == NULL, no exception (fast5_interface.c:236-247)
+    assert not f5lib.read_raw(str(tmp_path / "missing.fast5").encode(), True).raw
+    junk = tmp_path / "junk.fast5"
+    junk.write_bytes(b"not hdf5 at all")
+    assert not f5lib.read_raw(str(junk).encode(), True).raw
+
+
+@needs_hdf5
+@pytest.mark.parametrize("level", [0, 1])
+def test_write_summary_round_trip(tmp_path, f5lib, level):
+    host = C.CDLL(HOSTLIB)
+    host.make_flappie_imatrix.restype = C.POINTER(CIMat)
+    host.make_flappie_imatrix.argtypes = [C.c_size_t, C.c_size_t]
+    assert f5lib.open_or_create_hdf5(None) < 0
+    p = tmp_path / "trace.hdf5"
+    rng = np.random.default_rng(9)
+    for k, name in enumerate((b"read_a", b"read_b")):          # second pass re-opens the existing file
+        h = f5lib.open_or_create_hdf5(str(p).encode())
+        assert h >= 0
+        sig = rng.standard_normal(1000).astype(np.float32)
+        nblock, nstate = 40 + k, 8
+        tr = host.make_flappie_imatrix(nstate, nblock + 1)
+        vals = rng.integers(0, 256, (nblock + 1, nstate)).astype(np.int32)
+        np.ctypeslib.as_array(tr.contents.f, shape=(nblock + 1, tr.contents.stride))[:, :nstate] = vals
+        res = BasecallInfo(score=0.0, basecall=b"A", quality=b"!", basecall_length=1, nblock=nblock, trace=tr)
+        res.rt = RawTable(uuid=name, n=1000, start=100, end=900, raw=_f(sig))
+        f5lib.write_summary(h, name, res, 50, level)
+        assert f5lib.H5Fclose(h) >= 0
+        s, t = dump_trace(p, name.decode())
+        np.testing.assert_array_equal(s, sig[100:900])
+        np.testing.assert_array_equal(t, vals)
+    s, t = dump_trace(p, "read_a")                              # the first group survived the second open
+    assert s.size == 800 and t.shape == (41, 8)
+
+
+@needs_hdf5
+def test_cli_options_without_gpu(tmp_path):
+    run = lambda *a: subprocess.run([FLAPPIE] + list(a), capture_output=True, text=True, timeout=60)  # noqa: E731
+    r = run("--help")
+    assert r.returncode == 0
+    for opt in ("--delta", "--format", "--limit", "--model", "--output", "--prefix", "--temperature", "--trim", "--trace",
+                "--viterbi", "--segmentation", "--hdf5-compression", "--hdf5-chunk", "--uuid", "--no-uuid", "--licence", "--batch"):
+        assert opt in r.stdout, opt
+    r = run("--model", "help")
+    assert r.returncode == 0
+    for name in ("r941_native", "r941_5mC", "r941_rna002", "r103_native"):          # rle_r941_native belongs to runnie, not listed (flappie.c:184-190)
+        assert name in r.stdout
+    assert run("--licence").returncode == 0
+    assert run("--version").returncode == 0
+    assert run("--format", "bam", "x.fast5").returncode != 0
+    assert run("--model", "nonsense", "x.fast5").returncode != 0
+    assert run("--temperature", "-1", "x.fast5").returncode != 0
+    assert run("--segmentation", "50", "x.fast5").returncode != 0
+    assert run().returncode != 0                                  # no input files: usage
+
+
+# ------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def cli_inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    mdl = M.synthetic_model(M.NET_LSTM5, 48, seed=21, ident="r941native")
+    M.write_mdl(str(d / "flipflop5_r941native.h"), mdl)
+    reads = d / "reads"
+    reads.mkdir()
+    rng = np.random.default_rng(77)
+    raws = {}
+    for i, n in enumerate((4000, 4000, 3100, 4000, 2600)):
+        raw = synth_raw(rng, n)
+        write_fast5(reads / ("read_%02d.fast5" % i), "uuid-%04d" % i, raw)
+        raws["read_%02d.fast5" % i] = ("uuid-%04d" % i, raw)
+    return d, mdl, reads, raws
+
+
+def _oracle_calls(mdl, raws, viterbi=False, temperature=1.0, trim=(200, 10)):
+    from oracle import ffo
+    om = ffo.OracleModel(mdl)
+    out = {}
+    for fn, (uuid, raw) in raws.items():
+        x = (raw.astype(np.float32) + np.float32(10.0)) * (np.float32(1400.0) / np.float32(8192.0))
+        s, e = C.c_size_t(0), C.c_size_t(x.size)
+        assert ffo.lib().fo_trim_and_segment_raw(_f(x), x.size, C.byref(s), C.byref(e), trim[0], trim[1], 100, 0.0) == 0
+        y = x[s.value:e.value].copy()
+        ffo.lib().fo_medmad_normalise_array(_f(y), y.size)
+        ref = om.basecall(y, viterbi_only=viterbi, temperature=temperature)
+        ref.update(start=s.value, end=e.value, uuid=uuid, signal=y)
+        out[fn] = ref
+    return out
+
+
+def _parse_fastq(text):
+    lines = text.strip().split("\n")
+    recs = []
+    for k in range(0, len(lines), 4):
+        assert lines[k][0] == "@" and lines[k + 2] == "+"
+        recs.append((lines[k][1:].split("  {")[0], lines[k], lines[k + 1], lines[k + 3]))
+    return recs
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_cli_fastq_and_trace_match_oracle(cli_inputs, tmp_path):
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    trace = tmp_path / "trace.hdf5"
+    r = subprocess.run([FLAPPIE, "--model", "r941_native", "--trace", str(trace), "--batch", "2", str(reads)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    recs = _parse_fastq(r.stdout)
+    ref = _oracle_calls(mdl, raws)
+    assert sorted(x[0] for x in recs) == sorted(v["uuid"] for v in ref.values())      # --uuid is the default
+    by_uuid = {v["uuid"]: (fn, v) for fn, v in ref.items()}
+    for name, hdr, bases, quals in recs:
+        fn, v = by_uuid[name]
+        assert bases == v["basecall"] and quals == v["quality"], fn
+        assert '"filename" : "%s"' % fn in hdr and '"nblock" : %d' % v["nblock"] in hdr
+        assert '"trim" : [ %d, %d ]' % (v["start"], v["end"]) in hdr and '"nsample" : %d' % raws[fn][1].size in hdr
+        score = float(hdr.split('"normalised_score" : ')[1].split(",")[0])
+        assert abs(score - (-v["score"] / v["nblock"])) < 2e-4
+        sig, tr = dump_trace(trace, name)
+        np.testing.assert_array_equal(sig, v["signal"])
+        assert tr.shape == v["trace"].shape and np.abs(tr - v["trace"]).max() <= 1
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_cli_formats_limit_reverse_viterbi(cli_inputs, tmp_path):
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    files = [str(reads / fn) for fn in sorted(raws)]
+    ref = _oracle_calls(mdl, raws)
+    refv = _oracle_calls(mdl, raws, viterbi=True, temperature=0.7, trim=(150, 20))
+
+    out = tmp_path / "calls.fa"
+    r = subprocess.run([FLAPPIE, "-f", "fasta", "--no-uuid", "-p", "run1_", "-l", "3", "-o", str(out)] + files,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == "", r.stderr
+    lines = out.read_text().strip().split("\n")
+    assert len(lines) == 2 * 3                                      # --limit 3
+    for k, fn in enumerate(sorted(raws)[:3]):                       # explicit files: input order kept
+        assert lines[2 * k].startswith(">run1_%s  {" % fn)
+        assert lines[2 * k + 1] == ref[fn]["basecall"]
+
+    r = subprocess.run([FLAPPIE, "-f", "sam", "--reverse", "--viterbi", "--temperature", "0.7", "--trim", "150:20"] + files[:2],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 4
+    for k, fn in enumerate(sorted(raws)[:2]):
+        v = refv[fn]
+        cols = lines[2 * k].split("\t")
+        assert cols[0] == v["uuid"] and cols[1:9] == ["4", "*", "0", "0", "*", "*", "0", "0"]
+        assert cols[9] == v["basecall"][::-1] and cols[10] == v["quality"][::-1]
+        assert lines[2 * k + 1] == cols[9] + "\t" + cols[10]
+
+    # unreadable input: warning, other reads still called, exit status 0 (flappie.c:372-374)
+    bad = tmp_path / "bad.fast5"
+    bad.write_bytes(b"junk")
+    r = subprocess.run([FLAPPIE, str(bad), files[0]], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "No basecall returned" in r.stderr
+    assert len(_parse_fastq(r.stdout)) == 1
