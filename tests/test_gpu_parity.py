@@ -149,7 +149,7 @@ def test_recurrent_kernel_variants_agree(B, engine, kind, hidden):
         b.close(); dm.close()
     for tr, calls in outs[1:]:
         for a, c in zip(outs[0][0], tr):
-            assert np.abs(a - c).max() <= 2e-5
+            assert np.abs(a - c).max() <= 5e-5      # fp32 summation order differs between the variants
         assert calls == outs[0][1]
 
 
