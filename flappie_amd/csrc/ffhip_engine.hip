@@ -12,44 +12,24 @@
 
 #include "../../include/ffhip.h"
 #include "ffhip_internal.hpp"
+#include "ffhip_host.hpp"
 
 using namespace ffhip;
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
-static int set_err(int code, const char *fmt, ...) {
+int ffhip::set_err(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-#define HIP_TRY(expr, ret)                                                                          \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) {                                                                     \
-            set_err(FFHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return ret;                                                                             \
-        }                                                                                           \
-    } while (0)
 
 extern "C" const char *ffhip_last_error(void) { return g_err; }
 extern "C" const char *ffhip_version(void) { return "ffhip 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------------------------ engine
-struct ffhip_engine {
-    int device = 0;
-    hipDeviceProp_t prop;
-    hipStream_t streams[2] = { nullptr, nullptr };
-    int next_stream = 0;
-    int profiling = 0;
-    // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.
-    // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
-    // launches are chained through this event.
-    hipEvent_t persist_done = nullptr;
-    int persist_chained = 0;
-};
-
 extern "C" int ffhip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -134,22 +114,6 @@ static void *dev_upload(ffhip_model *m, const void *host, size_t bytes) {
     m->owned.push_back(d);
     return d;
 }
-
-// W(row m, k) accessor -> A-fragment order [Mt][K16][64 lanes][4]; rows/cols beyond the matrix are 0
-template <class F>
-static std::vector<float> pack_afrag(int Mt, int K16, F w) {
-    std::vector<float> out((size_t)Mt * K16 * 256, 0.0f);
-    for (int mt = 0; mt < Mt; mt++)
-        for (int k16 = 0; k16 < K16; k16++)
-            for (int lane = 0; lane < 64; lane++) {
-                const int i = lane & 15, kq = lane >> 4;
-                for (int e = 0; e < 4; e++)
-                    out[(((size_t)mt * K16 + k16) * 64 + lane) * 4 + e] = w(mt * 16 + i, k16 * 16 + kq * 4 + e);
-            }
-    return out;
-}
-
-static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" void ffhip_model_free(ffhip_model *m) {
     if (!m) return;
@@ -332,7 +296,7 @@ static void *dalloc(ffhip_batch *b, size_t bytes, bool zero) {
 // Column -> window-start table of one convolution: the reference's three regions (layers.c:220-271)
 // restated in index space.  With zero pads either side of the input a
 // partial edge window is a full window starting at x0 (possibly negative).
-static int build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<int> &bq) {
+int ffhip::build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<int> &bq) {
     const int padL = (winlen - 1) / 2, padR = winlen / 2;
     const int Tout = (T + s - 1) / s;
     const int ncolsL = (padL + s - 1) / s, shiftX = ncolsL * s - padL;
@@ -708,24 +672,6 @@ extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP],
 
 
 // ------------------------------------------------------------------------------------ single-matrix decode
-namespace {
-struct TmpDev {
-    std::vector<void *> p;
-    ~TmpDev() { for (void *q : p) hipFree(q); }
-    void *get(size_t bytes) {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return nullptr;
-        p.push_back(d);
-        return d;
-    }
-};
-bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
-    const int nb = (int)roundf((-1.0f + sqrtf(1.0f + 2.0f * (float)nparam)) / 2.0f);
-    if (nb < 1 || (size_t)(2 * nb * (nb + 1)) != nparam || 2 * nb > kMaxState || nparam > 64 || stride < nparam) return false;
-    *nbase = nb;
-    return true;
-}
-}  // namespace
 
 extern "C" int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nblock, size_t nparam, size_t stride,
                                int return_log, float *post_out) {

@@ -1,0 +1,80 @@
+// ffhip_host.hpp -- host-side helpers shared by ffhip_engine.hip and ffhip_layers.hip (not public).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <vector>
+
+#include "../../include/ffhip.h"
+#include "ffhip_internal.hpp"
+
+struct ffhip_engine {
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t streams[2] = { nullptr, nullptr };
+    int next_stream = 0;
+    int profiling = 0;
+    // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.
+    // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
+    // launches are chained through this event.
+    hipEvent_t persist_done = nullptr;
+    int persist_chained = 0;
+};
+
+namespace ffhip {
+
+int set_err(int code, const char *fmt, ...);        // records the thread's last error text, returns `code`
+
+#define HIP_TRY(expr, ret)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            ffhip::set_err(FFHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ret;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+// W(row m, k) accessor -> A-fragment order [Mt][K16][64 lanes][4]; rows/cols beyond the matrix are 0
+template <class F>
+static std::vector<float> pack_afrag(int Mt, int K16, F w) {
+    std::vector<float> out((size_t)Mt * K16 * 256, 0.0f);
+    for (int mt = 0; mt < Mt; mt++)
+        for (int k16 = 0; k16 < K16; k16++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int i = lane & 15, kq = lane >> 4;
+                for (int e = 0; e < 4; e++)
+                    out[(((size_t)mt * K16 + k16) * 64 + lane) * 4 + e] = w(mt * 16 + i, k16 * 16 + kq * 4 + e);
+            }
+    return out;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// strided-convolution column plan (layers.c:216-271 restated in index space); returns Tout, <0 on failure
+int build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<int> &bq);
+
+// scratch device allocations of one single-matrix call
+struct TmpDev {
+    std::vector<void *> p;
+    ~TmpDev() { for (void *q : p) hipFree(q); }
+    void *get(size_t bytes) {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        p.push_back(d);
+        return d;
+    }
+    void *upload(const void *host, size_t bytes, hipStream_t s) {
+        void *d = get(bytes);
+        if (d && hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+
+static inline bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
+    const int nb = (int)roundf((-1.0f + sqrtf(1.0f + 2.0f * (float)nparam)) / 2.0f);
+    if (nb < 1 || (size_t)(2 * nb * (nb + 1)) != nparam || 2 * nb > kMaxState || nparam > 64 || stride < nparam) return false;
+    *nbase = nb;
+    return true;
+}
+
+}  // namespace ffhip

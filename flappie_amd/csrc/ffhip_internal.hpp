@@ -79,7 +79,8 @@ int persist_blocks_per_cu(int kind, int H);
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale);
 // CRF partition function (fp64) + subtraction of (float)(logZ/Tb)
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps);
+// logz_out (optional): the fp64 partition function per read; subtract = 0 leaves `trans` untouched
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz_out = nullptr, int subtract = 1);
 // forward/backward transition posteriors, log-normalised per block
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
 // Viterbi + traceback + qpath

@@ -409,7 +409,7 @@ void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp,
 // i.e. the same quantity as the reference's pairwise chain up to fp64 rounding (the result is
 // rounded to fp32 after the division by the block count, layers.c:1089).
 __global__ void __launch_bounds__(64)
-k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps) {
+k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps, double *__restrict__ logz_out, int subtract) {
     __shared__ double term[64];
     __shared__ double smax[kMaxState];
     const int lane = threadIdx.x;
@@ -461,15 +461,17 @@ k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps) {
         const double v = __shfl(prev, st);
         logZ = fmax(logZ, v) + log1p(exp(-fabs(logZ - v)));
     }
+    if (logz_out && lane == 0) logz_out[blockIdx.x] = logZ;        // crf_manystay_partition_function's own result
+    if (!subtract) return;
     const float logZf = (float)(logZ / (double)Tb);
     const size_t n = (size_t)Tb * Ps;
     for (size_t i = lane; i < n; i += 64)
         if ((int)(i % Ps) < P) S[i] -= logZf;
 }
 
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps) {
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz_out, int subtract) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps);
+    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps, logz_out, subtract);
 }
 
 // ---- forward/backward transition posteriors ---------------------------------------------------

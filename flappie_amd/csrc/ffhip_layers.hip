@@ -1,0 +1,472 @@
+// ffhip_layers.hip -- the reference's per-layer operator interface (layers.h / flappie_matrix.h) on the GPU.
+//
+// Each ffhip_op_* takes host images of flappie matrices (column-major, column stride = 4*ceil(nr/4) floats),
+// converts them on the device into the layouts of ffhip_internal.hpp, runs the SAME kernels the batched
+// pipeline runs (convolution, MFMA projection, recurrent step / persistent recurrent layer, CRF head,
+// partition function) on a batch of one, and writes the result image back.  Activations are separate
+// element-wise calls over the whole image, pad lanes included, exactly as layers.c:24-120 applies them.
+// These entry points exist for drop-in and unit-test use; throughput comes from the batch API.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+
+#include "ffhip_host.hpp"
+#include "ffhip_math.hpp"
+
+using namespace ffhip;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------ layout kernels
+// image [nc][stride] -> sample-major rows [t][F] (dst points at sample 0; pads are zeroed by the caller)
+__global__ void k_img_to_sample(const float *__restrict__ img, size_t stride, int F, int T, float *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F) return;
+    const size_t t = i / F, f = i % F;
+    dst[i] = img[t * stride + f];
+}
+
+__global__ void k_sample_to_img(const float *__restrict__ src, int F, int T, float *__restrict__ img, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F) return;
+    const size_t t = i / F, f = i % F;
+    img[t * stride + f] = src[i];
+}
+
+// image -> tile-interleaved A[tile][k/4][r16][k%4] with K16tot*16 features per tile, this image's
+// features starting at quad k4_off.  single = 0: 16 consecutive columns are the 16 "reads" of a tile
+// (projection-style work, columns are independent); single = 1: column c is tile c, read 0 (recurrent work).
+__global__ void k_img_to_tiles(const float *__restrict__ img, size_t stride, int K, int nc, int K16, int K16tot, int k4_off,
+                               int single, int ntile, float *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ntile * K16 * 64) return;
+    const int tile = (int)(i / ((size_t)K16 * 64)), rem = (int)(i % ((size_t)K16 * 64));
+    const int k4 = rem / 16, r = rem % 16;
+    const int col = single ? (r == 0 ? tile : -1) : tile * 16 + r;
+    v4f v = { 0.f, 0.f, 0.f, 0.f };
+    if (col >= 0 && col < nc) {
+        const float *p = img + (size_t)col * stride + 4 * k4;
+        if (4 * k4 + 0 < K) v.x = p[0];
+        if (4 * k4 + 1 < K) v.y = p[1];
+        if (4 * k4 + 2 < K) v.z = p[2];
+        if (4 * k4 + 3 < K) v.w = p[3];
+    }
+    *(v4f *)(dst + ((size_t)tile * K16tot * 64 + (size_t)(k4_off + k4) * 16 + r) * 4) = v;
+}
+
+// D-fragment X[tile][mt][lane][4] (row 16*mt + 4*(lane>>4) + e, column 16*tile + (lane&15)) -> image
+__global__ void k_dfrag_to_img(const float *__restrict__ xa, int Mt, int M, int nc, int ntile, float *__restrict__ img, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ntile * Mt * 64) return;
+    const int lane = (int)(i % 64), mt = (int)((i / 64) % Mt), tile = (int)(i / ((size_t)64 * Mt));
+    const int col = tile * 16 + (lane & 15), row = 16 * mt + 4 * (lane >> 4);
+    if (col >= nc) return;
+    const v4f v = *(const v4f *)(xa + i * 4);
+    float *o = img + (size_t)col * stride + row;
+    if (row + 0 < M) o[0] = v.x;
+    if (row + 1 < M) o[1] = v.y;
+    if (row + 2 < M) o[2] = v.z;
+    if (row + 3 < M) o[3] = v.w;
+}
+
+// gate pre-activations of one read, image [T][stride] with rows g*H + u -> D-fragment [t][ut][lane][4]
+// (rows unit-major: lane (q, r) holds the G gates of unit 4*ut + q of read r; only read 0 is real)
+__global__ void k_gates_to_dfrag(const float *__restrict__ img, size_t stride, int H, int G, int Ut, int T, float *__restrict__ xa) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Ut * 64) return;
+    const int lane = (int)(i % 64), ut = (int)((i / 64) % Ut);
+    const size_t t = i / ((size_t)64 * Ut);
+    const int u = 4 * ut + (lane >> 4);
+    v4f v = { 0.f, 0.f, 0.f, 0.f };
+    if ((lane & 15) == 0 && u < H) {
+        const float *p = img + t * stride + u;
+        v.x = p[0];
+        v.y = p[(size_t)H];
+        v.z = p[(size_t)2 * H];
+        if (G > 3) v.w = p[(size_t)3 * H];
+    }
+    *(v4f *)(xa + i * 4) = v;
+}
+
+// tile-interleaved activations (one read tile, read 0) -> image [T][stride]
+__global__ void k_tiles_to_img(const float *__restrict__ act, int Hp, int H, int T, float *__restrict__ img, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * H) return;
+    const size_t t = i / H;
+    const int f = (int)(i % H);
+    img[t * stride + f] = act[t * Hp * 16 + (size_t)(f / 4) * 64 + (f % 4)];
+}
+
+// LSTM cell state of read 0: vector [H] <-> the step kernel's slot order [ut][lane = (q, r)]
+__global__ void k_vec_to_cstate(const float *__restrict__ v, int H, int Ut, float *__restrict__ c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ut * 64) return;
+    const int lane = i % 64, u = 4 * (i / 64) + (lane >> 4);
+    c[i] = ((lane & 15) == 0 && u < H) ? v[u] : 0.0f;
+}
+__global__ void k_cstate_to_vec(const float *__restrict__ c, int H, float *__restrict__ v) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= H) return;
+    v[u] = c[(u / 4) * 64 + (u % 4) * 16];
+}
+
+// ------------------------------------------------------------------------------------ element-wise
+__global__ void k_activation(float *__restrict__ x, size_t n, int act, float p0, float p1, size_t nr, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (act == FFHIP_ACT_SHIFT_SCALE && i % stride >= nr) return;          // the one loop that skips pad lanes
+    const float v = x[i];
+    float r;
+    switch (act) {
+    case FFHIP_ACT_SWISH: r = swish_ref(v); break;                                   // layers.c:24-33
+    case FFHIP_ACT_TANH: r = tanh_ref(v); break;                                     // layers.c:40-49
+    case FFHIP_ACT_EXP: r = exp_cephes(v); break;                                    // layers.c:56-66
+    case FFHIP_ACT_LOG: r = log_cephes(v); break;                                    // layers.c:73-81
+    case FFHIP_ACT_ELU: r = (v >= 0.0f) ? v : (exp_cephes(v) - 1.0f); break;         // layers.c:88-96, util.h:339-347
+    case FFHIP_ACT_ROBUSTLOG: r = log_cephes(p0 + p1 * v); break;                    // layers.c:109-124 (p0 = min_prob, p1 = 1 - min_prob)
+    case FFHIP_ACT_SHIFT_SCALE: r = (v - p0) / p1; break;                            // flappie_matrix.c:625-633
+    default: r = v;
+    }
+    x[i] = r;
+}
+
+__global__ void k_add_inplace(float *__restrict__ y, const float *__restrict__ x, size_t n) {      // layers.c:338-353
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = y[i] + x[i];
+}
+
+// row_normalise_inplace (flappie_matrix.c:425-447): four lane sums over the quads of a column, the pad
+// lanes of the last quad subtracted, ((s0+s1)+(s2+s3)), then a multiply by the reciprocal.
+__global__ void k_row_normalise(float *__restrict__ img, int nr, int nrq, int nc) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= nc) return;
+    float *c = img + (size_t)col * nrq * 4;
+    float s[4] = { c[0], c[1], c[2], c[3] };
+    for (int q = 1; q < nrq; q++)
+        for (int e = 0; e < 4; e++) s[e] = s[e] + c[4 * q + e];
+    const int npad = 4 * nrq - nr;
+    for (int e = 1; e < 4; e++)
+        if (npad >= 4 - e) s[e] = s[e] - c[4 * (nrq - 1) + e];
+    const float tsum = (s[0] + s[1]) + (s[2] + s[3]);
+    const float recip = 1.0f / tsum;
+    for (int i = 0; i < 4 * nrq; i++) c[i] = c[i] * recip;
+}
+
+// log_row_normalise_inplace (flappie_matrix.c:450-467): sequential logsumexpf chain over the nr rows
+__global__ void k_log_row_normalise(float *__restrict__ img, int nr, size_t stride, int nc) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= nc) return;
+    float *c = img + (size_t)col * stride;
+    float ls = c[0];
+    for (int r = 1; r < nr; r++) ls = logsumexpf_ref(ls, c[r]);
+    for (int r = 0; r < nr; r++) c[r] = c[r] - ls;
+}
+
+inline unsigned nblk(size_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+bool view_ok(const ffhip_mat &m) { return m.data && m.nr > 0 && m.nc > 0 && m.stride >= m.nr; }
+
+// image of a whole matrix, device side
+float *upload_img(TmpDev &t, const ffhip_mat &m, hipStream_t s) { return (float *)t.upload(m.data, m.nc * m.stride * sizeof(float), s); }
+
+// A-fragment weights of W^T for `W` an [K x M] flappie matrix (column m holds output row m)
+std::vector<float> pack_weight_T(const ffhip_mat &W, int Mt, int K16) {
+    return pack_afrag(Mt, K16, [&](int row, int k) -> float {
+        if ((size_t)row >= W.nc || (size_t)k >= W.nr) return 0.0f;
+        return W.data[(size_t)row * W.stride + k];
+    });
+}
+
+// recurrent weights with gate rows permuted unit-major (m = 4u + g), as ffhip_model_upload does
+std::vector<float> pack_recurrent(const ffhip_mat &sW, int H, int G, int Hp) {
+    return pack_afrag(Hp / 4, Hp / 16, [&](int row, int k) -> float {
+        const int u = row / 4, g = row % 4;
+        if (u >= H || g >= G || k >= H) return 0.0f;
+        return sW.data[(size_t)(g * H + u) * sW.stride + k];
+    });
+}
+
+}  // namespace
+
+#define OP_ENTER(eng_)                                                     \
+    if (!(eng_)) return set_err(FFHIP_EINVAL, "null engine");              \
+    hipSetDevice((eng_)->device);                                          \
+    hipStream_t s = (eng_)->streams[0];                                    \
+    TmpDev tmp
+#define OP_NOMEM() return set_err(FFHIP_ENOMEM, "device allocation failed")
+
+// ------------------------------------------------------------------------------------ element-wise ops
+extern "C" int ffhip_op_activation(ffhip_engine *eng, ffhip_mat C, int act, float p0, float p1) {
+    OP_ENTER(eng);
+    if (!view_ok(C) || act < FFHIP_ACT_NONE || act > FFHIP_ACT_SHIFT_SCALE) return set_err(FFHIP_EINVAL, "bad activation arguments");
+    const size_t n = C.nc * C.stride;
+    float *d = upload_img(tmp, C, s);
+    if (!d) OP_NOMEM();
+    hipLaunchKernelGGL(k_activation, dim3(nblk(n)), dim3(256), 0, s, d, n, act, p0, p1, C.nr, C.stride);
+    HIP_TRY(hipMemcpyAsync(C.data, d, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_op_add_inplace(ffhip_engine *eng, ffhip_mat Y, ffhip_mat X) {
+    OP_ENTER(eng);
+    if (!view_ok(Y) || !view_ok(X) || X.nr != Y.nr || X.nc != Y.nc || X.stride != Y.stride) return set_err(FFHIP_EINVAL, "residual: shapes differ");
+    const size_t n = Y.nc * Y.stride;
+    float *dy = upload_img(tmp, Y, s), *dx = upload_img(tmp, X, s);
+    if (!dy || !dx) OP_NOMEM();
+    hipLaunchKernelGGL(k_add_inplace, dim3(nblk(n)), dim3(256), 0, s, dy, dx, n);
+    HIP_TRY(hipMemcpyAsync(Y.data, dy, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_op_row_normalise(ffhip_engine *eng, ffhip_mat C, int log_space) {
+    OP_ENTER(eng);
+    if (!view_ok(C) || C.stride % 4 != 0) return set_err(FFHIP_EINVAL, "bad row-normalise arguments");
+    const size_t n = C.nc * C.stride;
+    float *d = upload_img(tmp, C, s);
+    if (!d) OP_NOMEM();
+    if (log_space) hipLaunchKernelGGL(k_log_row_normalise, dim3(nblk(C.nc, 64)), dim3(64), 0, s, d, (int)C.nr, C.stride, (int)C.nc);
+    else hipLaunchKernelGGL(k_row_normalise, dim3(nblk(C.nc, 64)), dim3(64), 0, s, d, (int)C.nr, (int)(C.stride / 4), (int)C.nc);
+    HIP_TRY(hipMemcpyAsync(C.data, d, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ convolution
+// layers.c:189-276.  C must be [W.nc x ceil(X.nc/stride)].  Thin layers (<= 32 filters) run the VALU
+// kernel, wide ones the MFMA implicit-GEMM kernel, as in the batched pipeline.
+extern "C" int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, size_t conv_stride, ffhip_mat C) {
+    OP_ENTER(eng);
+    if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C) || conv_stride < 1) return set_err(FFHIP_EINVAL, "bad convolution arguments");
+    const int Fin = (int)X.nr, nf_pad = round_up(Fin, 4), Fout = (int)W.nc, T = (int)X.nc, cs = (int)conv_stride;
+    const int wrows = round_up((int)W.nr, 4);
+    if (wrows % nf_pad != 0) return set_err(FFHIP_EINVAL, "convolution: filter rows do not match %d input features (layers.c:198)", Fin);
+    const int winlen = wrows / nf_pad;
+    if (b.nr != W.nc) return set_err(FFHIP_EINVAL, "convolution: bias length (layers.c:195)");
+    if (winlen > 48 || winlen * Fin > kSamplePad * Fin) return set_err(FFHIP_EINVAL, "convolution: window of %d samples not supported", winlen);
+    std::vector<int> pa, pb;
+    const int Tout = build_conv_plan(T, winlen, cs, pa, pb);
+    if (Tout < 0) return set_err(FFHIP_EINVAL, "convolution: %d samples is shorter than the window (%d)", T, winlen);
+    if ((size_t)Tout != C.nc || C.nr != (size_t)Fout) return set_err(FFHIP_EINVAL, "convolution: output must be %d x %d", Fout, Tout);
+
+    auto tap = [&](int f, int t, int j) -> float {
+        const size_t row = (size_t)t * nf_pad + j;
+        return row < W.nr ? W.data[(size_t)f * W.stride + row] : 0.0f;
+    };
+    const size_t in_rows = (size_t)T + 2 * kSamplePad;
+    float *d_x = upload_img(tmp, X, s);
+    float *d_in = (float *)tmp.get(in_rows * Fin * 4);
+    int *d_pa = (int *)tmp.upload(pa.data(), pa.size() * 4, s), *d_pb = (int *)tmp.upload(pb.data(), pb.size() * 4, s);
+    float *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    if (!d_x || !d_in || !d_pa || !d_pb || !d_c) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_in, 0, in_rows * Fin * 4, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_img_to_sample, dim3(nblk((size_t)T * Fin)), dim3(256), 0, s, d_x, X.stride, Fin, T, d_in + (size_t)kSamplePad * Fin);
+    SampleBuf in{ d_in, Fin, T, 0 };             // read stride 0: a batch of one (the MFMA kernel's 16 tile columns alias it)
+    const size_t K = (size_t)winlen * Fin;
+    if (Fout <= 32 && (Fout * K + Fout) * 4 <= 60 * 1024) {
+        std::vector<float> taps((size_t)Fout * K);
+        for (int f = 0; f < Fout; f++)
+            for (int t = 0; t < winlen; t++)
+                for (int j = 0; j < Fin; j++) taps[((size_t)f * winlen + t) * Fin + j] = tap(f, t, j);
+        float *d_w = (float *)tmp.upload(taps.data(), taps.size() * 4, s);
+        float *d_b = (float *)tmp.upload(b.data, (size_t)Fout * 4, s);
+        const size_t out_rows = (size_t)Tout + 2 * kSamplePad;
+        float *d_out = (float *)tmp.get(out_rows * Fout * 4);
+        if (!d_w || !d_b || !d_out) OP_NOMEM();
+        SampleBuf out{ d_out, Fout, Tout, 0 };
+        launch_conv_small(s, in, out, d_w, d_b, d_pa, d_pb, 1, Tout, winlen, ACT_NONE);
+        hipLaunchKernelGGL(k_sample_to_img, dim3(nblk((size_t)Tout * Fout)), dim3(256), 0, s, d_out + (size_t)kSamplePad * Fout, Fout, Tout, d_c, C.stride);
+    } else {
+        const int K16 = (int)((K + 15) / 16), Mpad = round_up(Fout, 16);
+        if ((size_t)K16 * 16 > (size_t)kSamplePad * Fin) return set_err(FFHIP_EINVAL, "convolution: window too long for the sample pad");
+        std::vector<float> wp = pack_afrag(Mpad / 16, K16, [&](int row, int k) -> float {
+            if (row >= Fout || (size_t)k >= K) return 0.0f;
+            return tap(row, k / Fin, k % Fin);
+        });
+        std::vector<float> bias(Mpad, 0.0f);
+        for (int f = 0; f < Fout; f++) bias[f] = b.data[f];
+        float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s);
+        float *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
+        float *d_out = (float *)tmp.get((size_t)Tout * Mpad * 16 * 4);
+        if (!d_w || !d_b || !d_out) OP_NOMEM();
+        launch_conv_mfma(s, in, d_out, (const float4 *)d_w, d_b, d_pa, d_pb, 1, Tout, Mpad, K16, ACT_NONE);
+        hipLaunchKernelGGL(k_tiles_to_img, dim3(nblk((size_t)Tout * Fout)), dim3(256), 0, s, d_out, Mpad, Fout, Tout, d_c, C.stride);
+    }
+    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ affine maps
+// affine_map / affine_map2 (flappie_matrix.c:361-419): C = Wf^T Xf (+ Wb^T Xb) + b.  Xb/Wb may be empty.
+extern "C" int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ffhip_mat Xb, ffhip_mat Wb, ffhip_mat b, ffhip_mat C) {
+    OP_ENTER(eng);
+    const bool two = Xb.data != nullptr;
+    if (!view_ok(Xf) || !view_ok(Wf) || !view_ok(b) || !view_ok(C) || (two && (!view_ok(Xb) || !view_ok(Wb))))
+        return set_err(FFHIP_EINVAL, "bad affine arguments");
+    if (Wf.nr != Xf.nr || b.nr != Wf.nc || C.nr != Wf.nc || C.nc != Xf.nc) return set_err(FFHIP_EINVAL, "affine: shapes do not agree (flappie_matrix.c:373)");
+    if (two && (Wb.nr != Xb.nr || Xb.nc != Xf.nc || Wb.nc != Wf.nc)) return set_err(FFHIP_EINVAL, "affine2: shapes do not agree (flappie_matrix.c:399-404)");
+    const int M = (int)Wf.nc, Mpad = round_up(M, 16), Mt = Mpad / 16, nc = (int)Xf.nc, ntile = (nc + 15) / 16;
+    const int K16f = (int)((Xf.nr + 15) / 16), K16b = two ? (int)((Xb.nr + 15) / 16) : 0, K16 = K16f + K16b;
+    std::vector<float> wp = pack_afrag(Mt, K16, [&](int row, int k) -> float {
+        if (row >= M) return 0.0f;
+        if (k < K16f * 16) return (size_t)k < Wf.nr ? Wf.data[(size_t)row * Wf.stride + k] : 0.0f;
+        const size_t kb = (size_t)k - (size_t)K16f * 16;
+        return kb < Wb.nr ? Wb.data[(size_t)row * Wb.stride + kb] : 0.0f;
+    });
+    std::vector<float> bias(Mpad, 0.0f);
+    for (int m = 0; m < M; m++) bias[m] = b.data[m];
+    float *d_xf = upload_img(tmp, Xf, s), *d_xb = two ? upload_img(tmp, Xb, s) : nullptr;
+    float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
+    float *d_in = (float *)tmp.get((size_t)ntile * K16 * 256 * 4), *d_xa = (float *)tmp.get((size_t)ntile * Mt * 256 * 4);
+    float *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    if (!d_xf || (two && !d_xb) || !d_w || !d_b || !d_in || !d_xa || !d_c) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)ntile * K16f * 64)), dim3(256), 0, s, d_xf, Xf.stride, (int)Xf.nr, nc, K16f, K16, 0, 0, ntile, d_in);
+    if (two)
+        hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)ntile * K16b * 64)), dim3(256), 0, s, d_xb, Xb.stride, (int)Xb.nr, nc, K16b, K16, 4 * K16f, 0, ntile, d_in);
+    launch_inproj(s, d_in, d_xa, (const float4 *)d_w, d_b, ntile, Mpad, K16);
+    hipLaunchKernelGGL(k_dfrag_to_img, dim3(nblk((size_t)ntile * Mt * 64)), dim3(256), 0, s, d_xa, Mt, M, nc, ntile, d_c, C.stride);
+    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ recurrent layers
+// lstm_forward/backward (layers.c:877-976) and grumod_forward/backward (layers.c:571-660): Xa holds the
+// already-projected input [G*H x T], sW is [H x G*H], out is [H x T].  The persistent recurrent kernel
+// runs the layer when it supports the shape, the launch-per-step kernels otherwise.
+extern "C" int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffhip_mat sW, int backward, ffhip_mat out) {
+    OP_ENTER(eng);
+    if (kind != FFHIP_NET_LSTM5 && kind != FFHIP_NET_GRUMOD5) return set_err(FFHIP_EINVAL, "unknown recurrent kind %d", kind);
+    if (!view_ok(Xa) || !view_ok(sW) || !view_ok(out)) return set_err(FFHIP_EINVAL, "bad recurrent-layer arguments");
+    const int G = (kind == FFHIP_NET_LSTM5) ? 4 : 3, H = (int)sW.nr, T = (int)Xa.nc;
+    if (H % 4 != 0 || sW.nc != (size_t)G * H || Xa.nr != (size_t)G * H || out.nr != (size_t)H || out.nc != Xa.nc)
+        return set_err(FFHIP_EINVAL, "recurrent layer: shapes do not agree (layers.c:884-889)");
+    const int Hp = round_up(H, 16), Ut = Hp / 4;
+    std::vector<float> sp = pack_recurrent(sW, H, G, Hp);
+    float *d_x = upload_img(tmp, Xa, s);
+    float *d_w = (float *)tmp.upload(sp.data(), sp.size() * 4, s);
+    float *d_xa = (float *)tmp.get((size_t)T * Ut * 256 * 4), *d_h = (float *)tmp.get((size_t)T * Hp * 16 * 4);
+    float *d_o = (float *)tmp.get(out.nc * out.stride * 4);
+    if (!d_x || !d_w || !d_xa || !d_h || !d_o) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, out.nc * out.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_gates_to_dfrag, dim3(nblk((size_t)T * Ut * 64)), dim3(256), 0, s, d_x, Xa.stride, H, G, Ut, T, d_xa);
+    unsigned h_abort = 0;
+    if (persist_supported(kind, Hp, eng->prop.multiProcessorCount)) {
+        unsigned *d_flags = (unsigned *)tmp.get(persist_flag_words(Hp, 1) * 4), *d_abort = (unsigned *)tmp.get(4);
+        if (!d_flags || !d_abort) OP_NOMEM();
+        HIP_TRY(hipMemsetAsync(d_flags, 0, persist_flag_words(Hp, 1) * 4, s), FFHIP_EHIP);
+        HIP_TRY(hipMemsetAsync(d_abort, 0, 4, s), FFHIP_EHIP);
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_h, (int)0xFFFFFFFF, (size_t)T * Hp * 16, s), FFHIP_EHIP);     // NaN sentinel = "not written yet"
+        if (eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, eng->persist_done, 0), FFHIP_EHIP);
+        if (!launch_rnn_persist(s, kind, (const float4 *)d_w, d_xa, d_h, d_flags, d_abort, T, 1, Hp, 0, 1, backward, 0))
+            return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
+        HIP_TRY(hipEventRecord(eng->persist_done, s), FFHIP_EHIP);
+        eng->persist_chained = 1;
+        HIP_TRY(hipMemcpyAsync(&h_abort, d_abort, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    } else {
+        float *d_c = (float *)tmp.get((size_t)Ut * 64 * 4);
+        if (!d_c) OP_NOMEM();
+        const size_t xa_step = (size_t)Ut * 256, h_step = (size_t)Hp * 16;
+        for (int i = 0; i < T; i++) {
+            const int t = backward ? T - 1 - i : i, tp = backward ? t + 1 : t - 1;
+            const float *hp = (i == 0) ? nullptr : d_h + (size_t)tp * h_step;
+            if (kind == FFHIP_NET_LSTM5) launch_lstm_step(s, (const float4 *)d_w, d_xa + (size_t)t * xa_step, hp, d_h + (size_t)t * h_step, d_c, 1, Hp, i == 0);
+            else launch_gru_step(s, (const float4 *)d_w, d_xa + (size_t)t * xa_step, hp, d_h + (size_t)t * h_step, 1, Hp, i == 0);
+        }
+    }
+    hipLaunchKernelGGL(k_tiles_to_img, dim3(nblk((size_t)T * H)), dim3(256), 0, s, d_h, Hp, H, T, d_o, out.stride);
+    HIP_TRY(hipMemcpyAsync(out.data, d_o, out.nc * out.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    if (h_abort) return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
+    return FFHIP_OK;
+}
+
+// lstm_step (layers.c:979-1026) / grumod_step (layers.c:664-715): one step from (x, h_prev[, c]) to h (and c).
+// x is the projected input [G*H x 1]; `state` (LSTM cell state, in/out) is ignored for GRUmod.
+extern "C" int ffhip_op_recurrent_step(ffhip_engine *eng, int kind, ffhip_mat x, ffhip_mat h_prev, ffhip_mat sW, ffhip_mat state, ffhip_mat h_out) {
+    OP_ENTER(eng);
+    if (kind != FFHIP_NET_LSTM5 && kind != FFHIP_NET_GRUMOD5) return set_err(FFHIP_EINVAL, "unknown recurrent kind %d", kind);
+    const bool lstm = (kind == FFHIP_NET_LSTM5);
+    if (!view_ok(x) || !view_ok(h_prev) || !view_ok(sW) || !view_ok(h_out) || (lstm && !view_ok(state))) return set_err(FFHIP_EINVAL, "bad recurrent-step arguments");
+    const int G = lstm ? 4 : 3, H = (int)sW.nr;
+    if (H % 4 != 0 || sW.nc != (size_t)G * H || x.nr != (size_t)G * H || h_prev.nr != (size_t)H || h_out.nr != (size_t)H || (lstm && state.nr != (size_t)H))
+        return set_err(FFHIP_EINVAL, "recurrent step: shapes do not agree (layers.c:985-994)");
+    const int Hp = round_up(H, 16), Ut = Hp / 4;
+    std::vector<float> sp = pack_recurrent(sW, H, G, Hp);
+    float *d_x = (float *)tmp.upload(x.data, x.stride * 4, s), *d_hp = (float *)tmp.upload(h_prev.data, h_prev.stride * 4, s);
+    float *d_w = (float *)tmp.upload(sp.data(), sp.size() * 4, s);
+    float *d_xa = (float *)tmp.get((size_t)Ut * 256 * 4), *d_hin = (float *)tmp.get((size_t)Hp * 16 * 4), *d_hout = (float *)tmp.get((size_t)Hp * 16 * 4);
+    float *d_c = (float *)tmp.get((size_t)Ut * 64 * 4), *d_v = (float *)tmp.get((size_t)Hp * 4);
+    if (!d_x || !d_hp || !d_w || !d_xa || !d_hin || !d_hout || !d_c || !d_v) OP_NOMEM();
+    hipLaunchKernelGGL(k_gates_to_dfrag, dim3(nblk((size_t)Ut * 64)), dim3(256), 0, s, d_x, x.stride, H, G, Ut, 1, d_xa);
+    hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)(Hp / 16) * 64)), dim3(256), 0, s, d_hp, h_prev.stride, H, 1, Hp / 16, Hp / 16, 0, 1, 1, d_hin);
+    if (lstm) {
+        float *d_s = (float *)tmp.upload(state.data, state.stride * 4, s);
+        if (!d_s) OP_NOMEM();
+        hipLaunchKernelGGL(k_vec_to_cstate, dim3(nblk((size_t)Ut * 64)), dim3(256), 0, s, d_s, H, Ut, d_c);
+        launch_lstm_step(s, (const float4 *)d_w, d_xa, d_hin, d_hout, d_c, 1, Hp, 0);
+        hipLaunchKernelGGL(k_cstate_to_vec, dim3(nblk(H)), dim3(256), 0, s, d_c, H, d_v);
+        HIP_TRY(hipMemcpyAsync(state.data, d_v, (size_t)H * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    } else {
+        launch_gru_step(s, (const float4 *)d_w, d_xa, d_hin, d_hout, 1, Hp, 0);
+    }
+    float *d_o = (float *)tmp.get(h_out.stride * 4);
+    if (!d_o) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, h_out.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_tiles_to_img, dim3(nblk(H)), dim3(256), 0, s, d_hout, Hp, H, 1, d_o, h_out.stride);
+    HIP_TRY(hipMemcpyAsync(h_out.data, d_o, (size_t)H * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ CRF head
+// crf_manystay_partition_function (layers.c:1035-1079): fp64 forward recursion over a [P x nblock] score matrix
+extern "C" int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(S) || !logZ || !flipflop_dims(S.nr, S.stride, &nbase)) return set_err(FFHIP_EINVAL, "bad partition-function arguments");
+    float *d = upload_img(tmp, S, s);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d || !d_z) OP_NOMEM();
+    launch_crf_norm(s, d, 1, (int)S.nc, nbase, (int)S.stride, d_z, 0);
+    HIP_TRY(hipMemcpyAsync(logZ, d_z, sizeof(double), hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// globalnorm_flipflop (layers.c:1082-1106): C = tanh(W^T X + b) / (temperature/5) - logZ/nblock
+extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C)) return set_err(FFHIP_EINVAL, "bad globalnorm arguments");
+    if (W.nr != X.nr || b.nr != W.nc || C.nr != W.nc || C.nc != X.nc) return set_err(FFHIP_EINVAL, "globalnorm: shapes do not agree");
+    if (!flipflop_dims(W.nc, C.stride, &nbase)) return set_err(FFHIP_EINVAL, "globalnorm: %zu rows is not a flip-flop parameterisation this engine supports", W.nc);
+    const int H = (int)X.nr, Hp = round_up(H, 16), K16 = Hp / 16, P = (int)W.nc, Mt = (P + 15) / 16, T = (int)X.nc;
+    std::vector<float> wp = pack_weight_T(W, Mt, K16);
+    std::vector<float> bias((size_t)Mt * 16, 0.0f);
+    for (int p = 0; p < P; p++) bias[p] = b.data[p];
+    float *d_x = upload_img(tmp, X, s);
+    float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
+    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    if (!d_x || !d_w || !d_b || !d_in || !d_c) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
+    launch_head(s, d_in, d_c, (const float4 *)d_w, d_b, T, 1, 1, P, (int)C.stride, K16, temperature / 5.0f);
+    launch_crf_norm(s, d_c, 1, T, nbase, (int)C.stride);
+    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}

@@ -37,6 +37,41 @@ __device__ __forceinline__ float exp_cephes(float x) {
     return y * __int_as_float((n + 0x7f) << 23);
 }
 
+// log_ps, sse_mathfun.h:123-208: x <= 0 gives NaN (all-ones mask), denormals are clamped to FLT_MIN
+__device__ __forceinline__ float log_cephes(float x) {
+    const bool invalid = (x <= 0.0f);
+    x = (x > 1.17549435e-38f) ? x : 1.17549435e-38f;
+    const int bits = __float_as_int(x);
+    float e = (float)((int)((unsigned)bits >> 23) - 0x7f);
+    x = __int_as_float((bits & ~0x7f800000) | 0x3f000000);     // mantissa in [0.5, 1)
+    e = e + 1.0f;
+    const bool small = (x < 0.707106781186547524f);
+    const float tmp0 = small ? x : 0.0f;
+    x = x - 1.0f;
+    e = e - (small ? 1.0f : 0.0f);
+    x = x + tmp0;
+    const float z = x * x;
+    float y = 7.0376836292E-2f;
+    y = y * x; y = y + -1.1514610310E-1f;
+    y = y * x; y = y + 1.1676998740E-1f;
+    y = y * x; y = y + -1.2420140846E-1f;
+    y = y * x; y = y + 1.4249322787E-1f;
+    y = y * x; y = y + -1.6668057665E-1f;
+    y = y * x; y = y + 2.0000714765E-1f;
+    y = y * x; y = y + -2.4999993993E-1f;
+    y = y * x; y = y + 3.3333331174E-1f;
+    y = y * x;
+    y = y * z;
+    float tmp = e * -2.12194440e-4f;
+    y = y + tmp;
+    tmp = z * 0.5f;
+    y = y - tmp;
+    tmp = e * 0.693359375f;
+    x = x + y;
+    x = x + tmp;
+    return invalid ? __int_as_float(-1) : x;
+}
+
 __device__ __forceinline__ float logistic_ref(float x) { return 1.0f / (1.0f + exp_cephes(-x)); }
 
 __device__ __forceinline__ float tanh_ref(float x) {

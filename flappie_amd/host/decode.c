@@ -9,11 +9,6 @@
 #include "../../include/networks.h"
 #include "../../include/ffhip.h"
 
-/* layers.c:1029-1032 */
-size_t nbase_from_flipflop_nparam(size_t nparam) {
-    return (size_t)roundf((-1.0f + sqrtf(1 + 2 * nparam)) / 2.0f);
-}
-
 /* decode.c:39-63 */
 char *collapse_repeats(int const *path, size_t npos, int modbase) {
     if (NULL == path || modbase <= 0 || 0 == npos) return NULL;
@@ -81,31 +76,4 @@ flappie_imatrix trace_from_posterior(flappie_matrix tpost) {
     for (size_t c = 0; c <= tpost->nc; c++) memcpy(trace->data.f + c * trace->stride, tmp + c * nstate, nstate * sizeof(int32_t));
     free(tmp);
     return trace;
-}
-
-/* layers.c:56-66 with the cephes exp of sse_mathfun.h:225-301, every stored element (pads too) */
-static float exp_cephes_host(float x) {
-    x = (x < 88.3762626647949f) ? x : 88.3762626647949f;
-    x = (x > -88.3762626647949f) ? x : -88.3762626647949f;
-    float fx = x * 1.44269504088896341f + 0.5f;
-    float tmp = (float)(int)fx;
-    fx = tmp - ((tmp > fx) ? 1.0f : 0.0f);
-    x = x - fx * 0.693359375f;
-    x = x - fx * -2.12194440e-4f;
-    const float z = x * x;
-    float y = 1.9875691500E-4f;
-    y = y * x + 1.3981999507E-3f;
-    y = y * x + 8.3334519073E-3f;
-    y = y * x + 4.1665795894E-2f;
-    y = y * x + 1.6666665459E-1f;
-    y = y * x + 5.0000001201E-1f;
-    y = y * z + x + 1.0f;
-    union { int i; float f; } p2 = { .i = ((int)fx + 0x7f) << 23 };
-    return y * p2.f;
-}
-
-void exp_activation_inplace(flappie_matrix C) {
-    if (NULL == C) return;
-    const size_t n = C->stride * C->nc;
-    for (size_t i = 0; i < n; i++) C->data.f[i] = exp_cephes_host(C->data.f[i]);
 }

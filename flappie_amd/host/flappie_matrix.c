@@ -129,6 +129,122 @@ int32_t *array_from_flappie_imatrix(const_flappie_imatrix mat) {
     return res;
 }
 
+flappie_imatrix copy_flappie_imatrix(const_flappie_imatrix M) {
+    if (NULL == M) return NULL;
+    flappie_imatrix C = make_flappie_imatrix(M->nr, M->nc);
+    if (NULL == C) return NULL;
+    memcpy(C->data.f, M->data.f, sizeof(int32_t) * C->stride * C->nc);
+    return C;
+}
+
+void zero_flappie_imatrix(flappie_imatrix M) {
+    if (NULL == M) return;
+    memset(M->data.f, 0, M->stride * M->nc * sizeof(int32_t));
+}
+
+/* ---- host-side inspection helpers (flappie_matrix.c:109-232,468-618): bookkeeping on host images, no
+ *      arithmetic of the network.  The compute entries of flappie_matrix.h (affine_map, affine_map2,
+ *      row_normalise_inplace, log_row_normalise_inplace, shift_scale_matrix_inplace) live in layers.c and run
+ *      on the GPU. ---- */
+void fprint_flappie_matrix(FILE *fh, const char *header, const_flappie_matrix mat, size_t nr, size_t nc, bool include_padding) {
+    if (NULL == fh || NULL == mat) return;
+    const size_t rlim = include_padding ? mat->stride : mat->nr;
+    if (nr <= 0 || nr > rlim) nr = rlim;
+    if (nc <= 0 || nc > mat->nc) nc = mat->nc;
+    if (NULL != header) {
+        if (fputs(header, fh) < 0) return;
+        fputc('\n', fh);
+    }
+    for (size_t c = 0; c < nc; c++) {
+        const size_t offset = c * mat->stride;
+        fprintf(fh, "%4zu : % 12e", c, mat->data.f[offset]);
+        for (size_t r = 1; r < nr; r++) fprintf(fh, "  % 12e", mat->data.f[offset + r]);
+        fputc('\n', fh);
+    }
+}
+
+/* flappie_matrix.c:150-232.  The reference compiles this to `return true` under NDEBUG (its Release build);
+ * here the checks always run. */
+bool validate_flappie_matrix(flappie_matrix mat, float lower, const float upper, const float maskval, const bool only_finite,
+                             const char *file, const int line) {
+    if (NULL == mat || NULL == mat->data.f || 0 == mat->nc || 0 == mat->nr || mat->stride < mat->nr || mat->nrq * 4 != mat->stride) return false;
+    const size_t nc = mat->nc, nr = mat->nr, ld = mat->stride;
+    for (size_t c = 0; c < nc; ++c) {
+        const float *col = mat->data.f + c * ld;
+        if (!isnan(maskval))
+            for (size_t r = nr; r < ld; ++r)
+                if (maskval != col[r]) { warnx("%s:%d  Matrix entry [%zu,%zu] = %f violates masking rules\n", file, line, r, c, col[r]); return false; }
+        for (size_t r = 0; r < nr; ++r) {
+            if (only_finite && !isfinite(col[r])) { warnx("%s:%d  Matrix entry [%zu,%zu] = %f contains a non-finite value\n", file, line, r, c, col[r]); return false; }
+            if (!isnan(lower) && col[r] + 1.1920929e-07f < lower) { warnx("%s:%d  Matrix entry [%zu,%zu] = %f (%e) violates lower bound\n", file, line, r, c, col[r], col[r] - lower); return false; }
+            if (!isnan(upper) && col[r] > upper + 1.1920929e-07f) { warnx("%s:%d  Matrix entry [%zu,%zu] = %f (%e) violates upper bound\n", file, line, r, c, col[r], col[r] - upper); return false; }
+        }
+    }
+    return true;
+}
+
+float max_flappie_matrix(const_flappie_matrix x) {
+    if (NULL == x) return NAN;
+    float amax = x->data.f[0];
+    for (size_t col = 0; col < x->nc; col++)
+        for (size_t r = 0; r < x->nr; r++)
+            if (amax < x->data.f[col * x->stride + r]) amax = x->data.f[col * x->stride + r];
+    return amax;
+}
+
+/* flappie_matrix.c:487-502 */
+float min_flappie_matrix(const_flappie_matrix x) {
+    if (NULL == x) return NAN;
+    float amin = x->data.f[0];
+    for (size_t col = 0; col < x->nc; col++)
+        for (size_t r = 0; r < x->nr; r++)
+            if (amin > x->data.f[col * x->stride + r]) amin = x->data.f[col * x->stride + r];
+    return amin;
+}
+
+bool validate_vector(float *vec, const size_t n, const float lower, const float upper, const char *file, const int line) {
+    if (NULL == vec) return false;
+    for (size_t i = 0; i < n; ++i) {
+        if (!isnan(lower) && lower > vec[i]) { warnx("%s:%d  Vector entry %zu = %f violates lower bound\n", file, line, i, vec[i]); return false; }
+        if (!isnan(upper) && upper < vec[i]) { warnx("%s:%d  Vector entry %zu = %f violates upper bound\n", file, line, i, vec[i]); return false; }
+    }
+    return true;
+}
+
+bool validate_ivector(int *vec, const size_t n, const int lower, const int upper, const char *file, const int line) {
+    if (NULL == vec) return false;
+    for (size_t i = 0; i < n; ++i) {
+        if (lower > vec[i]) { warnx("%s:%d  Vector entry %zu = %d violates lower bound\n", file, line, i, vec[i]); return false; }
+        if (upper < vec[i]) { warnx("%s:%d  Vector entry %zu = %d violates upper bound\n", file, line, i, vec[i]); return false; }
+    }
+    return true;
+}
+
+/* flappie_matrix.c:647-720: signal-conditioning helpers of the delta-sample path, element selection only */
+void clip_matrix_inplace(flappie_matrix C, float thresh) {
+    if (NULL == C) return;
+    for (size_t c = 0; c < C->nc; c++)
+        for (size_t r = 0; r < C->nr; r++) {
+            const float obs = C->data.f[c * C->stride + r];
+            C->data.f[c * C->stride + r] = copysignf(fminf(thresh, fabsf(obs)), obs);
+        }
+}
+
+void filter_matrix_inplace(flappie_matrix C, float fill_val, float thresh) {
+    if (NULL == C) return;
+    for (size_t c = 0; c < C->nc; c++)
+        for (size_t r = 0; r < C->nr; r++)
+            if (fabsf(C->data.f[c * C->stride + r]) > thresh) C->data.f[c * C->stride + r] = fill_val;
+}
+
+void difference_matrix_inplace(flappie_matrix C, float val) {
+    if (NULL == C) return;
+    for (size_t c = 1; c < C->nc; c++)
+        for (size_t r = 0; r < C->nr; r++)
+            C->data.f[(c - 1) * C->stride + r] = C->data.f[c * C->stride + r] - C->data.f[(c - 1) * C->stride + r];
+    for (size_t r = 0; r < C->nr; r++) C->data.f[(C->nc - 1) * C->stride + r] = val;
+}
+
 /* flappie_structures.c:13-24 */
 void free_raw_table(raw_table *tbl) {
     if (NULL == tbl) return;

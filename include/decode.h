@@ -6,6 +6,7 @@
 #define FFHIP_DECODE_H
 #include <stdbool.h>
 #include "flappie_matrix.h"
+#include "layers.h"      /* exp_activation_inplace, nbase_from_flipflop_nparam (flappie.c:299, decode.c:131) */
 #include "flappie_structures.h"
 
 #ifdef __cplusplus
@@ -29,10 +30,6 @@ flappie_matrix transpost_crf_flipflop(const_flappie_matrix trans, bool return_lo
 /* decode.c:499-543: tpost holds probabilities; returns [nstate x nblock+1] int32 */
 flappie_imatrix trace_from_posterior(flappie_matrix tpost);
 
-/* layers.c:56-66 (declared in layers.h in the reference; needed between the two calls above,
- * flappie.c:299-300) and layers.c:1029-1032 */
-void exp_activation_inplace(flappie_matrix C);
-size_t nbase_from_flipflop_nparam(size_t nparam);
 
 #ifdef __cplusplus
 }

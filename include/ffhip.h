@@ -135,6 +135,43 @@ int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblock, size_t 
 /* trace_from_posterior (decode.c:499-543): `post` holds PROBABILITIES; out[nblock+1][nstate] packed */
 int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t nparam, size_t stride, int32_t *out);
 
+/* ---- layer operators on single matrices ---------------------------------------------------------
+ * The reference's per-layer interface (layers.h:15-100, flappie_matrix.h:67-73) on the GPU, used by the
+ * wrappers in include/layers.h.  An ffhip_mat is a HOST image of a flappie matrix: column-major, `nc`
+ * columns of `stride` = 4*ceil(nr/4) floats.  Outputs must be allocated by the caller with the shape the
+ * reference function would return; every call is synchronous.  Batch-of-one use of the same kernels the
+ * batched pipeline runs. */
+typedef struct { float *data; size_t nr, nc, stride; } ffhip_mat;
+
+enum ffhip_activation {
+    FFHIP_ACT_NONE = 0,
+    FFHIP_ACT_SWISH = 1,        /* swish_activation_inplace, layers.c:24-33    */
+    FFHIP_ACT_TANH = 2,         /* tanh_activation_inplace, layers.c:40-49     */
+    FFHIP_ACT_EXP = 3,          /* exp_activation_inplace, layers.c:56-66      */
+    FFHIP_ACT_LOG = 4,          /* log_activation_inplace, layers.c:73-81      */
+    FFHIP_ACT_ELU = 5,          /* elu_activation_inplace, layers.c:88-96      */
+    FFHIP_ACT_ROBUSTLOG = 6,    /* robustlog_activation_inplace, layers.c:109-124: log(p0 + p1*x) */
+    FFHIP_ACT_SHIFT_SCALE = 7   /* shift_scale_matrix_inplace, flappie_matrix.c:625-633: (x - p0)/p1 */
+};
+/* element-wise over the whole image, pad lanes included (as the reference's SSE loops do) */
+int ffhip_op_activation(ffhip_engine *eng, ffhip_mat C, int act, float p0, float p1);
+/* residual_inplace (layers.c:338-353): Y += X */
+int ffhip_op_add_inplace(ffhip_engine *eng, ffhip_mat Y, ffhip_mat X);
+/* row_normalise_inplace / log_row_normalise_inplace (flappie_matrix.c:425-467) */
+int ffhip_op_row_normalise(ffhip_engine *eng, ffhip_mat C, int log_space);
+/* convolution (layers.c:189-276), including its strided right-edge behaviour; C is [W.nc x ceil(X.nc/stride)] */
+int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, size_t conv_stride, ffhip_mat C);
+/* affine_map / affine_map2 (flappie_matrix.c:361-419): C = Wf^T Xf (+ Wb^T Xb) + b; pass Xb.data == NULL for one input */
+int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ffhip_mat Xb, ffhip_mat Wb, ffhip_mat b, ffhip_mat C);
+/* lstm_forward/backward (layers.c:877-976), grumod_forward/backward (layers.c:571-660); kind = enum ffhip_net_kind */
+int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffhip_mat sW, int backward, ffhip_mat out);
+/* lstm_step (layers.c:979-1026) / grumod_step (layers.c:664-715); `state` = LSTM cell state, updated in place */
+int ffhip_op_recurrent_step(ffhip_engine *eng, int kind, ffhip_mat x, ffhip_mat h_prev, ffhip_mat sW, ffhip_mat state, ffhip_mat h_out);
+/* crf_manystay_partition_function (layers.c:1035-1079) */
+int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
+/* globalnorm_flipflop (layers.c:1082-1106) */
+int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* HIP-event timing of the kernel groups of one batch_run, on the stream they are launched on.
  * groups: 0 conv, 1 in-projection GEMMs, 2 recurrent, 3 head+CRF norm, 4 posterior, 5 viterbi+assembly */

@@ -63,6 +63,31 @@ flappie_imatrix make_flappie_imatrix(size_t nr, size_t nc);
 flappie_imatrix remake_flappie_imatrix(flappie_imatrix M, size_t nr, size_t nc);
 flappie_imatrix free_flappie_imatrix(flappie_imatrix mat);
 int32_t *array_from_flappie_imatrix(const_flappie_imatrix mat);
+flappie_imatrix copy_flappie_imatrix(const_flappie_imatrix mat);
+void zero_flappie_imatrix(flappie_imatrix M);
+
+/* flappie_matrix.h:48-55,75-83: host-side inspection helpers.  validate_* always check (the reference's
+ * Release build compiles them to `return true`); min_flappie_matrix returns the minimum (the reference's
+ * loop, flappie_matrix.c:487-502, compares the wrong way round and returns the maximum). */
+void fprint_flappie_matrix(FILE *fh, const char *header, const_flappie_matrix mat, size_t nr, size_t nc, bool include_padding);
+bool validate_flappie_matrix(flappie_matrix mat, float lower, const float upper, const float maskval, const bool only_finite,
+                             const char *file, const int line);
+float min_flappie_matrix(const_flappie_matrix mat);
+float max_flappie_matrix(const_flappie_matrix mat);
+bool validate_ivector(int *vec, const size_t n, const int lower, const int upper, const char *file, const int line);
+bool validate_vector(float *vec, const size_t n, const float lower, const float upper, const char *file, const int line);
+void clip_matrix_inplace(flappie_matrix C, float thresh);
+void filter_matrix_inplace(flappie_matrix C, float fill_val, float thresh);
+void difference_matrix_inplace(flappie_matrix C, float val);
+
+/* flappie_matrix.h:67-73,79: computed on the GPU (host/layers.c -> ffhip_op_affine / ffhip_op_row_normalise /
+ * ffhip_op_activation) */
+flappie_matrix affine_map(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, flappie_matrix C);
+flappie_matrix affine_map2(const_flappie_matrix Xf, const_flappie_matrix Xb, const_flappie_matrix Wf, const_flappie_matrix Wb,
+                           const_flappie_matrix b, flappie_matrix C);
+void row_normalise_inplace(flappie_matrix C);
+void log_row_normalise_inplace(flappie_matrix C);
+void shift_scale_matrix_inplace(flappie_matrix sigmat, float shift, float scale);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,79 @@ void fo_exp_inplace(fo_mat *C) {
     for (size_t i = 0; i < n; i++) C->f[i] = fo_expf_cephes(C->f[i]);
 }
 
+/* sse_mathfun.h:123-208 log_ps, one lane: x <= 0 -> NaN (all-ones), denormals clamped to FLT_MIN */
+float fo_logf_cephes(float x) {
+    const int invalid = (x <= 0.0f);
+    x = (x > 1.17549435e-38f) ? x : 1.17549435e-38f;
+    union { float f; int i; unsigned u; } b = { .f = x };
+    float e = (float)((int)(b.u >> 23) - 0x7f);
+    b.i = (b.i & ~0x7f800000) | 0x3f000000;
+    x = b.f;
+    e = e + 1.0f;
+    const int small = (x < 0.707106781186547524f);
+    const float tmp0 = small ? x : 0.0f;
+    x = x - 1.0f;
+    e = e - (small ? 1.0f : 0.0f);
+    x = x + tmp0;
+    const float z = x * x;
+    float y = 7.0376836292E-2f;
+    y = y * x; y = y + -1.1514610310E-1f;
+    y = y * x; y = y + 1.1676998740E-1f;
+    y = y * x; y = y + -1.2420140846E-1f;
+    y = y * x; y = y + 1.4249322787E-1f;
+    y = y * x; y = y + -1.6668057665E-1f;
+    y = y * x; y = y + 2.0000714765E-1f;
+    y = y * x; y = y + -2.4999993993E-1f;
+    y = y * x; y = y + 3.3333331174E-1f;
+    y = y * x;
+    y = y * z;
+    float tmp = e * -2.12194440e-4f;
+    y = y + tmp;
+    tmp = z * 0.5f;
+    y = y - tmp;
+    tmp = e * 0.693359375f;
+    x = x + y;
+    x = x + tmp;
+    if (invalid) { b.i = -1; return b.f; }
+    return x;
+}
+
+/* layers.c:73-81 */
+void fo_log_inplace(fo_mat *C) {
+    if (!C) return;
+    const size_t n = C->stride * C->nc;
+    for (size_t i = 0; i < n; i++) C->f[i] = fo_logf_cephes(C->f[i]);
+}
+
+/* layers.c:88-96 */
+void fo_elu_inplace(fo_mat *C) {
+    if (!C) return;
+    const size_t n = C->stride * C->nc;
+    for (size_t i = 0; i < n; i++) C->f[i] = fo_eluf(C->f[i]);
+}
+
+/* layers.c:109-124  log(min_prob + (1 - min_prob) * x) */
+void fo_robustlog_inplace(fo_mat *C, float min_prob) {
+    if (!C) return;
+    const size_t n = C->stride * C->nc;
+    const float mpm1 = 1.0f - min_prob;
+    for (size_t i = 0; i < n; i++) C->f[i] = fo_logf_cephes(min_prob + mpm1 * C->f[i]);
+}
+
+/* flappie_matrix.c:392-419  C = Wf^T Xf + Wb^T Xb + b, the two products accumulated one after the other */
+fo_mat *fo_affine_map2(const fo_mat *Xf, const fo_mat *Xb, const fo_mat *Wf, const fo_mat *Wb, const fo_mat *b) {
+    if (!Xf || !Xb || !Wf || !Wb || !b) return NULL;
+    fo_mat *C = fo_affine_map(Xf, Wf, b);
+    if (!C) return NULL;
+    for (size_t c = 0; c < C->nc; c++)
+        for (size_t r = 0; r < C->nr; r++) {
+            float acc = 0.0f;
+            for (size_t k = 0; k < Wb->nr; k++) acc += Wb->f[r * Wb->stride + k] * Xb->f[c * Xb->stride + k];
+            C->f[c * C->stride + r] += acc;
+        }
+    return C;
+}
+
 /* flappie_matrix.c:425-447   each column divided by the sum of its nr real rows.
  * The reference adds 4-lane partial sums, removes the pad lanes of the last quad, then hadd. */
 void fo_row_normalise_inplace(fo_mat *C) {

@@ -76,6 +76,11 @@ char fo_phredf(float p);
 void fo_swish_inplace(fo_mat *C);
 void fo_tanh_inplace(fo_mat *C);
 void fo_exp_inplace(fo_mat *C);
+float fo_logf_cephes(float x);
+void fo_log_inplace(fo_mat *C);
+void fo_elu_inplace(fo_mat *C);
+void fo_robustlog_inplace(fo_mat *C, float min_prob);
+fo_mat *fo_affine_map2(const fo_mat *Xf, const fo_mat *Xb, const fo_mat *Wf, const fo_mat *Wb, const fo_mat *b);
 void fo_row_normalise_inplace(fo_mat *C);
 void fo_log_row_normalise_inplace(fo_mat *C);
 fo_mat *fo_features_from_raw(const float *raw, size_t start, size_t end);

@@ -59,7 +59,7 @@ def lib():
     L.fo_free_mat.argtypes = [P(FoMat)]
     L.fo_free_imat.restype = P(FoIMat)
     L.fo_free_imat.argtypes = [P(FoIMat)]
-    for name in ("fo_expf_cephes", "fo_logisticf", "fo_tanhf", "fo_eluf"):
+    for name in ("fo_expf_cephes", "fo_logisticf", "fo_tanhf", "fo_eluf", "fo_logf_cephes"):
         getattr(L, name).restype = C.c_float
         getattr(L, name).argtypes = [C.c_float]
     L.fo_logsumexpf.restype = C.c_float
@@ -67,9 +67,13 @@ def lib():
     L.fo_phredf.restype = C.c_char
     L.fo_phredf.argtypes = [C.c_float]
     for name in ("fo_swish_inplace", "fo_tanh_inplace", "fo_exp_inplace", "fo_row_normalise_inplace",
-                 "fo_log_row_normalise_inplace"):
+                 "fo_log_row_normalise_inplace", "fo_log_inplace", "fo_elu_inplace"):
         getattr(L, name).restype = None
         getattr(L, name).argtypes = [P(FoMat)]
+    L.fo_robustlog_inplace.restype = None
+    L.fo_robustlog_inplace.argtypes = [P(FoMat), C.c_float]
+    L.fo_affine_map2.restype = P(FoMat)
+    L.fo_affine_map2.argtypes = [P(FoMat)] * 5
     L.fo_convolution.restype = P(FoMat)
     L.fo_convolution.argtypes = [P(FoMat), P(FoMat), P(FoMat), C.c_size_t]
     L.fo_affine_map.restype = P(FoMat)

@@ -40,7 +40,7 @@ def test_host_library_exports_reference_api():
     if not os.path.exists(path):
         pytest.skip("host layer not built yet")
     L = C.CDLL(path)
-    for hdr in ("flappie_matrix.h", "flappie_structures.h", "networks.h", "decode.h", "flappie_common.h"):
+    for hdr in ("flappie_matrix.h", "flappie_structures.h", "networks.h", "decode.h", "flappie_common.h", "layers.h", "flappie_output.h"):
         if not os.path.exists(os.path.join(ROOT, "include", hdr)):
             continue
         missing = [n for n in _declared_functions(hdr) if not hasattr(L, n)]
