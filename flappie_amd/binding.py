@@ -89,6 +89,17 @@ def lib():
     L.ffhip_batch_set_reads.argtypes = [vp, C.POINTER(CRawTable)]
     L.ffhip_batch_set_signals.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     L.ffhip_batch_run.argtypes = [vp, C.c_float, C.c_uint]
+    L.ffhip_prep_create.restype = vp
+    L.ffhip_prep_create.argtypes = [vp, C.POINTER(CRawTable), C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_float]
+    L.ffhip_prep_destroy.argtypes = [vp]
+    L.ffhip_prep_range.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ffhip_prep_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ffhip_prep_get_signal.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.ffhip_batch_set_prepared.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    L.ffhip_quantiles.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
+    L.ffhip_medmad_normalise.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ffhip_mad.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ffhip_array_transform.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_float, C.c_float]
     L.ffhip_batch_finish.argtypes = [vp]
     L.ffhip_batch_basecall.restype = C.c_void_p
     L.ffhip_batch_basecall.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
@@ -180,6 +191,46 @@ class DeviceModel:
             self.h = None
 
 
+PREP_MEDMAD, PREP_DELTA, PREP_NONE = 0, 1, 2
+
+
+class Prepared:
+    """Raw reads trimmed and normalised on the device (ffhip_prep): trim_and_segment_raw + medmad_normalise_array."""
+
+    def __init__(self, engine: "Engine", raws: List[np.ndarray], trim_start: int = 200, trim_end: int = 10,
+                 varseg_chunk: int = 100, varseg_thresh: float = 0.0, mode: int = PREP_MEDMAD, delta: float = 0.0):
+        self.engine = engine
+        self.n = len(raws)
+        arr = (CRawTable * self.n)()
+        keep = [np.ascontiguousarray(r, dtype=np.float32) for r in raws]
+        for i, r in enumerate(keep):
+            arr[i] = CRawTable(None, r.size, 0, r.size, _fptr(r))
+        self.h = lib().ffhip_prep_create(engine.h, arr, self.n, trim_start, trim_end, varseg_chunk, varseg_thresh, mode, delta)
+        if not self.h:
+            raise FFHipError(lib().ffhip_last_error().decode())
+
+    def range(self, i: int):
+        s, e = C.c_size_t(0), C.c_size_t(0)
+        _check(lib().ffhip_prep_range(self.h, i, C.byref(s), C.byref(e)))
+        return s.value, e.value
+
+    def stats(self, i: int):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().ffhip_prep_stats(self.h, i, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def signal(self, i: int) -> np.ndarray:
+        s, e = self.range(i)
+        out = np.zeros(max(e - s, 0), dtype=np.float32)
+        _check(lib().ffhip_prep_get_signal(self.h, i, _fptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().ffhip_prep_destroy(self.h)
+            self.h = None
+
+
 class Batch:
     """`nread` reads of `nsample` samples (ffhip_batch)."""
 
@@ -207,6 +258,12 @@ class Batch:
             keep.append(r)
             arr[i] = CRawTable(None, r.size, st, st + self.nsample, _fptr(r))
         _check(lib().ffhip_batch_set_reads(self.h, arr))
+
+    def set_prepared(self, prep: "Prepared", reads: List[int]):
+        """device-to-device: prepared reads `reads` (all of this batch's length) become the batch's input"""
+        assert len(reads) == self.nread
+        idx = (C.c_int * self.nread)(*reads)
+        _check(lib().ffhip_batch_set_prepared(self.h, prep.h, idx))
 
     def run(self, temperature: float = 1.0, flags: int = 0):
         _check(lib().ffhip_batch_run(self.h, temperature, flags))

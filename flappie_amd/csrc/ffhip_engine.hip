@@ -438,6 +438,22 @@ extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
     return FFHIP_OK;
 }
 
+// reads already trimmed and normalised on the device (ffhip_prep_create): device-to-device, no host copy
+extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads) {
+    if (!b || !prep || !reads) return set_err(FFHIP_EINVAL, "bad prepared-read arguments");
+    hipSetDevice(b->eng->device);
+    SampleBuf &sb = b->sbuf[0];
+    for (int r = 0; r < b->nread; r++) {
+        size_t len = 0;
+        const float *src = prep_device_signal(prep, reads[r], &len);
+        if (!src || len != (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: kept length must equal the batch's %d samples", reads[r], b->T);
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src, (size_t)b->T * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
 static void mark(ffhip_batch *b, int i) {
     if (b->eng->profiling) hipEventRecord(b->ev[i], b->stream);
 }

@@ -21,6 +21,8 @@ struct ffhip_engine {
     int persist_chained = 0;
 };
 
+struct ffhip_prep;
+
 namespace ffhip {
 
 int set_err(int code, const char *fmt, ...);        // records the thread's last error text, returns `code`
@@ -76,5 +78,8 @@ static inline bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
     *nbase = nb;
     return true;
 }
+
+// device address and length of a prepared read's kept samples (ffhip_prep.hip); nullptr if rejected
+const float *prep_device_signal(const struct ::ffhip_prep *p, int read, size_t *len);
 
 }  // namespace ffhip

@@ -164,38 +164,21 @@ static struct argp argp = { options, parse_arg, args_doc, doc };
 
 typedef struct {
     char *filename;                     /* owned */
-    struct _raw_basecall_info res;      /* rt filled by preparation; basecall == NULL until called */
-    int prepared;
+    struct _raw_basecall_info res;      /* rt filled by read_raw, start/end by the preparation; basecall == NULL until called */
+    int prepared;                       /* index into the chunk's ffhip_prep, or -1 */
 } item;
 
-/* flappie.c:248-262: read, trim/segment, normalise */
-static void prepare(item *it) {
-    raw_table rt = read_raw(it->filename, true);
-    if (NULL == rt.raw) return;
-    char *uuid = rt.uuid;
-    rt = trim_and_segment_raw(rt, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh);
-    if (NULL == rt.raw) { free(uuid); return; }
-    if (args.delta == 0.0f) {
-        medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
-    } else {
-        difference_array(rt.raw + rt.start, rt.end - rt.start);
-        shift_scale_array(rt.raw + rt.start, rt.end - rt.start, 0.0, args.delta);
-    }
-    it->res.rt = rt;
-    it->prepared = 1;
-}
-
-/* one batch of equal-length reads through the engine: the rest of calculate_post (flappie.c:264-316) */
-static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, item **its, int n) {
-    raw_table *rts = calloc(n, sizeof(raw_table));
-    for (int i = 0; i < n; i++) rts[i] = its[i]->res.rt;
-    const size_t len = rts[0].end - rts[0].start;
+/* one batch of equal-length prepared reads through the engine: calculate_post after normalisation (flappie.c:264-316) */
+static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n) {
+    int *idx = calloc(n, sizeof(int));
+    for (int i = 0; i < n; i++) idx[i] = its[i]->prepared;
+    const size_t len = its[0]->res.rt.end - its[0]->res.rt.start;
     ffhip_batch *b = ffhip_batch_create(eng, mdl, n, len);
     unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
-    if (NULL == b || 0 != ffhip_batch_set_reads(b, rts) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
+    if (NULL == b || 0 != ffhip_batch_set_prepared(b, prep, idx) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
         warnx("%s", ffhip_last_error());
         if (b) ffhip_batch_destroy(b);
-        free(rts);
+        free(idx);
         return;
     }
     const size_t nblock = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
@@ -222,24 +205,44 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
                 r->trace = free_flappie_imatrix(r->trace);
             }
             free(tmp);
+            /* write_summary stores the signal the network saw (fast5_interface.c:332-335) */
+            if (0 != ffhip_prep_get_signal(prep, idx[i], r->rt.raw + r->rt.start)) warnx("%s", ffhip_last_error());
         }
     }
     ffhip_batch_destroy(b);
-    free(rts);
+    free(idx);
 }
 
+/* flappie.c:248-262 for every read of the chunk in one device pass (trim/segment, then med-MAD or --delta),
+ * then batches of equal trimmed length, output in input order (flappie.c:371-384) */
 static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, hid_t hdf5out) {
     item **group = calloc(n > 0 ? n : 1, sizeof(item *));
     char *done = calloc(n > 0 ? n : 1, 1);
+    raw_table *rts = calloc(n > 0 ? n : 1, sizeof(raw_table));
+    int m = 0;
     for (int i = 0; i < n; i++) {
-        if (done[i] || !items[i].prepared) continue;
-        const size_t len = items[i].res.rt.end - items[i].res.rt.start;
-        int m = 0;
-        for (int j = i; j < n && m < args.batch; j++)
-            if (!done[j] && items[j].prepared && items[j].res.rt.end - items[j].res.rt.start == len) { group[m++] = &items[j]; done[j] = 1; }
-        call_batch(eng, mdl, group, m);
+        items[i].prepared = -1;
+        if (NULL != items[i].res.rt.raw) { rts[m] = items[i].res.rt; items[i].prepared = m++; }
     }
-    for (int i = 0; i < n; i++) {                               /* flappie.c:371-384, in input order */
+    ffhip_prep *prep = (m > 0) ? ffhip_prep_create(eng, rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
+                                                   (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
+    if (m > 0 && NULL == prep) warnx("%s", ffhip_last_error());
+    for (int i = 0; i < n; i++) {
+        if (items[i].prepared < 0) continue;
+        size_t st = 0, en = 0;
+        if (NULL == prep || 0 != ffhip_prep_range(prep, items[i].prepared, &st, &en) || st >= en) { items[i].prepared = -1; continue; }
+        items[i].res.rt.start = st;
+        items[i].res.rt.end = en;
+    }
+    for (int i = 0; i < n; i++) {
+        if (done[i] || items[i].prepared < 0) continue;
+        const size_t len = items[i].res.rt.end - items[i].res.rt.start;
+        int g = 0;
+        for (int j = i; j < n && g < args.batch; j++)
+            if (!done[j] && items[j].prepared >= 0 && items[j].res.rt.end - items[j].res.rt.start == len) { group[g++] = &items[j]; done[j] = 1; }
+        call_batch(eng, mdl, prep, group, g);
+    }
+    for (int i = 0; i < n; i++) {
         item *it = &items[i];
         if (NULL == it->res.basecall) {
             warnx("No basecall returned for %s", it->filename);
@@ -254,6 +257,8 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         free_raw_basecall_info(&it->res);
         free(it->filename);
     }
+    ffhip_prep_destroy(prep);
+    free(rts);
     free(group);
     free(done);
 }
@@ -293,7 +298,7 @@ int main(int argc, char *argv[]) {
             item *it = &items[nitem++];
             memset(it, 0, sizeof(*it));
             it->filename = strdup(globbuf.gl_pathv[f2]);
-            prepare(it);
+            it->res.rt = read_raw(it->filename, true);            /* flappie.c:248 */
             if (nitem == chunk_cap) { flush_chunk(eng, mdl, items, nitem, hdf5out); nitem = 0; }
         }
         globfree(&globbuf);

@@ -172,6 +172,34 @@ int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
 /* globalnorm_flipflop (layers.c:1082-1106) */
 int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
 
+/* ---- signal preparation on the GPU ------------------------------------------------------------------
+ * trim_and_segment_raw (flappie_common.c:13-81) followed by medmad_normalise_array (util.c:198-212) or the
+ * --delta transform (flappie.c:259-262) for a set of raw reads of any lengths, one workgroup per read; every
+ * order statistic is an exact selection, so ranges and signals equal the reference's qsort-based ones.
+ * The prepared signals stay in HBM; ffhip_batch_set_prepared feeds equal-length ones to a batch. */
+typedef struct ffhip_prep ffhip_prep;
+#define FFHIP_PREP_MEDMAD 0   /* medmad_normalise_array                                  */
+#define FFHIP_PREP_DELTA  1   /* difference_array + shift_scale_array(0, delta)          */
+#define FFHIP_PREP_NONE   2   /* trim only, samples copied                               */
+#define FFHIP_PREP_DIFFERENCE  3   /* difference_array (util.c:416-427), ffhip_array_transform only  */
+#define FFHIP_PREP_SHIFT_SCALE 4   /* shift_scale_array (util.c:214-223), ffhip_array_transform only */
+ffhip_prep *ffhip_prep_create(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
+                              size_t varseg_chunk, float varseg_thresh, int mode, float delta);
+void ffhip_prep_destroy(ffhip_prep *p);
+/* start >= end: the read was rejected (trim_and_segment_raw would have returned a NULL table) */
+int ffhip_prep_range(const ffhip_prep *p, int read, size_t *start, size_t *end);
+int ffhip_prep_stats(const ffhip_prep *p, int read, float *median, float *mad);      /* MEDMAD mode */
+int ffhip_prep_get_signal(const ffhip_prep *p, int read, float *out /* end-start floats */);
+int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep */);
+/* quantilef (util.c:100-139): p[] in, quantiles out */
+int ffhip_quantiles(ffhip_engine *eng, const float *x, size_t n, float *p, size_t np);
+/* difference_array / shift_scale_array / both (FFHIP_PREP_DELTA) on one host array, in place */
+int ffhip_array_transform(ffhip_engine *eng, float *x, size_t n, int mode, float shift, float scale);
+/* madf (util.c:164-187): 1.4826 * median(|x - med|); med == NULL: about the array's own median */
+int ffhip_mad(ffhip_engine *eng, const float *x, size_t n, const float *med, float *mad);
+/* medmad_normalise_array (util.c:198-212) in place; optionally returns the median and MAD used */
+int ffhip_medmad_normalise(ffhip_engine *eng, float *x, size_t n, float *median, float *mad);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* HIP-event timing of the kernel groups of one batch_run, on the stream they are launched on.
  * groups: 0 conv, 1 in-projection GEMMs, 2 recurrent, 3 head+CRF norm, 4 posterior, 5 viterbi+assembly */

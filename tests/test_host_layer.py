@@ -118,7 +118,9 @@ def test_matrix_type(host):
     host.free_flappie_matrix(mm)
 
 
+@pytest.mark.gpu
 def test_signal_prep_matches_reference_fixtures_and_oracle(host):
+    """The reference's own fixtures for this path (test_flappie_signal.c:67-111), through the C names, on the GPU."""
     from oracle import ffo
     sig = np.load(os.path.join(HERE, "golden", "signal_fixtures.npz"))
     unit = np.float32(1373.41) / np.float32(8192.0)
