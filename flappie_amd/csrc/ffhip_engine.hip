@@ -265,6 +265,8 @@ struct ffhip_batch {
     float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     float *xa = nullptr, *cstate = nullptr;
     float *trans = nullptr, *post = nullptr, *fwd = nullptr;
+    double *crf_logz = nullptr;         // fp64 partition function per read
+    double *crf_e = nullptr;            // exp(score - block max), workspace of the linear-space partition function
     uint8_t *tb = nullptr;
     int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
     char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
@@ -375,8 +377,10 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->xa = (float *)dalloc(b, Tb * Bp * Hp * 4 * 4, false))) BFAIL();
     if (!(b->cstate = (float *)dalloc(b, Bp * Hp * 4, true))) BFAIL();
     if (!(b->trans = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
+    if (!(b->crf_logz = (double *)dalloc(b, (size_t)nread * sizeof(double), true))) BFAIL();
+    if (!(b->crf_e = (double *)dalloc(b, (size_t)nread * Tb * crf_exp_stride(m->P) * sizeof(double), false))) BFAIL();
     if (!(b->post = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
-    if (!(b->fwd = (float *)dalloc(b, (size_t)nread * (Tb + 1) * kMaxState * 4, false))) BFAIL();
+    if (!(b->fwd = (float *)dalloc(b, (size_t)2 * nread * (Tb + 1) * kMaxState * 4, false))) BFAIL();      // forward + backward vectors
     if (!(b->tb = (uint8_t *)dalloc(b, (size_t)nread * Tb * kMaxState, false))) BFAIL();
     if (!(b->path = (int *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
     if (!(b->qpath = (float *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
@@ -547,8 +551,14 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     mark(b, 3);
     // ---- globalnorm_flipflop (layers.c:1082-1106)
     launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
-    launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps);
-    b->launches[3] += 2;
+    {
+        // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
+        // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
+        const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
+        if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz);
+        else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz);
+    }
+    b->launches[3] += 3;
     mark(b, 4);
     b->last_flags = flags;
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
@@ -697,7 +707,7 @@ extern "C" int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nbl
     hipStream_t s = eng->streams[0];
     TmpDev t;
     const size_t n = nblock * stride;
-    float *d_tr = (float *)t.get(n * 4), *d_po = (float *)t.get(n * 4), *d_fw = (float *)t.get((nblock + 1) * kMaxState * 4);
+    float *d_tr = (float *)t.get(n * 4), *d_po = (float *)t.get(n * 4), *d_fw = (float *)t.get(2 * (nblock + 1) * kMaxState * 4);
     if (!d_tr || !d_po || !d_fw) return set_err(FFHIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpyAsync(d_tr, trans, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(d_po, 0, n * 4, s), FFHIP_EHIP);

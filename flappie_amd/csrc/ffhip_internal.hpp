@@ -79,9 +79,20 @@ int persist_blocks_per_cu(int kind, int H);
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale);
 // CRF partition function (fp64) + subtraction of (float)(logZ/Tb)
-// logz_out (optional): the fp64 partition function per read; subtract = 0 leaves `trans` untouched
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz_out = nullptr, int subtract = 1);
-// forward/backward transition posteriors, log-normalised per block
+// logz: device buffer of nread doubles, receives the fp64 partition function per read; subtract = 0 leaves `trans` untouched
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract = 1);
+// the same in linear space (fp64 scaled forward recursion); E = workspace of nread*Tb*crf_exp_stride(P) doubles,
+// R = blocks between power-of-two rescalings (see crf_rescale_interval)
+inline int crf_exp_stride(int P) { return (P + 1 + 7) & ~7; }
+// per block the spread of alpha grows by at most exp(2*bound) (bound = max |score|) times nstate
+inline int crf_rescale_interval(float bound) {
+    const float bits = 2.0f * bound * 1.4427f + 4.0f;
+    const int r = (int)(900.0f / bits);
+    return r < 1 ? 0 : (r > 16 ? 16 : r);           // 0: range too wide for the linear form, use launch_crf_norm
+}
+void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
+                            double *logz, int subtract = 1);
+// forward/backward transition posteriors, log-normalised per block; fwd = workspace of 2*nread*(Tb+1)*kMaxState floats
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
 // Viterbi + traceback + qpath
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,

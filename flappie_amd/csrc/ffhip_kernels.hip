@@ -409,12 +409,12 @@ void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp,
 // i.e. the same quantity as the reference's pairwise chain up to fp64 rounding (the result is
 // rounded to fp32 after the division by the block count, layers.c:1089).
 __global__ void __launch_bounds__(64)
-k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps, double *__restrict__ logz_out, int subtract) {
+k_crf_norm(const float *__restrict__ trans, int Tb, int nbase, int P, int Ps, double *__restrict__ logz_out) {
     __shared__ double term[64];
     __shared__ double smax[kMaxState];
     const int lane = threadIdx.x;
     const int ns = 2 * nbase, off = nbase * ns;
-    float *S = trans + (size_t)blockIdx.x * Tb * Ps;
+    const float *S = trans + (size_t)blockIdx.x * Tb * Ps;
     // destination state of transition entry `lane`, and its source state
     const int src = lane % ns;
     int dst;
@@ -461,17 +461,149 @@ k_crf_norm(float *__restrict__ trans, int Tb, int nbase, int P, int Ps, double *
         const double v = __shfl(prev, st);
         logZ = fmax(logZ, v) + log1p(exp(-fabs(logZ - v)));
     }
-    if (logz_out && lane == 0) logz_out[blockIdx.x] = logZ;        // crf_manystay_partition_function's own result
-    if (!subtract) return;
-    const float logZf = (float)(logZ / (double)Tb);
-    const size_t n = (size_t)Tb * Ps;
-    for (size_t i = lane; i < n; i += 64)
-        if ((int)(i % Ps) < P) S[i] -= logZf;
+    if (lane == 0) logz_out[blockIdx.x] = logZ;        // crf_manystay_partition_function's own result
 }
 
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz_out, int subtract) {
+// S[r][blk][p] -= (float)(logZ[r] / Tb) for p < P (layers.c:1089-1096), all reads and blocks in parallel
+__global__ void __launch_bounds__(256)
+k_crf_sub(float *__restrict__ trans, const double *__restrict__ logz, int Tb, int P, int Ps, size_t n /*nread*Tb*Ps*/) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((int)(i % Ps) >= P) return;
+    const size_t r = i / ((size_t)Tb * Ps);
+    trans[i] -= (float)(logz[r] / (double)Tb);
+}
+
+static void launch_crf_sub(hipStream_t s, float *trans, const double *logz, int nread, int Tb, int P, int Ps) {
+    const size_t n = (size_t)nread * Tb * Ps;
+    hipLaunchKernelGGL(k_crf_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, logz, Tb, P, Ps, n);
+}
+
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps, logz_out, subtract);
+    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps, logz);
+    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps);
+}
+
+// ---- CRF partition function, linear-space form (the pipeline's default) -----------------------------
+// The log-space recursion above spends an fp64 exp and log per state per block ON the dependent chain
+// (Tb steps x ~3000 cycles).  The same quantity factorises: with m_t = max_p S[t][p] and
+// E_t[p] = exp(S[t][p] - m_t) (independent of the chain -> computed for all blocks in parallel),
+//     alpha_t[to] = sum_from E_t[to, from] * alpha_{t-1}[from],     alpha_{-1} = 1,
+//     logZ = log(sum_s alpha_{Tb-1}[s]) + ln2 * K + sum_t m_t,
+// where K collects the exact power-of-two rescalings applied every R blocks.  All in fp64; the chain is an
+// 8x8 sparse mat-vec per block (~250 cycles).  The result differs from the pairwise-logsumexp evaluation by
+// fp64 rounding only (<= 1e-12 relative, checked against the oracle), and is rounded to fp32 after the
+// division by the block count exactly as layers.c:1089 does.
+__global__ void __launch_bounds__(256)
+k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t n /*nread*Tb*Pd*/, int P, int Ps, int Pd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t blk = i / Pd;
+    const int p = (int)(i % Pd);
+    if (p > P) return;
+    const float *S = trans + blk * Ps;
+    float m = S[0];
+    for (int q = 1; q < P; q++) m = fmaxf(m, S[q]);
+    E[i] = (p == P) ? (double)m : exp((double)S[p] - (double)m);
+}
+
+// One wave per read.  E is streamed through LDS in chunks of kCrfChunk blocks: the loads of chunk c+1 are
+// issued (coalesced, all 64 lanes) before chunk c is walked and land in LDS after it, so the dependent
+// chain never waits on HBM.
+constexpr int kCrfChunk = 32;
+template <int NS>
+__global__ void __launch_bounds__(64)
+k_crf_chain(const double *__restrict__ E, int Tb, int P, int Pd, int R, double *__restrict__ logz_out) {
+    constexpr int nbase = NS / 2, off = nbase * NS;
+    constexpr int kMaxPd = 72;                                  // crf_exp_stride(64)
+    __shared__ double ebuf[2][kCrfChunk * kMaxPd];
+    __shared__ double al[2][NS];
+    const int lane = threadIdx.x;
+    const bool active = lane < NS, flip = lane < nbase;
+    const double *Er = E + (size_t)blockIdx.x * Tb * Pd;
+    const int per_chunk = kCrfChunk * Pd;                       // doubles per chunk (<= 2304)
+    constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 36 doubles per lane at most
+    double stage[kStage];
+    const int nchunk = (Tb + kCrfChunk - 1) / kCrfChunk;
+    auto fetch = [&](int c) {
+        const size_t base = (size_t)c * per_chunk, lim = (size_t)Tb * Pd;
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int j = k * 64 + lane;
+            stage[k] = (j < per_chunk && base + j < lim) ? Er[base + j] : 0.0;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int j = k * 64 + lane;
+            if (j < per_chunk) ebuf[buf][j] = stage[k];
+        }
+    };
+    if (active) al[0][lane] = 1.0;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    double msum = 0.0;
+    long long K = 0;
+    int cur = 0, since = 0;
+    for (int c = 0; c < nchunk; c++) {
+        if (c + 1 < nchunk) fetch(c + 1);
+        const double *eb = ebuf[c & 1];
+        const int t0 = c * kCrfChunk, t1 = min(Tb, t0 + kCrfChunk);
+        for (int t = t0; t < t1; t++) {
+            const double *row = eb + (t - t0) * Pd;
+            double acc = 0.0;
+            if (flip) {
+                // independent products, pairwise tree: 4 dependent fp64 operations instead of 16
+                double pr[NS];
+#pragma unroll
+                for (int f = 0; f < NS; f++) pr[f] = row[lane * NS + f] * al[cur][f];
+#pragma unroll
+                for (int w = 1; w < NS; w <<= 1)
+#pragma unroll
+                    for (int f = 0; f + w < NS; f += 2 * w) pr[f] = pr[f] + pr[f + w];
+                acc = pr[0];
+            } else if (active) {
+                acc = row[off + lane - nbase] * al[cur][lane - nbase] + row[off + lane] * al[cur][lane];
+            }
+            msum = msum + row[P];
+            if (++since == R || t + 1 == Tb) {
+                since = 0;
+                double mx = active ? acc : 0.0;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) mx = fmax(mx, __shfl_xor(mx, d));
+                const int ex = __builtin_amdgcn_readfirstlane((mx > 0.0) ? ilogb(mx) : 0);      // lane 0's 16-lane group holds the states
+                acc = ldexp(acc, -ex);
+                K += ex;
+            }
+            if (active) al[cur ^ 1][lane] = acc;
+            // one wave: LDS executes its instructions in order, only the compiler must not reorder them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cur ^= 1;
+        }
+        if (c + 1 < nchunk) commit((c + 1) & 1);
+        __syncthreads();
+    }
+    double total = 0.0;
+    for (int st = 0; st < NS; st++) total = total + al[cur][st];
+    const double logZ = log(total) + 0.693147180559945309417232121458 * (double)K + msum;
+    if (lane == 0) logz_out[blockIdx.x] = logZ;
+}
+
+void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
+                            double *logz, int subtract) {
+    const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
+    const size_t n = (size_t)nread * Tb * Pd;
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, E, n, P, Ps, Pd);
+    const int Rr = R < 1 ? 1 : R;
+    switch (2 * nbase) {
+#define CHAIN_CASE(NS) case NS: hipLaunchKernelGGL(k_crf_chain<NS>, dim3(nread), dim3(64), 0, s, E, Tb, P, Pd, Rr, logz); break;
+    CHAIN_CASE(2) CHAIN_CASE(4) CHAIN_CASE(6) CHAIN_CASE(8) CHAIN_CASE(10) CHAIN_CASE(12) CHAIN_CASE(14) CHAIN_CASE(16)
+#undef CHAIN_CASE
+    }
+    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps);
 }
 
 // ---- forward/backward transition posteriors ---------------------------------------------------
@@ -556,74 +688,92 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
 // :478-482): same value up to fp32 rounding of the association, 7x shorter dependent chain.
 __device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 + s; }
 
-__global__ void __launch_bounds__(64)
-k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, int Tb) {
+// Workgroup of 4 waves per read: wave 0 runs the forward recursion, wave 1 the backward recursion at the same
+// time (they are independent), then all 256 threads assemble and log-normalise one block each.  Same
+// arithmetic per value as a single-wave walk; the dependent chain is halved.
+__global__ void __launch_bounds__(256)
+k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int Tb) {
     constexpr int P = 40, Ps = 40, ns = 8;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
     float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
     float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
     const bool valid = lane < P, flip = lane < 32;
     const int st = lane & 7;
     const float NEG = -INFINITY;
 
-    // forwards: pv = fwd[blk][lane & 7]
-    float pv = 0.0f;
-    if (lane < ns) F[lane] = 0.0f;
-    float s_next = valid ? T[lane] : 0.0f;
-    for (int blk = 0; blk < Tb; blk++) {
-        const float s = s_next;
-        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-        const float term = valid ? s + pv : NEG;
-        float m = fmaxf(term, __shfl_xor(term, 4));
-        if (flip) { m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); }
-        float e = valid ? expf(term - m) : 0.0f;
-        e += __shfl_xor(e, 4);
-        if (flip) { e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); }
-        const float val = m + logf(e);
-        pv = __shfl(val, ff8_src_lane(st));
-        if (lane < ns) F[(size_t)(blk + 1) * kMaxState + lane] = pv;
-    }
-
-    // backwards: pb = bwd[blk][lane & 7]
-    int to;
-    if (lane < 32) to = lane >> 3;
-    else { const int idx = lane - 32; to = (idx < 4) ? idx + 4 : idx; }
-    float pb = 0.0f;
-    for (int blk = Tb; blk > 0; blk--) {
-        const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
-        const float f = F[(size_t)(blk - 1) * kMaxState + st];
-        const float pb_to = __shfl(pb, to & 7);
-        if (valid) Pp[(size_t)(blk - 1) * Ps + lane] = (f + pb_to) + s;          // decode.c:451-461
-        const float t2 = valid ? s + pb_to : NEG;
-        // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
-        const float f5 = __shfl(t2, 32 + st);
-        float m = fmaxf(t2, __shfl_xor(t2, 8));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, f5);
-        float e = flip ? expf(t2 - m) : 0.0f;
-        e += __shfl_xor(e, 8);
-        e += __shfl_xor(e, 16);
-        e += expf(f5 - m);
-        const float cur = m + logf(e);
-        pb = __shfl(cur, st);
+    if (wave == 0) {
+        // forwards: pv = fwd[blk][lane & 7]
+        float pv = 0.0f;
+        if (lane < ns) F[lane] = 0.0f;
+        float s_next = valid ? T[lane] : 0.0f;
+        for (int blk = 0; blk < Tb; blk++) {
+            const float s = s_next;
+            if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+            const float term = valid ? s + pv : NEG;
+            float m = fmaxf(term, __shfl_xor(term, 4));
+            if (flip) { m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); }
+            float e = valid ? expf(term - m) : 0.0f;
+            e += __shfl_xor(e, 4);
+            if (flip) { e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); }
+            const float val = m + logf(e);
+            pv = __shfl(val, ff8_src_lane(st));
+            if (lane < ns) F[(size_t)(blk + 1) * kMaxState + lane] = pv;
+        }
+    } else if (wave == 1) {
+        // backwards: pb = bwd[blk][lane & 7]; Bw[blk] is the vector that multiplies block blk-1's transitions
+        int to;
+        if (lane < 32) to = lane >> 3;
+        else { const int idx = lane - 32; to = (idx < 4) ? idx + 4 : idx; }
+        float pb = 0.0f;
+        float s_next = valid ? T[(size_t)(Tb - 1) * Ps + lane] : 0.0f;
+        for (int blk = Tb; blk > 0; blk--) {
+            const float s = s_next;
+            if (blk > 1) s_next = valid ? T[(size_t)(blk - 2) * Ps + lane] : 0.0f;
+            if (lane < ns) Bw[(size_t)blk * kMaxState + lane] = pb;
+            const float pb_to = __shfl(pb, to & 7);
+            const float t2 = valid ? s + pb_to : NEG;
+            // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
+            const float f5 = __shfl(t2, 32 + st);
+            float m = fmaxf(t2, __shfl_xor(t2, 8));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, f5);
+            float e = flip ? expf(t2 - m) : 0.0f;
+            e += __shfl_xor(e, 8);
+            e += __shfl_xor(e, 16);
+            e += expf(f5 - m);
+            const float cur = m + logf(e);
+            pb = __shfl(cur, st);
+        }
     }
     __syncthreads();
-    // per-block log-normalisation over the 40 entries (flappie_matrix.c:450-467), one block per lane
-    for (int blk = lane; blk < Tb; blk += 64) {
-        float *x = Pp + (size_t)blk * Ps;
+    // posterior of transition `r` of block blk = (fwd[blk][from] + bwd[blk+1][to]) + trans (decode.c:451-461), then the
+    // per-block log-normalisation over the 40 entries (flappie_matrix.c:450-467); one block per thread
+    for (int blk = threadIdx.x; blk < Tb; blk += 256) {
+        const float *x = T + (size_t)blk * Ps;
+        float *o = Pp + (size_t)blk * Ps;
+        float f[ns], bb[ns];
+#pragma unroll
+        for (int k = 0; k < ns; k++) { f[k] = F[(size_t)blk * kMaxState + k]; bb[k] = Bw[(size_t)(blk + 1) * kMaxState + k]; }
         float v[P];
         float m = NEG;
 #pragma unroll
-        for (int r = 0; r < P; r++) { v[r] = x[r]; m = fmaxf(m, v[r]); }
+        for (int r = 0; r < P; r++) {
+            const int from = r & 7;
+            const int to = (r < 32) ? (r >> 3) : ((r - 32 < 4) ? r - 32 + 4 : r - 32);
+            v[r] = (f[from] + bb[to]) + x[r];
+            m = fmaxf(m, v[r]);
+        }
         float sum = 0.0f;
 #pragma unroll
         for (int r = 0; r < P; r++) sum += expf(v[r] - m);
         const float lse = m + logf(sum);
 #pragma unroll
-        for (int r = 0; r < P; r++) x[r] = v[r] - lse;
+        for (int r = 0; r < P; r++) o[r] = v[r] - lse;
     }
 }
+
 
 
 
@@ -712,7 +862,7 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
-        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb);
+        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb);
     else if (!getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
     else

@@ -446,6 +446,24 @@ extern "C" int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, doubl
     return FFHIP_OK;
 }
 
+// the pipeline's linear-space evaluation of the same quantity (ffhip_kernels.hip, k_crf_chain); valid when every
+// |score| <= bound, FFHIP_EINVAL when the bound is too wide for it
+extern "C" int ffhip_op_partition_function_scaled(ffhip_engine *eng, ffhip_mat S, float bound, double *logZ) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(S) || !logZ || !flipflop_dims(S.nr, S.stride, &nbase)) return set_err(FFHIP_EINVAL, "bad partition-function arguments");
+    const int R = crf_rescale_interval(bound);
+    if (R < 1) return set_err(FFHIP_EINVAL, "score bound %g is too wide for the linear-space partition function", (double)bound);
+    float *d = upload_img(tmp, S, s);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    double *d_e = (double *)tmp.get(S.nc * (size_t)crf_exp_stride((int)S.nr) * sizeof(double));
+    if (!d || !d_z || !d_e) OP_NOMEM();
+    launch_crf_norm_linear(s, d, d_e, 1, (int)S.nc, nbase, (int)S.stride, R, d_z, 0);
+    HIP_TRY(hipMemcpyAsync(logZ, d_z, sizeof(double), hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
 // globalnorm_flipflop (layers.c:1082-1106): C = tanh(W^T X + b) / (temperature/5) - logZ/nblock
 extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
     OP_ENTER(eng);
@@ -464,7 +482,9 @@ extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhi
     HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
     launch_head(s, d_in, d_c, (const float4 *)d_w, d_b, T, 1, 1, P, (int)C.stride, K16, temperature / 5.0f);
-    launch_crf_norm(s, d_c, 1, T, nbase, (int)C.stride);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d_z) OP_NOMEM();
+    launch_crf_norm(s, d_c, 1, T, nbase, (int)C.stride, d_z);
     HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);

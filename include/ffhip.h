@@ -169,6 +169,8 @@ int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffhip_mat sW, 
 int ffhip_op_recurrent_step(ffhip_engine *eng, int kind, ffhip_mat x, ffhip_mat h_prev, ffhip_mat sW, ffhip_mat state, ffhip_mat h_out);
 /* crf_manystay_partition_function (layers.c:1035-1079) */
 int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
+/* the same quantity by the batched pipeline's scaled linear-space recursion; requires |S| <= bound everywhere */
+int ffhip_op_partition_function_scaled(ffhip_engine *eng, ffhip_mat S, float bound, double *logZ);
 /* globalnorm_flipflop (layers.c:1082-1106) */
 int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
 

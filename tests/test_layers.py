@@ -402,3 +402,20 @@ def test_globalnorm_and_partition_function(L, nbase, H, T):
     got = L.crf_manystay_partition_function(mk(L, s))
     assert abs(got - want) <= 1e-9 * max(1.0, abs(want))
     assert L.nbase_from_flipflop_nparam(P) == nbase
+    # the pipeline's scaled linear-space recursion gives the same fp64 number (ffhip_kernels.hip k_crf_chain)
+    from flappie_amd import binding as B
+
+    class FMat(C.Structure):
+        _fields_ = [("data", C.POINTER(C.c_float)), ("nr", C.c_size_t), ("nc", C.c_size_t), ("stride", C.c_size_t)]
+    eng = B.Engine(0)
+    fn = B.lib().ffhip_op_partition_function_scaled
+    fn.argtypes = [C.c_void_p, FMat, C.c_float, C.POINTER(C.c_double)]
+    for scale in (1.0, 5.0, 20.0):
+        s2 = np.clip(s * scale / 2, -scale * 2.5, scale * 2.5).astype(np.float32)
+        o = omat(s2)
+        want = lib.fo_partition_function(o.ptr)
+        z = C.c_double(0)
+        assert fn(eng.h, FMat(o.c.f, P, T, o.c.stride), float(np.abs(s2).max()), C.byref(z)) == 0
+        assert abs(z.value - want) <= 1e-11 * max(1.0, abs(want)), (scale, z.value, want)
+    assert fn(eng.h, FMat(o.c.f, P, T, o.c.stride), 1e4, C.byref(z)) != 0          # bound too wide: refused, not wrong
+    eng.close()
