@@ -134,18 +134,19 @@ def test_against_committed_vectors(B, engine, golden_dir, tag):
         b.close(); dm.close()
 
 
-@pytest.mark.parametrize("kind,hidden", [(M.NET_LSTM5, 96), (M.NET_GRUMOD5, 64)])
-def test_recurrent_kernel_variants_agree(B, engine, kind, hidden):
+@pytest.mark.parametrize("kind,hidden,nread,T", [(M.NET_LSTM5, 96, 18, 1500), (M.NET_GRUMOD5, 64, 18, 1500), (M.NET_LSTM5, 384, 40, 600),
+                                                 (M.NET_GRUMOD5, 256, 40, 400), (M.NET_LSTM5, 512, 33, 500)])
+def test_recurrent_kernel_variants_agree(B, engine, kind, hidden, nread, T):
     """Three implementations of the recurrent stack must agree to rounding: the fused persistent
     layer (projection + recurrence in one launch), the persistent recurrence behind a separate
     projection GEMM, and the launch-per-step kernels.  Each is also the others' cross-check on
     shapes the oracle is too slow for."""
     mdl = M.synthetic_model(kind, hidden, seed=13)
-    sig = np.random.default_rng(77).standard_normal((18, 1500)).astype(np.float32)
+    sig = np.random.default_rng(77).standard_normal((nread, T)).astype(np.float32)       # 2 or 3 read tiles, the last one partly filled
     outs = []
     for flags in (0, B.RUN_UNFUSED_RNN, B.RUN_STEPWISE_RNN):
         dm, b = run_batch(B, engine, mdl, sig, flags=flags)
-        outs.append(([b.transitions(r) for r in (0, 9, 17)], [b.basecall(r) for r in range(18)]))
+        outs.append(([b.transitions(r) for r in (0, nread // 2, nread - 1)], [b.basecall(r) for r in range(nread)]))
         b.close(); dm.close()
     for tr, calls in outs[1:]:
         for a, c in zip(outs[0][0], tr):
