@@ -96,7 +96,7 @@ struct RnnDev {
 
 struct ffhip_model {
     ffhip_engine *eng = nullptr;
-    int kind = 0, nconv = 0, G = 4;
+    int kind = 0, cell = 0, nconv = 0, G = 4;
     int H = 0, Hp = 0;          // hidden units, padded to a multiple of 16
     int P = 0, Ps = 0, nbase = 0, nstate = 0;
     int act = ACT_SWISH;
@@ -123,15 +123,16 @@ extern "C" void ffhip_model_free(ffhip_model *m) {
 
 extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_desc *d) {
     if (!eng || !d) { set_err(FFHIP_EINVAL, "null engine or descriptor"); return nullptr; }
-    if (d->kind != FFHIP_NET_LSTM5 && d->kind != FFHIP_NET_GRUMOD5) { set_err(FFHIP_EINVAL, "unknown network kind %d", d->kind); return nullptr; }
+    if (d->kind != FFHIP_NET_LSTM5 && d->kind != FFHIP_NET_GRUMOD5 && d->kind != FFHIP_NET_LSTM5_RLE) { set_err(FFHIP_EINVAL, "unknown network kind %d", d->kind); return nullptr; }
     if (d->nconv < 1 || d->nconv > 3) { set_err(FFHIP_EINVAL, "nconv must be 1..3"); return nullptr; }
     hipSetDevice(eng->device);
     ffhip_model *m = new ffhip_model();
     m->eng = eng;
     m->kind = d->kind;
     m->nconv = d->nconv;
-    m->G = (d->kind == FFHIP_NET_LSTM5) ? 4 : 3;
-    m->act = (d->kind == FFHIP_NET_LSTM5) ? ACT_SWISH : ACT_TANH;
+    m->cell = (d->kind == FFHIP_NET_GRUMOD5) ? 1 : 0;            // recurrent cell: 0 LSTM, 1 GRUmod
+    m->G = (m->cell == 0) ? 4 : 3;
+    m->act = (m->cell == 0) ? ACT_SWISH : ACT_TANH;
 #define FAIL(...) do { set_err(FFHIP_EINVAL, __VA_ARGS__); ffhip_model_free(m); return nullptr; } while (0)
     for (int l = 0; l < 5; l++)
         if (!d->rnn_iW[l] || !d->rnn_sW[l] || !d->rnn_b[l]) FAIL("missing recurrent layer %d", l);
@@ -393,8 +394,8 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->pabort = (unsigned *)dalloc(b, sizeof(unsigned), true))) BFAIL();
     if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
     *b->h_abort = 0;
-    if (persist_supported(m->kind, (int)Hp, eng->prop.multiProcessorCount)) {
-        const int maxt = persist_max_tiles(m->kind, (int)Hp, eng->prop.multiProcessorCount, fused_supported(m->kind, (int)Hp));
+    if (persist_supported(m->cell, (int)Hp, eng->prop.multiProcessorCount)) {
+        const int maxt = persist_max_tiles(m->cell, (int)Hp, eng->prop.multiProcessorCount, fused_supported(m->cell, (int)Hp));
         b->persist_concurrent_ok = 2 * b->B16 <= maxt;      // two such launches fit on the chip together
     }
     if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
@@ -497,9 +498,9 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // whole stack and the split is measured with per-layer events when profiling is on.
     int cur = 0;
     const bool prof = b->eng->profiling != 0;
-    const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->kind, Hp, b->eng->prop.multiProcessorCount);
+    const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
     if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
-    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->kind, Hp);
+    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     for (int l = 0; l < 5; l++) {
@@ -516,7 +517,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;
         if (use_persist) {
             // one launch per layer (and per chunk of read tiles that fits co-resident on the chip)
-            const int maxt = persist_max_tiles(m->kind, Hp, b->eng->prop.multiProcessorCount, fuse);
+            const int maxt = persist_max_tiles(m->cell, Hp, b->eng->prop.multiProcessorCount, fuse);
             // the output doubles as the hand-off flag: pre-fill with the NaN sentinel
             HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFFFFFFFF, (size_t)Tb * Bp * Hp, s), FFHIP_EHIP);
             for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
@@ -525,8 +526,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = !b->persist_concurrent_ok;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 const bool okl = fuse
-                    ? launch_lstm_fused(s, m->kind, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
-                    : launch_rnn_persist(s, m->kind, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode);
+                    ? launch_lstm_fused(s, m->cell, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
+                    : launch_rnn_persist(s, m->cell, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode);
                 if (!okl) return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -536,7 +537,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             const int t = backward ? Tb - 1 - i : i;
             const int tp = backward ? t + 1 : t - 1;
             const float *hp = (i == 0) ? nullptr : out + (size_t)tp * h_step;
-            if (m->kind == FFHIP_NET_LSTM5)
+            if (m->cell == 0)
                 launch_lstm_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, b->cstate, B16, Hp, i == 0);
             else
                 launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0);
@@ -549,32 +550,49 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     b->profiled = prof;
     b->final_act = cur;
     mark(b, 3);
-    // ---- globalnorm_flipflop (layers.c:1082-1106)
-    launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
-    {
+    const bool rle = (m->kind == FFHIP_NET_LSTM5_RLE);
+    if (rle) {
+        // ---- globalnorm_runlengthV2 (layers.c:1325-1358)
+        launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, 1.0f, 1);
+        launch_rle_head_finish(s, b->trans, b->crf_logz, b->nread, Tb, m->nbase, m->Ps, temperature);
+        b->launches[3] += 4;
+    } else {
+        // ---- globalnorm_flipflop (layers.c:1082-1106)
+        launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
         const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
         if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz);
         else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz);
+        b->launches[3] += 3;
     }
-    b->launches[3] += 3;
     mark(b, 4);
     b->last_flags = flags;
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
         const float *scores = b->trans;
         if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
-            launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);
+            if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);       // decode.c:1037-1159
+            else launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);
             scores = b->post;
             b->launches[4]++;
         }
         mark(b, 5);
-        launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
-        launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase);
-        b->launches[5] += 2;
-        if (!(flags & FFHIP_RUN_NO_TRACE)) {
-            launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1);
+        if (rle) {
+            // decode_crf_runlength (decode.c:927-1013); the run records are formed from the path by the caller
+            // (runnie.c:282-313), there are no base/quality strings or trace for this model
+            launch_rle_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
+            HIP_TRY(hipMemsetAsync(b->lens, 0, (size_t)b->nread * 4, s), FFHIP_EHIP);
+            HIP_TRY(hipMemsetAsync(b->bases, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
+            HIP_TRY(hipMemsetAsync(b->quals, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
             b->launches[5]++;
+        } else {
+            launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
+            launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase);
+            b->launches[5] += 2;
+            if (!(flags & FFHIP_RUN_NO_TRACE)) {
+                launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1);
+                b->launches[5]++;
+            }
         }
     } else {
         mark(b, 5);
@@ -655,7 +673,7 @@ extern "C" int ffhip_batch_get_posterior(ffhip_batch *b, int read, float *out) {
 }
 extern "C" int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out) {
     if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
-    if (b->last_flags & (FFHIP_RUN_NO_TRACE | FFHIP_RUN_NO_DECODE)) return set_err(FFHIP_EINVAL, "trace was not computed in this run");
+    if ((b->last_flags & (FFHIP_RUN_NO_TRACE | FFHIP_RUN_NO_DECODE)) || b->mdl->kind == FFHIP_NET_LSTM5_RLE) return set_err(FFHIP_EINVAL, "trace was not computed in this run");
     const size_t n = ((size_t)b->Tb + 1) * b->mdl->nstate;
     return d2h(b, out, b->trace + (size_t)read * n, n * 4);
 }

@@ -77,7 +77,7 @@ int persist_blocks_per_cu(int kind, int H);
 
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
-                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale);
+                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw = 0);      // raw = 1: W^T h + b only
 // CRF partition function (fp64) + subtraction of (float)(logZ/Tb)
 // logz: device buffer of nread doubles, receives the fp64 partition function per read; subtract = 0 leaves `trans` untouched
 void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract = 1);
@@ -103,6 +103,11 @@ void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *b
 // exp + trace_from_posterior
 void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log);
 void launch_exp_inplace(hipStream_t s, float *x, size_t n);
+// run-length (runnie) head and decoders, ffhip_rle.hip: activation rows + runlengthV2 partition function + subtraction
+void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature);
+void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps);
+void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
+void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps);
 // tile-interleaved -> dense [Tb][H] of one read (debug tap)
 void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H);
 

@@ -350,7 +350,7 @@ void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const 
 // layers.c:1084-1087 (+ shift_scale_matrix_inplace flappie_matrix.c:625-633: a true division).
 __global__ void __launch_bounds__(256)
 k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__restrict__ Wp,
-       const float *__restrict__ bias, int Tb, int B16, int nread, int P, int Ps, int Mt, int K16, float scale) {
+       const float *__restrict__ bias, int Tb, int B16, int nread, int P, int Ps, int Mt, int K16, float scale, int raw) {
     constexpr int TM = 4, TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntile = Tb * B16;
@@ -389,17 +389,17 @@ k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__res
             const float vv[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (p + e < P) o[e] = (tanh_ref(vv[e]) - 0.0f) / scale;
+                if (p + e < P) o[e] = raw ? vv[e] : (tanh_ref(vv[e]) - 0.0f) / scale;
         }
     }
 }
 
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
-                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale) {
+                 int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw) {
     const int Mt = (P + 15) / 16;
     const int ntile = Tb * B16;
     hipLaunchKernelGGL(k_head, dim3((ntile + 15) / 16), dim3(256), 0, s, in, trans, (const v4f *)Wp, bias, Tb, B16,
-                       nread, P, Ps, Mt, K16, scale);
+                       nread, P, Ps, Mt, K16, scale, raw);
 }
 
 // ---- CRF partition function + global normalisation -------------------------------------------

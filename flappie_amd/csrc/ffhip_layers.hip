@@ -490,3 +490,79 @@ extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhi
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     return FFHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------ run-length (runnie) head and decoders
+// globalnorm_runlengthV2 (layers.c:1325-1358)
+extern "C" int ffhip_op_globalnorm_runlength(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C)) return set_err(FFHIP_EINVAL, "bad globalnorm arguments");
+    if (W.nr != X.nr || b.nr != W.nc || C.nr != W.nc || C.nc != X.nc) return set_err(FFHIP_EINVAL, "globalnorm: shapes do not agree");
+    if (!flipflop_dims(W.nc, C.stride, &nbase)) return set_err(FFHIP_EINVAL, "globalnorm_runlengthV2: %zu rows is not 2*nbase*(nbase+1) with nbase <= 5", W.nc);
+    const int H = (int)X.nr, Hp = round_up(H, 16), K16 = Hp / 16, P = (int)W.nc, Mt = (P + 15) / 16, T = (int)X.nc;
+    std::vector<float> wp = pack_weight_T(W, Mt, K16);
+    std::vector<float> bias((size_t)Mt * 16, 0.0f);
+    for (int p = 0; p < P; p++) bias[p] = b.data[p];
+    float *d_x = upload_img(tmp, X, s);
+    float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
+    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d_x || !d_w || !d_b || !d_in || !d_c || !d_z) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
+    launch_head(s, d_in, d_c, (const float4 *)d_w, d_b, T, 1, 1, P, (int)C.stride, K16, 1.0f, 1);
+    launch_rle_head_finish(s, d_c, d_z, 1, T, nbase, (int)C.stride, temperature);
+    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// runlengthV2_partition_function (layers.c:1255-1302)
+extern "C" int ffhip_op_runlength_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(S) || !logZ || !flipflop_dims(S.nr, S.stride, &nbase)) return set_err(FFHIP_EINVAL, "bad partition-function arguments");
+    float *d = upload_img(tmp, S, s);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d || !d_z) OP_NOMEM();
+    launch_rle_partition(s, d, d_z, 1, (int)S.nc, nbase, (int)S.stride);
+    HIP_TRY(hipMemcpyAsync(logZ, d_z, sizeof(double), hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// transpost_crf_runlength (decode.c:1037-1159); post has the shape of param
+extern "C" int ffhip_runlength_transpost(ffhip_engine *eng, ffhip_mat param, ffhip_mat post) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(param) || !view_ok(post) || post.nr != param.nr || post.nc != param.nc || post.stride != param.stride ||
+        !flipflop_dims(param.nr, param.stride, &nbase)) return set_err(FFHIP_EINVAL, "bad run-length posterior arguments");
+    const size_t n = param.nc * param.stride;
+    float *d_p = upload_img(tmp, param, s), *d_o = (float *)tmp.get(n * 4), *d_f = (float *)tmp.get(2 * (param.nc + 1) * kMaxState * 4);
+    if (!d_p || !d_o || !d_f) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, n * 4, s), FFHIP_EHIP);
+    launch_rle_transpost(s, d_p, d_o, d_f, 1, (int)param.nc, nbase, (int)param.stride);
+    HIP_TRY(hipMemcpyAsync(post.data, d_o, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// decode_crf_runlength (decode.c:927-1013): path[nblock] of states 0..2*nbase-1, returns the best score through *score
+extern "C" int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *path, float *score) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(param) || !path || !flipflop_dims(param.nr, param.stride, &nbase)) return set_err(FFHIP_EINVAL, "bad run-length decode arguments");
+    const size_t nblock = param.nc;
+    float *d_p = upload_img(tmp, param, s), *d_q = (float *)tmp.get((nblock + 1) * 4), *d_s = (float *)tmp.get(4);
+    uint8_t *d_tb = (uint8_t *)tmp.get(nblock * kMaxState);
+    int *d_path = (int *)tmp.get((nblock + 1) * 4);
+    if (!d_p || !d_q || !d_s || !d_tb || !d_path) OP_NOMEM();
+    launch_rle_viterbi(s, d_p, d_tb, d_path, d_q, d_s, 1, (int)nblock, nbase, (int)param.stride);
+    float sc = NAN;
+    HIP_TRY(hipMemcpyAsync(path, d_path, nblock * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(&sc, d_s, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    if (score) *score = sc;
+    return FFHIP_OK;
+}

@@ -1,0 +1,263 @@
+// ffhip_rle.hip -- run-length ("runnie", model rle_r941_native) head and decoders on the GPU.
+//
+// The network trunk is the LSTM5 one (networks.c:672-725); what differs from the flip-flop path:
+//   * head  globalnorm_runlengthV2 (layers.c:1325-1358): rows [0,nbase) shape = 1 + softplus, [nbase,2nbase)
+//     scale = 1e-8 + softplus, the 2*nbase*nbase transition rows 5 tanh(x)/temperature, globally normalised
+//     with runlengthV2_partition_function (layers.c:1255-1302: fp64 recursion over nbase move + nbase stay states,
+//     the stay update through the FLOAT logsumexpf -- reproduced);
+//   * transpost_crf_runlength (decode.c:1037-1159): forward/backward transition posteriors, not normalised per
+//     block, shape/scale rows copied through;
+//   * decode_crf_runlength (decode.c:927-1013): Viterbi over the 2*nbase states.
+// One workgroup per read, one lane per state, log-space chains in the reference's order of operations (libm
+// expf/log1pf/tanhf are ocml here, <= 1-2 ulp apart).  These are Tb-step dependent chains; forward and backward
+// posteriors run on two concurrent waves.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "ffhip_internal.hpp"
+#include "ffhip_math.hpp"
+
+namespace ffhip {
+
+namespace {
+
+__device__ __forceinline__ int rle_idx(int base_from, int stay_from, int base_to, int nbase) {      // layers.c:1241-1246
+    return base_to * 2 * nbase + base_from + (stay_from ? nbase : 0);
+}
+__device__ __forceinline__ double lse64(double x, double y) { return fmax(x, y) + log1p(exp(-fabs(x - y))); }
+__device__ __forceinline__ float softplus_ref(float x) { return log1pf(expf(-fabsf(x))) + ((x >= 0.0f) ? x : 0.f); }
+
+// rows of the head output after the affine map (k_head writes W^T h + b untouched in mode 1)
+__global__ void __launch_bounds__(256)
+k_rle_activate(float *__restrict__ param, size_t n /*nread*Tb*Ps*/, int nbase, int P, int Ps, float temperature) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = (int)(i % Ps);
+    if (p >= P) return;
+    const float x = param[i];
+    float r;
+    if (p < nbase) r = 1.0f + softplus_ref(x);
+    else if (p < 2 * nbase) r = 1e-8f + softplus_ref(x);
+    else r = 5.0f * tanhf(x) / temperature;
+    param[i] = r;
+}
+
+// runlengthV2_partition_function: one wave per read, lane = state
+__global__ void __launch_bounds__(64)
+k_rle_partition(const float *__restrict__ param, int Tb, int nbase, int Ps, double *__restrict__ logz) {
+    __shared__ double st[2][kMaxState];
+    const int lane = threadIdx.x, ns = 2 * nbase;
+    const float *C = param + (size_t)blockIdx.x * Tb * Ps + ns;
+    if (lane < ns) st[0][lane] = 0.0;
+    __syncthreads();
+    int cur = 0;
+    for (int c = 0; c < Tb; c++) {
+        const float *S = C + (size_t)c * Ps;
+        const double *prev = st[cur];
+        double v = 0.0;
+        if (lane < nbase) {
+            const int b1 = lane;
+            v = -HUGE_VAL;
+            for (int b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                v = lse64(v, prev[b2] + (double)S[rle_idx(b2, 0, b1, nbase)]);
+                v = lse64(v, prev[b2 + nbase] + (double)S[rle_idx(b2, 1, b1, nbase)]);
+            }
+        } else if (lane < ns) {
+            const int b = lane - nbase;
+            const float x = (float)(prev[b] + (double)S[rle_idx(b, 0, b, nbase)]);
+            const float y = (float)(prev[b + nbase] + (double)S[rle_idx(b, 1, b, nbase)]);
+            v = (double)logsumexpf_ref(x, y);
+        }
+        if (lane < ns) st[cur ^ 1][lane] = v;
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (lane == 0) {
+        double z = st[cur][0];
+        for (int s = 1; s < ns; s++) z = lse64(z, st[cur][s]);
+        logz[blockIdx.x] = z;
+    }
+}
+
+// rows [2*nbase, P) -= (float)(logZ / Tb)   (layers.c:1349-1356: `const float logZ = partition / (float)nc`)
+__global__ void __launch_bounds__(256)
+k_rle_sub(float *__restrict__ param, const double *__restrict__ logz, int Tb, int nbase, int P, int Ps, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = (int)(i % Ps);
+    if (p < 2 * nbase || p >= P) return;
+    const size_t r = i / ((size_t)Tb * Ps);
+    param[i] -= (float)(logz[r] / (double)(float)Tb);
+}
+
+// transpost_crf_runlength: wave 0 forward, wave 1 backward, then one block per thread
+__global__ void __launch_bounds__(256)
+k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf,
+                int Tb, int nbase, int P, int Ps) {
+    __shared__ float fs[2][kMaxState], bs[2][kMaxState];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ns = 2 * nbase;
+    const float *T = param + (size_t)blockIdx.x * Tb * Ps;
+    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    if (wave == 0) {
+        if (lane < ns) { fs[0][lane] = 0.0f; F[lane] = 0.0f; }
+        __builtin_amdgcn_wave_barrier();
+        int cur = 0;
+        for (int blk = 0; blk < Tb; blk++) {
+            const float *S = T + (size_t)blk * Ps + ns;
+            const float *prev = fs[cur];
+            float v = 0.0f;
+            if (lane < nbase) {
+                const int b1 = lane;
+                v = -HUGE_VALF;
+                for (int b2 = 0; b2 < nbase; b2++) {
+                    if (b1 == b2) continue;
+                    const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
+                    const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
+                    v = logsumexpf_ref(v, logsumexpf_ref(stay_score, move_score));
+                }
+            } else if (lane < ns) {
+                const int b = lane - nbase;
+                const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
+                const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
+                v = logsumexpf_ref(stay_score, move_score);
+            }
+            if (lane < ns) { fs[cur ^ 1][lane] = v; F[(size_t)(blk + 1) * kMaxState + lane] = v; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
+        }
+    } else if (wave == 1) {
+        if (lane < ns) bs[0][lane] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        int cur = 0;
+        for (int blk = Tb; blk > 0; blk--) {
+            const float *S = T + (size_t)(blk - 1) * Ps + ns;
+            const float *prev = bs[cur];
+            if (lane < ns) Bw[(size_t)blk * kMaxState + lane] = prev[lane];      // the vector that meets block blk-1's transitions
+            float v = 0.0f;
+            if (lane < nbase) {
+                const int b1 = lane;
+                v = -HUGE_VALF;
+                for (int b2 = 0; b2 < nbase; b2++) {
+                    if (b1 == b2) continue;
+                    v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 0, b2, nbase)]);
+                }
+                v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 0, b1, nbase)]);
+            } else if (lane < ns) {
+                const int b1 = lane - nbase;
+                v = -HUGE_VALF;
+                for (int b2 = 0; b2 < nbase; b2++) {
+                    if (b1 == b2) continue;
+                    v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 1, b2, nbase)]);
+                }
+                v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 1, b1, nbase)]);
+            }
+            if (lane < ns) bs[cur ^ 1][lane] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+    for (int blk = threadIdx.x; blk < Tb; blk += 256) {
+        const float *x = T + (size_t)blk * Ps;
+        float *o = Pp + (size_t)blk * Ps;
+        const float *f = F + (size_t)blk * kMaxState, *bb = Bw + (size_t)(blk + 1) * kMaxState;
+        for (int p = 0; p < ns; p++) o[p] = x[p];                                   // shape and scale rows, decode.c:1131-1135
+        const float *S = x + ns;
+        float *Q = o + ns;
+        for (int b1 = 0; b1 < nbase; b1++)
+            for (int b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                const int mi = rle_idx(b1, 0, b2, nbase), si = rle_idx(b1, 1, b2, nbase);
+                Q[mi] = f[b1] + bb[b2] + S[mi];                                     // :1106
+                Q[si] = f[b1 + nbase] + bb[b2] + S[si];                             // :1110
+            }
+        for (int b = 0; b < nbase; b++) {
+            const int i0 = rle_idx(b, 0, b, nbase), i1 = rle_idx(b, 1, b, nbase);
+            Q[i0] = f[b] + S[i0] + bb[b + nbase];                                   // :1118
+            Q[i1] = f[b + nbase] + S[i1] + bb[b + nbase];                           // :1124
+        }
+    }
+}
+
+// decode_crf_runlength: Viterbi, traceback bytes in HBM, one wave per read
+__global__ void __launch_bounds__(64)
+k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
+              float *__restrict__ score_out, int Tb, int nbase, int Ps) {
+    __shared__ float vs[2][kMaxState];
+    const int lane = threadIdx.x, ns = 2 * nbase;
+    const float *T = param + (size_t)blockIdx.x * Tb * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    if (lane < ns) vs[0][lane] = 0.0f;
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < Tb; blk++) {
+        const float *S = T + (size_t)blk * Ps + ns;
+        const float *prev = vs[cur];
+        float v = -HUGE_VALF;
+        int arg = 0;
+        if (lane < nbase) {
+            const int b1 = lane;
+            for (int b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
+                if (move_score > v) { v = move_score; arg = b2; }
+                const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
+                if (stay_score > v) { v = stay_score; arg = b2 + nbase; }
+            }
+        } else if (lane < ns) {
+            const int b = lane - nbase;
+            const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
+            const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
+            if (stay_score > move_score) { v = stay_score; arg = b + nbase; }
+            else { v = move_score; arg = b; }
+        }
+        if (lane < ns) { vs[cur ^ 1][lane] = v; tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg; }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (lane == 0) {
+        int last = 0;
+        for (int s = 1; s < ns; s++) if (vs[cur][s] > vs[cur][last]) last = s;     // argmaxf: first maximum
+        score_out[blockIdx.x] = vs[cur][last];
+        pth[Tb] = 0;
+        qp[Tb] = NAN;
+        for (int blk = Tb; blk > 0; blk--) {
+            const int state = tb[(size_t)(blk - 1) * kMaxState + last];
+            pth[blk - 1] = last;
+            qp[blk - 1] = NAN;
+            last = state;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature) {
+    const int P = 2 * nbase * (nbase + 1);
+    const size_t n = (size_t)nread * Tb * Ps;
+    hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, n, nbase, P, Ps, temperature);
+    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz);
+    hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, logz, Tb, nbase, P, Ps, n);
+}
+
+void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps) {
+    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz);
+}
+
+void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
+    const int P = 2 * nbase * (nbase + 1);
+    hipLaunchKernelGGL(k_rle_transpost, dim3(nread), dim3(256), 0, s, param, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps);
+}
+
+void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps) {
+    hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps);
+}
+
+}  // namespace ffhip

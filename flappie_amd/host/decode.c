@@ -77,3 +77,28 @@ flappie_imatrix trace_from_posterior(flappie_matrix tpost) {
     free(tmp);
     return trace;
 }
+
+/* ---- run-length decoders (decode.c:927-1159) ---- */
+static ffhip_mat mview(const_flappie_matrix m) {
+    ffhip_mat v = { m->data.f, m->nr, m->nc, m->stride };
+    return v;
+}
+
+float decode_crf_runlength(const_flappie_matrix param, int *path) {
+    if (NULL == param || NULL == path) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    float score = NAN;
+    if (NULL == eng) return NAN;
+    if (0 != ffhip_runlength_viterbi(eng, mview(param), path, &score)) { warnx("%s: %s", __func__, ffhip_last_error()); return NAN; }
+    return score;
+}
+
+flappie_matrix transpost_crf_runlength(const_flappie_matrix param) {
+    if (NULL == param) return NULL;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    flappie_matrix post = make_flappie_matrix(param->nr, param->nc);
+    if (NULL == post) return NULL;
+    if (0 != ffhip_runlength_transpost(eng, mview(param), mview(post))) { warnx("%s: %s", __func__, ffhip_last_error()); return free_flappie_matrix(post); }
+    return post;
+}

@@ -27,7 +27,11 @@
 
 const char *argp_program_version = "flappie (MI355X/HIP) 0.1, interface of flappie 2.1.3";
 const char *argp_program_bug_address = "<this repository>";
+#ifdef BUILD_RUNNIE
+static char doc[] = "Runnie basecaller -- basecall from raw signal";
+#else
 static char doc[] = "Flappie basecaller -- basecall from raw signal";
+#endif
 static char args_doc[] = "fast5 [fast5 ...]";
 static struct argp_option options[] = {
     {"delta", 'd', "factor", 0, "Using delta samples model with scaling factor"},
@@ -55,7 +59,13 @@ static struct argp_option options[] = {
     {0}
 };
 
+#ifdef BUILD_RUNNIE
+/* runnie.c:71: the run-length model; its --format/--model/--trace/--reverse options are commented out in the
+ * reference (runnie.c:42-60) and are ignored here with a warning */
+#define DEFAULT_MODEL RUNNIE_MODEL_R941_NATIVE
+#else
 #define DEFAULT_MODEL FLAPPIE_MODEL_R941_NATIVE
+#endif
 
 static struct {
     int compression_level, compression_chunk_size;
@@ -166,6 +176,7 @@ typedef struct {
     char *filename;                     /* owned */
     struct _raw_basecall_info res;      /* rt filled by read_raw, start/end by the preparation; basecall == NULL until called */
     int prepared;                       /* index into the chunk's ffhip_prep, or -1 */
+    char *rle_text;                     /* runnie: the read's records, formatted (runnie.c:282-313) */
 } item;
 
 /* one batch of equal-length prepared reads through the engine: calculate_post after normalisation (flappie.c:264-316) */
@@ -182,6 +193,41 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         return;
     }
     const size_t nblock = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
+#ifdef BUILD_RUNNIE
+    {   /* runnie.c:262-313: path from decode_crf_runlength, then one line per emitted base with the discrete-Weibull
+         * shape and scale of the block that emitted it and the dwell in blocks */
+        const size_t nbase = ffhip_model_nbase(mdl), P = ffhip_model_nparam(mdl);
+        int *path = malloc((nblock + 1) * sizeof(int));
+        float *qp = malloc((nblock + 1) * sizeof(float)), *mat = malloc(nblock * P * sizeof(float));
+        for (int i = 0; path && qp && mat && i < n; i++) {
+            if (0 != ffhip_batch_get_path(b, i, path, qp)) continue;
+            if (0 != (args.viterbi_only ? ffhip_batch_get_transitions(b, i, mat) : ffhip_batch_get_posterior(b, i, mat))) continue;
+            size_t cap = 64 * (nblock + 1), len = 0;
+            char *text = malloc(cap);
+            if (NULL == text) continue;
+            text[0] = 0;
+            int dwell = 1, last_blk = -1;
+            for (size_t blk = 0; blk <= nblock; blk++) {
+                const int emit = (blk < nblock) ? (path[blk] < (int)nbase) : 1;      /* the final pass flushes the last run */
+                if (!emit) { dwell += 1; continue; }
+                if (last_blk >= 0) {
+                    const int base = path[last_blk];
+                    len += snprintf(text + len, cap - len, "%c\t%f\t%f\t%d\n", basechar(base), mat[(size_t)last_blk * P + base],
+                                    mat[(size_t)last_blk * P + nbase + base], dwell);
+                }
+                last_blk = (int)blk;
+                dwell = 1;
+            }
+            its[i]->rle_text = text;
+            its[i]->res.score = ffhip_batch_score(b, i);
+            its[i]->res.nblock = nblock;
+        }
+        free(path); free(qp); free(mat);
+        ffhip_batch_destroy(b);
+        free(idx);
+        return;
+    }
+#endif
     for (int i = 0; i < n; i++) {
         struct _raw_basecall_info *r = &its[i]->res;
         size_t blen = 0;
@@ -244,6 +290,18 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
     }
     for (int i = 0; i < n; i++) {
         item *it = &items[i];
+#ifdef BUILD_RUNNIE
+        if (NULL != it->rle_text) {
+            fprintf(args.output, "# %s\n%s", it->res.rt.uuid ? it->res.rt.uuid : "", it->rle_text);      /* runnie.c:280 */
+            free(it->rle_text);
+            it->rle_text = NULL;
+        } else {
+            warnx("No basecall returned for %s", it->filename);
+        }
+        free_raw_basecall_info(&it->res);
+        free(it->filename);
+        continue;
+#endif
         if (NULL == it->res.basecall) {
             warnx("No basecall returned for %s", it->filename);
         } else {

@@ -250,3 +250,25 @@ flappie_matrix globalnorm_manystay(const_flappie_matrix X, const_flappie_matrix 
 flappie_matrix globalnorm_flipflop(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature, flappie_matrix C) {
     return globalnorm_manystay(X, W, b, temperature, C);
 }
+
+/* ---- run-length head (layers.c:1230-1358) ---- */
+size_t nbase_from_crf_runlength_nparam(size_t nparam) { return nbase_from_flipflop_nparam(nparam); }
+
+double runlengthV2_partition_function(const_flappie_matrix C) {
+    if (NULL == C) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    double logZ = NAN;
+    if (NULL == eng || 0 != check(ffhip_op_runlength_partition_function(eng, view(C), &logZ), __func__)) return NAN;
+    return logZ;
+}
+
+flappie_matrix globalnorm_runlengthV2(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature, flappie_matrix C) {
+    if (NULL == X) return NULL;
+    if (NULL == W || NULL == b) { warnx("globalnorm_runlengthV2: missing weights or bias"); return NULL; }
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    C = remake_flappie_matrix(C, W->nc, X->nc);
+    if (NULL == C) return NULL;
+    if (0 != check(ffhip_op_globalnorm_runlength(eng, view(X), view(W), view(b), temperature, view(C)), __func__)) return free_flappie_matrix(C);
+    return C;
+}

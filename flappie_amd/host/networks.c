@@ -33,27 +33,30 @@ static const registry_entry registry[] = {
                                  FFHIP_NET_GRUMOD5, "flipflop_r941native5mC.h", "flipflop", "r941native5mC" },
     [FLAPPIE_MODEL_R103_NATIVE] = { "r103_native", "R10.3 model for MinION.  Trained from native DNA library",
                                     FFHIP_NET_LSTM5, "flipflop5_r103native.h", "flipflop5", "r103native" },
+    /* runnie's model (networks.c:14,364-399): the LSTM5 trunk with the run-length head */
+    [RUNNIE_MODEL_R941_NATIVE] = { "rle_r941_native", "R9.4.1 run-length encoded model for MinION.  Trained from native DNA library",
+                                   FFHIP_NET_LSTM5_RLE, "runlength5_r941native.h", "rle5", "r941native" },
 };
+#define NSLOT ((int)RUNNIE_MODEL_INVALID)
+static int valid_model(int model) { return model >= 0 && model < NSLOT && NULL != registry[model].name; }
 
 static struct {
     ffhip_engine *engine;
-    ffhip_model *model[FLAPPIE_MODEL_INVALID];
-    int tried[FLAPPIE_MODEL_INVALID];
+    ffhip_model *model[RUNNIE_MODEL_INVALID];
+    int tried[RUNNIE_MODEL_INVALID];
 } g;
 
 /* networks.c:21-39 */
 enum model_type get_flappie_model_type(const char *modelstr) {
     if (NULL == modelstr) return FLAPPIE_MODEL_INVALID;
-    for (int i = 0; i < FLAPPIE_MODEL_INVALID; i++)
-        if (0 == strcmp(modelstr, registry[i].name)) return (enum model_type)i;
-    if (0 == strcmp(modelstr, "rle_r941_native")) return RUNNIE_MODEL_R941_NATIVE;
+    for (int i = 0; i < NSLOT; i++)
+        if (valid_model(i) && 0 == strcmp(modelstr, registry[i].name)) return (enum model_type)i;
     return FLAPPIE_MODEL_INVALID;
 }
 
 /* networks.c:42-61 */
 const char *flappie_model_string(const enum model_type model) {
-    if ((int)model >= 0 && model < FLAPPIE_MODEL_INVALID) return registry[model].name;
-    if (model == RUNNIE_MODEL_R941_NATIVE) return "rle_r941_native";
+    if (valid_model((int)model)) return registry[model].name;
     if (model == FLAPPIE_MODEL_INVALID || model == RUNNIE_MODEL_INVALID) errx(EXIT_FAILURE, "Invalid model  %s:%d", __FILE__, __LINE__);
     errx(EXIT_FAILURE, "Flappie enum failure -- report as bug. %s:%d \n", __FILE__, __LINE__);
     return NULL;
@@ -61,8 +64,7 @@ const char *flappie_model_string(const enum model_type model) {
 
 /* networks.c:64-83 */
 const char *flappie_model_description(const enum model_type model) {
-    if ((int)model >= 0 && model < FLAPPIE_MODEL_INVALID) return registry[model].description;
-    if (model == RUNNIE_MODEL_R941_NATIVE) return "R9.4.1 run-length encoded model for MinION.  Trained from native DNA library";
+    if (valid_model((int)model)) return registry[model].description;
     if (model == FLAPPIE_MODEL_INVALID || model == RUNNIE_MODEL_INVALID) errx(EXIT_FAILURE, "Invalid Flappie model  %s:%d", __FILE__, __LINE__);
     errx(EXIT_FAILURE, "Flappie enum failure -- report as bug. %s:%d \n", __FILE__, __LINE__);
     return NULL;
@@ -108,9 +110,9 @@ static const_flappie_matrix need(const mdl_file *m, const char *fmt, const char 
     return x;
 }
 
-/* tensor names: networks.c:218-253 (flipflop5 / LSTM) and :294-323 (flipflop / GRU) */
+/* tensor names: networks.c:218-253 (flipflop5 / LSTM), :294-323 (flipflop / GRU), :364-399 (rle5 / LSTM) */
 int flappie_hip_load_model(enum model_type model, const char *mdl_path) {
-    if ((int)model < 0 || model >= FLAPPIE_MODEL_INVALID || NULL == mdl_path) return -1;
+    if (!valid_model((int)model) || NULL == mdl_path) return -1;
     ffhip_engine *eng = flappie_hip_engine();
     if (NULL == eng) return -1;
     const registry_entry *r = &registry[model];
@@ -122,7 +124,7 @@ int flappie_hip_load_model(enum model_type model, const char *mdl_path) {
     int ok = 1;
     char def[MDL_NAME_MAX];
     static const char *tags[5] = { "B1", "F2", "B3", "F4", "B5" };
-    if (r->kind == FFHIP_NET_LSTM5) {
+    if (r->kind != FFHIP_NET_GRUMOD5) {
         d.nconv = 3;
         static const char *cn[3] = { "conv1", "conv2", "conv3" };
         for (int i = 0; i < 3; i++) {
@@ -144,7 +146,7 @@ int flappie_hip_load_model(enum model_type model, const char *mdl_path) {
         d.conv_stride[0] = mdl_define(m, def, 0);
         if (!d.conv_W[0] || !d.conv_b[0] || d.conv_stride[0] <= 0) { warnx("%s: convolution incomplete", mdl_path); ok = 0; }
     }
-    const char *cell = (r->kind == FFHIP_NET_LSTM5) ? "lstm" : "gru";
+    const char *cell = (r->kind != FFHIP_NET_GRUMOD5) ? "lstm" : "gru";
     for (int i = 0; i < 5; i++) {
         char stem[MDL_NAME_MAX];
         snprintf(stem, sizeof(stem), "%s%s_rnnrf_%s_%s_", cell, tags[i], r->family, r->ident);
@@ -172,7 +174,7 @@ int flappie_hip_load_model(enum model_type model, const char *mdl_path) {
 }
 
 const struct ffhip_model *flappie_hip_model(enum model_type model) {
-    if ((int)model < 0 || model >= FLAPPIE_MODEL_INVALID) return NULL;
+    if (!valid_model((int)model)) return NULL;
     if (NULL == g.model[model] && !g.tried[model]) {
         g.tried[model] = 1;
         const char *dir = getenv("FLAPPIE_MODEL_DIR");
@@ -189,7 +191,7 @@ const struct ffhip_model *flappie_hip_model(enum model_type model) {
 }
 
 void flappie_hip_shutdown(void) {
-    for (int i = 0; i < FLAPPIE_MODEL_INVALID; i++) {
+    for (int i = 0; i < NSLOT; i++) {
         if (g.model[i]) ffhip_model_free(g.model[i]);
         g.model[i] = NULL;
         g.tried[i] = 0;
@@ -238,8 +240,7 @@ flappie_matrix flipflop_transitions_r941native5mC(const raw_table signal, float 
 flappie_matrix flipflop5_transitions_r103native(const raw_table signal, float temperature) {
     return transitions_for(signal, temperature, FLAPPIE_MODEL_R103_NATIVE);
 }
+/* networks.c:740-743 */
 flappie_matrix runlength5_transitions_r941native(const raw_table signal, float temperature) {
-    (void)signal; (void)temperature;
-    warnx("rle_r941_native (runnie) is not part of this build");
-    return NULL;
+    return transitions_for(signal, temperature, RUNNIE_MODEL_R941_NATIVE);
 }

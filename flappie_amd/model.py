@@ -22,6 +22,7 @@ import numpy as np
 
 NET_LSTM5 = 0    # flipflop5_guppy_transitions, networks.c:539-586 (r941_native, r941_rna002, r103_native)
 NET_GRUMOD5 = 1  # flipflop_guppy_transitions,  networks.c:450-489 (r941_5mC)
+NET_LSTM5_RLE = 2  # runlength5_guppy_transitions, networks.c:672-725 (runnie's rle_r941_native): LSTM5 trunk, run-length head
 
 # registry: networks.h:18-26, networks.c:21-105.  `ident` is the <id> in the tensor names.
 REGISTRY = {
@@ -33,6 +34,8 @@ REGISTRY = {
                      description="R9.4.1 model for PromethION; 5mC aware.  Trained from native NA12878 library"),
     "r103_native": dict(kind=NET_LSTM5, ident="r103native", enum=3,
                         description="R10.3 model for MinION.  Trained from native DNA library"),
+    "rle_r941_native": dict(kind=NET_LSTM5_RLE, ident="r941native", enum=5,
+                            description="R9.4.1 run-length encoded model for MinION.  Trained from native DNA library"),
 }
 # hidden sizes inferred from the LFS stub byte counts; never hard-coded in kernels
 INFERRED_HIDDEN = {"r941_native": 384, "r941_rna002": 384, "r941_5mC": 256, "r103_native": 512}
@@ -111,7 +114,7 @@ class FlipflopModel:
 
     @property
     def ngate(self) -> int:
-        return 4 if self.kind == NET_LSTM5 else 3
+        return 3 if self.kind == NET_GRUMOD5 else 4
 
     @property
     def nparam(self) -> int:
@@ -168,7 +171,7 @@ def _conv_mat(rng, nf, nfilter, winlen) -> Mat:
 # stack forgets its input and every read decodes to the same periodic string; these values make the
 # transition scores input-driven (a mix of stays and moves, varied bases) while keeping the network
 # non-chaotic (a 1e-6 input perturbation moves the scores by < 5e-5), so parity tests are meaningful.
-SYNTH_GAINS = {NET_LSTM5: (5.0, 2.5, 10.0, 0.6), NET_GRUMOD5: (2.0, 1.0, 4.0, 0.3)}
+SYNTH_GAINS = {NET_LSTM5: (5.0, 2.5, 10.0, 0.6), NET_GRUMOD5: (2.0, 1.0, 4.0, 0.3), NET_LSTM5_RLE: (5.0, 2.5, 10.0, 0.6)}
 
 
 def synthetic_model(kind: int = NET_LSTM5, hidden: int = 384, seed: int = 1,
@@ -185,7 +188,7 @@ def synthetic_model(kind: int = NET_LSTM5, hidden: int = 384, seed: int = 1,
         a = 1.0 / math.sqrt(nin)
         return Mat.from_dense(rng.uniform(-a, a, size=(nout, nin)).astype(np.float32))
 
-    if kind == NET_LSTM5:
+    if kind in (NET_LSTM5, NET_LSTM5_RLE):
         convs = [ConvLayer(_conv_mat(rng, 1, 4, 5), bias(4), 1, 1, 5),
                  ConvLayer(_conv_mat(rng, 4, 16, 5), bias(16), 1, 4, 5),
                  ConvLayer(_conv_mat(rng, 16, H, 19), bias(H), 5, 16, 19)]
@@ -206,10 +209,14 @@ def synthetic_model(kind: int = NET_LSTM5, hidden: int = 384, seed: int = 1,
     nstate = 2 * nbase
     FF_W, FF_b = dense(H, P), bias(P)
     FF_W.data *= np.float32(gf)
-    for to in range(nbase):                       # flip self-transitions
-        FF_b.data[0, to * nstate + to] += np.float32(stay)
-    for b2 in range(nbase, nstate):               # flop stays
-        FF_b.data[0, nbase * nstate + b2] += np.float32(stay)
+    if kind == NET_LSTM5_RLE:                     # stay -> stay transitions of the run-length head (layers.c:1241-1246)
+        for b in range(nbase):
+            FF_b.data[0, nstate + b * nstate + b + nbase] += np.float32(stay)
+    else:
+        for to in range(nbase):                   # flip self-transitions
+            FF_b.data[0, to * nstate + to] += np.float32(stay)
+        for b2 in range(nbase, nstate):           # flop stays
+            FF_b.data[0, nbase * nstate + b2] += np.float32(stay)
     return FlipflopModel(kind, convs, rnns, FF_W, FF_b, ident)
 
 
@@ -237,8 +244,8 @@ def _write_mat(fh, name: str, m: Mat, vector: bool = False) -> None:
 def tensor_names(kind: int, ident: str) -> Dict[str, str]:
     """Logical name -> symbol name, as networks.c:218-323 expects them."""
     names = {}
-    if kind == NET_LSTM5:
-        fam, cell = "flipflop5", "lstm"
+    if kind in (NET_LSTM5, NET_LSTM5_RLE):
+        fam, cell = ("flipflop5" if kind == NET_LSTM5 else "rle5"), "lstm"
         for i in (1, 2, 3):
             names["conv%d" % i] = "conv%d_rnnrf_%s_%s_" % (i, fam, ident)
     else:
@@ -301,7 +308,7 @@ def load_mdl(path: str, kind: int, ident: str) -> FlipflopModel:
         mats, defs = parse_mdl_text(fh.read())
     names = tensor_names(kind, ident)
     convs = []
-    nconv = 3 if kind == NET_LSTM5 else 1
+    nconv = 1 if kind == NET_GRUMOD5 else 3
     nf = 1
     for i in range(nconv):
         p = names["conv%d" % (i + 1)]

@@ -30,6 +30,13 @@ flappie_matrix transpost_crf_flipflop(const_flappie_matrix trans, bool return_lo
 /* decode.c:499-543: tpost holds probabilities; returns [nstate x nblock+1] int32 */
 flappie_imatrix trace_from_posterior(flappie_matrix tpost);
 
+/* ---- run-length model (runnie) ----
+ * decode.c:927-1013: Viterbi over nbase move + nbase stay states; path needs nblock ints (states 0..2*nbase-1,
+ * < nbase marks a newly emitted base); returns the best score or NAN */
+float decode_crf_runlength(const_flappie_matrix transparam, int *path);
+/* decode.c:1037-1159: transition posteriors (not normalised per block); shape/scale rows copied through */
+flappie_matrix transpost_crf_runlength(const_flappie_matrix trans);
+
 
 #ifdef __cplusplus
 }

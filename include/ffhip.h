@@ -43,7 +43,10 @@ typedef struct ffhip_batch ffhip_batch;
 
 enum ffhip_net_kind {
     FFHIP_NET_LSTM5 = 0,    /* flipflop5_guppy_transitions, networks.c:539-586 */
-    FFHIP_NET_GRUMOD5 = 1   /* flipflop_guppy_transitions,  networks.c:450-489 */
+    FFHIP_NET_GRUMOD5 = 1,  /* flipflop_guppy_transitions,  networks.c:450-489 */
+    FFHIP_NET_LSTM5_RLE = 2 /* runlength5_guppy_transitions, networks.c:672-725: LSTM5 trunk, globalnorm_runlengthV2 head;
+                             * decode = transpost_crf_runlength + decode_crf_runlength (runnie.c:262-276): results are the
+                             * path (ffhip_batch_get_path, states 0..2*nbase-1), score and parameter/posterior matrices */
 };
 
 /* Host-side weight bundle.  Mirrors `guppy_stride5_model` (networks.c:181-215) and `guppy_model`
@@ -173,6 +176,14 @@ int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
 int ffhip_op_partition_function_scaled(ffhip_engine *eng, ffhip_mat S, float bound, double *logZ);
 /* globalnorm_flipflop (layers.c:1082-1106) */
 int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
+
+/* ---- run-length (runnie) head and decoders on single matrices ------------------------------------------
+ * globalnorm_runlengthV2 (layers.c:1325-1358), runlengthV2_partition_function (layers.c:1255-1302),
+ * transpost_crf_runlength (decode.c:1037-1159), decode_crf_runlength (decode.c:927-1013). */
+int ffhip_op_globalnorm_runlength(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
+int ffhip_op_runlength_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
+int ffhip_runlength_transpost(ffhip_engine *eng, ffhip_mat param, ffhip_mat post);
+int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *path /* nblock */, float *score);
 
 /* ---- signal preparation on the GPU ------------------------------------------------------------------
  * trim_and_segment_raw (flappie_common.c:13-81) followed by medmad_normalise_array (util.c:198-212) or the

@@ -8,8 +8,8 @@
  *  synchronous.  On a machine without a usable gfx950 device the functions warn and return NULL.
  *
  *  Not provided (outside the flip-flop hot path): gru_forward/backward/step and
- *  gru_relu_* (sloika GRU, unused by any shipped model), globalnorm_runlength / globalnorm_runlengthV2 and
- *  their nbase helpers (runnie).
+ *  gru_relu_* (sloika GRU, unused by any shipped model), and the first-generation globalnorm_runlength head
+ *  (layers.c:1115-1228; the shipped runnie model uses V2, which is provided).
  */
 #ifndef FFHIP_LAYERS_H
 #define FFHIP_LAYERS_H
@@ -69,6 +69,12 @@ flappie_matrix globalnorm_manystay(const_flappie_matrix X, const_flappie_matrix 
 size_t nbase_from_flipflop_nparam(size_t nparam);
 flappie_matrix globalnorm_flipflop(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
                                    flappie_matrix C);
+/* layers.c:1230-1358: the run-length head of runnie's model (shape = 1 + softplus, scale = 1e-8 + softplus,
+ * transitions 5 tanh / temperature, globally normalised) and its fp64 partition function */
+size_t nbase_from_crf_runlength_nparam(size_t nparam);
+double runlengthV2_partition_function(const_flappie_matrix C);
+flappie_matrix globalnorm_runlengthV2(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
+                                      flappie_matrix C);
 
 #ifdef __cplusplus
 }

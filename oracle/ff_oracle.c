@@ -473,7 +473,7 @@ fo_mat *fo_transitions(const float *raw, size_t start, size_t end, float tempera
     fo_mat *x = fo_features_from_raw(raw, start, end);
     for (int l = 0; x && l < net->nconv; l++) {
         fo_mat *y = fo_convolution(x, net->conv_W[l], net->conv_b[l], (size_t)net->conv_stride[l]);
-        if (net->kind == FO_NET_LSTM5) fo_swish_inplace(y); else fo_tanh_inplace(y);
+        if (net->kind != FO_NET_GRUMOD5) fo_swish_inplace(y); else fo_tanh_inplace(y);
         fo_free_mat(x);
         x = y;
     }
@@ -481,12 +481,13 @@ fo_mat *fo_transitions(const float *raw, size_t start, size_t end, float tempera
         const int backward = (l % 2 == 0);                   /* B,F,B,F,B */
         fo_mat *in = fo_affine_map(x, net->rnn_iW[l], net->rnn_b[l]);
         fo_free_mat(x);
-        x = (net->kind == FO_NET_LSTM5) ? fo_lstm(in, net->rnn_sW[l], backward)
+        x = (net->kind != FO_NET_GRUMOD5) ? fo_lstm(in, net->rnn_sW[l], backward)
                                         : fo_grumod(in, net->rnn_sW[l], backward);
         fo_free_mat(in);
     }
     if (!x) return NULL;
-    fo_mat *trans = fo_globalnorm_flipflop(x, net->FF_W, net->FF_b, temperature);
+    fo_mat *trans = (net->kind == FO_NET_LSTM5_RLE) ? fo_globalnorm_runlengthV2(x, net->FF_W, net->FF_b, temperature)    /* networks.c:716-722 */
+                                                    : fo_globalnorm_flipflop(x, net->FF_W, net->FF_b, temperature);
     fo_free_mat(x);
     return trans;
 }
@@ -788,4 +789,179 @@ int fo_trim_and_segment_raw(const float *raw, size_t n, size_t *start, size_t *e
     *start = (n - *start) > trim_start ? *start + trim_start : n;
     *end = (*end > trim_end) ? *end - trim_end : 0;
     return (*start >= *end) ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------ run-length (runnie) head and decoders */
+
+/* util.h:83-85 */
+float fo_softplusf(float x) { return log1pf(expf(-fabsf(x))) + ((x >= 0.0f) ? x : 0.f); }
+
+/* layers.c:1241-1246 */
+static size_t rle_trans_lookup(size_t base_from, int stay_from, size_t base_to, int stay_to, size_t nbase) {
+    (void)stay_to;
+    return base_to * 2 * nbase + base_from + (stay_from ? nbase : 0);
+}
+
+/* layers.c:1255-1302  fp64 forward recursion; the stay states are combined with the FLOAT logsumexpf, as the reference does */
+double fo_runlengthV2_partition_function(const fo_mat *C) {
+    if (!C) return NAN;
+    const size_t nbase = fo_nbase_from_nparam(C->nr), nstate = 2 * nbase;
+    double mem[2 * 32] = { 0 };
+    if (nstate > 32) return NAN;
+    double *curr = mem, *prev = mem + nstate;
+    for (size_t c = 0; c < C->nc; c++) {
+        const float *S = C->f + c * C->stride + nstate;
+        { double *tmp = curr; curr = prev; prev = tmp; }
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                curr[b1] = fo_logsumexp(curr[b1], prev[b2] + S[rle_trans_lookup(b2, 0, b1, 0, nbase)]);
+                curr[b1] = fo_logsumexp(curr[b1], prev[b2 + nbase] + S[rle_trans_lookup(b2, 1, b1, 0, nbase)]);
+            }
+        }
+        for (size_t b = 0; b < nbase; b++)
+            curr[b + nbase] = fo_logsumexpf(prev[b] + S[rle_trans_lookup(b, 0, b, 1, nbase)],
+                                            prev[b + nbase] + S[rle_trans_lookup(b, 1, b, 1, nbase)]);
+    }
+    double logZ = curr[0];
+    for (size_t st = 1; st < nstate; st++) logZ = fo_logsumexp(logZ, curr[st]);
+    return logZ;
+}
+
+/* layers.c:1325-1358 */
+fo_mat *fo_globalnorm_runlengthV2(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature) {
+    fo_mat *C = fo_affine_map(X, W, b);
+    if (!C) return NULL;
+    const size_t nbase = fo_nbase_from_nparam(C->nr), nrunparam = 2 * nbase;
+    for (size_t c = 0; c < C->nc; c++) {
+        float *x = C->f + c * C->stride;
+        for (size_t k = 0; k < nbase; k++) {
+            x[k] = 1.0f + fo_softplusf(x[k]);
+            x[nbase + k] = 1e-8f + fo_softplusf(x[nbase + k]);
+        }
+        for (size_t p = nrunparam; p < C->nr; p++) x[p] = 5.0f * tanhf(x[p]) / temperature;
+    }
+    const float logZ = fo_runlengthV2_partition_function(C) / (float)C->nc;
+    for (size_t c = 0; c < C->nc; c++)
+        for (size_t r = nrunparam; r < C->nr; r++) C->f[c * C->stride + r] -= logZ;
+    return C;
+}
+
+/* decode.c:927-1013  Viterbi over move/stay states; path[blk] in [0, 2*nbase): < nbase = a new base */
+float fo_decode_crf_runlength(const fo_mat *param, int *path) {
+    if (!param || !path) return NAN;
+    const size_t nblk = param->nc, nbase = fo_nbase_from_nparam(param->nr), nstate = 2 * nbase;
+    float *mem = calloc(2 * nstate, sizeof(float));
+    char *traceback = calloc(nstate * nblk, sizeof(char));
+    if (!mem || !traceback) { free(mem); free(traceback); return NAN; }
+    float *prev = mem, *curr = mem + nstate;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const float *S = param->f + blk * param->stride + nstate;
+        char *tb = traceback + blk * nstate;
+        { float *tmp = prev; prev = curr; curr = tmp; }
+        for (size_t st = 0; st < nstate; st++) curr[st] = -HUGE_VAL;
+        for (size_t b1 = 0; b1 < nbase; b1++)
+            for (size_t b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                const float move_score = prev[b2] + S[rle_trans_lookup(b2, 0, b1, 0, nbase)];
+                if (move_score > curr[b1]) { curr[b1] = move_score; tb[b1] = (char)b2; }
+                const float stay_score = prev[b2 + nbase] + S[rle_trans_lookup(b2, 1, b1, 0, nbase)];
+                if (stay_score > curr[b1]) { curr[b1] = stay_score; tb[b1] = (char)(b2 + nbase); }
+            }
+        for (size_t b = 0; b < nbase; b++) {
+            const float stay_score = prev[b + nbase] + S[rle_trans_lookup(b, 1, b, 1, nbase)];
+            const float move_score = prev[b] + S[rle_trans_lookup(b, 0, b, 1, nbase)];
+            if (stay_score > move_score) { curr[b + nbase] = stay_score; tb[b + nbase] = (char)(b + nbase); }
+            else { curr[b + nbase] = move_score; tb[b + nbase] = (char)b; }
+        }
+    }
+    size_t last_state = 0;                                   /* argmaxf: first maximum (util.c:17-31) */
+    for (size_t st = 1; st < nstate; st++) if (curr[st] > curr[last_state]) last_state = st;
+    const float logscore = curr[last_state];
+    for (size_t blk = nblk; blk > 0; blk--) {
+        const char state = traceback[(blk - 1) * nstate + last_state];
+        path[blk - 1] = (int)last_state;
+        last_state = (size_t)state;
+    }
+    free(traceback);
+    free(mem);
+    return logscore;
+}
+
+/* decode.c:1037-1159  transition posteriors (NOT normalised per block, unlike the flip-flop version); the shape
+ * and scale rows are copied through */
+fo_mat *fo_transpost_crf_runlength(const fo_mat *param) {
+    if (!param) return NULL;
+    const size_t nblk = param->nc, nparam = param->nr, nbase = fo_nbase_from_nparam(nparam), nstate = 2 * nbase;
+    fo_mat *fwd = fo_make_mat(nstate, nblk + 1), *post = fo_make_mat(nparam, nblk);
+    float *mem = calloc(2 * nstate, sizeof(float));
+    if (!fwd || !post || !mem) { fo_free_mat(fwd); fo_free_mat(post); free(mem); return NULL; }
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const float *S = param->f + blk * param->stride + nstate;
+        const float *prev = fwd->f + blk * fwd->stride;
+        float *curr = fwd->f + (blk + 1) * fwd->stride;
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                const float stay_score = prev[b2 + nbase] + S[rle_trans_lookup(b2, 1, b1, 0, nbase)];
+                const float move_score = prev[b2] + S[rle_trans_lookup(b2, 0, b1, 0, nbase)];
+                curr[b1] = fo_logsumexpf(curr[b1], fo_logsumexpf(stay_score, move_score));
+            }
+        }
+        for (size_t b = 0; b < nbase; b++) {
+            const float stay_score = prev[b + nbase] + S[rle_trans_lookup(b, 1, b, 1, nbase)];
+            const float move_score = prev[b] + S[rle_trans_lookup(b, 0, b, 1, nbase)];
+            curr[b + nbase] = fo_logsumexpf(stay_score, move_score);
+        }
+    }
+    float *prev = mem, *curr = mem + nstate;
+    for (size_t blk = nblk; blk > 0; blk--) {
+        const float *F = fwd->f + (blk - 1) * fwd->stride;
+        const float *S = param->f + (blk - 1) * param->stride + nstate;
+        float *P = post->f + (blk - 1) * post->stride + nstate;
+        { float *tmp = curr; curr = prev; prev = tmp; }
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            curr[b1 + nbase] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                const size_t move_idx = rle_trans_lookup(b1, 0, b2, 0, nbase);
+                curr[b1] = fo_logsumexpf(curr[b1], prev[b2] + S[move_idx]);
+                P[move_idx] = F[b1] + prev[b2] + S[move_idx];
+                const size_t stay_idx = rle_trans_lookup(b1, 1, b2, 0, nbase);
+                curr[b1 + nbase] = fo_logsumexpf(curr[b1 + nbase], prev[b2] + S[stay_idx]);
+                P[stay_idx] = F[b1 + nbase] + prev[b2] + S[stay_idx];
+            }
+        }
+        for (size_t b = 0; b < nbase; b++) {
+            const size_t idx = rle_trans_lookup(b, 0, b, 1, nbase);
+            curr[b] = fo_logsumexpf(curr[b], prev[b + nbase] + S[idx]);
+            P[idx] = F[b] + S[idx] + prev[b + nbase];
+        }
+        for (size_t b = 0; b < nbase; b++) {
+            const size_t idx = rle_trans_lookup(b, 1, b, 1, nbase);
+            curr[b + nbase] = fo_logsumexpf(curr[b + nbase], prev[b + nbase] + S[idx]);
+            P[idx] = F[b + nbase] + S[idx] + prev[b + nbase];
+        }
+        for (size_t p = 0; p < nstate; p++) post->f[(blk - 1) * post->stride + p] = param->f[(blk - 1) * param->stride + p];
+    }
+    free(mem);
+    fo_free_mat(fwd);
+    return post;
+}
+
+/* runnie.c:282-313  one record per called base: (base index, block of the call, dwell); returns the count */
+size_t fo_runlength_records(const int *path, size_t nblock, size_t nbase, int *base, int *block, int *dwell) {
+    size_t n = 0;
+    int d = 1, last_blk = -1;
+    for (size_t blk = 0; blk < nblock; blk++) {
+        if ((size_t)path[blk] >= nbase) { d += 1; continue; }
+        if (last_blk >= 0) { base[n] = path[last_blk]; block[n] = last_blk; dwell[n] = d; n++; }
+        last_blk = (int)blk;
+        d = 1;
+    }
+    if (last_blk >= 0) { base[n] = path[last_blk]; block[n] = last_blk; dwell[n] = d; n++; }
+    return n;
 }

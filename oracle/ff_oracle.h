@@ -41,7 +41,8 @@ typedef struct {
 } fo_imat;
 
 enum { FO_NET_LSTM5 = 0,      /* flipflop5_guppy_transitions  networks.c:539-586 */
-       FO_NET_GRUMOD5 = 1 };  /* flipflop_guppy_transitions   networks.c:450-489 */
+       FO_NET_GRUMOD5 = 1,    /* flipflop_guppy_transitions   networks.c:450-489 */
+       FO_NET_LSTM5_RLE = 2 };/* runlength5_guppy_transitions networks.c:672-725: LSTM5 trunk, globalnorm_runlengthV2 head */
 
 typedef struct {
     int kind;
@@ -95,6 +96,13 @@ fo_mat *fo_transitions(const float *raw, size_t start, size_t end, float tempera
 
 /* decode */
 size_t fo_nbase_from_nparam(size_t nparam);
+/* run-length (runnie) head and decoders: layers.c:1241-1358, decode.c:927-1159, runnie.c:282-313 */
+float fo_softplusf(float x);
+double fo_runlengthV2_partition_function(const fo_mat *C);
+fo_mat *fo_globalnorm_runlengthV2(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature);
+float fo_decode_crf_runlength(const fo_mat *param, int *path);
+fo_mat *fo_transpost_crf_runlength(const fo_mat *param);
+size_t fo_runlength_records(const int *path, size_t nblock, size_t nbase, int *base, int *block, int *dwell);
 fo_mat *fo_transpost(const fo_mat *trans, int return_log);
 float fo_decode_viterbi(const fo_mat *trans, int combine_stays, int *path, float *qpath);
 size_t fo_change_positions(const int *path, size_t npos, int *chpos);

@@ -86,6 +86,18 @@ def lib():
     L.fo_partition_function.argtypes = [P(FoMat)]
     L.fo_globalnorm_flipflop.restype = P(FoMat)
     L.fo_globalnorm_flipflop.argtypes = [P(FoMat), P(FoMat), P(FoMat), C.c_float]
+    L.fo_softplusf.restype = C.c_float
+    L.fo_softplusf.argtypes = [C.c_float]
+    L.fo_runlengthV2_partition_function.restype = C.c_double
+    L.fo_runlengthV2_partition_function.argtypes = [P(FoMat)]
+    L.fo_globalnorm_runlengthV2.restype = P(FoMat)
+    L.fo_globalnorm_runlengthV2.argtypes = [P(FoMat), P(FoMat), P(FoMat), C.c_float]
+    L.fo_decode_crf_runlength.restype = C.c_float
+    L.fo_decode_crf_runlength.argtypes = [P(FoMat), P(C.c_int)]
+    L.fo_transpost_crf_runlength.restype = P(FoMat)
+    L.fo_transpost_crf_runlength.argtypes = [P(FoMat)]
+    L.fo_runlength_records.restype = C.c_size_t
+    L.fo_runlength_records.argtypes = [P(C.c_int), C.c_size_t, C.c_size_t, P(C.c_int), P(C.c_int), P(C.c_int)]
     L.fo_transitions.restype = P(FoMat)
     L.fo_transitions.argtypes = [P(C.c_float), C.c_size_t, C.c_size_t, C.c_float, P(FoModel)]
     L.fo_transpost.restype = P(FoMat)
@@ -204,6 +216,28 @@ class OracleModel:
         sig = np.ascontiguousarray(signal, dtype=np.float32)
         p = lib().fo_transitions(_fptr(sig), 0, sig.size, temperature, C.byref(self.c))
         return take(p)          # [nblock, P]
+
+    def runlength_call(self, signal: np.ndarray, temperature: float = 1.0, viterbi_only: bool = False):
+        """runnie's calculate_post (runnie.c:241-316) for a prepared signal: parameters, posterior, path, score and the
+        (base, shape, scale, dwell) records."""
+        param = self.transitions(signal, temperature)                     # [nblock, P]
+        nblock, P = param.shape
+        nbase = self.model.nbase
+        pm = HostMat.from_dense(param)
+        scores = pm
+        post = None
+        if not viterbi_only:
+            post = take(lib().fo_transpost_crf_runlength(pm.ptr))
+            scores = HostMat.from_dense(post)
+        path = np.zeros(nblock, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        score = lib().fo_decode_crf_runlength(scores.ptr, path.ctypes.data_as(ip))
+        base, block, dwell = (np.zeros(nblock, dtype=np.int32) for _ in range(3))
+        n = lib().fo_runlength_records(path.ctypes.data_as(ip), nblock, nbase, base.ctypes.data_as(ip), block.ctypes.data_as(ip),
+                                       dwell.ctypes.data_as(ip))
+        src = post if post is not None else param
+        records = [("ACGTZ"[base[k]], float(src[block[k], base[k]]), float(src[block[k], nbase + base[k]]), int(dwell[k])) for k in range(n)]
+        return dict(param=param, post=post, path=path, score=score, records=records)
 
     def basecall(self, signal: np.ndarray, temperature: float = 1.0, viterbi_only: bool = False,
                  want_trans: bool = True):

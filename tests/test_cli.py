@@ -283,3 +283,48 @@ def test_cli_formats_limit_reverse_viterbi(cli_inputs, tmp_path):
     r = subprocess.run([FLAPPIE, str(bad), files[0]], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "No basecall returned" in r.stderr
     assert len(_parse_fastq(r.stdout)) == 1
+
+
+RUNNIE = os.path.join(ROOT, "flappie_amd", "runnie")
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_runnie_records_match_oracle(tmp_path):
+    """runnie (runnie.c:241-316) on generated fast5 files: `# uuid` then one `base<TAB>shape<TAB>scale<TAB>dwell` line per
+    emitted base, against the oracle's run-length pipeline on the same prepared signal."""
+    from oracle import ffo
+    mdl = M.synthetic_model(M.NET_LSTM5_RLE, 48, seed=9, ident="r941native")
+    M.write_mdl(str(tmp_path / "runlength5_r941native.h"), mdl)
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    rng = np.random.default_rng(31)
+    raws = {}
+    for i, n in enumerate((3000, 2400, 3000)):
+        raw = synth_raw(rng, n)
+        write_fast5(reads / ("r%d.fast5" % i), "rle-%02d" % i, raw)
+        raws["r%d.fast5" % i] = ("rle-%02d" % i, raw)
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(tmp_path))
+    files = [str(reads / fn) for fn in sorted(raws)]
+    for extra, viterbi in (([], False), (["--viterbi"], True)):
+        r = subprocess.run([RUNNIE] + extra + files, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        blocks = r.stdout.strip().split("# ")[1:]
+        assert len(blocks) == len(files)
+        om = ffo.OracleModel(mdl)
+        for blk, fn in zip(blocks, sorted(raws)):
+            lines = blk.strip().split("\n")
+            uuid, raw = raws[fn]
+            assert lines[0] == uuid
+            x = (raw.astype(np.float32) + np.float32(10.0)) * (np.float32(1400.0) / np.float32(8192.0))
+            s, e = C.c_size_t(0), C.c_size_t(x.size)
+            assert ffo.lib().fo_trim_and_segment_raw(_f(x), x.size, C.byref(s), C.byref(e), 200, 10, 100, 0.0) == 0
+            y = x[s.value:e.value].copy()
+            ffo.lib().fo_medmad_normalise_array(_f(y), y.size)
+            ref = om.runlength_call(y, viterbi_only=viterbi)
+            got = [ln.split("\t") for ln in lines[1:]]
+            assert [g[0] for g in got] == [rec[0] for rec in ref["records"]]
+            assert [int(g[3]) for g in got] == [rec[3] for rec in ref["records"]]
+            assert sum(int(g[3]) for g in got) <= ref["param"].shape[0]
+            for g, rec in zip(got, ref["records"]):
+                assert abs(float(g[1]) - rec[1]) <= 2e-4 and abs(float(g[2]) - rec[2]) <= 2e-4
