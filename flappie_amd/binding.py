@@ -89,6 +89,9 @@ def lib():
     L.ffhip_batch_set_reads.argtypes = [vp, C.POINTER(CRawTable)]
     L.ffhip_batch_set_signals.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     L.ffhip_batch_run.argtypes = [vp, C.c_float, C.c_uint]
+    L.ffhip_batch_read_nblock.restype = C.c_size_t
+    L.ffhip_batch_read_nblock.argtypes = [vp, C.c_int]
+    L.ffhip_batch_set_signals_ragged.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
     L.ffhip_prep_create.restype = vp
     L.ffhip_prep_create.argtypes = [vp, C.POINTER(CRawTable), C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_float]
     L.ffhip_prep_destroy.argtypes = [vp]
@@ -249,6 +252,20 @@ class Batch:
         assert s.shape == (self.nread, self.nsample), s.shape
         _check(lib().ffhip_batch_set_signals(self.h, _fptr(s), s.shape[1]))
 
+    def set_signals_ragged(self, signals: List[np.ndarray]):
+        """reads of different lengths (each <= the batch's nsample); results are then per-read sized"""
+        assert len(signals) == self.nread
+        ld = max(int(x.size) for x in signals)
+        buf = np.zeros((self.nread, ld), dtype=np.float32)
+        lens = (C.c_size_t * self.nread)()
+        for i, x in enumerate(signals):
+            buf[i, :x.size] = x
+            lens[i] = x.size
+        _check(lib().ffhip_batch_set_signals_ragged(self.h, _fptr(buf), ld, lens))
+
+    def read_nblock(self, read: int) -> int:
+        return int(lib().ffhip_batch_read_nblock(self.h, read))
+
     def set_reads(self, raws: List[np.ndarray], starts: List[int]):
         """raw_table path: raws[i][starts[i]:starts[i]+nsample] is read i."""
         arr = (CRawTable * self.nread)()
@@ -288,23 +305,23 @@ class Batch:
         return float(lib().ffhip_batch_score(self.h, read))
 
     def path(self, read: int):
-        path = np.zeros(self.nblock + 1, dtype=np.int32)
-        qpath = np.zeros(self.nblock + 1, dtype=np.float32)
+        path = np.zeros(self.read_nblock(read) + 1, dtype=np.int32)
+        qpath = np.zeros(self.read_nblock(read) + 1, dtype=np.float32)
         _check(lib().ffhip_batch_get_path(self.h, read, path.ctypes.data_as(C.POINTER(C.c_int)), _fptr(qpath)))
         return path, qpath
 
     def transitions(self, read: int) -> np.ndarray:
-        out = np.zeros((self.nblock, self.P), dtype=np.float32)
+        out = np.zeros((self.read_nblock(read), self.P), dtype=np.float32)
         _check(lib().ffhip_batch_get_transitions(self.h, read, _fptr(out)))
         return out
 
     def posterior(self, read: int) -> np.ndarray:
-        out = np.zeros((self.nblock, self.P), dtype=np.float32)
+        out = np.zeros((self.read_nblock(read), self.P), dtype=np.float32)
         _check(lib().ffhip_batch_get_posterior(self.h, read, _fptr(out)))
         return out
 
     def trace(self, read: int) -> np.ndarray:
-        out = np.zeros((self.nblock + 1, self.nstate), dtype=np.int32)
+        out = np.zeros((self.read_nblock(read) + 1, self.nstate), dtype=np.int32)
         _check(lib().ffhip_batch_get_trace(self.h, read, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 

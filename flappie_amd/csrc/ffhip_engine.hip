@@ -8,6 +8,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <map>
 #include <string>
 
 #include "../../include/ffhip.h"
@@ -259,8 +260,13 @@ struct ffhip_batch {
     const ffhip_model *mdl = nullptr;
     hipStream_t stream = nullptr;
     int nread = 0, B16 = 0, Bp = 0;
-    int T = 0, Tb = 0;
+    int T = 0, Tb = 0;                  // capacity: samples / blocks of the longest read the batch can take
     ConvPlan plan[3];
+    // ragged batch (reads of different lengths, all <= T): per-read window tables, block counts and tile maxima
+    bool ragged = false;
+    std::vector<int> hT, hTb;           // samples / blocks of each read
+    int *d_tbs = nullptr, *d_tbt = nullptr;
+    int *rag_x0a[3] = { nullptr, nullptr, nullptr }, *rag_x0b[3] = { nullptr, nullptr, nullptr };
     SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
     float *act[2] = { nullptr, nullptr };
     float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -373,6 +379,8 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
         Tin = Tout;
     }
     b->Tb = Tin;
+    b->hT.assign(nread, b->T);
+    b->hTb.assign(nread, b->Tb);
     const size_t Tb = b->Tb, Bp = b->Bp, Hp = m->Hp, Ps = m->Ps, ns = m->nstate;
     for (int i = 0; i < 2; i++) if (!(b->act[i] = (float *)dalloc(b, Tb * Bp * Hp * 4, false))) BFAIL();
     if (!(b->xa = (float *)dalloc(b, Tb * Bp * Hp * 4 * 4, false))) BFAIL();
@@ -415,10 +423,75 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
 }
 
 extern "C" size_t ffhip_batch_nblock(const ffhip_batch *b) { return b ? (size_t)b->Tb : 0; }
+extern "C" size_t ffhip_batch_read_nblock(const ffhip_batch *b, int read) {
+    return (b && read >= 0 && read < b->nread) ? (size_t)b->hTb[read] : 0;
+}
+
+// Records the reads' lengths.  All equal to the capacity: the uniform fast path (shared window tables, no
+// masks).  Otherwise the batch becomes ragged: every read gets its own column -> window-start rows (its right
+// edge is where the reference's quirk lives), its block count, and every read tile its maximum.
+static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
+    const ffhip_model *m = b->mdl;
+    bool uniform = true;
+    for (int r = 0; r < b->nread; r++) {
+        if (lens[r] <= 0 || lens[r] > b->T) return set_err(FFHIP_EINVAL, "read %d: %d samples, the batch takes 1..%d", r, lens[r], b->T);
+        uniform = uniform && lens[r] == b->T;
+    }
+    b->hT = lens;
+    if (uniform) { b->ragged = false; b->hTb.assign(b->nread, b->Tb); return FFHIP_OK; }
+    std::vector<int> cur(lens);
+    for (int l = 0; l < m->nconv; l++) {
+        const int Tmax = b->plan[l].Tout;
+        const size_t n = (size_t)b->Bp * Tmax;
+        if (!b->rag_x0a[l]) {
+            b->rag_x0a[l] = (int *)dalloc(b, n * 4, false);
+            b->rag_x0b[l] = (int *)dalloc(b, n * 4, false);
+            if (!b->rag_x0a[l] || !b->rag_x0b[l]) return FFHIP_ENOMEM;
+        }
+        std::vector<int> ta(n, kZeroCol), tq(n, kZeroCol);
+        std::map<int, std::pair<std::vector<int>, std::vector<int>>> cache;
+        for (int r = 0; r < b->nread; r++) {
+            auto it = cache.find(cur[r]);
+            if (it == cache.end()) {
+                std::vector<int> a, bq;
+                if (build_conv_plan(cur[r], m->conv[l].winlen, m->conv[l].stride, a, bq) < 0)
+                    return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", r, cur[r], l, m->conv[l].winlen);
+                it = cache.emplace(cur[r], std::make_pair(std::move(a), std::move(bq))).first;
+            }
+            const std::vector<int> &a = it->second.first, &bq = it->second.second;
+            memcpy(ta.data() + (size_t)r * Tmax, a.data(), a.size() * 4);
+            memcpy(tq.data() + (size_t)r * Tmax, bq.data(), bq.size() * 4);
+            cur[r] = (int)a.size();
+        }
+        HIP_TRY(hipMemcpyAsync(b->rag_x0a[l], ta.data(), n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->rag_x0b[l], tq.data(), n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);        // ta/tq go out of scope
+    }
+    b->hTb = cur;
+    if (!b->d_tbs) {
+        b->d_tbs = (int *)dalloc(b, (size_t)b->Bp * 4, true);
+        b->d_tbt = (int *)dalloc(b, (size_t)b->B16 * 4, true);
+        if (!b->d_tbs || !b->d_tbt) return FFHIP_ENOMEM;
+    }
+    std::vector<int> tbs(b->Bp, 0), tbt(b->B16, 0);
+    for (int r = 0; r < b->nread; r++) { tbs[r] = cur[r]; tbt[r / 16] = std::max(tbt[r / 16], cur[r]); }
+    HIP_TRY(hipMemcpy(b->d_tbs, tbs.data(), tbs.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+    HIP_TRY(hipMemcpy(b->d_tbt, tbt.data(), tbt.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+    b->ragged = true;
+    return FFHIP_OK;
+}
+
+// the signal rows must be zero beyond each read's end (they are the convolution's right padding)
+static int clear_signals(ffhip_batch *b) {
+    SampleBuf &sb = b->sbuf[0];
+    HIP_TRY(hipMemsetAsync(sb.p, 0, (size_t)b->Bp * sb.rs * 4, b->stream), FFHIP_EHIP);
+    return FFHIP_OK;
+}
 
 extern "C" int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, size_t ld) {
     if (!b || !signals || ld < (size_t)b->T) return set_err(FFHIP_EINVAL, "bad signal arguments");
     hipSetDevice(b->eng->device);
+    if (int rc = apply_lengths(b, std::vector<int>(b->nread, b->T))) return rc;
     SampleBuf &sb = b->sbuf[0];
     HIP_TRY(hipMemcpy2DAsync((void *)(sb.p + kSamplePad), sb.rs * 4, signals, ld * 4, (size_t)b->T * 4, b->nread,
                              hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
@@ -427,17 +500,42 @@ extern "C" int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, siz
     return FFHIP_OK;
 }
 
+// rows of `ld` floats, read r uses its first nsample[r] <= capacity samples
+extern "C" int ffhip_batch_set_signals_ragged(ffhip_batch *b, const float *signals, size_t ld, const size_t *nsample) {
+    if (!b || !signals || !nsample) return set_err(FFHIP_EINVAL, "bad signal arguments");
+    hipSetDevice(b->eng->device);
+    std::vector<int> lens(b->nread);
+    for (int r = 0; r < b->nread; r++) {
+        if (nsample[r] > ld || nsample[r] > (size_t)b->T) return set_err(FFHIP_EINVAL, "read %d: %zu samples exceed the row / the batch's %d", r, nsample[r], b->T);
+        lens[r] = (int)nsample[r];
+    }
+    if (int rc = apply_lengths(b, lens)) return rc;
+    if (int rc = clear_signals(b)) return rc;
+    SampleBuf &sb = b->sbuf[0];
+    for (int r = 0; r < b->nread; r++)
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), signals + (size_t)r * ld, (size_t)lens[r] * 4,
+                               hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
     if (!b || !reads) return set_err(FFHIP_EINVAL, "bad read arguments");
     hipSetDevice(b->eng->device);
-    SampleBuf &sb = b->sbuf[0];
+    std::vector<int> lens(b->nread);
     for (int r = 0; r < b->nread; r++) {
         const raw_table &rt = reads[r];
-        if (!rt.raw || rt.end <= rt.start || rt.end - rt.start != (size_t)b->T)
-            return set_err(FFHIP_EINVAL, "read %d: end-start must equal the batch's %d samples", r, b->T);
-        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), rt.raw + rt.start, (size_t)b->T * 4,
-                               hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        if (!rt.raw || rt.end <= rt.start || rt.end - rt.start > (size_t)b->T)
+            return set_err(FFHIP_EINVAL, "read %d: end-start must be within the batch's %d samples", r, b->T);
+        lens[r] = (int)(rt.end - rt.start);
     }
+    if (int rc = apply_lengths(b, lens)) return rc;
+    if (b->ragged) if (int rc = clear_signals(b)) return rc;
+    SampleBuf &sb = b->sbuf[0];
+    for (int r = 0; r < b->nread; r++)
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), reads[r].raw + reads[r].start, (size_t)lens[r] * 4,
+                               hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     b->ran = b->finished = 0;
     return FFHIP_OK;
@@ -447,13 +545,19 @@ extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
 extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads) {
     if (!b || !prep || !reads) return set_err(FFHIP_EINVAL, "bad prepared-read arguments");
     hipSetDevice(b->eng->device);
-    SampleBuf &sb = b->sbuf[0];
+    std::vector<int> lens(b->nread);
+    std::vector<const float *> src(b->nread);
     for (int r = 0; r < b->nread; r++) {
         size_t len = 0;
-        const float *src = prep_device_signal(prep, reads[r], &len);
-        if (!src || len != (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: kept length must equal the batch's %d samples", reads[r], b->T);
-        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src, (size_t)b->T * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
+        src[r] = prep_device_signal(prep, reads[r], &len);
+        if (!src[r] || len > (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: rejected by trimming, or longer than the batch's %d samples", reads[r], b->T);
+        lens[r] = (int)len;
     }
+    if (int rc = apply_lengths(b, lens)) return rc;
+    if (b->ragged) if (int rc = clear_signals(b)) return rc;
+    SampleBuf &sb = b->sbuf[0];
+    for (int r = 0; r < b->nread; r++)
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src[r], (size_t)lens[r] * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     b->ran = b->finished = 0;
     return FFHIP_OK;
@@ -471,6 +575,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const int Tb = b->Tb, B16 = b->B16, Bp = b->Bp, Hp = m->Hp;
     const bool keep = (flags & FFHIP_RUN_KEEP_ACTS) != 0;
     memset(b->launches, 0, sizeof(b->launches));
+    const int *tbs = b->ragged ? b->d_tbs : nullptr, *tbt = b->ragged ? b->d_tbt : nullptr;      // ragged batch: per-read / per-tile block counts
     auto keep_copy = [&](int slot, const float *src) -> int {
         if (!keep) return FFHIP_OK;
         if (!b->keep[slot] && !(b->keep[slot] = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4, false))) return FFHIP_ENOMEM;
@@ -483,11 +588,11 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     for (int l = 0; l < m->nconv; l++) {
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
-            launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->plan[l].x0a, b->plan[l].x0b, Bp,
-                              b->plan[l].Tout, c.winlen, m->act);
+            launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
+                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0);
         } else {
-            launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->plan[l].x0a, b->plan[l].x0b, B16, Tb, c.Mpad,
-                             c.K16, m->act);
+            launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
+                             b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0);
         }
         b->launches[0]++;
     }
@@ -526,8 +631,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = !b->persist_concurrent_ok;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 const bool okl = fuse
-                    ? launch_lstm_fused(s, m->cell, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode)
-                    : launch_rnn_persist(s, m->cell, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode);
+                    ? launch_lstm_fused(s, m->cell, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode, tbs, tbt)
+                    : launch_rnn_persist(s, m->cell, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode, tbs, tbt);
                 if (!okl) return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -538,9 +643,9 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             const int tp = backward ? t + 1 : t - 1;
             const float *hp = (i == 0) ? nullptr : out + (size_t)tp * h_step;
             if (m->cell == 0)
-                launch_lstm_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, b->cstate, B16, Hp, i == 0);
+                launch_lstm_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, b->cstate, B16, Hp, i == 0, t, tbs);
             else
-                launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0);
+                launch_gru_step(s, r.sWp, b->xa + (size_t)t * xa_step, hp, out + (size_t)t * h_step, B16, Hp, i == 0, t, tbs);
         }
         if (!use_persist) b->launches[2] += Tb;
         if (prof) hipEventRecord(b->lev[l][2], s);
@@ -554,7 +659,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     if (rle) {
         // ---- globalnorm_runlengthV2 (layers.c:1325-1358)
         launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, 1.0f, 1);
-        launch_rle_head_finish(s, b->trans, b->crf_logz, b->nread, Tb, m->nbase, m->Ps, temperature);
+        launch_rle_head_finish(s, b->trans, b->crf_logz, b->nread, Tb, m->nbase, m->Ps, temperature, tbs);
         b->launches[3] += 4;
     } else {
         // ---- globalnorm_flipflop (layers.c:1082-1106)
@@ -562,8 +667,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
         const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
-        if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz);
-        else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz);
+        if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz, 1, tbs);
+        else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz, 1, tbs);
         b->launches[3] += 3;
     }
     mark(b, 4);
@@ -571,8 +676,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
         const float *scores = b->trans;
         if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
-            if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);       // decode.c:1037-1159
-            else launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps);
+            if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);       // decode.c:1037-1159
+            else launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);
             scores = b->post;
             b->launches[4]++;
         }
@@ -580,17 +685,17 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         if (rle) {
             // decode_crf_runlength (decode.c:927-1013); the run records are formed from the path by the caller
             // (runnie.c:282-313), there are no base/quality strings or trace for this model
-            launch_rle_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
+            launch_rle_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps, tbs);
             HIP_TRY(hipMemsetAsync(b->lens, 0, (size_t)b->nread * 4, s), FFHIP_EHIP);
             HIP_TRY(hipMemsetAsync(b->bases, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
             HIP_TRY(hipMemsetAsync(b->quals, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
             b->launches[5]++;
         } else {
-            launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps);
-            launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase);
+            launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps, tbs);
+            launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase, tbs);
             b->launches[5] += 2;
             if (!(flags & FFHIP_RUN_NO_TRACE)) {
-                launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1);
+                launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1, tbs);
                 b->launches[5]++;
             }
         }
@@ -650,20 +755,20 @@ static int d2h(ffhip_batch *b, void *dst, const void *src, size_t bytes) {
 
 extern "C" int ffhip_batch_get_path(ffhip_batch *b, int read, int *path, float *qpath) {
     if (!results_ok(b, read)) return FFHIP_EINVAL;
-    const size_t L = (size_t)b->Tb + 1;
-    if (path) if (int rc = d2h(b, path, b->path + (size_t)read * L, L * 4)) return rc;
-    if (qpath) if (int rc = d2h(b, qpath, b->qpath + (size_t)read * L, L * 4)) return rc;
+    const size_t L = (size_t)b->Tb + 1, n = (size_t)b->hTb[read] + 1;      // stride / this read's entries
+    if (path) if (int rc = d2h(b, path, b->path + (size_t)read * L, n * 4)) return rc;
+    if (qpath) if (int rc = d2h(b, qpath, b->qpath + (size_t)read * L, n * 4)) return rc;
     return FFHIP_OK;
 }
 
 static int get_scores(ffhip_batch *b, const float *src, int read, float *out) {
     if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
     const ffhip_model *m = b->mdl;
-    const size_t Tb = b->Tb;
-    if (m->Ps == m->P) return d2h(b, out, src + (size_t)read * Tb * m->Ps, Tb * m->P * 4);
-    std::vector<float> tmp(Tb * m->Ps);
+    const size_t Tb = b->Tb, nb = b->hTb[read];             // stride / this read's blocks
+    if (m->Ps == m->P) return d2h(b, out, src + (size_t)read * Tb * m->Ps, nb * m->P * 4);
+    std::vector<float> tmp(nb * m->Ps);
     if (int rc = d2h(b, tmp.data(), src + (size_t)read * Tb * m->Ps, tmp.size() * 4)) return rc;
-    for (size_t c = 0; c < Tb; c++) memcpy(out + c * m->P, tmp.data() + c * m->Ps, (size_t)m->P * 4);
+    for (size_t c = 0; c < nb; c++) memcpy(out + c * m->P, tmp.data() + c * m->Ps, (size_t)m->P * 4);
     return FFHIP_OK;
 }
 extern "C" int ffhip_batch_get_transitions(ffhip_batch *b, int read, float *out) { return b ? get_scores(b, b->trans, read, out) : FFHIP_EINVAL; }
@@ -675,7 +780,7 @@ extern "C" int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out) {
     if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
     if ((b->last_flags & (FFHIP_RUN_NO_TRACE | FFHIP_RUN_NO_DECODE)) || b->mdl->kind == FFHIP_NET_LSTM5_RLE) return set_err(FFHIP_EINVAL, "trace was not computed in this run");
     const size_t n = ((size_t)b->Tb + 1) * b->mdl->nstate;
-    return d2h(b, out, b->trace + (size_t)read * n, n * 4);
+    return d2h(b, out, b->trace + (size_t)read * n, ((size_t)b->hTb[read] + 1) * b->mdl->nstate * 4);
 }
 
 extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out) {

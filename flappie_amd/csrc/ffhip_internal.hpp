@@ -32,6 +32,7 @@ namespace ffhip {
 constexpr int kSamplePad = 64;     // zero rows either side of a sample-major buffer
 constexpr int kMaxState = 16;      // nstate <= 16 (nbase <= 8)
 constexpr int kNoWindow = INT32_MIN;
+constexpr int kZeroCol = INT32_MIN + 1;   // window-table entry of a column beyond a read's end in a ragged batch
 
 struct SampleBuf {                 // sample-major activation buffer
     float *p;
@@ -48,11 +49,11 @@ void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf ds
 
 // VALU convolution for the thin front layers; W dense taps [Fout][winlen][Fin]
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act);
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0);     // ldp: entries per read of a per-read window table (0 = shared)
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
-                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act);
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0);
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
@@ -60,19 +61,21 @@ void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, 
 
 // one recurrent step for all reads (launch-per-step path)
 void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
-                      float *cstate, int B16, int H, int first);
+                      float *cstate, int B16, int H, int first, int t = 0, const int *tbs = nullptr);
 void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
-                     int B16, int H, int first);
+                     int B16, int H, int first, int t = 0, const int *tbs = nullptr);
 
 // persistent recurrent layer (ffhip_rnn_persist.hip): one launch per layer and chunk of read tiles
 bool persist_supported(int kind, int H, int ncu);
 int persist_max_tiles(int kind, int H, int ncu, int fused);      // read tiles one launch can take (all workgroups co-resident)
 bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
-                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
+                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                        const int *tbs = nullptr, const int *tbt = nullptr);      // ragged batch: blocks per read / max per tile
 size_t persist_flag_words(int H, int nrt);
 bool fused_supported(int kind, int H);
 bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
-                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode);
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                       const int *tbs = nullptr, const int *tbt = nullptr);
 int persist_blocks_per_cu(int kind, int H);
 
 // head: trans = tanh(W^T h + b) / (temperature/5)
@@ -80,7 +83,8 @@ void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw = 0);      // raw = 1: W^T h + b only
 // CRF partition function (fp64) + subtraction of (float)(logZ/Tb)
 // logz: device buffer of nread doubles, receives the fp64 partition function per read; subtract = 0 leaves `trans` untouched
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract = 1);
+// tbs (optional, here and below): device array of the blocks of each read of a ragged batch; Tb is then the stride
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract = 1, const int *tbs = nullptr);
 // the same in linear space (fp64 scaled forward recursion); E = workspace of nread*Tb*crf_exp_stride(P) doubles,
 // R = blocks between power-of-two rescalings (see crf_rescale_interval)
 inline int crf_exp_stride(int P) { return (P + 1 + 7) & ~7; }
@@ -91,23 +95,23 @@ inline int crf_rescale_interval(float bound) {
     return r < 1 ? 0 : (r > 16 ? 16 : r);           // 0: range too wide for the linear form, use launch_crf_norm
 }
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
-                            double *logz, int subtract = 1);
+                            double *logz, int subtract = 1, const int *tbs = nullptr);
 // forward/backward transition posteriors, log-normalised per block; fwd = workspace of 2*nread*(Tb+1)*kMaxState floats
-void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
+void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
 // Viterbi + traceback + qpath
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
-                    int nread, int Tb, int nbase, int Ps);
+                    int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
 // change positions -> base / quality strings
 void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
-                     int nread, int Tb, int nbase);
+                     int nread, int Tb, int nbase, const int *tbs = nullptr);
 // exp + trace_from_posterior
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log);
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs = nullptr);
 void launch_exp_inplace(hipStream_t s, float *x, size_t n);
 // run-length (runnie) head and decoders, ffhip_rle.hip: activation rows + runlengthV2 partition function + subtraction
-void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature);
-void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps);
-void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps);
-void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps);
+void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs = nullptr);
+void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
+void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
+void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
 // tile-interleaved -> dense [Tb][H] of one read (debug tap)
 void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H);
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 template <int MAXF>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
-             const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act) {
+             const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp) {
     extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
     const int Fin = in.F, Fout = out.F, K = winlen * Fin;
     for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
@@ -63,7 +63,13 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
     float acc[MAXF];
 #pragma unroll
     for (int f = 0; f < MAXF; f++) acc[f] = (f < Fout) ? w_lds[Fout * K + f] : 0.0f;
-    const int xs[2] = { x0a[c], x0b[c] };
+    // ldp = 0: one window table shared by all reads; otherwise one row of ldp entries per read (ragged batch)
+    const int xs[2] = { x0a[(size_t)r * ldp + c], x0b[(size_t)r * ldp + c] };
+    if (xs[0] == kZeroCol) {                     // beyond this read's end: the next layer must see zero padding there
+        float *o0 = out.p + (size_t)r * out.rs + (size_t)(kSamplePad + c) * Fout;
+        for (int f = 0; f < Fout; f++) o0[f] = 0.0f;
+        return;
+    }
 #pragma unroll
     for (int wdw = 0; wdw < 2; wdw++) {
         if (xs[wdw] == kNoWindow) continue;
@@ -82,15 +88,15 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act) {
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp) {
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
     if (out.F <= 4)
-        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
     else if (out.F <= 16)
-        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
     else
-        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act);
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -141,7 +147,7 @@ __device__ __forceinline__ void mma_tiles(const v4f *(&ap)[TM], const float *(&b
 template <bool BVEC>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, const float *__restrict__ bias,
-            const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act) {
+            const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act, int ldp) {
     constexpr int TM = 4, TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -170,15 +176,16 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
         for (int j = 0; j < TN; j++) {
             const int nt = min(nt0 + j, ntile - 1);
             const int c = nt / B16, rt = nt % B16;
-            int x0 = pass == 0 ? x0a[c] : x0b[c];
+            const size_t pi = (size_t)(rt * 16 + rl) * ldp + c;       // ldp = 0: shared table; else this lane's read has its own row
+            int x0 = pass == 0 ? x0a[pi] : x0b[pi];
             // a missing window contributes zero: point it at the leading zero pad
-            const bool have = (x0 != kNoWindow);
+            const bool have = (x0 != kNoWindow && x0 != kZeroCol);
             any |= have;
             if (!have) x0 = -kSamplePad;
             bp[j] = in.p + (size_t)(rt * 16 + rl) * in.rs + (size_t)(kSamplePad + x0) * in.F + kq * 4;
         }
-        // `any` is uniform per wave (x0 depends on c only): skip the whole pass when nothing is there
-        if (pass == 1 && !__builtin_amdgcn_readfirstlane(any)) break;
+        // skip the whole second pass when no lane of the wave has a second window
+        if (pass == 1 && !__any(any)) break;
         mma_tiles<TM, TN, BVEC>(ap, bp, 16, K16, acc);
     }
 #pragma unroll
@@ -198,16 +205,16 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
 }
 
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
-                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act) {
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp) {
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
     if (vec)
         hipLaunchKernelGGL(k_conv_mfma<true>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act);
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp);
     else
         hipLaunchKernelGGL(k_conv_mfma<false>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act);
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp);
 }
 
 // ---- input projection: Xa[nt][mt] = Wp[mt] . act[nt] + b ----------------------------------
@@ -269,7 +276,7 @@ void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, 
 // state never leaves its lane's slot.
 __global__ void __launch_bounds__(256)
 k_lstm_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const float *__restrict__ h_prev,
-            float *__restrict__ h_out, float *__restrict__ cstate, int Ut, int K16, int first) {
+            float *__restrict__ h_out, float *__restrict__ cstate, int Ut, int K16, int first, int t, const int *__restrict__ tbs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ut = blockIdx.x * 4 + wave, rt = blockIdx.y;
     if (ut >= Ut) return;
@@ -292,17 +299,18 @@ k_lstm_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const flo
     const float forget = logistic_ref(acc.y) * c;
     const float update = logistic_ref(acc.x) * tanh_ref(acc.z);
     c = forget + update;
-    const float h = logistic_ref(acc.w) * tanh_ref(c);
-    cstate[((size_t)rt * Ut + ut) * 64 + lane] = c;
+    float h = logistic_ref(acc.w) * tanh_ref(c);
     const int q = lane >> 4, rl = lane & 15;
+    if (tbs && t >= tbs[rt * 16 + rl]) { h = 0.0f; c = 0.0f; }        // beyond this read's end (ragged batch)
+    cstate[((size_t)rt * Ut + ut) * 64 + lane] = c;
     h_out[((size_t)rt * Ut + ut) * 64 + rl * 4 + q] = h;
 }
 
 void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
-                      float *cstate, int B16, int H, int first) {
+                      float *cstate, int B16, int H, int first, int t, const int *tbs) {
     const int Ut = H / 4, K16 = H / 16;
     hipLaunchKernelGGL(k_lstm_step, dim3((Ut + 3) / 4, B16), dim3(256), 0, s, (const v4f *)sWp, (const v4f *)xa_t,
-                       h_prev, h_out, cstate, Ut, K16, first);
+                       h_prev, h_out, cstate, Ut, K16, first, t, tbs);
 }
 
 // grumod_step, layers.c:664-715.  Gate rows per unit: z, r, candidate, (unused).  The recurrent
@@ -310,7 +318,7 @@ void launch_lstm_step(hipStream_t s, const float4 *sWp, const float *xa_t, const
 // the reference zeroes that chunk before the GEMV (:691) and adds x afterwards (:705).
 __global__ void __launch_bounds__(256)
 k_gru_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const float *__restrict__ h_prev,
-           float *__restrict__ h_out, int Ut, int K16, int first) {
+           float *__restrict__ h_out, int Ut, int K16, int first, int t, const int *__restrict__ tbs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ut = blockIdx.x * 4 + wave, rt = blockIdx.y;
     if (ut >= Ut) return;
@@ -335,15 +343,16 @@ k_gru_step(const v4f *__restrict__ sWp, const v4f *__restrict__ xa_t, const floa
     const float r = logistic_ref(acc.y);
     float hbar = r * acc.z + x.z;
     hbar = tanh_ref(hbar);
-    const float h = z * hp + (1.0f - z) * hbar;
+    float h = z * hp + (1.0f - z) * hbar;
+    if (tbs && t >= tbs[rt * 16 + rl]) h = 0.0f;                        // beyond this read's end (ragged batch)
     h_out[((size_t)rt * Ut + ut) * 64 + rl * 4 + q] = h;
 }
 
 void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const float *h_prev, float *h_out,
-                     int B16, int H, int first) {
+                     int B16, int H, int first, int t, const int *tbs) {
     const int Ut = H / 4, K16 = H / 16;
     hipLaunchKernelGGL(k_gru_step, dim3((Ut + 3) / 4, B16), dim3(256), 0, s, (const v4f *)sWp, (const v4f *)xa_t,
-                       h_prev, h_out, Ut, K16, first);
+                       h_prev, h_out, Ut, K16, first, t, tbs);
 }
 
 // ---- CRF head: trans[r][blk][p] = tanh(W^T h + b) / (temperature/5) --------------------------
@@ -409,12 +418,13 @@ void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp,
 // i.e. the same quantity as the reference's pairwise chain up to fp64 rounding (the result is
 // rounded to fp32 after the division by the block count, layers.c:1089).
 __global__ void __launch_bounds__(64)
-k_crf_norm(const float *__restrict__ trans, int Tb, int nbase, int P, int Ps, double *__restrict__ logz_out) {
+k_crf_norm(const float *__restrict__ trans, int TbS, int nbase, int P, int Ps, double *__restrict__ logz_out, const int *__restrict__ tbs) {
     __shared__ double term[64];
     __shared__ double smax[kMaxState];
     const int lane = threadIdx.x;
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *S = trans + (size_t)blockIdx.x * Tb * Ps;
+    const float *S = trans + (size_t)blockIdx.x * TbS * Ps;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     // destination state of transition entry `lane`, and its source state
     const int src = lane % ns;
     int dst;
@@ -466,23 +476,26 @@ k_crf_norm(const float *__restrict__ trans, int Tb, int nbase, int P, int Ps, do
 
 // S[r][blk][p] -= (float)(logZ[r] / Tb) for p < P (layers.c:1089-1096), all reads and blocks in parallel
 __global__ void __launch_bounds__(256)
-k_crf_sub(float *__restrict__ trans, const double *__restrict__ logz, int Tb, int P, int Ps, size_t n /*nread*Tb*Ps*/) {
+k_crf_sub(float *__restrict__ trans, const double *__restrict__ logz, int TbS, int P, int Ps, size_t n /*nread*TbS*Ps*/,
+          const int *__restrict__ tbs) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if ((int)(i % Ps) >= P) return;
-    const size_t r = i / ((size_t)Tb * Ps);
+    const size_t r = i / ((size_t)TbS * Ps);
+    const int Tb = tbs ? tbs[r] : TbS;
+    if ((int)((i / Ps) % TbS) >= Tb) return;
     trans[i] -= (float)(logz[r] / (double)Tb);
 }
 
-static void launch_crf_sub(hipStream_t s, float *trans, const double *logz, int nread, int Tb, int P, int Ps) {
+static void launch_crf_sub(hipStream_t s, float *trans, const double *logz, int nread, int Tb, int P, int Ps, const int *tbs) {
     const size_t n = (size_t)nread * Tb * Ps;
-    hipLaunchKernelGGL(k_crf_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, logz, Tb, P, Ps, n);
+    hipLaunchKernelGGL(k_crf_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, logz, Tb, P, Ps, n, tbs);
 }
 
-void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract) {
+void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, int Ps, double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps, logz);
-    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps);
+    hipLaunchKernelGGL(k_crf_norm, dim3(nread), dim3(64), 0, s, trans, Tb, nbase, P, Ps, logz, tbs);
+    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps, tbs);
 }
 
 // ---- CRF partition function, linear-space form (the pipeline's default) -----------------------------
@@ -496,12 +509,14 @@ void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, 
 // fp64 rounding only (<= 1e-12 relative, checked against the oracle), and is rounded to fp32 after the
 // division by the block count exactly as layers.c:1089 does.
 __global__ void __launch_bounds__(256)
-k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t n /*nread*Tb*Pd*/, int P, int Ps, int Pd) {
+k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t n /*nread*TbS*Pd*/, int P, int Ps, int Pd, int TbS,
+          const int *__restrict__ tbs) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t blk = i / Pd;
     const int p = (int)(i % Pd);
     if (p > P) return;
+    if (tbs && (int)(blk % TbS) >= tbs[blk / TbS]) return;
     const float *S = trans + blk * Ps;
     float m = S[0];
     for (int q = 1; q < P; q++) m = fmaxf(m, S[q]);
@@ -514,14 +529,15 @@ k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t n /*nr
 constexpr int kCrfChunk = 32;
 template <int NS>
 __global__ void __launch_bounds__(64)
-k_crf_chain(const double *__restrict__ E, int Tb, int P, int Pd, int R, double *__restrict__ logz_out) {
+k_crf_chain(const double *__restrict__ E, int TbS, int P, int Pd, int R, double *__restrict__ logz_out, const int *__restrict__ tbs) {
     constexpr int nbase = NS / 2, off = nbase * NS;
     constexpr int kMaxPd = 72;                                  // crf_exp_stride(64)
     __shared__ double ebuf[2][kCrfChunk * kMaxPd];
     __shared__ double al[2][NS];
     const int lane = threadIdx.x;
     const bool active = lane < NS, flip = lane < nbase;
-    const double *Er = E + (size_t)blockIdx.x * Tb * Pd;
+    const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const int per_chunk = kCrfChunk * Pd;                       // doubles per chunk (<= 2304)
     constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 36 doubles per lane at most
     double stage[kStage];
@@ -593,17 +609,17 @@ k_crf_chain(const double *__restrict__ E, int Tb, int P, int Pd, int R, double *
 }
 
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
-                            double *logz, int subtract) {
+                            double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
     const size_t n = (size_t)nread * Tb * Pd;
-    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, E, n, P, Ps, Pd);
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, E, n, P, Ps, Pd, Tb, tbs);
     const int Rr = R < 1 ? 1 : R;
     switch (2 * nbase) {
-#define CHAIN_CASE(NS) case NS: hipLaunchKernelGGL(k_crf_chain<NS>, dim3(nread), dim3(64), 0, s, E, Tb, P, Pd, Rr, logz); break;
+#define CHAIN_CASE(NS) case NS: hipLaunchKernelGGL(k_crf_chain<NS>, dim3(nread), dim3(64), 0, s, E, Tb, P, Pd, Rr, logz, tbs); break;
     CHAIN_CASE(2) CHAIN_CASE(4) CHAIN_CASE(6) CHAIN_CASE(8) CHAIN_CASE(10) CHAIN_CASE(12) CHAIN_CASE(14) CHAIN_CASE(16)
 #undef CHAIN_CASE
     }
-    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps);
+    if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps, tbs);
 }
 
 // ---- forward/backward transition posteriors ---------------------------------------------------
@@ -611,12 +627,13 @@ void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, i
 // 0..P-1 carry the block's transition scores.  The logsumexpf chains keep the reference's order.
 __global__ void __launch_bounds__(64)
 k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf,
-            int Tb, int nbase, int P, int Ps) {
+            int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
     const int lane = threadIdx.x;
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
-    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
-    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
+    float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool is_state = lane < ns, is_flip = lane < nbase;
 
     // forwards (:396-423)
@@ -692,13 +709,15 @@ __device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 +
 // time (they are independent), then all 256 threads assemble and log-normalise one block each.  Same
 // arithmetic per value as a single-wave walk; the dependent chain is halved.
 __global__ void __launch_bounds__(256)
-k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int Tb) {
+k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int TbS,
+             const int *__restrict__ tbs) {
     constexpr int P = 40, Ps = 40, ns = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
-    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
-    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
-    float *Bw = bwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
+    float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool valid = lane < P, flip = lane < 32;
     const int st = lane & 7;
     const float NEG = -INFINITY;
@@ -782,14 +801,15 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
 // State lanes (lane < nstate) own one state each; entry lanes (lane < P) own one transition score.
 __global__ void __launch_bounds__(64)
 k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf,
-                int Tb, int nbase, int P, int Ps) {
+                int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
     __shared__ float term[64];
     __shared__ float svec[kMaxState];
     const int lane = threadIdx.x;
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *T = trans + (size_t)blockIdx.x * Tb * Ps;
-    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
-    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
+    float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool valid = lane < P, is_state = lane < ns, is_flip = lane < nbase;
     const int src = lane % ns;                  // source state of entry `lane` (off is a multiple of ns)
     int dst;                                    // destination state of entry `lane`
@@ -859,14 +879,14 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
     }
 }
 
-void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
+void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
-        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb);
+        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs);
     else if (!getenv("FFHIP_EXACT_ORDER"))
-        hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
+        hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps, tbs);
     else
-        hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps);
+        hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps, tbs);
 }
 
 // ---- Viterbi ---------------------------------------------------------------------------------
@@ -877,15 +897,16 @@ void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd
 constexpr int kTbChunk = 2048;
 __global__ void __launch_bounds__(64)
 k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path,
-          float *__restrict__ qpath, float *__restrict__ score_out, int Tb, int nbase, int P, int Ps) {
+          float *__restrict__ qpath, float *__restrict__ score_out, int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
     __shared__ uint8_t tb_lds[kTbChunk * kMaxState];
     __shared__ int path_lds[kTbChunk + 1];
     const int lane = threadIdx.x;
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *T = M + (size_t)blockIdx.x * Tb * Ps;
-    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
-    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
-    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    const float *T = M + (size_t)blockIdx.x * TbS * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * TbS * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool is_state = lane < ns, is_flip = lane < nbase;
 
     float prev = 0.0f;
@@ -949,15 +970,16 @@ k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restr
 // strictly greater).
 __global__ void __launch_bounds__(64)
 k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path,
-           float *__restrict__ qpath, float *__restrict__ score_out, int Tb) {
+           float *__restrict__ qpath, float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
     constexpr int P = 40, Ps = 40, ns = 8, nbase = 4, off = 32;
     __shared__ uint8_t tb_lds[kTbChunk * kMaxState];
     __shared__ int path_lds[kTbChunk + 1];
     const int lane = threadIdx.x;
-    const float *T = M + (size_t)blockIdx.x * Tb * Ps;
-    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
-    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
-    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    const float *T = M + (size_t)blockIdx.x * TbS * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * TbS * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool valid = lane < P, flip = lane < 32;
     const int st = lane & 7;
     const float NEG = -INFINITY;
@@ -1019,12 +1041,12 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
 }
 
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
-                    int nread, int Tb, int nbase, int Ps) {
+                    int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40)
-        hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb);
+        hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
     else
-        hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps);
+        hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps, tbs);
 }
 
 // ---- change positions -> base and quality strings ---------------------------------------------
@@ -1032,12 +1054,13 @@ void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *pat
 // path[nblock] and the base of path[0] are never emitted, as in the reference.
 __global__ void __launch_bounds__(64)
 k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *__restrict__ bases,
-           char *__restrict__ quals, int *__restrict__ lens, int Tb, int nbase) {
+           char *__restrict__ quals, int *__restrict__ lens, int TbS, int nbase, const int *__restrict__ tbs) {
     const int lane = threadIdx.x;
-    const int *pth = path + (size_t)blockIdx.x * (Tb + 1);
-    const float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
-    char *bs = bases + (size_t)blockIdx.x * (Tb + 1);
-    char *qs = quals + (size_t)blockIdx.x * (Tb + 1);
+    const int *pth = path + (size_t)blockIdx.x * (TbS + 1);
+    const float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    char *bs = bases + (size_t)blockIdx.x * (TbS + 1);
+    char *qs = quals + (size_t)blockIdx.x * (TbS + 1);
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     int count = 0;
     for (int p0 = 1; p0 < Tb; p0 += 64) {
         const int pos = p0 + lane;
@@ -1061,8 +1084,8 @@ k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *
 }
 
 void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
-                     int nread, int Tb, int nbase) {
-    hipLaunchKernelGGL(k_assemble, dim3(nread), dim3(64), 0, s, path, qpath, bases, quals, lens, Tb, nbase);
+                     int nread, int Tb, int nbase, const int *tbs) {
+    hipLaunchKernelGGL(k_assemble, dim3(nread), dim3(64), 0, s, path, qpath, bases, quals, lens, Tb, nbase, tbs);
 }
 
 // ---- trace --------------------------------------------------------------------------------------
@@ -1070,10 +1093,11 @@ void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *b
 // (decode.c:499-543): column 0 sums block 0 by from-state, column blk+1 sums block blk by to-state.
 // The posterior buffer is left in log space (the reference's in-place exp is folded in here).
 __global__ void __launch_bounds__(256)
-k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int Tb, int nbase, int P, int Ps, int is_log) {
+k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int TbS, int nbase, int P, int Ps, int is_log, const int *__restrict__ tbs) {
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *Pp = post + (size_t)blockIdx.y * Tb * Ps;
-    int32_t *tr = trace + (size_t)blockIdx.y * (Tb + 1) * ns;
+    const float *Pp = post + (size_t)blockIdx.y * TbS * Ps;
+    int32_t *tr = trace + (size_t)blockIdx.y * (TbS + 1) * ns;
+    const int Tb = tbs ? tbs[blockIdx.y] : TbS;          // this read's blocks; TbS is the batch's stride
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (column, state)
     if (i >= (Tb + 1) * ns) return;
     const int col = i / ns, stt = i % ns;
@@ -1095,10 +1119,10 @@ k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int Tb, int
     tr[i] = (int32_t)roundf(255.0f * sum);
 }
 
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log) {
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     const int n = (Tb + 1) * 2 * nbase;
-    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps, is_log);
+    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps, is_log, tbs);
 }
 
 // exp_activation_inplace (layers.c:56-66) on the meaningful rows

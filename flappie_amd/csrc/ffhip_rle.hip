@@ -44,10 +44,11 @@ k_rle_activate(float *__restrict__ param, size_t n /*nread*Tb*Ps*/, int nbase, i
 
 // runlengthV2_partition_function: one wave per read, lane = state
 __global__ void __launch_bounds__(64)
-k_rle_partition(const float *__restrict__ param, int Tb, int nbase, int Ps, double *__restrict__ logz) {
+k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, double *__restrict__ logz, const int *__restrict__ tbs) {
     __shared__ double st[2][kMaxState];
     const int lane = threadIdx.x, ns = 2 * nbase;
-    const float *C = param + (size_t)blockIdx.x * Tb * Ps + ns;
+    const float *C = param + (size_t)blockIdx.x * TbS * Ps + ns;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (lane < ns) st[0][lane] = 0.0;
     __syncthreads();
     int cur = 0;
@@ -82,25 +83,28 @@ k_rle_partition(const float *__restrict__ param, int Tb, int nbase, int Ps, doub
 
 // rows [2*nbase, P) -= (float)(logZ / Tb)   (layers.c:1349-1356: `const float logZ = partition / (float)nc`)
 __global__ void __launch_bounds__(256)
-k_rle_sub(float *__restrict__ param, const double *__restrict__ logz, int Tb, int nbase, int P, int Ps, size_t n) {
+k_rle_sub(float *__restrict__ param, const double *__restrict__ logz, int TbS, int nbase, int P, int Ps, size_t n, const int *__restrict__ tbs) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = (int)(i % Ps);
     if (p < 2 * nbase || p >= P) return;
-    const size_t r = i / ((size_t)Tb * Ps);
+    const size_t r = i / ((size_t)TbS * Ps);
+    const int Tb = tbs ? tbs[r] : TbS;
+    if ((int)((i / Ps) % TbS) >= Tb) return;
     param[i] -= (float)(logz[r] / (double)(float)Tb);
 }
 
 // transpost_crf_runlength: wave 0 forward, wave 1 backward, then one block per thread
 __global__ void __launch_bounds__(256)
 k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf,
-                int Tb, int nbase, int P, int Ps) {
+                int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
     __shared__ float fs[2][kMaxState], bs[2][kMaxState];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ns = 2 * nbase;
-    const float *T = param + (size_t)blockIdx.x * Tb * Ps;
-    float *Pp = post + (size_t)blockIdx.x * Tb * Ps;
-    float *F = fwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
-    float *Bw = bwdbuf + (size_t)blockIdx.x * (Tb + 1) * kMaxState;
+    const float *T = param + (size_t)blockIdx.x * TbS * Ps;
+    float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (wave == 0) {
         if (lane < ns) { fs[0][lane] = 0.0f; F[lane] = 0.0f; }
         __builtin_amdgcn_wave_barrier();
@@ -187,13 +191,14 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
 // decode_crf_runlength: Viterbi, traceback bytes in HBM, one wave per read
 __global__ void __launch_bounds__(64)
 k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
-              float *__restrict__ score_out, int Tb, int nbase, int Ps) {
+              float *__restrict__ score_out, int TbS, int nbase, int Ps, const int *__restrict__ tbs) {
     __shared__ float vs[2][kMaxState];
     const int lane = threadIdx.x, ns = 2 * nbase;
-    const float *T = param + (size_t)blockIdx.x * Tb * Ps;
-    uint8_t *tb = tbbuf + (size_t)blockIdx.x * Tb * kMaxState;
-    int *pth = path + (size_t)blockIdx.x * (Tb + 1);
-    float *qp = qpath + (size_t)blockIdx.x * (Tb + 1);
+    const float *T = param + (size_t)blockIdx.x * TbS * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * TbS * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (lane < ns) vs[0][lane] = 0.0f;
     __syncthreads();
     int cur = 0;
@@ -239,25 +244,25 @@ k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int 
 
 }  // namespace
 
-void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature) {
+void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     const size_t n = (size_t)nread * Tb * Ps;
     hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, n, nbase, P, Ps, temperature);
-    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz);
-    hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, logz, Tb, nbase, P, Ps, n);
+    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
+    hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, logz, Tb, nbase, P, Ps, n, tbs);
 }
 
-void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps) {
-    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz);
+void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps, const int *tbs) {
+    hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
 }
 
-void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps) {
+void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_rle_transpost, dim3(nread), dim3(256), 0, s, param, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps);
+    hipLaunchKernelGGL(k_rle_transpost, dim3(nread), dim3(256), 0, s, param, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps, tbs);
 }
 
-void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps) {
-    hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps);
+void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs) {
+    hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps, tbs);
 }
 
 }  // namespace ffhip

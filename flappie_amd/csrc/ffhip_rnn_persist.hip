@@ -59,6 +59,9 @@ struct PersistArgs {
     int Tb, B16, Ut, K16, G, rt0, nrt, backward;
     unsigned long long *dbg; // optional phase timestamps [Tb][4 waves][6]
     int fast_gates;        // opt-in (FFHIP_FAST_GATES=1): hardware exp2/rcp gate math, NOT bit-compatible with the reference's exp_ps
+    const int *tbs;        // ragged batch: blocks of each read [16*B16] (nullptr = all Tb); a read's steps t >= tbs[r] give h = c = 0,
+                           // which is a fresh start for backward layers and inert padding for forward ones
+    const int *tbt;        // ragged batch: max blocks per read tile [B16]
     int mode;              // 0 = verify placement, use the L2-local hand-off when a group shares an XCD; 1 = always write-through
 };
 
@@ -81,7 +84,7 @@ k_rnn_persist(PersistArgs a) {
     __shared__ int lds_abort;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int G = a.G, Ut = a.Ut, K16 = a.K16, Tb = a.Tb;
+    const int G = a.G, Ut = a.Ut, K16 = a.K16;
     // block -> (group g, member m).  Hardware places block b on XCD b % 8: when the group count
     // is a multiple of 8 give every XCD whole groups (speed only, never correctness).
     int g, m;
@@ -91,6 +94,8 @@ k_rnn_persist(PersistArgs a) {
         else { g = b / G; m = b % G; }
     }
     const int rt = a.rt0 + g;
+    const int Tb = a.tbt ? a.tbt[rt] : a.Tb;                     // steps of this read tile
+    const int my_tb = a.tbs ? a.tbs[rt * 16 + (threadIdx.x & 15)] : a.Tb;      // blocks of the read this lane does gate math for
     const int ut0 = m * UPC;
     if (threadIdx.x == 0) lds_abort = 0;
 
@@ -266,6 +271,7 @@ k_rnn_persist(PersistArgs a) {
             // gather the 4 units of a read into one lane: lanes 0..15 then hold 16 contiguous bytes
             // each, and the wave writes its 256 B (two whole 128-B lines) with ONE store instruction,
             // so a consumer never finds a half-written line that L2 would have to complete from HBM.
+            if (t >= my_tb) { h = 0.0f; c = 0.0f; hprev_own = 0.0f; }      // beyond this read's end (ragged batch)
             v4f hv;
             hv.x = __shfl(h, rl);
             hv.y = __shfl(h, rl + 16);
@@ -304,7 +310,7 @@ k_lstm_fused(PersistArgs a) {
     __shared__ int lds_fast;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int G = a.G, Ut = a.Ut, K16 = a.K16, Tb = a.Tb;
+    const int G = a.G, Ut = a.Ut, K16 = a.K16;
     int g, m;
     {
         const int b = blockIdx.x;
@@ -312,6 +318,8 @@ k_lstm_fused(PersistArgs a) {
         else { g = b / G; m = b % G; }
     }
     const int rt = a.rt0 + g;
+    const int Tb = a.tbt ? a.tbt[rt] : a.Tb;                     // steps of this read tile
+    const int my_tb = a.tbs ? a.tbs[rt * 16 + (threadIdx.x & 15)] : a.Tb;      // blocks of the read this lane does gate math for
     const int ut0 = m * UPC;
     if (threadIdx.x == 0) lds_abort = 0;
     if (threadIdx.x < 64) {
@@ -510,6 +518,7 @@ k_lstm_fused(PersistArgs a) {
                 c = forget + update;
                 h = L.w * tanh_ref(c);
             }
+            if (t >= my_tb) { h = 0.0f; c = 0.0f; hprev_own = 0.0f; }      // beyond this read's end (ragged batch)
             v4f hv;
             hv.x = __shfl(h, rl);
             hv.y = __shfl(h, rl + 16);
@@ -588,7 +597,7 @@ size_t persist_flag_words(int H, int nrt) { return (size_t)nrt * pick_group(H / 
 // kernels use <= 64 SGPRs, outside the band where the API over-reports -- MI355X_MICROARCH.md)
 int persist_blocks_per_cu(int kind, int H) {
     g_query_blocks = 0;
-    launch_rnn_persist(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1);
+    launch_rnn_persist(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1, nullptr, nullptr);
     const int n = g_query_blocks;
     g_query_blocks = -1;
     return n;
@@ -625,12 +634,14 @@ static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
 }
 
 bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 *iWp, const float *bias, const float *xin, float *hout,
-                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                       const int *tbs, const int *tbt) {
     PersistArgs a;
     a.sWp = (const v4f *)sWp; a.iWp = (const v4f *)iWp; a.bias = bias; a.xin = xin; a.xa = nullptr; a.hout = hout;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward; a.mode = mode; a.dbg = g_persist_dbg;
+    a.tbs = tbs; a.tbt = tbt;
     a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
@@ -653,13 +664,15 @@ bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 
 
 // One recurrent layer over read tiles [rt0, rt0+nrt).  nrt <= persist_max_tiles().
 bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float *xa, float *hout, unsigned *flags,
-                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode) {
+                        unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                        const int *tbs, const int *tbt) {
     PersistArgs a;
     a.sWp = (const v4f *)sWp; a.iWp = nullptr; a.xin = nullptr; a.bias = nullptr;
     a.xa = (const v4f *)xa; a.hout = hout; a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
     a.backward = backward;
     a.mode = mode;
+    a.tbs = tbs; a.tbt = tbt;
     a.fast_gates = 0;
     a.dbg = g_persist_dbg;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);

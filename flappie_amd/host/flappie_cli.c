@@ -183,7 +183,11 @@ typedef struct {
 static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n) {
     int *idx = calloc(n, sizeof(int));
     for (int i = 0; i < n; i++) idx[i] = its[i]->prepared;
-    const size_t len = its[0]->res.rt.end - its[0]->res.rt.start;
+    size_t len = 0;                                          /* capacity = the longest read of the (sorted) group */
+    for (int i = 0; i < n; i++) {
+        const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
+        if (li > len) len = li;
+    }
     ffhip_batch *b = ffhip_batch_create(eng, mdl, n, len);
     unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
     if (NULL == b || 0 != ffhip_batch_set_prepared(b, prep, idx) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
@@ -192,14 +196,16 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         free(idx);
         return;
     }
-    const size_t nblock = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
+    const size_t nblock_cap = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
+    (void)nblock_cap; (void)nstate;
 #ifdef BUILD_RUNNIE
     {   /* runnie.c:262-313: path from decode_crf_runlength, then one line per emitted base with the discrete-Weibull
          * shape and scale of the block that emitted it and the dwell in blocks */
         const size_t nbase = ffhip_model_nbase(mdl), P = ffhip_model_nparam(mdl);
-        int *path = malloc((nblock + 1) * sizeof(int));
-        float *qp = malloc((nblock + 1) * sizeof(float)), *mat = malloc(nblock * P * sizeof(float));
+        int *path = malloc((nblock_cap + 1) * sizeof(int));
+        float *qp = malloc((nblock_cap + 1) * sizeof(float)), *mat = malloc(nblock_cap * P * sizeof(float));
         for (int i = 0; path && qp && mat && i < n; i++) {
+            const size_t nblock = ffhip_batch_read_nblock(b, i);
             if (0 != ffhip_batch_get_path(b, i, path, qp)) continue;
             if (0 != (args.viterbi_only ? ffhip_batch_get_transitions(b, i, mat) : ffhip_batch_get_posterior(b, i, mat))) continue;
             size_t cap = 64 * (nblock + 1), len = 0;
@@ -230,6 +236,7 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
 #endif
     for (int i = 0; i < n; i++) {
         struct _raw_basecall_info *r = &its[i]->res;
+        const size_t nblock = ffhip_batch_read_nblock(b, i);
         size_t blen = 0;
         const char *bases = ffhip_batch_basecall(b, i, &blen);
         r->basecall = strdup(bases);
@@ -259,6 +266,12 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     free(idx);
 }
 
+static int by_length_desc(const void *x, const void *y) {
+    const item *a = *(item *const *)x, *b = *(item *const *)y;
+    const size_t la = a->res.rt.end - a->res.rt.start, lb = b->res.rt.end - b->res.rt.start;
+    return (la < lb) - (la > lb);
+}
+
 /* flappie.c:248-262 for every read of the chunk in one device pass (trim/segment, then med-MAD or --delta),
  * then batches of equal trimmed length, output in input order (flappie.c:371-384) */
 static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, hid_t hdf5out) {
@@ -280,13 +293,18 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         items[i].res.rt.start = st;
         items[i].res.rt.end = en;
     }
-    for (int i = 0; i < n; i++) {
-        if (done[i] || items[i].prepared < 0) continue;
-        const size_t len = items[i].res.rt.end - items[i].res.rt.start;
-        int g = 0;
-        for (int j = i; j < n && g < args.batch; j++)
-            if (!done[j] && items[j].prepared >= 0 && items[j].res.rt.end - items[j].res.rt.start == len) { group[g++] = &items[j]; done[j] = 1; }
-        call_batch(eng, mdl, prep, group, g);
+    {   /* ragged batches: reads sorted by trimmed length, a batch takes up to --batch consecutive ones as long as the
+         * shortest is at least 3/4 of the longest (a read tile of 16 costs what its longest read costs) */
+        int m2 = 0;
+        for (int i = 0; i < n; i++) if (items[i].prepared >= 0) group[m2++] = &items[i];
+        qsort(group, m2, sizeof(item *), by_length_desc);
+        for (int i = 0; i < m2; ) {
+            const size_t longest = group[i]->res.rt.end - group[i]->res.rt.start;
+            int g = 1;
+            while (i + g < m2 && g < args.batch && 4 * (group[i + g]->res.rt.end - group[i + g]->res.rt.start) >= 3 * longest) g++;
+            call_batch(eng, mdl, prep, group + i, g);
+            i += g;
+        }
     }
     for (int i = 0; i < n; i++) {
         item *it = &items[i];

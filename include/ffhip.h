@@ -98,10 +98,19 @@ void ffhip_batch_destroy(ffhip_batch *b);
 size_t ffhip_batch_nblock(const ffhip_batch *b);
 
 /* replaces features_from_raw (nnfeatures.c:15-28): copies raw[start..end) of every read to HBM.
- * `reads[i].end - reads[i].start` must equal nsample. */
+ * `reads[i].end - reads[i].start` may be anything from the convolution window up to nsample: `nsample` is the
+ * batch's CAPACITY.  When the lengths differ the batch is RAGGED: every read is evaluated whole and exactly as
+ * if it were alone (its own right-edge convolution windows, recurrent state started at its own end for the
+ * backward layers, its own block count in the CRF normaliser and the decoders); a read tile of 16 reads costs
+ * what its longest member costs, so callers should sort reads by length.  Equal lengths take the uniform path. */
 int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads);
-/* same from a packed host array signals[nread][ld] */
+/* same from a packed host array signals[nread][ld], all reads nsample long */
 int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, size_t ld);
+/* same, read r uses the first nsample[r] <= capacity samples of its row */
+int ffhip_batch_set_signals_ragged(ffhip_batch *b, const float *signals, size_t ld, const size_t *nsample);
+/* blocks of one read of the batch (ffhip_batch_nblock is the capacity's); sizes of that read's results:
+ * path/qpath nblock+1, transitions/posterior nblock x nparam, trace (nblock+1) x nstate */
+size_t ffhip_batch_read_nblock(const ffhip_batch *b, int read);
 
 /* replaces calculate_transitions (networks.c:108) + transpost_crf_flipflop (decode.c:377) +
  * decode_crf_flipflop (decode.c:119) + change_positions / base+quality assembly
@@ -203,7 +212,7 @@ void ffhip_prep_destroy(ffhip_prep *p);
 int ffhip_prep_range(const ffhip_prep *p, int read, size_t *start, size_t *end);
 int ffhip_prep_stats(const ffhip_prep *p, int read, float *median, float *mad);      /* MEDMAD mode */
 int ffhip_prep_get_signal(const ffhip_prep *p, int read, float *out /* end-start floats */);
-int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep */);
+int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep; lengths <= capacity */);
 /* quantilef (util.c:100-139): p[] in, quantiles out */
 int ffhip_quantiles(ffhip_engine *eng, const float *x, size_t n, float *p, size_t np);
 /* difference_array / shift_scale_array / both (FFHIP_PREP_DELTA) on one host array, in place */

@@ -189,7 +189,7 @@ def cli_inputs(tmp_path_factory):
     reads.mkdir()
     rng = np.random.default_rng(77)
     raws = {}
-    for i, n in enumerate((4000, 4000, 3100, 4000, 2600)):
+    for i, n in enumerate((4000, 4000, 3100, 4013, 2600, 3977, 1250, 3100)):     # mixed lengths: ragged batches inside the CLI
         raw = synth_raw(rng, n)
         write_fast5(reads / ("read_%02d.fast5" % i), "uuid-%04d" % i, raw)
         raws["read_%02d.fast5" % i] = ("uuid-%04d" % i, raw)
