@@ -15,7 +15,10 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
+#include <semaphore.h>
 #include <string.h>
+#include <time.h>
 #include <strings.h>
 
 #include "../../include/decode.h"
@@ -172,12 +175,35 @@ static error_t parse_arg(int key, char *arg, struct argp_state *state) {
 
 static struct argp argp = { options, parse_arg, args_doc, doc };
 
+/* FLAPPIE_CLI_TIMING=1: wall-clock split of the driver's phases on stderr at exit */
+static double t_phase[6];
+static const char *phase_name[6] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output" };
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 typedef struct {
     char *filename;                     /* owned */
     struct _raw_basecall_info res;      /* rt filled by read_raw, start/end by the preparation; basecall == NULL until called */
     int prepared;                       /* index into the chunk's ffhip_prep, or -1 */
     char *rle_text;                     /* runnie: the read's records, formatted (runnie.c:282-313) */
 } item;
+
+/* Batch objects own gigabytes of workspace; creating one per group costs more than running it.  Full-size groups
+ * (--batch reads) share one cached object whose capacity grows when a longer read turns up. */
+static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache;
+
+static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, int n, size_t len, int *cached) {
+    *cached = 0;
+    if (n != args.batch) return ffhip_batch_create(eng, mdl, n, len);
+    if (NULL == batch_cache.b || batch_cache.cap < len) {
+        if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
+        batch_cache.cap = len + len / 8;
+        batch_cache.nread = n;
+        batch_cache.b = ffhip_batch_create(eng, mdl, n, batch_cache.cap);
+        if (NULL == batch_cache.b) { batch_cache.cap = 0; return NULL; }
+    }
+    *cached = 1;
+    return batch_cache.b;
+}
 
 /* one batch of equal-length prepared reads through the engine: calculate_post after normalisation (flappie.c:264-316) */
 static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n) {
@@ -188,14 +214,18 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
         if (li > len) len = li;
     }
-    ffhip_batch *b = ffhip_batch_create(eng, mdl, n, len);
+    double t0 = now_s();
+    int cached = 0;
+    ffhip_batch *b = acquire_batch(eng, mdl, n, len, &cached);
+    t_phase[2] += now_s() - t0; t0 = now_s();
     unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
     if (NULL == b || 0 != ffhip_batch_set_prepared(b, prep, idx) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
         warnx("%s", ffhip_last_error());
-        if (b) ffhip_batch_destroy(b);
+        if (b && !cached) ffhip_batch_destroy(b);
         free(idx);
         return;
     }
+    t_phase[3] += now_s() - t0; t0 = now_s();
     const size_t nblock_cap = ffhip_batch_nblock(b), nstate = 2 * ffhip_model_nbase(mdl);
     (void)nblock_cap; (void)nstate;
 #ifdef BUILD_RUNNIE
@@ -229,7 +259,9 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
             its[i]->res.nblock = nblock;
         }
         free(path); free(qp); free(mat);
-        ffhip_batch_destroy(b);
+        t_phase[4] += now_s() - t0; t0 = now_s();
+        if (!cached) ffhip_batch_destroy(b);
+        t_phase[2] += now_s() - t0;
         free(idx);
         return;
     }
@@ -262,7 +294,9 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
             if (0 != ffhip_prep_get_signal(prep, idx[i], r->rt.raw + r->rt.start)) warnx("%s", ffhip_last_error());
         }
     }
-    ffhip_batch_destroy(b);
+    t_phase[4] += now_s() - t0; t0 = now_s();
+    if (!cached) ffhip_batch_destroy(b);
+    t_phase[2] += now_s() - t0;
     free(idx);
 }
 
@@ -283,8 +317,10 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         items[i].prepared = -1;
         if (NULL != items[i].res.rt.raw) { rts[m] = items[i].res.rt; items[i].prepared = m++; }
     }
+    double tp0 = now_s();
     ffhip_prep *prep = (m > 0) ? ffhip_prep_create(eng, rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
                                                    (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
+    t_phase[1] += now_s() - tp0;
     if (m > 0 && NULL == prep) warnx("%s", ffhip_last_error());
     for (int i = 0; i < n; i++) {
         if (items[i].prepared < 0) continue;
@@ -306,6 +342,7 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
             i += g;
         }
     }
+    const double to0 = now_s();
     for (int i = 0; i < n; i++) {
         item *it = &items[i];
 #ifdef BUILD_RUNNIE
@@ -333,10 +370,74 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         free_raw_basecall_info(&it->res);
         free(it->filename);
     }
+    t_phase[5] += now_s() - to0;
     ffhip_prep_destroy(prep);
     free(rts);
     free(group);
     free(done);
+}
+
+/* ---- input side: the list of files (flappie.c:336-358), read one chunk ahead of the GPU by a reader thread ---- */
+typedef struct { char **path; size_t n, cap; } file_list;
+
+static void list_files(file_list *fl) {
+    const int reads_limit = args.limit;
+    for (int fn = 0; args.files && args.files[fn]; fn++) {
+        if (reads_limit > 0 && (int)fl->n >= reads_limit) break;
+        glob_t globbuf;
+        /* a directory means every .fast5 file inside it (flappie.c:341-353) */
+        const size_t rootlen = strlen(args.files[fn]);
+        char *globpath = calloc(rootlen + 9, sizeof(char));
+        memcpy(globpath, args.files[fn], rootlen);
+        DIR *dirp = opendir(args.files[fn]);
+        if (NULL != dirp) { memcpy(globpath + rootlen, "/*.fast5", 8); closedir(dirp); }
+        const int globret = glob(globpath, GLOB_NOSORT, NULL, &globbuf);
+        free(globpath);
+        if (0 != globret) {
+            if (GLOB_NOMATCH == globret) warnx("File or directory \"%s\" does not exist or no fast5 files found.", args.files[fn]);
+            globfree(&globbuf);
+            continue;
+        }
+        for (size_t f2 = 0; f2 < globbuf.gl_pathc; f2++) {
+            if (reads_limit > 0 && (int)fl->n >= reads_limit) break;
+            if (fl->n == fl->cap) { fl->cap = fl->cap ? 2 * fl->cap : 1024; fl->path = realloc(fl->path, fl->cap * sizeof(char *)); }
+            fl->path[fl->n++] = strdup(globbuf.gl_pathv[f2]);
+        }
+        globfree(&globbuf);
+    }
+}
+
+typedef struct {
+    const file_list *fl;
+    int chunk_cap;
+    item *items[2];
+    int nitem[2];
+    sem_t filled[2], empty[2];
+} reader_state;
+
+static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *items, int *nitem) {
+    int n = 0;
+    for (size_t f = first; f < fl->n && n < chunk_cap; f++, n++) {
+        item *it = &items[n];
+        memset(it, 0, sizeof(*it));
+        it->filename = fl->path[f];                                   /* ownership moves to the item */
+        const double tr0 = now_s();
+        it->res.rt = read_raw(it->filename, true);                    /* flappie.c:248 */
+        t_phase[0] += now_s() - tr0;
+    }
+    *nitem = n;
+}
+
+static void *reader_main(void *arg) {
+    reader_state *rs = arg;
+    size_t first = 0;
+    for (int k = 0; first < rs->fl->n; k ^= 1) {
+        sem_wait(&rs->empty[k]);
+        read_chunk(rs->fl, first, rs->chunk_cap, rs->items[k], &rs->nitem[k]);
+        first += rs->nitem[k];
+        sem_post(&rs->filled[k]);
+    }
+    return NULL;
 }
 
 int main(int argc, char *argv[]) {
@@ -347,42 +448,38 @@ int main(int argc, char *argv[]) {
     struct ffhip_engine *eng = flappie_hip_engine();
     hid_t hdf5out = open_or_create_hdf5(args.trace);
 
-    const int chunk_cap = 4 * args.batch;
-    item *items = calloc(chunk_cap, sizeof(item));
-    int nitem = 0, reads_started = 0;
-    const int reads_limit = args.limit;
-    for (int fn = 0; args.files && args.files[fn]; fn++) {
-        if (reads_limit > 0 && reads_started >= reads_limit) continue;
-        glob_t globbuf;
-        {   /* a directory means every .fast5 file inside it (flappie.c:341-353) */
-            const size_t rootlen = strlen(args.files[fn]);
-            char *globpath = calloc(rootlen + 9, sizeof(char));
-            memcpy(globpath, args.files[fn], rootlen);
-            DIR *dirp = opendir(args.files[fn]);
-            if (NULL != dirp) { memcpy(globpath + rootlen, "/*.fast5", 8); closedir(dirp); }
-            const int globret = glob(globpath, GLOB_NOSORT, NULL, &globbuf);
-            free(globpath);
-            if (0 != globret) {
-                if (GLOB_NOMATCH == globret) warnx("File or directory \"%s\" does not exist or no fast5 files found.", args.files[fn]);
-                globfree(&globbuf);
-                continue;
-            }
-        }
-        for (size_t f2 = 0; f2 < globbuf.gl_pathc; f2++) {
-            if (reads_limit > 0 && reads_started >= reads_limit) continue;
-            reads_started += 1;
-            item *it = &items[nitem++];
-            memset(it, 0, sizeof(*it));
-            it->filename = strdup(globbuf.gl_pathv[f2]);
-            it->res.rt = read_raw(it->filename, true);            /* flappie.c:248 */
-            if (nitem == chunk_cap) { flush_chunk(eng, mdl, items, nitem, hdf5out); nitem = 0; }
-        }
-        globfree(&globbuf);
+    file_list fl = { NULL, 0, 0 };
+    list_files(&fl);
+    reader_state rs;
+    memset(&rs, 0, sizeof(rs));
+    rs.fl = &fl;
+    rs.chunk_cap = 4 * args.batch;
+    for (int k = 0; k < 2; k++) {
+        rs.items[k] = calloc(rs.chunk_cap, sizeof(item));
+        sem_init(&rs.filled[k], 0, 0);
+        sem_init(&rs.empty[k], 0, 1);
     }
-    flush_chunk(eng, mdl, items, nitem, hdf5out);
-    free(items);
+    /* The HDF5 library here is not built thread-safe: with --trace the main thread writes HDF5 too, so the files are
+     * then read on the main thread between chunks instead of one chunk ahead on the reader thread. */
+    const int threaded = (hdf5out < 0) && !getenv("FLAPPIE_NO_READER_THREAD");
+    pthread_t reader;
+    if (threaded && 0 != pthread_create(&reader, NULL, reader_main, &rs)) errx(EXIT_FAILURE, "could not start the reader thread");
+    size_t done = 0;
+    for (int k = 0; done < fl.n; k ^= 1) {
+        if (threaded) sem_wait(&rs.filled[k]);
+        else read_chunk(&fl, done, rs.chunk_cap, rs.items[k], &rs.nitem[k]);
+        flush_chunk(eng, mdl, rs.items[k], rs.nitem[k], hdf5out);
+        done += rs.nitem[k];
+        if (threaded) sem_post(&rs.empty[k]);
+    }
+    if (threaded) pthread_join(reader, NULL);
+    for (int k = 0; k < 2; k++) free(rs.items[k]);
+    free(fl.path);
     if (hdf5out >= 0) H5Fclose(hdf5out);
     if (stdout != args.output) fclose(args.output);
+    if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
+    if (getenv("FLAPPIE_CLI_TIMING"))
+        for (int k = 0; k < 6; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
     flappie_hip_shutdown();
     return EXIT_SUCCESS;
 }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the `flappie` binary on generated single-read fast5 files of mixed lengths
+(fast5 read -> GPU signal preparation -> ragged batches -> FASTQ).  Development tool; run on the GPU box."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flappie_amd import model as M  # noqa: E402
+
+hidden = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+counts = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["256", "1024"])]
+d = tempfile.mkdtemp(prefix="flappie_cli_")
+t0 = time.time()
+M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native"))
+print("model file written in %.1f s" % (time.time() - t0), flush=True)
+tool = os.path.join(ROOT, "flappie_amd", "fast5_tool")
+rng = np.random.default_rng(1)
+nmax = max(counts)
+reads = os.path.join(d, "reads")
+os.mkdir(reads)
+t0 = time.time()
+total = []
+for i in range(nmax):
+    n = int(rng.integers(3500, 5500))
+    x = rng.normal(500, 60, n)
+    x[:300] = rng.normal(520, 4, 300)
+    raw = np.clip(np.rint(x), 0, 8191).astype("<i2")
+    tmp = os.path.join(d, "r.i16")
+    raw.tofile(tmp)
+    subprocess.run([tool, "write", os.path.join(reads, "read_%05d.fast5" % i), "uuid-%05d" % i, "8192", "10", "1400", "4000", tmp], check=True)
+    total.append(n)
+print("%d fast5 files written in %.1f s" % (nmax, time.time() - t0), flush=True)
+env = dict(os.environ, FLAPPIE_MODEL_DIR=d)
+res = []
+for n in counts:
+    t0 = time.time()
+    env["FLAPPIE_CLI_TIMING"] = "1"
+    r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie"), "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
+                       capture_output=True, text=True)
+    dt = time.time() - t0
+    nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
+    print("flappie --limit %d: rc %d, %d records, %.2f s   %s" % (n, r.returncode, nrec, dt, "\n" + r.stderr.strip()[-600:]), flush=True)
+    res.append((n, dt))
+if len(res) >= 2:
+    (n0, t0_), (n1, t1_) = res[0], res[-1]
+    per_read = (t1_ - t0_) / (n1 - n0)
+    print("marginal cost %.3f ms per read (~%d samples) = %.2f Msamples/s; fixed cost %.1f s" % (per_read * 1e3, int(np.mean(total)),
+          np.mean(total) / per_read / 1e6, t0_ - n0 * per_read))
