@@ -383,7 +383,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     b->hTb.assign(nread, b->Tb);
     const size_t Tb = b->Tb, Bp = b->Bp, Hp = m->Hp, Ps = m->Ps, ns = m->nstate;
     for (int i = 0; i < 2; i++) if (!(b->act[i] = (float *)dalloc(b, Tb * Bp * Hp * 4, false))) BFAIL();
-    if (!(b->xa = (float *)dalloc(b, Tb * Bp * Hp * 4 * 4, false))) BFAIL();
+    // b->xa (gate pre-activations, 4x the size of an activation buffer) exists only on the unfused path: allocated on first use
     if (!(b->cstate = (float *)dalloc(b, Bp * Hp * 4, true))) BFAIL();
     if (!(b->trans = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
     if (!(b->crf_logz = (double *)dalloc(b, (size_t)nread * sizeof(double), true))) BFAIL();
@@ -615,6 +615,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         const bool fuse = use_persist && use_fused;
         if (prof) hipEventRecord(b->lev[l][0], s);
         if (!fuse) {
+            if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
             launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
             b->launches[1]++;
         }
