@@ -799,16 +799,20 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
 // ---- any nstate: same max + log(sum exp) formulation with the segmented reductions through LDS ----
 // Used for the 5-base (ACGTZ, nstate 10) models where the 8-lane butterflies above do not apply.
 // State lanes (lane < nstate) own one state each; entry lanes (lane < P) own one transition score.
-__global__ void __launch_bounds__(64)
-k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf,
+// Any nstate <= 16 (the 5mC model has 10): the same max + log-sum-exp scheme through LDS.  As in k_transpost8,
+// wave 0 runs the forward recursion while wave 1 runs the backward one, then every thread assembles and
+// log-normalises whole blocks.
+__global__ void __launch_bounds__(256)
+k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf,
                 int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
-    __shared__ float term[64];
-    __shared__ float svec[kMaxState];
-    const int lane = threadIdx.x;
+    __shared__ float term[2][64];
+    __shared__ float svec[2][kMaxState];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ns = 2 * nbase, off = nbase * ns;
     const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
     float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
     float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     const bool valid = lane < P, is_state = lane < ns, is_flip = lane < nbase;
     const int src = lane % ns;                  // source state of entry `lane` (off is a multiple of ns)
@@ -816,62 +820,79 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
     if (lane < off) dst = lane / ns;
     else { const int idx = lane - off; dst = (idx < nbase) ? idx + nbase : idx; }
     if (!valid) dst = 0;
+    // one wave: LDS executes its instructions in order; only the compiler has to be kept from reordering
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-    // forwards
-    if (is_state) { F[lane] = 0.0f; svec[lane] = 0.0f; }
-    __syncthreads();
-    float s_next = valid ? T[lane] : 0.0f;
-    for (int blk = 0; blk < Tb; blk++) {
-        const float s = s_next;
-        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-        term[lane] = valid ? s + svec[src] : -INFINITY;
-        __syncthreads();
-        float val = 0.0f;
-        if (is_state) {
-            if (is_flip) {
-                float m = term[lane * ns];
-                for (int f = 1; f < ns; f++) m = fmaxf(m, term[lane * ns + f]);
-                float e = 0.0f;
-                for (int f = 0; f < ns; f++) e += expf(term[lane * ns + f] - m);
-                val = m + logf(e);
-            } else {
-                const float a = term[off + lane], b = term[off + lane - nbase];
-                const float m = fmaxf(a, b);
-                val = m + logf(expf(a - m) + expf(b - m));
+    if (wave == 0) {
+        // forwards
+        float *tm = term[0], *sv = svec[0];
+        if (is_state) { F[lane] = 0.0f; sv[lane] = 0.0f; }
+        WAVE_SYNC();
+        float s_next = valid ? T[lane] : 0.0f;
+        for (int blk = 0; blk < Tb; blk++) {
+            const float s = s_next;
+            if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
+            tm[lane] = valid ? s + sv[src] : -INFINITY;
+            WAVE_SYNC();
+            float val = 0.0f;
+            if (is_state) {
+                if (is_flip) {
+                    float m = tm[lane * ns];
+                    for (int f = 1; f < ns; f++) m = fmaxf(m, tm[lane * ns + f]);
+                    float e = 0.0f;
+                    for (int f = 0; f < ns; f++) e += expf(tm[lane * ns + f] - m);
+                    val = m + logf(e);
+                } else {
+                    const float a = tm[off + lane], b = tm[off + lane - nbase];
+                    const float m = fmaxf(a, b);
+                    val = m + logf(expf(a - m) + expf(b - m));
+                }
+                F[(size_t)(blk + 1) * kMaxState + lane] = val;
             }
-            F[(size_t)(blk + 1) * kMaxState + lane] = val;
+            WAVE_SYNC();
+            if (is_state) sv[lane] = val;
+            WAVE_SYNC();
         }
-        __syncthreads();
-        if (is_state) svec[lane] = val;
-        __syncthreads();
+    } else if (wave == 1) {
+        // backwards; Bw[blk] is the vector that meets block blk-1's transitions
+        float *tm = term[1], *sv = svec[1];
+        if (is_state) sv[lane] = 0.0f;
+        WAVE_SYNC();
+        for (int blk = Tb; blk > 0; blk--) {
+            const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
+            if (is_state) Bw[(size_t)blk * kMaxState + lane] = sv[lane];
+            const float pb_to = sv[dst];
+            tm[lane] = valid ? s + pb_to : -INFINITY;
+            WAVE_SYNC();
+            float cur = 0.0f;
+            if (is_state) {
+                float m = tm[off + lane];
+                for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, tm[b1 * ns + lane]);
+                float e = expf(tm[off + lane] - m);
+                for (int b1 = 0; b1 < nbase; b1++) e += expf(tm[b1 * ns + lane] - m);
+                cur = m + logf(e);
+            }
+            WAVE_SYNC();
+            if (is_state) sv[lane] = cur;
+            WAVE_SYNC();
+        }
     }
-
-    // backwards
-    if (is_state) svec[lane] = 0.0f;
+#undef WAVE_SYNC
     __syncthreads();
-    for (int blk = Tb; blk > 0; blk--) {
-        const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
-        const float f = valid ? F[(size_t)(blk - 1) * kMaxState + src] : 0.0f;
-        const float pb_to = svec[dst];
-        if (valid) Pp[(size_t)(blk - 1) * Ps + lane] = (f + pb_to) + s;
-        term[lane] = valid ? s + pb_to : -INFINITY;
-        __syncthreads();
-        float cur = 0.0f;
-        if (is_state) {
-            float m = term[off + lane];
-            for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, term[b1 * ns + lane]);
-            float e = expf(term[off + lane] - m);
-            for (int b1 = 0; b1 < nbase; b1++) e += expf(term[b1 * ns + lane] - m);
-            cur = m + logf(e);
-        }
-        __syncthreads();
-        if (is_state) svec[lane] = cur;
-        __syncthreads();
-    }
-    for (int blk = lane; blk < Tb; blk += 64) {
+    for (int blk = threadIdx.x; blk < Tb; blk += 256) {
+        const float *sc = T + (size_t)blk * Ps;
         float *x = Pp + (size_t)blk * Ps;
-        float m = x[0];
-        for (int r = 1; r < P; r++) m = fmaxf(m, x[r]);
+        const float *f = F + (size_t)blk * kMaxState, *bb = Bw + (size_t)(blk + 1) * kMaxState;
+        float m = -INFINITY;
+        for (int r = 0; r < P; r++) {
+            const int from = r % ns;
+            int to;
+            if (r < off) to = r / ns;
+            else { const int idx = r - off; to = (idx < nbase) ? idx + nbase : idx; }
+            const float v = (f[from] + bb[to]) + sc[r];                      // decode.c:451-461
+            x[r] = v;
+            m = fmaxf(m, v);
+        }
         float sum = 0.0f;
         for (int r = 0; r < P; r++) sum += expf(x[r] - m);
         const float lse = m + logf(sum);
@@ -884,7 +905,7 @@ void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs);
     else if (!getenv("FFHIP_EXACT_ORDER"))
-        hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps, tbs);
+        hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps, tbs);
     else
         hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps, tbs);
 }

@@ -30,10 +30,25 @@ def run(eng, kind, H, nread, T, check_reads=(0,), label=""):
     b.close(); dm.close()
 
 
+def run_rle(eng):
+    mdl = M.synthetic_model(M.NET_LSTM5_RLE, 384, seed=3)
+    dm = B.DeviceModel(eng, mdl)
+    sig = np.random.default_rng(5).standard_normal((256, 4000)).astype(np.float32)
+    b = B.Batch(dm, 256, 4000)
+    b.set_signals(sig)
+    b.run(); b.finish()
+    t0 = time.time(); b.run(); b.finish(); dt = time.time() - t0
+    eng.set_profiling(True); b.run(); b.finish(); prof = b.profile(); eng.set_profiling(False)
+    print("runnie-shape H 384 256 x 4000: %.1f ms = %.2f Msamples/s | " % (dt * 1e3, 256 * 4000 / dt / 1e6) + " ".join("%s %.2f" % (k, v["ms"]) for k, v in prof.items()), flush=True)
+    b.close(); dm.close()
+
+
 if __name__ == "__main__":
     eng = B.Engine(0)
     what = sys.argv[1:] or ["c4", "h256", "h512", "c5"]
     if "h256" in what: run(eng, M.NET_LSTM5, 256, 256, 4000, label="r941_native(20200220)-shape")
     if "c4" in what: run(eng, M.NET_GRUMOD5, 256, 256, 4000, label="C4 r941_5mC-shape")
     if "h512" in what: run(eng, M.NET_LSTM5, 512, 256, 4000, label="r103_native-shape")
-    if "c5" in what: run(eng, M.NET_LSTM5, 512, 16, 100000, check_reads=(), label="C5 long reads")
+    if "c5" in what: run(eng, M.NET_LSTM5, 512, 16, 100000, check_reads=(), label="C5 long reads (16)")
+    if "c5big" in what: run(eng, M.NET_LSTM5, 512, 256, 100000, check_reads=(), label="C5 long reads (256)")
+    if "rle" in what: run_rle(eng)
