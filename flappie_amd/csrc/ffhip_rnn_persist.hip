@@ -605,7 +605,17 @@ int persist_blocks_per_cu(int kind, int H) {
 
 int persist_max_tiles(int kind, int H, int ncu, int fused) {
     const int G = pick_group(H / 4);
-    if (fused) return (2 * ncu) / G;          // k_lstm_fused: launch_bounds(256,2), 240 VGPRs at H = 384
+    if (fused) {
+        // k_lstm_fused: launch_bounds(256,2) guarantees two per CU (243 VGPRs at H = 384); smaller shapes need fewer
+        // registers and admit three or four, which is what latency-bound layers want
+        g_query_blocks = 0;
+        launch_lstm_fused(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1, nullptr, nullptr);
+        int per_cu = g_query_blocks;
+        g_query_blocks = -1;
+        if (per_cu < 2) per_cu = 2;
+        if (per_cu > 4) per_cu = 4;
+        return (per_cu * ncu) / G;
+    }
     // every workgroup of a launch must be co-resident because groups spin on each other: at least two
     // per CU are guaranteed (launch_bounds(256,2), <= 33 KiB LDS); use what the occupancy query admits.
     int per_cu = persist_blocks_per_cu(kind, H);
@@ -625,7 +635,14 @@ bool fused_supported(int kind, int H) {
 
 template <int KIND, int UPC>
 static bool dispatch_fused(hipStream_t s, const PersistArgs &a, int kpw) {
-#define FUSED_CASE(K) case K: if (UPC * K <= 18) { hipLaunchKernelGGL((k_lstm_fused<KIND, UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
+#define FUSED_CASE(K) case K: if (UPC * K <= 18) {                                                                       \
+        if (g_query_blocks >= 0) {                                                                                        \
+            int n = 0;                                                                                                    \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_lstm_fused<KIND, UPC, (UPC * K <= 18 ? K : 1)>, 256, 0) != hipSuccess) n = 0; \
+            g_query_blocks = n;                                                                                           \
+            return true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_lstm_fused<KIND, UPC, (UPC * K <= 18 ? K : 1)>), dim3(a.nrt * a.G), dim3(256), 0, s, a); return true; } return false;
     switch (kpw) {
     FUSED_CASE(1) FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(6) FUSED_CASE(8)
     default: return false;

@@ -52,3 +52,9 @@ if __name__ == "__main__":
     if "c5" in what: run(eng, M.NET_LSTM5, 512, 16, 100000, check_reads=(), label="C5 long reads (16)")
     if "c5big" in what: run(eng, M.NET_LSTM5, 512, 256, 100000, check_reads=(), label="C5 long reads (256)")
     if "rle" in what: run_rle(eng)
+    if "nread" in what:
+        for n in (256, 384, 512):
+            run(eng, M.NET_GRUMOD5, 256, n, 4000, check_reads=(), label="C4 nread %d" % n)
+            run(eng, M.NET_LSTM5, 256, n, 4000, check_reads=(), label="H256 nread %d" % n)
+        for n in (256, 512):
+            run(eng, M.NET_LSTM5, 384, n, 4000, check_reads=(), label="H384 nread %d" % n)
