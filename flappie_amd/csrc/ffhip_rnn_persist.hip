@@ -608,10 +608,15 @@ int persist_max_tiles(int kind, int H, int ncu, int fused) {
     if (fused) {
         // k_lstm_fused: launch_bounds(256,2) guarantees two per CU (243 VGPRs at H = 384); smaller shapes need fewer
         // registers and admit three or four, which is what latency-bound layers want
-        g_query_blocks = 0;
-        launch_lstm_fused(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1, nullptr, nullptr);
-        int per_cu = g_query_blocks;
-        g_query_blocks = -1;
+        static int cache_per_cu[2][129];                          // [kind][H/16], 0 = not asked yet (host side, one engine thread per GPU)
+        int &cached = cache_per_cu[kind & 1][(H / 16) & 127];
+        if (cached == 0) {
+            g_query_blocks = 0;
+            launch_lstm_fused(nullptr, kind, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, H, 0, 1, 0, 1, nullptr, nullptr);
+            cached = g_query_blocks > 0 ? g_query_blocks : 2;
+            g_query_blocks = -1;
+        }
+        int per_cu = cached;
         if (per_cu < 2) per_cu = 2;
         if (per_cu > 4) per_cu = 4;
         return (per_cu * ncu) / G;
