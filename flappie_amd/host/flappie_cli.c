@@ -175,6 +175,9 @@ static error_t parse_arg(int key, char *arg, struct argp_state *state) {
 
 static struct argp argp = { options, parse_arg, args_doc, doc };
 
+/* this libhdf5 is not built thread-safe: every HDF5 call of either thread is made under this lock */
+static pthread_mutex_t hdf5_lock = PTHREAD_MUTEX_INITIALIZER;
+
 /* FLAPPIE_CLI_TIMING=1: wall-clock split of the driver's phases on stderr at exit */
 static double t_phase[6];
 static const char *phase_name[6] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output" };
@@ -364,7 +367,11 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
             const char *base = basename(fn);
             const char *uuid = it->res.rt.uuid ? it->res.rt.uuid : "";
             fprintf_format(args.outformat, args.output, uuid, base, args.uuid, args.prefix, it->res);
-            write_summary(hdf5out, args.uuid ? uuid : base, it->res, args.compression_chunk_size, args.compression_level);
+            if (hdf5out >= 0) {
+                pthread_mutex_lock(&hdf5_lock);
+                write_summary(hdf5out, args.uuid ? uuid : base, it->res, args.compression_chunk_size, args.compression_level);
+                pthread_mutex_unlock(&hdf5_lock);
+            }
             free(fn);
         }
         free_raw_basecall_info(&it->res);
@@ -422,7 +429,9 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
         memset(it, 0, sizeof(*it));
         it->filename = fl->path[f];                                   /* ownership moves to the item */
         const double tr0 = now_s();
+        pthread_mutex_lock(&hdf5_lock);
         it->res.rt = read_raw(it->filename, true);                    /* flappie.c:248 */
+        pthread_mutex_unlock(&hdf5_lock);
         t_phase[0] += now_s() - tr0;
     }
     *nitem = n;
@@ -459,9 +468,7 @@ int main(int argc, char *argv[]) {
         sem_init(&rs.filled[k], 0, 0);
         sem_init(&rs.empty[k], 0, 1);
     }
-    /* The HDF5 library here is not built thread-safe: with --trace the main thread writes HDF5 too, so the files are
-     * then read on the main thread between chunks instead of one chunk ahead on the reader thread. */
-    const int threaded = (hdf5out < 0) && !getenv("FLAPPIE_NO_READER_THREAD");
+    const int threaded = !getenv("FLAPPIE_NO_READER_THREAD");
     pthread_t reader;
     if (threaded && 0 != pthread_create(&reader, NULL, reader_main, &rs)) errx(EXIT_FAILURE, "could not start the reader thread");
     size_t done = 0;
@@ -475,7 +482,7 @@ int main(int argc, char *argv[]) {
     if (threaded) pthread_join(reader, NULL);
     for (int k = 0; k < 2; k++) free(rs.items[k]);
     free(fl.path);
-    if (hdf5out >= 0) H5Fclose(hdf5out);
+    if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);
     if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
     if (getenv("FLAPPIE_CLI_TIMING"))
