@@ -232,3 +232,37 @@ def test_full_size_properties(B, engine):
             compare_read(b, r, om.basecall(sig[r]))
     finally:
         b.close(); dm.close()
+
+
+@pytest.mark.parametrize("label,kind,H,nread,T,nstate", [
+    ("config 4: r941_5mC shape (GRUmod, stride 2, 10 states)", M.NET_GRUMOD5, 256, 48, 4000, 10),
+    ("config 5: r103 shape, 100 000-sample reads with trace", M.NET_LSTM5, 512, 16, 100000, 8),
+])
+def test_other_baseline_configs_properties(B, engine, label, kind, H, nread, T, nstate):
+    """BASELINE.json configs 4 and 5 at their real shapes, through the size-independent properties (the oracle
+    needs minutes per read here): duplicates identical, global normalisation, posteriors sum to one, trace bounded."""
+    from oracle import ffo
+    mdl = M.synthetic_model(kind, H, seed=2)
+    rng = np.random.default_rng(H + T)
+    sig = rng.standard_normal((nread, T)).astype(np.float32)
+    sig[nread - 1] = sig[1]
+    dm, b = run_batch(B, engine, mdl, sig)
+    try:
+        nblock = b.nblock
+        assert nblock == mdl.nblock(T)
+        assert np.array_equal(b.transitions(nread - 1), b.transitions(1))
+        assert b.basecall(nread - 1) == b.basecall(1) and b.quality(nread - 1) == b.quality(1)
+        for r in (0, nread // 2):
+            tr = b.transitions(r)
+            assert np.isfinite(tr).all()
+            logZ = ffo.lib().fo_partition_function(ffo.HostMat.from_dense(tr).ptr)
+            assert abs(logZ) / nblock <= 2e-6, label
+            post = b.posterior(r)
+            assert np.abs(np.exp(post.astype(np.float64)).sum(axis=1) - 1.0).max() <= 2e-4
+            path, qpath = b.path(r)
+            assert path.min() >= 0 and path.max() < nstate
+            trc = b.trace(r)
+            assert trc.shape == (nblock + 1, nstate) and trc.min() >= 0 and trc.max() <= 255
+            assert len(b.basecall(r)) == len(b.quality(r)) > 0
+    finally:
+        b.close(); dm.close()
