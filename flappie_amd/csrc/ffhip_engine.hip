@@ -267,6 +267,7 @@ struct ffhip_batch {
     std::vector<int> hT, hTb;           // samples / blocks of each read
     int *d_tbs = nullptr, *d_tbt = nullptr;
     int *rag_x0a[3] = { nullptr, nullptr, nullptr }, *rag_x0b[3] = { nullptr, nullptr, nullptr };
+    int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
     SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
     float *act[2] = { nullptr, nullptr };
     float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -442,6 +443,18 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
     std::vector<int> cur(lens);
     for (int l = 0; l < m->nconv; l++) {
         const int Tmax = b->plan[l].Tout;
+        if (m->conv[l].stride == 1 && l < m->nconv - 1) {
+            // stride 1: column c's window starts at c - padL for every length; the kernel only needs the lengths
+            if (!b->rag_tin[l] && !(b->rag_tin[l] = (int *)dalloc(b, (size_t)b->Bp * 4, true))) return FFHIP_ENOMEM;
+            std::vector<int> tin(b->Bp, 0);
+            for (int r = 0; r < b->nread; r++) {
+                if (cur[r] < m->conv[l].winlen)
+                    return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", r, cur[r], l, m->conv[l].winlen);
+                tin[r] = cur[r];
+            }
+            HIP_TRY(hipMemcpy(b->rag_tin[l], tin.data(), tin.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+            continue;                                                  // output length = input length
+        }
         const size_t n = (size_t)b->Bp * Tmax;
         if (!b->rag_x0a[l]) {
             b->rag_x0a[l] = (int *)dalloc(b, n * 4, false);
@@ -589,7 +602,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
             launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
-                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0);
+                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
+                              b->ragged ? b->rag_tin[l] : nullptr);
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0);

@@ -49,7 +49,8 @@ void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf ds
 
 // VALU convolution for the thin front layers; W dense taps [Fout][winlen][Fin]
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0);     // ldp: entries per read of a per-read window table (0 = shared)
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0,     // ldp: entries per read of a per-read window table (0 = shared)
+                       const int *tin = nullptr);                                 // stride-1 layer of a ragged batch: per-read input lengths instead of a table
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,

@@ -51,7 +51,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 template <int MAXF>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
-             const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp) {
+             const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp,
+             const int *__restrict__ tin) {
     extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
     const int Fin = in.F, Fout = out.F, K = winlen * Fin;
     for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
@@ -64,7 +65,11 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 #pragma unroll
     for (int f = 0; f < MAXF; f++) acc[f] = (f < Fout) ? w_lds[Fout * K + f] : 0.0f;
     // ldp = 0: one window table shared by all reads; otherwise one row of ldp entries per read (ragged batch)
-    const int xs[2] = { x0a[(size_t)r * ldp + c], x0b[(size_t)r * ldp + c] };
+    // tin (stride-1 layers of a ragged batch): per-read input length; the window of column c starts at c - padL
+    // (layers.c:216-271 degenerates to the zero-padded "same" convolution for stride 1), zeros beyond the read
+    int xs[2];
+    if (tin) { xs[0] = (c < tin[r]) ? c - (winlen - 1) / 2 : kZeroCol; xs[1] = kNoWindow; }
+    else { xs[0] = x0a[(size_t)r * ldp + c]; xs[1] = x0b[(size_t)r * ldp + c]; }
     if (xs[0] == kZeroCol) {                     // beyond this read's end: the next layer must see zero padding there
         float *o0 = out.p + (size_t)r * out.rs + (size_t)(kSamplePad + c) * Fout;
         for (int f = 0; f < Fout; f++) o0[f] = 0.0f;
@@ -88,15 +93,15 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp) {
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin) {
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
     if (out.F <= 4)
-        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
     else if (out.F <= 16)
-        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
     else
-        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp);
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
 }
 
 // ------------------------------------------------------------------------------------------
