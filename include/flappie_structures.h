@@ -11,31 +11,26 @@
 extern "C" {
 #endif
 
-/* flappie_structures.h:16-22.  Passed BY VALUE; the callee reads raw[start..end) and never takes
- * ownership of `raw` or `uuid`. */
+/* One read's raw signal (flappie_structures.h:16-22; member order is ABI).  Passed BY VALUE; the callee reads
+ * raw[start..end) and never takes ownership of `raw` or `uuid`. */
 typedef struct {
-    char *uuid;
-    size_t n;
-    size_t start;
-    size_t end;
-    float *raw;
+    char *uuid;                 /* read identifier from the fast5 file, or NULL         */
+    size_t n, start, end;       /* samples in raw[]; the range kept after trimming      */
+    float *raw;                 /* n samples                                             */
 } raw_table;
 
-/* flappie_structures.h:24-35 */
+/* Everything the CLI keeps per called read (flappie_structures.h:24-35; member order is ABI). */
 struct _raw_basecall_info {
-    float score;
+    float score;                /* path score of the decode                              */
     raw_table rt;
-
-    char *basecall;
-    char *quality;
+    char *basecall, *quality;   /* NUL-terminated, basecall_length characters each       */
     size_t basecall_length;
-    flappie_imatrix trace;
-
-    int *pos;
+    flappie_imatrix trace;      /* [nstate x nblock+1] or NULL                           */
+    int *pos;                   /* change positions (unused by the batched driver)       */
     size_t nblock;
 };
 
-/* flappie_structures.c:13-24 */
+/* release the owned members and NULL them (flappie_structures.c:13-24) */
 void free_raw_table(raw_table *tbl);
 void free_raw_basecall_info(struct _raw_basecall_info *ptr);
 

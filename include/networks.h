@@ -19,42 +19,37 @@
 extern "C" {
 #endif
 
-/* networks.h:16 */
+/* a model's single-read network: signal and temperature in, transition score matrix out (networks.h:16) */
 typedef flappie_matrix (*transition_function_ptr)(const raw_table, float);
 
-/* networks.h:18-26 */
+/* Registry slots; numeric values are part of the ABI (networks.h:18-26).  The two *_INVALID entries double as the
+ * counts of flappie and runnie models (networks.h:28-29). */
 enum model_type {
-    FLAPPIE_MODEL_R941_NATIVE = 0,
-    FLAPPIE_MODEL_R941_RNA002,
-    FLAPPIE_MODEL_R941_5mC,
-    FLAPPIE_MODEL_R103_NATIVE,
-    FLAPPIE_MODEL_INVALID,
-    RUNNIE_MODEL_R941_NATIVE,
-    RUNNIE_MODEL_INVALID
+    FLAPPIE_MODEL_R941_NATIVE = 0, FLAPPIE_MODEL_R941_RNA002 = 1, FLAPPIE_MODEL_R941_5mC = 2, FLAPPIE_MODEL_R103_NATIVE = 3,
+    FLAPPIE_MODEL_INVALID = 4,
+    RUNNIE_MODEL_R941_NATIVE = 5,
+    RUNNIE_MODEL_INVALID = 6
 };
-
-/* networks.h:28-29 */
 static const enum model_type flappie_nmodel = FLAPPIE_MODEL_INVALID;
 static const enum model_type runnie_nmodel = (enum model_type)(RUNNIE_MODEL_INVALID - FLAPPIE_MODEL_INVALID);
 
-/* networks.h:31-34 / networks.c:21-105.  Invalid enum values exit via errx(EXIT_FAILURE), as the reference. */
-enum model_type get_flappie_model_type(const char *modelstr);
-const char *flappie_model_string(const enum model_type model);
-const char *flappie_model_description(const enum model_type model);
-transition_function_ptr get_transition_function(const enum model_type model);
+/* name <-> slot (networks.c:21-83); an invalid slot ends the process through errx(EXIT_FAILURE), as the reference */
+enum model_type get_flappie_model_type(const char *name);
+const char *flappie_model_string(enum model_type slot);
+const char *flappie_model_description(enum model_type slot);
 
-/* networks.h:36 / networks.c:108-111.  Returns a host matrix [nstate*(nbase+1) x nblock] owned by the
- * caller (free_flappie_matrix), or NULL if signal.n == 0, signal.raw == NULL (networks.c:540-541),
- * the model file is missing, or the GPU path fails. */
-flappie_matrix calculate_transitions(const raw_table signal, float temperature, enum model_type model);
+/* networks.c:86-111.  calculate_transitions returns a host matrix [nstate*(nbase+1) x nblock] owned by the caller
+ * (free_flappie_matrix), or NULL if read.n == 0, read.raw == NULL (networks.c:540-541), the model file is missing,
+ * or the GPU path fails. */
+transition_function_ptr get_transition_function(enum model_type slot);
+flappie_matrix calculate_transitions(raw_table read, float temperature, enum model_type slot);
 
-/* networks.h:38-42 */
-flappie_matrix flipflop5_transitions_r941native(const raw_table signal, float temperature);
-flappie_matrix flipflop5_transitions_r941rna002(const raw_table signal, float temperature);
-flappie_matrix flipflop_transitions_r941native5mC(const raw_table signal, float temperature);
-flappie_matrix flipflop5_transitions_r103native(const raw_table signal, float temperature);
-/* runnie's run-length model is outside this build: always NULL + warning */
-flappie_matrix runlength5_transitions_r941native(const raw_table signal, float temperature);
+/* the per-model entry points behind get_transition_function (networks.c:725-743) */
+flappie_matrix flipflop5_transitions_r941native(raw_table read, float temperature);       /* LSTM x5, flip-flop head   */
+flappie_matrix flipflop5_transitions_r941rna002(raw_table read, float temperature);
+flappie_matrix flipflop5_transitions_r103native(raw_table read, float temperature);
+flappie_matrix flipflop_transitions_r941native5mC(raw_table read, float temperature);     /* GRUmod x5, 5-base alphabet */
+flappie_matrix runlength5_transitions_r941native(raw_table read, float temperature);      /* LSTM x5, run-length head   */
 
 /* ---- additions ---------------------------------------------------------------------------- */
 struct ffhip_engine;
