@@ -30,6 +30,11 @@ struct _raw_basecall_info {
     size_t nblock;
 };
 
+/* Small accessors used by the batched driver and the engine's argument checks (not in the reference). */
+static inline size_t raw_table_kept(const raw_table *rt) { return (rt && rt->raw && rt->end > rt->start) ? rt->end - rt->start : 0; }
+static inline const float *raw_table_first(const raw_table *rt) { return (rt && rt->raw) ? rt->raw + rt->start : NULL; }
+static inline int raw_table_valid(const raw_table *rt) { return rt && rt->raw && rt->n > 0 && rt->start <= rt->end && rt->end <= rt->n; }
+
 /* release the owned members and NULL them (flappie_structures.c:13-24) */
 void free_raw_table(raw_table *tbl);
 void free_raw_basecall_info(struct _raw_basecall_info *ptr);
