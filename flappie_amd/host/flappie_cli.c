@@ -457,8 +457,10 @@ int main(int argc, char *argv[]) {
     struct ffhip_engine *eng = flappie_hip_engine();
     hid_t hdf5out = open_or_create_hdf5(args.trace);
 
+    const double t_start = now_s();
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
+    const double t_listed = now_s();
     reader_state rs;
     memset(&rs, 0, sizeof(rs));
     rs.fl = &fl;
@@ -472,9 +474,12 @@ int main(int argc, char *argv[]) {
     pthread_t reader;
     if (threaded && 0 != pthread_create(&reader, NULL, reader_main, &rs)) errx(EXIT_FAILURE, "could not start the reader thread");
     size_t done = 0;
+    double t_wait = 0.0;
     for (int k = 0; done < fl.n; k ^= 1) {
+        const double tw0 = now_s();
         if (threaded) sem_wait(&rs.filled[k]);
         else read_chunk(&fl, done, rs.chunk_cap, rs.items[k], &rs.nitem[k]);
+        t_wait += now_s() - tw0;
         flush_chunk(eng, mdl, rs.items[k], rs.nitem[k], hdf5out);
         done += rs.nitem[k];
         if (threaded) sem_post(&rs.empty[k]);
@@ -485,8 +490,11 @@ int main(int argc, char *argv[]) {
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);
     if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
-    if (getenv("FLAPPIE_CLI_TIMING"))
+    if (getenv("FLAPPIE_CLI_TIMING")) {
         for (int k = 0; k < 6; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
+        fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
+                "files listed -> done", now_s() - t_listed);
+    }
     flappie_hip_shutdown();
     return EXIT_SUCCESS;
 }
