@@ -369,8 +369,11 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
         b->plan[l].x0a = (int *)dalloc(b, (size_t)Tout * 4, false);
         b->plan[l].x0b = (int *)dalloc(b, (size_t)Tout * 4, false);
         if (!b->plan[l].x0a || !b->plan[l].x0b) BFAIL();
-        hipMemcpy(b->plan[l].x0a, a.data(), (size_t)Tout * 4, hipMemcpyHostToDevice);
-        hipMemcpy(b->plan[l].x0b, bq.data(), (size_t)Tout * 4, hipMemcpyHostToDevice);
+        if (hipMemcpy(b->plan[l].x0a, a.data(), (size_t)Tout * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b->plan[l].x0b, bq.data(), (size_t)Tout * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            set_err(FFHIP_EHIP, "upload of the convolution window table failed");
+            BFAIL();
+        }
         // input buffer of this conv
         SampleBuf &sb = b->sbuf[l];
         sb.F = m->conv[l].Fin; sb.T = Tin;
