@@ -13,8 +13,10 @@ from flappie_amd import binding as B  # noqa: E402
 from flappie_amd import model as M  # noqa: E402
 
 niter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else M.NET_LSTM5
+hidden = int(sys.argv[3]) if len(sys.argv) > 3 else 384
 eng = B.Engine(0)
-mdl = M.synthetic_model(M.NET_LSTM5, 384, seed=1)
+mdl = M.synthetic_model(kind, hidden, seed=1)
 dm = B.DeviceModel(eng, mdl)
 rng = np.random.default_rng(0)
 probe = rng.standard_normal(3777).astype(np.float32)
@@ -35,7 +37,7 @@ for it in range(niter):
     sigs = [probe if i == slot else rng.standard_normal(int(n)).astype(np.float32) for i, n in enumerate(lens)]
     b.set_signals_ragged(sigs)
     b.run(); b.finish()
-    got = (b.basecall(slot), b.quality(slot), b.transitions(slot).tobytes())
+    got = (b.basecall(slot), b.quality(slot), b.transitions(slot).tobytes(), b.path(slot)[0].tobytes())
     if ref is None:
         ref = got
     assert got == ref, "probe read changed in iteration %d (slot %d, mode %d)" % (it, slot, mode)
