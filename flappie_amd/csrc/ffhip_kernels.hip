@@ -701,6 +701,20 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
 }
 
 
+// ---- lane exchanges inside a row of 16 lanes as DPP moves (a few cycles) instead of ds_bpermute (an LDS-crossbar
+// round trip of ~100 cycles): these sit on the Tb-step dependent chains of the decode kernels.
+//   quad_perm [1,0,3,2] = xor 1, [2,3,0,1] = xor 2; row_shl:4 / row_shr:4 under bank masks = xor 4; row_ror:8 = xor 8
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
+__device__ __forceinline__ int xor1_i(int x) { return dpp_i<0xB1, 0xf>(x, x); }
+__device__ __forceinline__ int xor2_i(int x) { return dpp_i<0x4E, 0xf>(x, x); }
+__device__ __forceinline__ int xor4_i(int x) { return dpp_i<0x114, 0xA>(dpp_i<0x104, 0x5>(x, x), x); }
+__device__ __forceinline__ int xor8_i(int x) { return dpp_i<0x128, 0xf>(x, x); }
+__device__ __forceinline__ float xor1_f(float x) { return __int_as_float(xor1_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor2_f(float x) { return __int_as_float(xor2_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor4_f(float x) { return __int_as_float(xor4_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor8_f(float x) { return __int_as_float(xor8_i(__float_as_int(x))); }
+
 // ---- fast path for nstate == 8 (ACGT models) ---------------------------------------------------
 // Lane l < 40 owns transition entry l: flip entries l = 8*to + from (l < 32), flop entries
 // l = 32 + idx (idx >= 4: stay in flop idx; idx < 4: move flip idx -> flop idx+4).  The source state
@@ -736,11 +750,11 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
             const float s = s_next;
             if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
             const float term = valid ? s + pv : NEG;
-            float m = fmaxf(term, __shfl_xor(term, 4));
-            if (flip) { m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); }
+            float m = fmaxf(term, xor4_f(term));
+            if (flip) { m = fmaxf(m, xor1_f(m)); m = fmaxf(m, xor2_f(m)); }
             float e = valid ? expf(term - m) : 0.0f;
-            e += __shfl_xor(e, 4);
-            if (flip) { e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); }
+            e += xor4_f(e);
+            if (flip) { e += xor1_f(e); e += xor2_f(e); }
             const float val = m + logf(e);
             pv = __shfl(val, ff8_src_lane(st));
             if (lane < ns) F[(size_t)(blk + 1) * kMaxState + lane] = pv;
@@ -760,11 +774,11 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
             const float t2 = valid ? s + pb_to : NEG;
             // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
             const float f5 = __shfl(t2, 32 + st);
-            float m = fmaxf(t2, __shfl_xor(t2, 8));
+            float m = fmaxf(t2, xor8_f(t2));
             m = fmaxf(m, __shfl_xor(m, 16));
             m = fmaxf(m, f5);
             float e = flip ? expf(t2 - m) : 0.0f;
-            e += __shfl_xor(e, 8);
+            e += xor8_f(e);
             e += __shfl_xor(e, 16);
             e += expf(f5 - m);
             const float cur = m + logf(e);
@@ -1018,7 +1032,7 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
         float v = valid ? s + pv : NEG;
         int a = st;
         // flop pair (lanes 32..39): partner = lane ^ 4; stay = idx >= 4
-        const float o4 = __shfl_xor(v, 4);
+        const float o4 = xor4_f(v);
         if (!flip) {
             const bool i_am_stay = (lane & 4) != 0;
             const float stay = i_am_stay ? v : o4, move = i_am_stay ? o4 : v;
@@ -1027,8 +1041,8 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
         } else {
             // flip groups: argmax over from-state, lowest index on ties
             { const int oa = a ^ 4; if (o4 > v || (o4 == v && oa < a)) { v = o4; a = oa; } }
-            { const float ov = __shfl_xor(v, 1); const int oa = __shfl_xor(a, 1); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
-            { const float ov = __shfl_xor(v, 2); const int oa = __shfl_xor(a, 2); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+            { const float ov = xor1_f(v); const int oa = xor1_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+            { const float ov = xor2_f(v); const int oa = xor2_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
         }
         const int src = ff8_src_lane(st);
         pv = __shfl(v, src);
