@@ -503,6 +503,27 @@ void launch_crf_norm(hipStream_t s, float *trans, int nread, int Tb, int nbase, 
     if (subtract) launch_crf_sub(s, trans, logz, nread, Tb, P, Ps, tbs);
 }
 
+// ---- lane exchanges inside a row of 16 lanes as DPP moves (a few cycles) instead of ds_bpermute (an LDS-crossbar
+// round trip of ~100 cycles): these sit on the Tb-step dependent chains of the decode kernels.
+//   quad_perm [1,0,3,2] = xor 1, [2,3,0,1] = xor 2; row_shl:4 / row_shr:4 under bank masks = xor 4; row_ror:8 = xor 8
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
+__device__ __forceinline__ int xor1_i(int x) { return dpp_i<0xB1, 0xf>(x, x); }
+__device__ __forceinline__ int xor2_i(int x) { return dpp_i<0x4E, 0xf>(x, x); }
+__device__ __forceinline__ int xor4_i(int x) { return dpp_i<0x114, 0xA>(dpp_i<0x104, 0x5>(x, x), x); }
+__device__ __forceinline__ int xor8_i(int x) { return dpp_i<0x128, 0xf>(x, x); }
+__device__ __forceinline__ float xor1_f(float x) { return __int_as_float(xor1_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor2_f(float x) { return __int_as_float(xor2_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor4_f(float x) { return __int_as_float(xor4_i(__float_as_int(x))); }
+__device__ __forceinline__ float xor8_f(float x) { return __int_as_float(xor8_i(__float_as_int(x))); }
+
+__device__ __forceinline__ double xor1_d(double x) { return __hiloint2double(xor1_i(__double2hiint(x)), xor1_i(__double2loint(x))); }
+__device__ __forceinline__ double xor2_d(double x) { return __hiloint2double(xor2_i(__double2hiint(x)), xor2_i(__double2loint(x))); }
+__device__ __forceinline__ double xor4_d(double x) { return __hiloint2double(xor4_i(__double2hiint(x)), xor4_i(__double2loint(x))); }
+// lane holding the new value of state s after the grouped reductions of the 8-state kernels: flip state s < 4 in
+// lanes 8s..8s+7, flop state s in lanes 32+s-4 and 32+s
+__device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 + s; }
+
 // ---- CRF partition function, linear-space form (the pipeline's default) -----------------------------
 // The log-space recursion above spends an fp64 exp and log per state per block ON the dependent chain
 // (Tb steps x ~3000 cycles).  The same quantity factorises: with m_t = max_p S[t][p] and
@@ -613,12 +634,87 @@ k_crf_chain(const double *__restrict__ E, int TbS, int P, int Pd, int R, double 
     if (lane == 0) logz_out[blockIdx.x] = logZ;
 }
 
+// nstate = 8 (ACGT): the 40 transitions of a block live one per lane; every lane carries alpha of its source state,
+// the per-destination sums are DPP reductions inside groups of 8 lanes (flip) / pairs (flop), and one gather hands
+// every lane the new alpha of its source.  No LDS on the chain except the staged E values.
+__global__ void __launch_bounds__(64)
+k_crf_chain8(const double *__restrict__ E, int TbS, int Pd, int R, double *__restrict__ logz_out, const int *__restrict__ tbs) {
+    constexpr int P = 40, kMaxPd = 48;
+    __shared__ double ebuf[2][kCrfChunk * kMaxPd];
+    const int lane = threadIdx.x;
+    const bool valid = lane < P;
+    const int gather = ff8_src_lane(lane & 7);
+    const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    const int per_chunk = kCrfChunk * Pd;
+    constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 24 doubles per lane
+    double stage[kStage];
+    const int nchunk = (Tb + kCrfChunk - 1) / kCrfChunk;
+    auto fetch = [&](int c) {
+        const size_t base = (size_t)c * per_chunk, lim = (size_t)Tb * Pd;
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int j = k * 64 + lane;
+            stage[k] = (j < per_chunk && base + j < lim) ? Er[base + j] : 0.0;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int j = k * 64 + lane;
+            if (j < per_chunk) ebuf[buf][j] = stage[k];
+        }
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    double a_src = 1.0, msum = 0.0;
+    long long K = 0;
+    int since = 0;
+    for (int c = 0; c < nchunk; c++) {
+        if (c + 1 < nchunk) fetch(c + 1);
+        const double *eb = ebuf[c & 1];
+        const int t0 = c * kCrfChunk, t1 = min(Tb, t0 + kCrfChunk);
+        double e_next = valid ? eb[lane] : 0.0, m_next = eb[P];
+        for (int t = t0; t < t1; t++) {
+            const double e = e_next, mt = m_next;
+            if (t + 1 < t1) { const double *row = eb + (t + 1 - t0) * Pd; e_next = valid ? row[lane] : 0.0; m_next = row[P]; }
+            const double term = e * a_src;
+            const double pair = term + xor4_d(term);                  // flop destinations: entries b - nbase and b
+            double grp = pair + xor1_d(pair);
+            grp = grp + xor2_d(grp);                                  // flip destinations: all 8 sources
+            const double val = (lane < 32) ? grp : pair;
+            a_src = __shfl(val, gather);
+            msum = msum + mt;
+            if (++since == R || t + 1 == Tb) {
+                since = 0;
+                double mx = fmax(a_src, xor4_d(a_src));               // lanes 0..7 hold alpha of states 0..7
+                mx = fmax(mx, xor1_d(mx));
+                mx = fmax(mx, xor2_d(mx));
+                const int ex = __builtin_amdgcn_readfirstlane((mx > 0.0) ? ilogb(mx) : 0);
+                a_src = ldexp(a_src, -ex);
+                K += ex;
+            }
+        }
+        if (c + 1 < nchunk) commit((c + 1) & 1);
+        __syncthreads();
+    }
+    double total = a_src + xor4_d(a_src);
+    total = total + xor1_d(total);
+    total = total + xor2_d(total);
+    const double logZ = log(total) + 0.693147180559945309417232121458 * (double)K + msum;
+    if (lane == 0) logz_out[blockIdx.x] = logZ;
+}
+
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
                             double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
     const size_t n = (size_t)nread * Tb * Pd;
     hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, E, n, P, Ps, Pd, Tb, tbs);
     const int Rr = R < 1 ? 1 : R;
+    if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
+        hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
+    } else
     switch (2 * nbase) {
 #define CHAIN_CASE(NS) case NS: hipLaunchKernelGGL(k_crf_chain<NS>, dim3(nread), dim3(64), 0, s, E, Tb, P, Pd, Rr, logz, tbs); break;
     CHAIN_CASE(2) CHAIN_CASE(4) CHAIN_CASE(6) CHAIN_CASE(8) CHAIN_CASE(10) CHAIN_CASE(12) CHAIN_CASE(14) CHAIN_CASE(16)
@@ -701,20 +797,6 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
 }
 
 
-// ---- lane exchanges inside a row of 16 lanes as DPP moves (a few cycles) instead of ds_bpermute (an LDS-crossbar
-// round trip of ~100 cycles): these sit on the Tb-step dependent chains of the decode kernels.
-//   quad_perm [1,0,3,2] = xor 1, [2,3,0,1] = xor 2; row_shl:4 / row_shr:4 under bank masks = xor 4; row_ror:8 = xor 8
-template <int CTRL, int BANK>
-__device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
-__device__ __forceinline__ int xor1_i(int x) { return dpp_i<0xB1, 0xf>(x, x); }
-__device__ __forceinline__ int xor2_i(int x) { return dpp_i<0x4E, 0xf>(x, x); }
-__device__ __forceinline__ int xor4_i(int x) { return dpp_i<0x114, 0xA>(dpp_i<0x104, 0x5>(x, x), x); }
-__device__ __forceinline__ int xor8_i(int x) { return dpp_i<0x128, 0xf>(x, x); }
-__device__ __forceinline__ float xor1_f(float x) { return __int_as_float(xor1_i(__float_as_int(x))); }
-__device__ __forceinline__ float xor2_f(float x) { return __int_as_float(xor2_i(__float_as_int(x))); }
-__device__ __forceinline__ float xor4_f(float x) { return __int_as_float(xor4_i(__float_as_int(x))); }
-__device__ __forceinline__ float xor8_f(float x) { return __int_as_float(xor8_i(__float_as_int(x))); }
-
 // ---- fast path for nstate == 8 (ACGT models) ---------------------------------------------------
 // Lane l < 40 owns transition entry l: flip entries l = 8*to + from (l < 32), flop entries
 // l = 32 + idx (idx >= 4: stay in flop idx; idx < 4: move flip idx -> flop idx+4).  The source state
@@ -722,7 +804,6 @@ __device__ __forceinline__ float xor8_f(float x) { return __int_as_float(xor8_i(
 // shuffle on the operand side.  Every per-destination logsumexp is evaluated as max + log(sum exp)
 // with wave butterflies instead of the reference's sequential pairwise chain (decode.c:417-421,
 // :478-482): same value up to fp32 rounding of the association, 7x shorter dependent chain.
-__device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 + s; }
 
 // Workgroup of 4 waves per read: wave 0 runs the forward recursion, wave 1 the backward recursion at the same
 // time (they are independent), then all 256 threads assemble and log-normalise one block each.  Same
