@@ -534,19 +534,32 @@ __device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 +
 // 8x8 sparse mat-vec per block (~250 cycles).  The result differs from the pairwise-logsumexp evaluation by
 // fp64 rounding only (<= 1e-12 relative, checked against the oracle), and is rounded to fp32 after the
 // division by the block count exactly as layers.c:1089 does.
+// One workgroup stages 64 blocks of scores in LDS (coalesced), finds each block's maximum once, then every thread
+// produces exp(S - max) for its share of the 64 x Pd outputs.
+constexpr int kExpBlocks = 64;
 __global__ void __launch_bounds__(256)
-k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t n /*nread*TbS*Pd*/, int P, int Ps, int Pd, int TbS,
+k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t nblk /*nread*TbS*/, int P, int Ps, int Pd, int TbS,
           const int *__restrict__ tbs) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const size_t blk = i / Pd;
-    const int p = (int)(i % Pd);
-    if (p > P) return;
-    if (tbs && (int)(blk % TbS) >= tbs[blk / TbS]) return;
-    const float *S = trans + blk * Ps;
-    float m = S[0];
-    for (int q = 1; q < P; q++) m = fmaxf(m, S[q]);
-    E[i] = (p == P) ? (double)m : exp((double)S[p] - (double)m);
+    __shared__ float sc[kExpBlocks * 64];
+    __shared__ float mx[kExpBlocks];
+    const size_t b0 = (size_t)blockIdx.x * kExpBlocks;
+    const int nb = (int)min((size_t)kExpBlocks, nblk - b0);
+    for (int i = threadIdx.x; i < nb * Ps; i += 256) sc[i] = trans[b0 * Ps + i];
+    __syncthreads();
+    if (threadIdx.x < nb) {
+        const float *S = sc + threadIdx.x * Ps;
+        float m = S[0];
+        for (int q = 1; q < P; q++) m = fmaxf(m, S[q]);
+        mx[threadIdx.x] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * Pd; i += 256) {
+        const int k = i / Pd, p = i % Pd;
+        if (p > P) continue;
+        const size_t blk = b0 + k;
+        if (tbs && (int)(blk % TbS) >= tbs[blk / TbS]) continue;
+        E[blk * Pd + p] = (p == P) ? (double)mx[k] : exp((double)sc[k * Ps + p] - (double)mx[k]);
+    }
 }
 
 // One wave per read.  E is streamed through LDS in chunks of kCrfChunk blocks: the loads of chunk c+1 are
@@ -709,8 +722,8 @@ k_crf_chain8(const double *__restrict__ E, int TbS, int Pd, int R, double *__res
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
                             double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
-    const size_t n = (size_t)nread * Tb * Pd;
-    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, trans, E, n, P, Ps, Pd, Tb, tbs);
+    const size_t nblk = (size_t)nread * Tb;
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs);
     const int Rr = R < 1 ? 1 : R;
     if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
         hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
