@@ -15,8 +15,15 @@
 //   * per step a wave waits for the producers of ITS K slice only, loads that slice of h(t-1)
 //     straight from L2 in B-fragment order (KPW coalesced 1 KiB loads), issues UPC*KPW*4 MFMAs,
 //     and drops its partial tile sums in LDS; after one barrier wave j (j < UPC) adds the four
-//     partials to Xa(t), does the gate math lane-locally (cell state lives in a register for the
-//     whole layer), stores its 4 units x 16 reads of h(t) and publishes a per-unit-tile step counter.
+//     partials (and Xa(t) in k_rnn_persist; in k_lstm_fused the projection Wi x(t) + b was accumulated
+//     by the same MFMA stream from a second set of resident weights), does the gate math lane-locally
+//     (cell state lives in a register for the whole layer) and stores its 4 units x 16 reads of h(t).
+//     The stored values themselves are the hand-off signal (see below): no counters, no flags.
+//
+// Kernels here: k_rnn_persist (recurrence only, behind a separate projection GEMM) and k_lstm_fused
+// (projection + recurrence, the default wherever its 2 x UPC x KPW weight fragments fit two workgroups
+// per CU).  Ragged batches: a read tile runs for the block count of its longest read and lanes force
+// h = c = 0 beyond their own read's end (PersistArgs::tbs / tbt).
 //
 // Two workgroups are resident per CU (<= 256 VGPRs, 24 KiB LDS each): while one waits for its
 // group's hand-off the other one's MFMAs own the matrix pipes, so the hand-off latency is hidden
