@@ -192,40 +192,58 @@ typedef struct {
 
 /* Batch objects own gigabytes of workspace; creating one per group costs more than running it.  Full-size groups
  * (--batch reads) share one cached object whose capacity grows when a longer read turns up. */
-static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache;
+static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache[2];       /* two: one batch runs while the next is set up */
 
-static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, int n, size_t len, int *cached) {
+static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, int n, size_t len, int slot, int *cached) {
     *cached = 0;
     if (n != args.batch) return ffhip_batch_create(eng, mdl, n, len);
-    if (NULL == batch_cache.b || batch_cache.cap < len) {
-        if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
-        batch_cache.cap = len + len / 8;
-        batch_cache.nread = n;
-        batch_cache.b = ffhip_batch_create(eng, mdl, n, batch_cache.cap);
-        if (NULL == batch_cache.b) { batch_cache.cap = 0; return NULL; }
+    if (NULL == batch_cache[slot].b || batch_cache[slot].cap < len) {
+        if (batch_cache[slot].b) ffhip_batch_destroy(batch_cache[slot].b);
+        batch_cache[slot].cap = len + len / 8;
+        batch_cache[slot].nread = n;
+        batch_cache[slot].b = ffhip_batch_create(eng, mdl, n, batch_cache[slot].cap);
+        if (NULL == batch_cache[slot].b) { batch_cache[slot].cap = 0; return NULL; }
     }
     *cached = 1;
-    return batch_cache.b;
+    return batch_cache[slot].b;
 }
 
-/* one batch of equal-length prepared reads through the engine: calculate_post after normalisation (flappie.c:264-316) */
-static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n) {
-    int *idx = calloc(n, sizeof(int));
-    for (int i = 0; i < n; i++) idx[i] = its[i]->prepared;
+/* A group of prepared reads in flight: submitted (upload + network + decode enqueued on the batch's stream), collected
+ * later (flappie.c:264-316 after normalisation) -- so the host side of the next group overlaps the GPU side of this one. */
+typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_prep *prep; } pending_batch;
+
+static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, int slot) {
+    pending_batch pb = { NULL, 0, n, calloc(n, sizeof(int)), malloc(n * sizeof(item *)), prep };
+    memcpy(pb.its, its, n * sizeof(item *));
+    for (int i = 0; i < n; i++) pb.idx[i] = its[i]->prepared;
     size_t len = 0;                                          /* capacity = the longest read of the (sorted) group */
     for (int i = 0; i < n; i++) {
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
         if (li > len) len = li;
     }
     double t0 = now_s();
-    int cached = 0;
-    ffhip_batch *b = acquire_batch(eng, mdl, n, len, &cached);
+    pb.b = acquire_batch(eng, mdl, n, len, slot, &pb.cached);
     t_phase[2] += now_s() - t0; t0 = now_s();
-    unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
-    if (NULL == b || 0 != ffhip_batch_set_prepared(b, prep, idx) || 0 != ffhip_batch_run(b, args.temperature, flags) || 0 != ffhip_batch_finish(b)) {
+    const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
+    if (NULL == pb.b || 0 != ffhip_batch_set_prepared(pb.b, prep, pb.idx) || 0 != ffhip_batch_run(pb.b, args.temperature, flags)) {
         warnx("%s", ffhip_last_error());
-        if (b && !cached) ffhip_batch_destroy(b);
-        free(idx);
+        if (pb.b && !pb.cached) ffhip_batch_destroy(pb.b);
+        pb.b = NULL;
+    }
+    t_phase[3] += now_s() - t0;
+    return pb;
+}
+
+static void collect_batch(const struct ffhip_model *mdl, pending_batch *pb) {
+    ffhip_batch *b = pb->b;
+    item **its = pb->its;
+    const int n = pb->n, cached = pb->cached, *idx = pb->idx;
+    const ffhip_prep *prep = pb->prep;
+    double t0 = now_s();
+    if (NULL == b || 0 != ffhip_batch_finish(b)) {
+        if (b) { warnx("%s", ffhip_last_error()); if (!cached) ffhip_batch_destroy(b); }
+        free(pb->idx); free(pb->its);
+        pb->b = NULL;
         return;
     }
     t_phase[3] += now_s() - t0; t0 = now_s();
@@ -265,7 +283,8 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         t_phase[4] += now_s() - t0; t0 = now_s();
         if (!cached) ffhip_batch_destroy(b);
         t_phase[2] += now_s() - t0;
-        free(idx);
+        free(pb->idx); free(pb->its);
+        pb->b = NULL;
         return;
     }
 #endif
@@ -300,7 +319,8 @@ static void call_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     t_phase[4] += now_s() - t0; t0 = now_s();
     if (!cached) ffhip_batch_destroy(b);
     t_phase[2] += now_s() - t0;
-    free(idx);
+    free(pb->idx); free(pb->its);
+    pb->b = NULL;
 }
 
 static int by_length_desc(const void *x, const void *y) {
@@ -337,13 +357,20 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         int m2 = 0;
         for (int i = 0; i < n; i++) if (items[i].prepared >= 0) group[m2++] = &items[i];
         qsort(group, m2, sizeof(item *), by_length_desc);
+        pending_batch prev = { NULL, 0, 0, NULL, NULL, NULL };
+        int have_prev = 0, slot = 0;
         for (int i = 0; i < m2; ) {
             const size_t longest = group[i]->res.rt.end - group[i]->res.rt.start;
             int g = 1;
             while (i + g < m2 && g < args.batch && 4 * (group[i + g]->res.rt.end - group[i + g]->res.rt.start) >= 3 * longest) g++;
-            call_batch(eng, mdl, prep, group + i, g);
+            pending_batch cur = submit_batch(eng, mdl, prep, group + i, g, slot);
+            if (have_prev) collect_batch(mdl, &prev);
+            prev = cur;
+            have_prev = 1;
+            slot ^= 1;
             i += g;
         }
+        if (have_prev) collect_batch(mdl, &prev);
     }
     const double to0 = now_s();
     for (int i = 0; i < n; i++) {
@@ -489,7 +516,7 @@ int main(int argc, char *argv[]) {
     free(fl.path);
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);
-    if (batch_cache.b) ffhip_batch_destroy(batch_cache.b);
+    for (int k = 0; k < 2; k++) if (batch_cache[k].b) ffhip_batch_destroy(batch_cache[k].b);
     if (getenv("FLAPPIE_CLI_TIMING")) {
         for (int k = 0; k < 6; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
         fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
