@@ -438,8 +438,8 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
     const ffhip_model *m = b->mdl;
     bool uniform = true;
     for (int r = 0; r < b->nread; r++) {
-        if (lens[r] <= 0 || lens[r] > b->T) return set_err(FFHIP_EINVAL, "read %d: %d samples, the batch takes 1..%d", r, lens[r], b->T);
-        uniform = uniform && lens[r] == b->T;
+        if (lens[r] < 0 || lens[r] > b->T) return set_err(FFHIP_EINVAL, "read %d: %d samples, the batch takes up to %d", r, lens[r], b->T);
+        uniform = uniform && lens[r] == b->T;          // 0 = an empty slot: no work, no results
     }
     b->hT = lens;
     if (uniform) { b->ragged = false; b->hTb.assign(b->nread, b->Tb); return FFHIP_OK; }
@@ -451,7 +451,7 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
             if (!b->rag_tin[l] && !(b->rag_tin[l] = (int *)dalloc(b, (size_t)b->Bp * 4, true))) return FFHIP_ENOMEM;
             std::vector<int> tin(b->Bp, 0);
             for (int r = 0; r < b->nread; r++) {
-                if (cur[r] < m->conv[l].winlen)
+                if (cur[r] != 0 && cur[r] < m->conv[l].winlen)
                     return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", r, cur[r], l, m->conv[l].winlen);
                 tin[r] = cur[r];
             }
@@ -467,6 +467,7 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
         std::vector<int> ta(n, kZeroCol), tq(n, kZeroCol);
         std::map<int, std::pair<std::vector<int>, std::vector<int>>> cache;
         for (int r = 0; r < b->nread; r++) {
+            if (cur[r] == 0) continue;                                 // empty slot: its row stays all kZeroCol
             auto it = cache.find(cur[r]);
             if (it == cache.end()) {
                 std::vector<int> a, bq;
@@ -529,8 +530,9 @@ extern "C" int ffhip_batch_set_signals_ragged(ffhip_batch *b, const float *signa
     if (int rc = clear_signals(b)) return rc;
     SampleBuf &sb = b->sbuf[0];
     for (int r = 0; r < b->nread; r++)
-        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), signals + (size_t)r * ld, (size_t)lens[r] * 4,
-                               hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        if (lens[r] > 0)
+            HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), signals + (size_t)r * ld, (size_t)lens[r] * 4,
+                                   hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     b->ran = b->finished = 0;
     return FFHIP_OK;
@@ -565,6 +567,7 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
     std::vector<const float *> src(b->nread);
     for (int r = 0; r < b->nread; r++) {
         size_t len = 0;
+        if (reads[r] < 0) { src[r] = nullptr; lens[r] = 0; continue; }            // empty slot
         src[r] = prep_device_signal(prep, reads[r], &len);
         if (!src[r] || len > (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: rejected by trimming, or longer than the batch's %d samples", reads[r], b->T);
         lens[r] = (int)len;
@@ -573,7 +576,8 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
     if (b->ragged) if (int rc = clear_signals(b)) return rc;
     SampleBuf &sb = b->sbuf[0];
     for (int r = 0; r < b->nread; r++)
-        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src[r], (size_t)lens[r] * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
+        if (lens[r] > 0)
+            HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src[r], (size_t)lens[r] * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     b->ran = b->finished = 0;
     return FFHIP_OK;
@@ -747,6 +751,7 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
 
 static bool results_ok(const ffhip_batch *b, int read) {
     if (!b || !b->finished || read < 0 || read >= b->nread) { set_err(FFHIP_EINVAL, "results not available (finish the batch, check the read index)"); return false; }
+    if (b->hTb[read] == 0) { set_err(FFHIP_EINVAL, "slot %d of the batch is empty", read); return false; }
     return true;
 }
 

@@ -102,6 +102,7 @@ k_rnn_persist(PersistArgs a) {
     }
     const int rt = a.rt0 + g;
     const int Tb = a.tbt ? a.tbt[rt] : a.Tb;                     // steps of this read tile
+    if (Tb <= 0) return;                                         // a tile of empty slots (uniform for the whole group)
     const int my_tb = a.tbs ? a.tbs[rt * 16 + (threadIdx.x & 15)] : a.Tb;      // blocks of the read this lane does gate math for
     const int ut0 = m * UPC;
     if (threadIdx.x == 0) lds_abort = 0;
@@ -326,6 +327,7 @@ k_lstm_fused(PersistArgs a) {
     }
     const int rt = a.rt0 + g;
     const int Tb = a.tbt ? a.tbt[rt] : a.Tb;                     // steps of this read tile
+    if (Tb <= 0) return;                                         // a tile of empty slots (uniform for the whole group)
     const int my_tb = a.tbs ? a.tbs[rt * 16 + (threadIdx.x & 15)] : a.Tb;      // blocks of the read this lane does gate math for
     const int ut0 = m * UPC;
     if (threadIdx.x == 0) lds_abort = 0;

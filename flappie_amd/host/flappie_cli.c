@@ -194,17 +194,21 @@ typedef struct {
  * (--batch reads) share one cached object whose capacity grows when a longer read turns up. */
 static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache[2];       /* two: one batch runs while the next is set up */
 
-static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, int n, size_t len, int slot, int *cached) {
+/* *nslot = reads the returned batch was created for: args.batch for the cached objects (groups of at least a quarter of
+ * that are padded with empty slots), the group's own size for small groups */
+static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, int n, size_t len, int slot, int *cached, int *nslot) {
     *cached = 0;
-    if (n != args.batch) return ffhip_batch_create(eng, mdl, n, len);
+    *nslot = n;
+    if (4 * n < args.batch) return ffhip_batch_create(eng, mdl, n, len);
     if (NULL == batch_cache[slot].b || batch_cache[slot].cap < len) {
         if (batch_cache[slot].b) ffhip_batch_destroy(batch_cache[slot].b);
         batch_cache[slot].cap = len + len / 8;
-        batch_cache[slot].nread = n;
-        batch_cache[slot].b = ffhip_batch_create(eng, mdl, n, batch_cache[slot].cap);
+        batch_cache[slot].nread = args.batch;
+        batch_cache[slot].b = ffhip_batch_create(eng, mdl, args.batch, batch_cache[slot].cap);
         if (NULL == batch_cache[slot].b) { batch_cache[slot].cap = 0; return NULL; }
     }
     *cached = 1;
+    *nslot = args.batch;
     return batch_cache[slot].b;
 }
 
@@ -213,16 +217,19 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
 typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_prep *prep; } pending_batch;
 
 static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, int slot) {
-    pending_batch pb = { NULL, 0, n, calloc(n, sizeof(int)), malloc(n * sizeof(item *)), prep };
+    const int nmax = (n > args.batch) ? n : args.batch;
+    pending_batch pb = { NULL, 0, n, malloc(nmax * sizeof(int)), malloc(n * sizeof(item *)), prep };
     memcpy(pb.its, its, n * sizeof(item *));
-    for (int i = 0; i < n; i++) pb.idx[i] = its[i]->prepared;
+    for (int i = 0; i < nmax; i++) pb.idx[i] = (i < n) ? its[i]->prepared : -1;             /* -1: empty slot */
     size_t len = 0;                                          /* capacity = the longest read of the (sorted) group */
     for (int i = 0; i < n; i++) {
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
         if (li > len) len = li;
     }
     double t0 = now_s();
-    pb.b = acquire_batch(eng, mdl, n, len, slot, &pb.cached);
+    int nslot = n;
+    pb.b = acquire_batch(eng, mdl, n, len, slot, &pb.cached, &nslot);
+    (void)nslot;
     t_phase[2] += now_s() - t0; t0 = now_s();
     const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
     if (NULL == pb.b || 0 != ffhip_batch_set_prepared(pb.b, prep, pb.idx) || 0 != ffhip_batch_run(pb.b, args.temperature, flags)) {

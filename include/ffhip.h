@@ -106,7 +106,8 @@ size_t ffhip_batch_nblock(const ffhip_batch *b);
 int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads);
 /* same from a packed host array signals[nread][ld], all reads nsample long */
 int ffhip_batch_set_signals(ffhip_batch *b, const float *signals, size_t ld);
-/* same, read r uses the first nsample[r] <= capacity samples of its row */
+/* same, read r uses the first nsample[r] <= capacity samples of its row; nsample[r] == 0 leaves slot r empty
+ * (no work, no results) so that one batch object can serve groups of fewer reads */
 int ffhip_batch_set_signals_ragged(ffhip_batch *b, const float *signals, size_t ld, const size_t *nsample);
 /* blocks of one read of the batch (ffhip_batch_nblock is the capacity's); sizes of that read's results:
  * path/qpath nblock+1, transitions/posterior nblock x nparam, trace (nblock+1) x nstate */
@@ -212,7 +213,7 @@ void ffhip_prep_destroy(ffhip_prep *p);
 int ffhip_prep_range(const ffhip_prep *p, int read, size_t *start, size_t *end);
 int ffhip_prep_stats(const ffhip_prep *p, int read, float *median, float *mad);      /* MEDMAD mode */
 int ffhip_prep_get_signal(const ffhip_prep *p, int read, float *out /* end-start floats */);
-int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep; lengths <= capacity */);
+int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep (-1 = empty slot); lengths <= capacity */);
 /* quantilef (util.c:100-139): p[] in, quantiles out */
 int ffhip_quantiles(ffhip_engine *eng, const float *x, size_t n, float *p, size_t np);
 /* difference_array / shift_scale_array / both (FFHIP_PREP_DELTA) on one host array, in place */

@@ -129,3 +129,26 @@ def test_ragged_runlength_and_prepared(B, engine):
         ref = om.basecall(oracle_prep(raws[i])[2])
         assert b.basecall(k) == ref["basecall"] and b.quality(k) == ref["quality"]
     b.close(); p.close(); dm.close()
+
+
+def test_empty_slots(B, engine):
+    """slots left empty (length 0 / prepared index -1) cost nothing and leave the other reads' results untouched: one
+    batch object serves groups of any size up to its own"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=11)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(2)
+    nslot = 40                                                   # three read tiles, the last two mostly / wholly empty
+    lens = [900, 0, 650, 0, 0, 901] + [0] * 12 + [333] + [0] * 21
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    b = B.Batch(dm, nslot, 1000)
+    b.set_signals_ragged(sigs)
+    b.run(); b.finish()
+    for r, x in enumerate(sigs):
+        if x.size:
+            check_read(b, r, om.basecall(x))
+        else:
+            assert b.read_nblock(r) == 0
+            with pytest.raises(B.FFHipError):
+                b.transitions(r)
+    b.close(); dm.close()
