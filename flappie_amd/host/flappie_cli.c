@@ -476,7 +476,8 @@ static void *reader_main(void *arg) {
     size_t first = 0;
     for (int k = 0; first < rs->fl->n; k ^= 1) {
         sem_wait(&rs->empty[k]);
-        read_chunk(rs->fl, first, rs->chunk_cap, rs->items[k], &rs->nitem[k]);
+        /* the first chunk is one batch only, so that the GPU starts after --batch files instead of four times as many */
+        read_chunk(rs->fl, first, first == 0 ? rs->chunk_cap / 4 : rs->chunk_cap, rs->items[k], &rs->nitem[k]);
         first += rs->nitem[k];
         sem_post(&rs->filled[k]);
     }
@@ -512,7 +513,7 @@ int main(int argc, char *argv[]) {
     for (int k = 0; done < fl.n; k ^= 1) {
         const double tw0 = now_s();
         if (threaded) sem_wait(&rs.filled[k]);
-        else read_chunk(&fl, done, rs.chunk_cap, rs.items[k], &rs.nitem[k]);
+        else read_chunk(&fl, done, done == 0 ? rs.chunk_cap / 4 : rs.chunk_cap, rs.items[k], &rs.nitem[k]);
         t_wait += now_s() - tw0;
         flush_chunk(eng, mdl, rs.items[k], rs.nitem[k], hdf5out);
         done += rs.nitem[k];
