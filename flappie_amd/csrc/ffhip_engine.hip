@@ -93,6 +93,7 @@ struct RnnDev {
     float4 *iWp = nullptr, *sWp = nullptr;
     float *bias = nullptr;      // [4*Hp] permuted rows
     int Kin16 = 0;
+    void *Wsplit = nullptr;     // both matrices as three bf16 slices in MFMA 16x16x32 A order (ffhip_rnn_split.hip), or nullptr
 };
 
 struct ffhip_model {
@@ -214,6 +215,28 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
         r.sWp = (float4 *)dev_upload(m, sp.data(), sp.size() * 4);
         r.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
         if (!r.iWp || !r.sWp || !r.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        if (split_supported(m->cell, Hp) && H == Hp) {
+            // W = w0 + w1 + w2 exactly, each a bf16 (round to nearest even): [mat][ut][k/32][slice][lane][8]
+            const int Ut = Hp / 4, Hc = Hp / 32;
+            std::vector<uint16_t> sp3((size_t)2 * Ut * Hc * 3 * 64 * 8);
+            auto rne = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+            auto val = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            for (int mat = 0; mat < 2; mat++)
+                for (int ut = 0; ut < Ut; ut++)
+                    for (int c = 0; c < Hc; c++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int e = 0; e < 8; e++) {
+                                const float w = rowcol(mat == 0 ? iW : sW, ut * 16 + (lane & 15), c * 32 + (lane >> 4) * 8 + e);
+                                const uint16_t b0 = rne(w);
+                                const float r1 = w - val(b0);
+                                const uint16_t b1 = rne(r1);
+                                const uint16_t b2 = rne(r1 - val(b1));
+                                const size_t base = ((((size_t)mat * Ut + ut) * Hc + c) * 3) * 64 * 8 + (size_t)lane * 8 + e;
+                                sp3[base] = b0; sp3[base + 64 * 8] = b1; sp3[base + 2 * 64 * 8] = b2;
+                            }
+            r.Wsplit = dev_upload(m, sp3.data(), sp3.size() * 2);
+            if (!r.Wsplit) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        }
     }
 
     // ---- output layer
@@ -270,6 +293,7 @@ struct ffhip_batch {
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
     SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
     float *act[2] = { nullptr, nullptr };
+    void *actS[2] = { nullptr, nullptr };      // the same two buffers in the split-bf16 layout (ffhip_rnn_split.hip), allocated on first use
     float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     float *xa = nullptr, *cstate = nullptr;
     float *trans = nullptr, *post = nullptr, *fwd = nullptr;
@@ -629,12 +653,47 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
+    // split-bf16 layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM, H = 128/256/384)
+    const bool use_split = use_persist && use_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+                           split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
+    if (use_split) {
+        const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
+        for (int i = 0; i < 2; i++)
+            if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
+        launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp);
+        b->launches[0]++;
+    }
     for (int l = 0; l < 5; l++) {
         const RnnDev &r = m->rnn[l];
         const bool backward = (l % 2 == 0);
         float *in = b->act[cur], *out = b->act[cur ^ 1];
         const bool fuse = use_persist && use_fused;
         if (prof) hipEventRecord(b->lev[l][0], s);
+        if (use_split) {
+            if (prof) hipEventRecord(b->lev[l][1], s);
+            const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
+            void *outS = b->actS[cur ^ 1];
+            // the output doubles as the hand-off flag: pre-fill with the sentinel (two bf16 NaNs per dword)
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)outS, (int)0xFFFFFFFF, split_bytes((size_t)Tb * B16, Hp) / 4, s), FFHIP_EHIP);
+            // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
+            float *out_f32 = (l == 4 || keep) ? out : nullptr;
+            for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
+                const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
+                HIP_TRY(hipMemsetAsync(b->pflags, 0, split_flag_words(nrt) * sizeof(unsigned), s), FFHIP_EHIP);
+                // one workgroup per CU: two such launches are co-resident only if together they need no more CUs than there are
+                const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
+                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (!launch_lstm_split(s, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
+                                       backward, persist_mode, tbs, tbt))
+                    return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
+                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
+                b->launches[2]++;
+            }
+            if (prof) hipEventRecord(b->lev[l][2], s);
+            cur ^= 1;
+            if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
+            continue;
+        }
         if (!fuse) {
             if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
             launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);

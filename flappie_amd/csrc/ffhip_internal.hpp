@@ -79,6 +79,18 @@ bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 
                        const int *tbs = nullptr, const int *tbt = nullptr);
 int persist_blocks_per_cu(int kind, int H);
 
+// persistent LSTM layer on bf16 MFMAs over three-way split operands (ffhip_rnn_split.hip): fp32-exact products at 2.7x
+// the f32 MFMA rate.  Activations in the SPLIT layout A[t][rt][k/32][slice 0..2][lane][8 bf16] (6 bytes per value).
+bool split_supported(int kind, int H);
+int split_max_tiles(int ncu);                              // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU
+size_t split_flag_words(int nrt);
+inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 96; }      // 16 reads x H x 6 B
+bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                       const int *tbs = nullptr, const int *tbt = nullptr);
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H);      // tile-interleaved fp32 -> split
+void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H);
+
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw = 0);      // raw = 1: W^T h + b only

@@ -1,0 +1,418 @@
+// ffhip_rnn_split.hip -- persistent LSTM layer on the bf16 matrix pipes with fp32-exact products.
+//
+// Same layer as k_lstm_fused (ffhip_rnn_persist.hip; lstm_forward/lstm_backward + lstm_step, layers.c:877-1026)
+// but the two GEMMs of a step, Wi x(t) and sW h(t-1), run as bf16 MFMAs over a three-way split of BOTH operands:
+//
+//     v = v0 + v1 + v2,   v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1)      (round to nearest even)
+//
+// The split is EXACT for every fp32 value (8 + 8 + 8 mantissa bits), each bf16 x bf16 product is exact in
+// fp32, and the six products kept -- w0x0, w0x1, w1x0, w1x1, w0x2, w2x0 -- cover every term down to 2^-24 of
+// the largest one: the three that are dropped (w1x2, w2x1, w2x2) are below the rounding of an fp32 product.
+// Measured on K = 768 dot products of this network's magnitudes: max error against fp64 9.4e-7 for the six-term
+// form, 3.4e-6 for a plain fp32 GEMM -- the accumulation rounding is the same fp32
+// rounding either way, the products are better than fp32's.  Six `v_mfma_f32_16x16x32_bf16` (16 cycles each,
+// 16 reads x 16 rows x 32 k) replace eight `v_mfma_f32_16x16x4_f32` (32 cycles each): 2.67x the rate.
+//
+// Activations travel between layers ALREADY SPLIT, so that the split is computed once by the lane that produces
+// a value and not by each of its 32 consumers:
+//
+//   split layout   A[t][rt][c = k/32][s = 0..2][lane 0..63] 16 B      (H*6 bytes per read and block)
+//                  lane l = (kq = l>>4, r = l&15) holds slice s of k = 32c + 8kq + 0..7 of read r: exactly the
+//                  B operand of v_mfma_f32_16x16x32_bf16, one 1 KiB coalesced load per (chunk, slice).
+//   weights        W[mat][ut][c][s][lane] 16 B: A operand, lane l = (row i = l&15 of unit tile ut, kq) holds slice s
+//                  of W[16ut + i][32c + 8kq + 0..7]; rows unit-major/gate-minor as everywhere else.
+//
+// Work decomposition (H = 128 N, N = 1..3; H = 384 is the headline shape):
+//   * one GROUP of 32 workgroups per PAIR of read tiles (32 reads); 256 CUs = 8 groups = 256 reads per launch, one
+//     workgroup of 8 waves per CU (the weights of a CU, 48 rows x 768 k x 6 B = 221 KiB, live in VGPRs: 108 per
+//     lane).  Member m owns N unit tiles (4N hidden units x 4 gates);
+//   * waves 0-3 ("x waves") hold the input weights of the member's rows, K split four ways, and compute the
+//     projection Wi x(t+1) one step AHEAD, under the hand-off latency of step t;
+//     waves 4-7 ("h waves") hold the recurrent weights, poll their K slice of h(t-1) and compute sW h(t-1);
+//   * partial tiles meet in LDS; six of the eight waves then do the gate math of one 16 x 16 tile each (4 gates of
+//     one unit of one read per lane, cell state in a register), split h(t) and store it.
+//   * hand-off: the payload is the flag, as in ffhip_rnn_persist.hip: the output is pre-filled with 0xFFFFFFFF
+//     (two bf16 NaNs -- never a pair of slices of a finite value) and consumers re-sweep until no dword is the
+//     sentinel; plain stores when the 32 members verifiably share one XCD (= one L2), write-through otherwise.
+//   * a second barrier closes the gate phase so that no x wave starts its MFMAs next to a gate wave on the same
+//     SIMD (a dependent VALU chain beside a saturated MFMA stream runs ~3x slower).
+#include "ffhip_internal.hpp"
+#include "ffhip_math.hpp"
+#include <stdlib.h>
+
+namespace ffhip {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+struct SplitArgs {
+    const v4u *Wp;            // [2][Ut][Hc][3][64] 16 B; mat 0 = input weights, 1 = recurrent weights
+    const float *bias;        // [16*Ut] permuted (4u + g)
+    const unsigned char *xin; // layer input, split layout
+    unsigned char *hout;      // layer output, split layout, pre-filled with the sentinel
+    float *hout_f32;          // optional fp32 tile-interleaved copy of the output (for the CRF head), or nullptr
+    unsigned *flags;          // [ngroup][32] XCC ids (zeroed before launch)
+    unsigned *abort_word;
+    int Tb, B16, H, rt0, nrt, backward, mode;
+    const int *tbs, *tbt;     // ragged batch (see PersistArgs)
+    unsigned long long *dbg;
+};
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned kSplitSentinel = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned bf16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
+
+// three-way split of 4 values; returns the packed slice `which` (0..2) as two dwords
+__device__ __forceinline__ v2u split4(v4f v, int which) {
+    unsigned s[4];
+    const float f[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const unsigned b0 = bf16_bits(f[e]);
+        const float r1 = f[e] - bf16_val(b0);
+        const unsigned b1 = bf16_bits(r1);
+        const float r2 = r1 - bf16_val(b1);
+        const unsigned b2 = bf16_bits(r2);
+        s[e] = which == 0 ? b0 : (which == 1 ? b1 : b2);
+    }
+    return (v2u){ s[0] | (s[1] << 16), s[2] | (s[3] << 16) };
+}
+
+__device__ __forceinline__ v4f mm(v4u a, v4u b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+
+// the six kept products of one (row tile, chunk): smallest terms first
+__device__ __forceinline__ v4f mm6(const v4u (&w)[3], const v4u (&x)[3], v4f c) {
+    c = mm(w[2], x[0], c);
+    c = mm(w[0], x[2], c);
+    c = mm(w[1], x[1], c);
+    c = mm(w[1], x[0], c);
+    c = mm(w[0], x[1], c);
+    c = mm(w[0], x[0], c);
+    return c;
+}
+
+template <int N>
+__global__ void __launch_bounds__(512, 1)
+k_lstm_split(SplitArgs a) {
+    __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
+    __shared__ v4f ph[4][2][N][64];         // recurrent partials
+    __shared__ int lds_abort;
+    __shared__ int lds_fast;
+    constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
+    constexpr size_t tileB = (size_t)Hc * 3 * 1024;      // bytes of one (t, read tile) in the split layout
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool xw = wave < 4;
+    const int kw = wave & 3;
+    const int ngroup = (a.nrt + 1) >> 1;
+    int g, m;
+    {
+        const int b = blockIdx.x;
+        if ((ngroup & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
+        else { g = b / G; m = b % G; }
+    }
+    const int rtA = a.rt0 + 2 * g;
+    const bool haveB = (2 * g + 1 < a.nrt);
+    const int TbA = a.tbt ? a.tbt[rtA] : a.Tb;
+    const int TbB = haveB ? (a.tbt ? a.tbt[rtA + 1] : a.Tb) : 0;
+    const int Tb = TbA > TbB ? TbA : TbB;                 // steps of this pair of read tiles
+    if (Tb <= 0) return;                                  // empty slots only (uniform for the whole group)
+    const int ntl = (TbB > 0) ? 2 : 1;
+    const int ut0 = m * N;
+    if (threadIdx.x == 0) lds_abort = 0;
+    if (threadIdx.x < 64) {
+        int fast_l = 0;
+        if (a.mode == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc = (xcc & 0xfu) + 1u;
+            unsigned *ids = a.flags + (size_t)g * G;
+            if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
+            unsigned v = xcc;
+            for (unsigned spin = 0; spin < 2000000u; spin++) {
+                v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
+                if (__all(v != 0u)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            fast_l = __all(v == xcc) ? 1 : 0;
+        }
+        if (lane == 0) lds_fast = fast_l;
+    }
+    // resident weights of this wave: rows of my N unit tiles, chunks kw*N .. kw*N+N-1, three slices
+    v4u wf[N][N][3];
+    {
+        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * Ut * Hc * 3 * 64;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+#pragma unroll
+            for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                for (int s = 0; s < 3; s++)
+                    wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + (kw * N + cc)) * 3 + s) * 64 + lane];
+    }
+    // gate role: wave gt < ntl*N does tile (ts = gt / N of the pair, unit tile j = gt % N)
+    const int gts = wave / N, gj = wave % N;
+    const bool gate_wave = wave < ntl * N;
+    const int q = lane >> 4, rl = lane & 15;
+    v4f bias = { 0.f, 0.f, 0.f, 0.f };
+    int my_tb = 0;
+    if (gate_wave) {
+        bias = *(const v4f *)(a.bias + (size_t)(ut0 + gj) * 16 + q * 4);
+        my_tb = a.tbs ? a.tbs[(rtA + gts) * 16 + rl] : a.Tb;
+    }
+    float c = 0.0f;
+    __syncthreads();
+    const bool fast = lds_fast != 0;
+    if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
+    auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
+
+    // ---- the gate phase of step i (layers.c:1005-1025 on one 16 x 16 tile per wave), between its two barriers
+    auto gate_phase = [&](int i) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (lds_abort) return false;
+        if (gate_wave) {
+            const int t = step_t(i);
+            v4f s = bias;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) s = s + px[i & 1][w2][gts][gj][lane];
+            if (i > 0) {
+#pragma unroll
+                for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            }
+            const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+            const float tanh_g = (L.z + L.z) - 1.0f;
+            const float forget = L.y * c;
+            const float update = L.x * tanh_g;
+            c = forget + update;
+            float h = L.w * tanh_ref(c);
+            if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
+            v4f hv;
+            hv.x = __shfl(h, rl);
+            hv.y = __shfl(h, rl + 16);
+            hv.z = __shfl(h, rl + 32);
+            hv.w = __shfl(h, rl + 48);
+            // quarter-wave q stores slice q of the 4 units of read rl: 8 bytes at k = 4*ut .. 4*ut+3
+            const int ut = ut0 + gj;
+            const v2u sl = split4(hv, q);
+            const unsigned off = (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8);
+            unsigned char *tp_out = a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB;
+            if (q < 3) {
+                if (fast) *(v2u *)(tp_out + off) = sl;
+                else {
+                    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tp_out, 0, (int)tileB, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b64(sl, wr, off, 0, 16 /*sc1*/);
+                }
+            } else if (a.hout_f32) {
+                *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
+            }
+        }
+        // close the gate phase before the next step's MFMAs start (and before px / ph are rewritten)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        return true;
+    };
+
+    // The two roles run their own copy of the step loop (same barrier count per step), so that the register allocator
+    // sees each role's live ranges alone: an x wave keeps x(step i+1) in flight across the gate phase, an h wave keeps
+    // nothing but its weights.
+    if (xw) {
+        // ---- x waves: projection of step i+1 under the hand-off latency of step i
+        v4u xb[2][N][3];
+        auto load_x = [&](int i) {
+            const int t = step_t(i);
+#pragma unroll
+            for (int ts = 0; ts < 2; ts++) {
+                if (ts >= ntl) continue;
+                const v4u *p = (const v4u *)(tile_ptr(a.xin, t, ts) + lane_off);
+#pragma unroll
+                for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                    for (int s = 0; s < 3; s++) xb[ts][cc][s] = p[((kw * N + cc) * 3 + s) * 64];
+            }
+        };
+        auto project = [&](int i) {           // xb holds x(step i): partial Wi x -> px[i & 1]
+#pragma unroll
+            for (int ts = 0; ts < 2; ts++) {
+                if (ts >= ntl) continue;
+                v4f acc[N];
+#pragma unroll
+                for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                    for (int j = 0; j < N; j++) acc[j] = mm6(wf[j][cc], xb[ts][cc], acc[j]);
+#pragma unroll
+                for (int j = 0; j < N; j++) px[i & 1][kw][ts][j][lane] = acc[j];
+            }
+        };
+        load_x(0);
+        project(0);
+        if (Tb > 1) load_x(1);
+        for (int i = 0; i < Tb; i++) {
+            if (i + 1 < Tb) {
+                project(i + 1);
+                if (i + 2 < Tb) load_x(i + 2);
+            }
+            if (!gate_phase(i)) return;
+        }
+    } else {
+        // ---- h waves: sweep my K slice of h(step i-1) until every dword has been published, then sW h
+        for (int i = 0; i < Tb; i++) {
+            if (i > 0) {
+                const int tp = step_t(i - 1);
+                __amdgpu_buffer_rsrc_t rs[2];
+#pragma unroll
+                for (int ts = 0; ts < 2; ts++)
+                    rs[ts] = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.hout, tp, ts < ntl ? ts : 0), 0, (int)tileB, 0x00020000);
+                v4u raw[2][N][3];
+                auto sweep = [&]() {
+#pragma unroll
+                    for (int ts = 0; ts < 2; ts++) {
+                        if (ts >= ntl) continue;
+#pragma unroll
+                        for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                            for (int s = 0; s < 3; s++)
+                                raw[ts][cc][s] = __builtin_amdgcn_raw_buffer_load_b128(rs[ts], (((kw * N + cc) * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                    }
+                };
+                sweep();
+                bool timed_out = false;
+                for (unsigned spin = 0;; spin++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int ts = 0; ts < 2; ts++) {
+                        if (ts >= ntl) continue;
+#pragma unroll
+                        for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                            for (int s = 0; s < 3; s++) {
+                                const v4u r = raw[ts][cc][s];
+                                ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
+                            }
+                    }
+                    if (__all(ok)) break;
+                    if (spin > 3000000u || (spin & 255u) == 255u) {
+                        const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                        if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    sweep();
+                }
+                if (timed_out) {
+                    if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
+                } else {
+#pragma unroll
+                    for (int ts = 0; ts < 2; ts++) {
+                        if (ts >= ntl) continue;
+                        v4f acc[N];
+#pragma unroll
+                        for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                        for (int cc = 0; cc < N; cc++)
+#pragma unroll
+                            for (int j = 0; j < N; j++) acc[j] = mm6(wf[j][cc], raw[ts][cc], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < N; j++) ph[kw][ts][j][lane] = acc[j];
+                    }
+                }
+            }
+            if (!gate_phase(i)) return;
+        }
+    }
+}
+
+// ---- layout converters -------------------------------------------------------------------------
+// fp32 tile-interleaved [tile][Ut][16 reads][4] <-> split [tile][Hc][3][64][8 bf16]; one thread per (tile, pair of unit tiles, read)
+__global__ void __launch_bounds__(256)
+k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, size_t npair, int Ut) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npair) return;
+    const int rl = (int)(idx & 15);
+    const size_t pr = idx >> 4;                         // (tile, unit-tile pair)
+    const int up = (int)(pr % (Ut / 2));
+    const size_t tile = pr / (Ut / 2);
+    const float *src = in + (tile * Ut + 2 * up) * 64 + rl * 4;
+    const v4f lo = *(const v4f *)src, hi = *(const v4f *)(src + 64);
+    unsigned char *dst = out + tile * ((size_t)Ut / 8 * 3 * 1024);
+    const int c = up >> 2, kq = up & 3;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const v2u a = split4(lo, s), b = split4(hi, s);
+        *(v4u *)(dst + (size_t)(((c * 3 + s) * 64 + kq * 16 + rl) * 16)) = (v4u){ a.x, a.y, b.x, b.y };
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_f32_from_split(const unsigned char *__restrict__ in, float *__restrict__ out, size_t npair, int Ut) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npair) return;
+    const int rl = (int)(idx & 15);
+    const size_t pr = idx >> 4;
+    const int up = (int)(pr % (Ut / 2));
+    const size_t tile = pr / (Ut / 2);
+    const unsigned char *src = in + tile * ((size_t)Ut / 8 * 3 * 1024);
+    const int c = up >> 2, kq = up & 3;
+    float v[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    // smallest slice first: the sum of the three slices is exact in any order (they partition the mantissa)
+#pragma unroll
+    for (int s = 2; s >= 0; s--) {
+        const v4u w = *(const v4u *)(src + (size_t)(((c * 3 + s) * 64 + kq * 16 + rl) * 16));
+        const unsigned d[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[2 * e] += __uint_as_float(d[e] << 16);
+            v[2 * e + 1] += __uint_as_float(d[e] & 0xFFFF0000u);
+        }
+    }
+    float *dst = out + (tile * Ut + 2 * up) * 64 + rl * 4;
+    *(v4f *)dst = (v4f){ v[0], v[1], v[2], v[3] };
+    *(v4f *)(dst + 64) = (v4f){ v[4], v[5], v[6], v[7] };
+}
+
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H) {
+    const size_t npair = ntile * (size_t)(H / 8) * 16;
+    hipLaunchKernelGGL(k_split_from_f32, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, in, (unsigned char *)out, npair, H / 4);
+}
+void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H) {
+    const size_t npair = ntile * (size_t)(H / 8) * 16;
+    hipLaunchKernelGGL(k_f32_from_split, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (const unsigned char *)in, out, npair, H / 4);
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+bool split_supported(int kind, int H) { return kind == 0 && H % 128 == 0 && H >= 128 && H <= 384; }
+// read tiles (of 16) one launch takes: one workgroup per CU, 32 per pair of tiles
+int split_max_tiles(int ncu) { return 2 * (ncu / 32); }
+size_t split_flag_words(int nrt) { return (size_t)((nrt + 1) / 2) * 32; }
+
+unsigned long long *g_split_dbg = nullptr;
+
+bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
+                       unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
+                       const int *tbs, const int *tbt) {
+    SplitArgs a;
+    a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
+    a.flags = flags; a.abort_word = abort_word;
+    a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
+    a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
+    const int ngroup = (nrt + 1) / 2;
+    switch (H / 128) {
+    case 1: hipLaunchKernelGGL(k_lstm_split<1>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
+    case 2: hipLaunchKernelGGL(k_lstm_split<2>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
+    case 3: hipLaunchKernelGGL(k_lstm_split<3>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
+    }
+    return false;
+}
+
+}  // namespace ffhip

@@ -70,6 +70,7 @@ typedef struct {
 #define FFHIP_RUN_NO_DECODE      4u   /* stop after calculate_transitions (networks.c:108-111)                */
 #define FFHIP_RUN_STEPWISE_RNN   8u   /* force the launch-per-step recurrent kernels (debug / cross-check)    */
 #define FFHIP_RUN_UNFUSED_RNN   32u   /* separate input-projection GEMM + recurrent kernel (cross-check)      */
+#define FFHIP_RUN_F32_RNN       64u   /* f32-input MFMA recurrent kernel instead of the split-bf16 one (cross-check) */
 #define FFHIP_RUN_KEEP_ACTS     16u   /* keep every layer's activations for ffhip_batch_get_activation        */
 
 const char *ffhip_last_error(void);
