@@ -86,22 +86,24 @@ __device__ __forceinline__ v4f mm(v4u a, v4u b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
 }
 
-// the six kept products of one (row tile, chunk): smallest terms first
-__device__ __forceinline__ v4f mm6(const v4u (&w)[3], const v4u (&x)[3], v4f c) {
-    c = mm(w[2], x[0], c);
-    c = mm(w[0], x[2], c);
-    c = mm(w[1], x[1], c);
-    c = mm(w[1], x[0], c);
-    c = mm(w[0], x[1], c);
-    c = mm(w[0], x[0], c);
-    return c;
+// The six kept products of one K chunk for the N row tiles of a wave, smallest terms first.  Issue order is term-major,
+// row tile minor: consecutive MFMAs write DIFFERENT accumulators, so the matrix pipe never waits for its own result
+// (a dependent v_mfma_f32_16x16x32_bf16 issues every ~28 cycles, an independent one every 16).
+template <int N>
+__device__ __forceinline__ void mm6(const v4u (&w)[N][N][3], int cc, const v4u (&x)[3], v4f (&acc)[N]) {
+    constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
+#pragma unroll
+    for (int term = 0; term < 6; term++)
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] = mm(w[j][cc][WS[term]], x[XS[term]], acc[j]);
 }
 
 template <int N>
 __global__ void __launch_bounds__(512, 1)
 k_lstm_split(SplitArgs a) {
     __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
-    __shared__ v4f ph[4][2][N][64];         // recurrent partials
+    __shared__ v4f ph[4][2][N][64];         // gate pre-activations by K quarter: projection partial + recurrent partial
+    __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
     __shared__ int lds_abort;
     __shared__ int lds_fast;
     constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
@@ -126,6 +128,7 @@ k_lstm_split(SplitArgs a) {
     const int ntl = (TbB > 0) ? 2 : 1;
     const int ut0 = m * N;
     if (threadIdx.x == 0) lds_abort = 0;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4);
     if (threadIdx.x < 64) {
         int fast_l = 0;
         if (a.mode == 0) {
@@ -156,17 +159,7 @@ k_lstm_split(SplitArgs a) {
                 for (int s = 0; s < 3; s++)
                     wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + (kw * N + cc)) * 3 + s) * 64 + lane];
     }
-    // gate role: wave gt < ntl*N does tile (ts = gt / N of the pair, unit tile j = gt % N)
-    const int gts = wave / N, gj = wave % N;
-    const bool gate_wave = wave < ntl * N;
     const int q = lane >> 4, rl = lane & 15;
-    v4f bias = { 0.f, 0.f, 0.f, 0.f };
-    int my_tb = 0;
-    if (gate_wave) {
-        bias = *(const v4f *)(a.bias + (size_t)(ut0 + gj) * 16 + q * 4);
-        my_tb = a.tbs ? a.tbs[(rtA + gts) * 16 + rl] : a.Tb;
-    }
-    float c = 0.0f;
     __syncthreads();
     const bool fast = lds_fast != 0;
     if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
@@ -174,60 +167,69 @@ k_lstm_split(SplitArgs a) {
     const unsigned lane_off = (unsigned)lane * 16u;
     auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
-
-    // ---- the gate phase of step i (layers.c:1005-1025 on one 16 x 16 tile per wave), between its two barriers
-    auto gate_phase = [&](int i) {
+    auto raw_barrier = [&]() {               // LDS-only barrier: no vmcnt drain, prefetches stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (lds_abort) return false;
-        if (gate_wave) {
-            const int t = step_t(i);
-            v4f s = bias;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; w2++) s = s + px[i & 1][w2][gts][gj][lane];
-            if (i > 0) {
-#pragma unroll
-                for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
-            }
-            const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
-            const float tanh_g = (L.z + L.z) - 1.0f;
-            const float forget = L.y * c;
-            const float update = L.x * tanh_g;
-            c = forget + update;
-            float h = L.w * tanh_ref(c);
-            if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
-            v4f hv;
-            hv.x = __shfl(h, rl);
-            hv.y = __shfl(h, rl + 16);
-            hv.z = __shfl(h, rl + 32);
-            hv.w = __shfl(h, rl + 48);
-            // quarter-wave q stores slice q of the 4 units of read rl: 8 bytes at k = 4*ut .. 4*ut+3
-            const int ut = ut0 + gj;
-            const v2u sl = split4(hv, q);
-            const unsigned off = (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8);
-            unsigned char *tp_out = a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB;
-            if (q < 3) {
-                if (fast) *(v2u *)(tp_out + off) = sl;
-                else {
-                    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tp_out, 0, (int)tileB, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b64(sl, wr, off, 0, 16 /*sc1*/);
-                }
-            } else if (a.hout_f32) {
-                *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
-            }
-        }
-        // close the gate phase before the next step's MFMAs start (and before px / ph are rewritten)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        return true;
     };
 
-    // The two roles run their own copy of the step loop (same barrier count per step), so that the register allocator
-    // sees each role's live ranges alone: an x wave keeps x(step i+1) in flight across the gate phase, an h wave keeps
-    // nothing but its weights.
+#ifdef FFHIP_TIMELINE
+#define TL(k) do { if (a.dbg && i >= 100 && i < 132 && lane == 0) a.dbg[((((size_t)blockIdx.x * 8 + wave) * 32 + (i - 100)) * 16 + (k))] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
+
+    // ---- gate math of one 16 x 16 tile (4 units x 4 gates x 16 reads; layers.c:1005-1025) and the store of its h(t), already
+    // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
+    auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
+        const int t = step_t(i);
+        v4f s = sbias[gj][q];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+        const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+        const float tanh_g = (L.z + L.z) - 1.0f;
+        const float forget = L.y * c;
+        const float update = L.x * tanh_g;
+        c = forget + update;
+        float h = L.w * tanh_ref(c);
+        if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
+        v4f hv;
+        hv.x = __shfl(h, rl);
+        hv.y = __shfl(h, rl + 16);
+        hv.z = __shfl(h, rl + 32);
+        hv.w = __shfl(h, rl + 48);
+        // quarter-wave q stores slice q of the 4 units of read rl: 8 bytes at k = 4*ut .. 4*ut+3
+        const int ut = ut0 + gj;
+        const v2u sl = split4(hv, q);
+        const unsigned off = (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8);
+        unsigned char *tp_out = a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB;
+        if (q < 3) {
+            if (fast) *(v2u *)(tp_out + off) = sl;
+            else {
+                __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tp_out, 0, (int)tileB, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b64(sl, wr, off, 0, 16 /*sc1*/);
+            }
+        } else if (a.hout_f32) {
+            *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
+        }
+    };
+    // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
+    // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
+    // the hardware on one SIMD run in ~2500 cycles, two tiles back to back in one wave in ~3300).
+    const int g6 = xw ? 4 + wave : kw;
+    const bool gate_wave = (xw ? wave < 2 : true) && g6 < ntl * N;
+    const int my_gts = g6 / N, my_gj = g6 % N;
+    int my_tb = 0;
+    if (gate_wave) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
+    float c = 0.0f;
+
+    // The two roles run their own step loop (two barriers per step each), so that the register allocator sees each
+    // role's live ranges alone.
     if (xw) {
-        // ---- x waves: projection of step i+1 under the hand-off latency of step i
+        // ---- x waves: projection of step i+1 under the hand-off latency of step i.  x(step i+2) is prefetched into
+        // registers right after the MFMAs that consumed x(step i+1): a whole step ahead of its use (it comes from HBM),
+        // and never in the gate phase, where the issue of 18 KiB of loads per wave (the CU's path to L2 takes 64 B/clk)
+        // would delay a gating x wave and with it the critical path.
         v4u xb[2][N][3];
         auto load_x = [&](int i) {
             const int t = step_t(i);
@@ -249,9 +251,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                 for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-                for (int cc = 0; cc < N; cc++)
-#pragma unroll
-                    for (int j = 0; j < N; j++) acc[j] = mm6(wf[j][cc], xb[ts][cc], acc[j]);
+                for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[ts][cc], acc);
 #pragma unroll
                 for (int j = 0; j < N; j++) px[i & 1][kw][ts][j][lane] = acc[j];
             }
@@ -259,76 +259,127 @@ k_lstm_split(SplitArgs a) {
         load_x(0);
         project(0);
         if (Tb > 1) load_x(1);
+        raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
+            TL(0);
             if (i + 1 < Tb) {
                 project(i + 1);
                 if (i + 2 < Tb) load_x(i + 2);
             }
-            if (!gate_phase(i)) return;
+            TL(2);
+            raw_barrier();
+            TL(3);
+            if (lds_abort) return;
+            if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            TL(4);
+            raw_barrier();                                   // closes the gate phase
+            TL(5);
         }
     } else {
-        // ---- h waves: sweep my K slice of h(step i-1) until every dword has been published, then sW h
+        // ---- h waves: recurrent half of step i on top of the projection partial of my K quarter, then one gate tile.
+        // Hand-off of h(step i-1): (1) a LIGHT poll -- one dword per producing gate wave of my K slice (16N lanes, one
+        // load) until none is the sentinel; a full sweep is 24N KiB per wave and 64 B/clk per CU, far too heavy to
+        // repeat; (2) ONE full sweep, software-pipelined two chunks ahead of the MFMAs that consume it, with the sentinel
+        // check riding along; (3) only if that check fails (a producer's store instruction became visible line by line)
+        // the classic re-sweep loop and a recomputation.
+        constexpr int NPROD = 8 * N;                      // unit tiles (= producing gate waves' tiles per read tile) in my K slice
+        constexpr int NCH = 2 * N;                        // (tile, chunk) pairs of my K slice
+        raw_barrier();                                        // matches the x waves' prologue barrier
         for (int i = 0; i < Tb; i++) {
-            if (i > 0) {
-                const int tp = step_t(i - 1);
-                __amdgpu_buffer_rsrc_t rs[2];
+            TL(0);
+            v4f acc[2][N];
+            auto init_acc = [&]() {
 #pragma unroll
                 for (int ts = 0; ts < 2; ts++)
-                    rs[ts] = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.hout, tp, ts < ntl ? ts : 0), 0, (int)tileB, 0x00020000);
-                v4u raw[2][N][3];
-                auto sweep = [&]() {
 #pragma unroll
-                    for (int ts = 0; ts < 2; ts++) {
-                        if (ts >= ntl) continue;
-#pragma unroll
-                        for (int cc = 0; cc < N; cc++)
-#pragma unroll
-                            for (int s = 0; s < 3; s++)
-                                raw[ts][cc][s] = __builtin_amdgcn_raw_buffer_load_b128(rs[ts], (((kw * N + cc) * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
-                    }
-                };
-                sweep();
+                    for (int j = 0; j < N; j++) acc[ts][j] = px[i & 1][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+            };
+            init_acc();
+            if (i > 0) {
+                const int tp = step_t(i - 1);
+                const unsigned char *hp = tile_ptr(a.hout, tp, 0);          // the pair's two tiles are adjacent
+                __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(2 * tileB), 0x00020000);
                 bool timed_out = false;
-                for (unsigned spin = 0;; spin++) {
+                {
+                    const int ul = lane % NPROD, pts = lane / NPROD;
+                    const int put = kw * NPROD + ul;
+                    const bool act = pts < ntl;
+                    const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * 3 * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
+                    for (unsigned spin = 0;; spin++) {
+                        const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
+                        if (__all(v != kSplitSentinel)) break;
+                        if (spin > 6000000u || (spin & 511u) == 511u) {
+                            const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                            if (ab != 0u || spin > 6000000u) { timed_out = true; break; }
+                        }
+                    }
+                }
+                TL(1);
+                v4u raw[NCH][3];
+                // Both tiles of the pair are always swept and multiplied (an absent second tile re-reads the first one and
+                // its products are dropped): a branch on ntl between the loads makes the outstanding-load count path
+                // dependent, and the compiler then waits vmcnt(0) before the first MFMA instead of counting.
+                const int offB = (ntl > 1) ? (int)tileB : 0;
+                auto load_chunk = [&](int k) {          // k = ts*N + cc
+                    const int ts = k / N, cc = k % N;
+#pragma unroll
+                    for (int s = 0; s < 3; s++)
+                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + (((kw * N + cc) * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                };
+                // acc += sW h over my K slice; false if a sentinel was among the operands.  The four h waves share one
+                // 64 B/clk path to L2: a wave that issued its whole sweep at once would get its first chunk behind the other
+                // waves' 54 KiB; two chunks in flight per wave keep the queue round-robin and every wave's MFMAs fed.
+                auto recur = [&]() -> bool {
                     bool ok = true;
 #pragma unroll
-                    for (int ts = 0; ts < 2; ts++) {
-                        if (ts >= ntl) continue;
+                    for (int k = 0; k < NCH; k++) load_chunk(k);
 #pragma unroll
-                        for (int cc = 0; cc < N; cc++)
+                    for (int k = 0; k < NCH; k++) {
 #pragma unroll
-                            for (int s = 0; s < 3; s++) {
-                                const v4u r = raw[ts][cc][s];
-                                ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
+                        for (int s = 0; s < 3; s++) {
+                            const v4u r = raw[k][s];
+                            ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
+                        }
+                        mm6<N>(wf, k % N, raw[k], acc[k / N]);
+                        __builtin_amdgcn_sched_barrier(0);      // keep each chunk's check and MFMAs behind ITS loads only: the sweep streams under the MFMAs
+                    }
+                    return __all(ok) != 0;
+                };
+                if (!timed_out) {
+                    // gfx9 counts loads and stores on ONE counter and they complete out of order with respect to each other:
+                    // while this wave's gate-phase stores of step i-1 may be pending the compiler can only wait vmcnt(0).
+                    // They completed long ago (the poll above outlasts them) -- say so, and the sweep gets counted waits.
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                    if (!recur()) {
+                        for (unsigned spin = 0;; spin++) {
+                            if (spin > 3000000u || (spin & 255u) == 255u) {
+                                const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                                if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                             }
-                    }
-                    if (__all(ok)) break;
-                    if (spin > 3000000u || (spin & 255u) == 255u) {
-                        const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
-                        if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    sweep();
-                }
-                if (timed_out) {
-                    if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
-                } else {
-#pragma unroll
-                    for (int ts = 0; ts < 2; ts++) {
-                        if (ts >= ntl) continue;
-                        v4f acc[N];
-#pragma unroll
-                        for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-                        for (int cc = 0; cc < N; cc++)
-#pragma unroll
-                            for (int j = 0; j < N; j++) acc[j] = mm6(wf[j][cc], raw[ts][cc], acc[j]);
-#pragma unroll
-                        for (int j = 0; j < N; j++) ph[kw][ts][j][lane] = acc[j];
+                            __builtin_amdgcn_s_sleep(1);
+                            init_acc();
+                            if (recur()) break;
+                        }
                     }
                 }
+                if (timed_out && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
             }
-            if (!gate_phase(i)) return;
+#pragma unroll
+            for (int ts = 0; ts < 2; ts++) {
+                if (ts >= ntl) continue;
+#pragma unroll
+                for (int j = 0; j < N; j++) ph[kw][ts][j][lane] = acc[ts][j];
+            }
+            TL(2);
+            raw_barrier();
+            TL(3);
+            if (lds_abort) return;
+            if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            TL(4);
+            // close the gate phase before ph is rewritten (and before the x waves' MFMAs start next to gate VALU work)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            TL(5);
         }
     }
 }
