@@ -882,6 +882,22 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
     return FFHIP_OK;
 }
 
+extern "C" int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden) {
+    if (!eng || !in || !out || ntile == 0 || hidden <= 0 || hidden % 128 != 0) return set_err(FFHIP_EINVAL, "split round trip: bad arguments");
+    hipSetDevice(eng->device);
+    TmpDev tmp;
+    const size_t nf = ntile * 16 * (size_t)hidden;
+    float *d_in = (float *)tmp.get(nf * 4), *d_out = (float *)tmp.get(nf * 4);
+    void *d_split = tmp.get(split_bytes(ntile, hidden));
+    if (!d_in || !d_out || !d_split) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(d_in, in, nf * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+    launch_split_from_f32(nullptr, d_in, d_split, ntile, hidden);
+    launch_f32_from_split(nullptr, d_split, d_out, ntile, hidden);
+    HIP_TRY(hipDeviceSynchronize(), FFHIP_EHIP);
+    HIP_TRY(hipMemcpy(out, d_out, nf * 4, hipMemcpyDeviceToHost), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launches[FFHIP_NGROUP]) {
     if (!b || !b->profiled || !b->finished) return set_err(FFHIP_EINVAL, "the last run was not profiled or the batch is not finished");
     float t01 = 0, t34 = 0, t45 = 0, t56 = 0;

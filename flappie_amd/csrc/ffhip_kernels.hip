@@ -430,6 +430,7 @@ k_crf_norm(const float *__restrict__ trans, int TbS, int nbase, int P, int Ps, d
     const int ns = 2 * nbase, off = nbase * ns;
     const float *S = trans + (size_t)blockIdx.x * TbS * Ps;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     // destination state of transition entry `lane`, and its source state
     const int src = lane % ns;
     int dst;
@@ -577,6 +578,7 @@ k_crf_chain(const double *__restrict__ E, int TbS, int P, int Pd, int R, double 
     const bool active = lane < NS, flip = lane < nbase;
     const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const int per_chunk = kCrfChunk * Pd;                       // doubles per chunk (<= 2304)
     constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 36 doubles per lane at most
     double stage[kStage];
@@ -659,6 +661,7 @@ k_crf_chain8(const double *__restrict__ E, int TbS, int Pd, int R, double *__res
     const int gather = ff8_src_lane(lane & 7);
     const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    if (Tb <= 0) return;                                 // an empty slot
     const int per_chunk = kCrfChunk * Pd;
     constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 24 doubles per lane
     double stage[kStage];
@@ -748,6 +751,7 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
     float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
     float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool is_state = lane < ns, is_flip = lane < nbase;
 
     // forwards (:396-423)
@@ -831,6 +835,7 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
     float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool valid = lane < P, flip = lane < 32;
     const int st = lane & 7;
     const float NEG = -INFINITY;
@@ -927,6 +932,7 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
     float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool valid = lane < P, is_state = lane < ns, is_flip = lane < nbase;
     const int src = lane % ns;                  // source state of entry `lane` (off is a multiple of ns)
     int dst;                                    // destination state of entry `lane`
@@ -1041,6 +1047,7 @@ k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restr
     int *pth = path + (size_t)blockIdx.x * (TbS + 1);
     float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool is_state = lane < ns, is_flip = lane < nbase;
 
     float prev = 0.0f;
@@ -1114,6 +1121,7 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
     int *pth = path + (size_t)blockIdx.x * (TbS + 1);
     float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool valid = lane < P, flip = lane < 32;
     const int st = lane & 7;
     const float NEG = -INFINITY;
@@ -1195,6 +1203,7 @@ k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *
     char *bs = bases + (size_t)blockIdx.x * (TbS + 1);
     char *qs = quals + (size_t)blockIdx.x * (TbS + 1);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     int count = 0;
     for (int p0 = 1; p0 < Tb; p0 += 64) {
         const int pos = p0 + lane;

@@ -49,6 +49,7 @@ k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, dou
     const int lane = threadIdx.x, ns = 2 * nbase;
     const float *C = param + (size_t)blockIdx.x * TbS * Ps + ns;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     if (lane < ns) st[0][lane] = 0.0;
     __syncthreads();
     int cur = 0;
@@ -105,6 +106,7 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
     float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     if (wave == 0) {
         if (lane < ns) { fs[0][lane] = 0.0f; F[lane] = 0.0f; }
         __builtin_amdgcn_wave_barrier();
@@ -199,6 +201,7 @@ k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int 
     int *pth = path + (size_t)blockIdx.x * (TbS + 1);
     float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
+    if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     if (lane < ns) vs[0][lane] = 0.0f;
     __syncthreads();
     int cur = 0;

@@ -135,6 +135,9 @@ int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][ns
 /* debug taps used by the parity tests: activations after conv stack (layer -1) or after RNN layer l
  * (0..4) as dense [nblock][hidden] */
 int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
+/* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split-bf16 activation layout of
+ * the recurrent layer kernel and back; out == in bit for bit (three bf16 slices hold any fp32 exactly) */
+int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden);
 
 /* ---- single-matrix decode entry points -------------------------------------------------------
  * Used by the reference-compatible wrappers in include/decode.h.  `trans` / `scores` / `post` are

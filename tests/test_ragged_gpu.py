@@ -152,3 +152,24 @@ def test_empty_slots(B, engine):
             with pytest.raises(B.FFHipError):
                 b.transitions(r)
     b.close(); dm.close()
+
+
+def test_leading_empty_slots(B, engine):
+    """an empty FIRST slot / first read tile: the decode kernels of an empty read must not touch block Tb - 1 = -1,
+    which for read 0 lies in front of the buffers"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=5)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(9)
+    lens = [0] * 17 + [700, 699, 0, 19, 400]
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    b = B.Batch(dm, len(lens), 700)
+    for flags in (0, B.RUN_VITERBI_ONLY):
+        b.set_signals_ragged(sigs)
+        b.run(1.0, flags); b.finish()
+        for r, x in enumerate(sigs):
+            if x.size:
+                check_read(b, r, om.basecall(x, viterbi_only=bool(flags)), bool(flags))
+            else:
+                assert b.read_nblock(r) == 0
+    b.close(); dm.close()

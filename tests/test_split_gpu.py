@@ -1,0 +1,115 @@
+"""The split-bf16 recurrent layer kernel (flappie_amd/csrc/ffhip_rnn_split.hip): LSTM layers of H = 128/256/384 run as bf16
+MFMAs over a three-way split of both operands (six products per fp32 product, every term down to 2^-24 kept).  It is the
+default for those shapes, so the rest of the GPU suite (H = 36..96) never reaches it; these tests do, against the oracle
+where the oracle is quick (H = 128) and against the f32-input MFMA kernel (FFHIP_RUN_F32_RNN) at the larger shapes.
+Tolerances are those of the rest of the suite: 1e-4 on transition scores, identical base and quality strings."""
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+from oracle import ffo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    from flappie_amd import binding
+    return binding
+
+
+@pytest.fixture(scope="module")
+def engine(B):
+    e = B.Engine(0)
+    yield e
+    e.close()
+
+
+def check_read(b, r, ref):
+    assert b.read_nblock(r) == ref["nblock"]
+    assert np.abs(b.transitions(r) - ref["trans"]).max() <= 1e-4
+    path, _ = b.path(r)
+    assert np.array_equal(path, ref["path"])
+    assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
+    assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
+    assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
+
+
+def test_split_kernel_against_oracle_odd_tile_count(B, engine):
+    """40 reads = three read tiles: the second pair of tiles has one member only"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=7)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(1623)
+    sig = rng.standard_normal((40, 1500)).astype(np.float32)
+    b = B.Batch(dm, 40, 1500)
+    b.set_signals(sig)
+    b.run(); b.finish()
+    for r in range(40):
+        check_read(b, r, om.basecall(sig[r]))
+    b.close()
+    dm.close()
+
+
+def test_split_kernel_ragged_and_empty_slots(B, engine):
+    """per-read lengths, tiles whose block counts differ inside a pair, a tile of empty slots, and bitwise independence
+    of a read's result from its slot and its neighbours"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=11)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(5)
+    lens = [1200, 1199, 600, 601, 37, 19, 1000, 800, 801, 802, 803, 804, 805, 806, 807, 808,       # tile 0
+            300, 1200, 45]                                                                    # tile 1 (short) -> pair (0, 1)
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    b = B.Batch(dm, 40, 1200)                       # slots 19..39 stay empty: tile 2 is all empty, pair (2, -) never runs
+    b.set_signals_ragged(sigs + [np.zeros(0, dtype=np.float32)] * (40 - len(sigs)))
+    b.run(); b.finish()
+    for r, x in enumerate(sigs):
+        check_read(b, r, om.basecall(x))
+    first = [b.transitions(r).copy() for r in range(len(sigs))]
+    # the same reads in other slots (other tile of the pair, other neighbours): bit-identical per read
+    order = list(reversed(range(len(sigs))))
+    b.set_signals_ragged([np.zeros(0, dtype=np.float32)] * 17 + [sigs[k] for k in order] + [np.zeros(0, dtype=np.float32)] * (40 - 17 - len(sigs)))
+    b.run(); b.finish()
+    for slot, k in enumerate(order):
+        assert np.array_equal(b.transitions(17 + slot), first[k]), k
+    b.close()
+    dm.close()
+
+
+@pytest.mark.parametrize("hidden,nread,T", [(256, 48, 2000), (384, 32, 1500), (128, 272, 500)])
+def test_split_kernel_agrees_with_f32_kernel(B, engine, hidden, nread, T):
+    """H = 256 and 384 (two and three unit tiles per workgroup); 272 reads = 17 read tiles, one more than a launch takes"""
+    mdl = M.synthetic_model(M.NET_LSTM5, hidden, seed=hidden)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(nread)
+    sig = rng.standard_normal((nread, T)).astype(np.float32)
+    res = []
+    for flags in (B.RUN_KEEP_ACTS, B.RUN_KEEP_ACTS | B.RUN_F32_RNN):
+        b = B.Batch(dm, nread, T)
+        b.set_signals(sig)
+        b.run(1.0, flags); b.finish()
+        res.append(([b.transitions(r) for r in range(nread)], [b.basecall(r) for r in range(nread)],
+                    [b.quality(r) for r in range(nread)], [b.activation(4, r) for r in (0, nread - 1)]))
+        b.close()
+    assert max(float(np.abs(x - y).max()) for x, y in zip(res[0][0], res[1][0])) <= 1e-4
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    # last recurrent layer's output: what the fp32 copy written next to the split layout holds
+    assert max(float(np.abs(x - y).max()) for x, y in zip(res[0][3], res[1][3])) <= 2e-5
+    dm.close()
+
+
+def test_split_layout_round_trip(B, engine):
+    """fp32 -> three bf16 slices -> fp32 is the identity (8 + 8 + 8 mantissa bits; the middle and low slices may be negative)"""
+    import ctypes as C
+    L = B.lib()
+    if not hasattr(L, "ffhip_debug_split_round_trip"):
+        pytest.skip("debug entry point not built")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(16 * 128 * 3).astype(np.float32)
+    x[:8] = np.float32([0.0, 1.0, -1.0, 1e-20, 0.99999994, -0.99999994, 1.17549435e-38, 65504.0])
+    y = np.empty_like(x)
+    L.ffhip_debug_split_round_trip.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t, C.c_int]
+    L.ffhip_debug_split_round_trip.restype = C.c_int
+    assert L.ffhip_debug_split_round_trip(engine.h, x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)), 3, 128) == 0
+    assert np.array_equal(x, y)
