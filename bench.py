@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
+SPLIT_PRODUCTS = 6                # bf16 MFMA products the split-bf16 layer kernel issues per fp32-exact product (ffhip_rnn_split.hip)
 HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size inferred from the model's size
 NREAD, NSAMPLE = int(os.environ.get('FFHIP_BENCH_NREAD', '256')), 4000
 
@@ -70,17 +72,18 @@ def cpu_baseline(hidden, budget_s=12.0, max_reads=6):
                 per_core=round(nread * NSAMPLE / dt / 1e6 / ncore, 6))
 
 
-def measured_traffic(hidden, fused):
+def measured_traffic(hidden, rnn_path):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus
     WRITE_SIZE, separate passes).  Counters cannot be read inside this process, so the value is the
-    profile's, keyed by shape; null when no profile of this shape is committed."""
+    profile's, keyed by shape and kernel; null when no profile of this shape and kernel is committed."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
-        if t.get("hidden") == hidden and t.get("nread") == NREAD and t.get("nsample") == NSAMPLE and bool(t.get("fused")) == fused:
-            return t.get("recurrent_layer_hbm_bytes_per_launch")
+        for e in (t if isinstance(t, list) else [t]):
+            if e.get("hidden") == hidden and e.get("nread") == NREAD and e.get("nsample") == NSAMPLE and e.get("rnn_path", 2 if e.get("fused") else 1) == rnn_path:
+                return e.get("recurrent_layer_hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     return None
@@ -174,25 +177,42 @@ def main():
         # runs fused (projection and recurrence in one persistent launch; `inproj` then has 0 launches).
         rec = prof[-1]["recurrent"]
         fused = prof[-1]["inproj"]["launches"] == 0
+        rnn_path = batches[-1].rnn_path()
         flop_layer = (2.0 if fused else 1.0) * 2.0 * args.hidden * 4 * args.hidden * NREAD * nblock
         launches_per_layer = rec["launches"] / 5.0
         ms_layer = rec["ms"] / 5.0
         achieved = flop_layer / (ms_layer * 1e-3) / 1e12
-        kname = ("k_lstm_fused (input projection + recurrence of one layer, %d dependent steps)" if fused
-                 else "k_rnn_persist (recurrence of one layer, %d dependent steps)") % nblock
+        if rnn_path == 3:
+            # fp32-exact products out of bf16 MFMAs: each algorithmic (fp32) multiply-add is six bf16 MFMA products
+            # (three-way split of both operands, the three smallest cross terms dropped).  `achieved` counts the
+            # ALGORITHMIC fp32 FLOPs; the ceiling of this formulation is the dense bf16 peak / 6.
+            kname = "k_lstm_split<%d> (input projection + recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps)" % (args.hidden // 128, nblock)
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+            peak_note = ("dense bf16 MFMA peak %.0f TFLOP/s / %d products per fp32-exact product; the kernel issues %.1f TFLOP/s of bf16 MFMA work "
+                         "= %.3f of the bf16 peak; against the f32-input MFMA peak (%.1f) the algorithmic rate is %.3f"
+                         % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS,
+                            PEAK_F32_MFMA_TFLOPS, achieved / PEAK_F32_MFMA_TFLOPS))
+            dtype = "f32 (products as 6 bf16 MFMA terms over 3-way split operands, f32 accumulate; gate math f32)"
+        else:
+            kname = ("k_lstm_fused (input projection + recurrence of one layer, %d dependent steps)" if fused
+                     else "k_rnn_persist (recurrence of one layer, %d dependent steps)") % nblock
+            peak = PEAK_F32_MFMA_TFLOPS
+            peak_note = "f32-input MFMA peak (v_mfma_f32_16x16x4_f32)"
+            dtype = "f32"
         out = {
             "metric": "Msamples/s basecalled (r941_native, 4k-sample chunks)",
             "value": round(value, 4), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the r941_native architecture)",
             "config": {"workload": "r941_native-shape LSTM5 H=%d, batch=256 synthetic 4000-sample reads per GPU, "
                                    "posterior decode + trace (BASELINE.json configs[1])" % args.hidden,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
             "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.hidden, fused),
+                         "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.hidden, rnn_path),
+                         "peak_note": peak_note,
                          "flop_per_launch": flop_layer / launches_per_layer,
                          "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
                          "launches_per_layer": launches_per_layer},

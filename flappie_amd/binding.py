@@ -331,6 +331,13 @@ class Batch:
         _check(lib().ffhip_batch_get_activation(self.h, layer, read, _fptr(out)))
         return out
 
+    def rnn_path(self) -> int:
+        """0 launch per step, 1 persistent recurrence + projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel"""
+        L = lib()
+        L.ffhip_batch_rnn_path.argtypes = [C.c_void_p]
+        L.ffhip_batch_rnn_path.restype = C.c_int
+        return int(L.ffhip_batch_rnn_path(self.h))
+
     def profile(self):
         ms = (C.c_float * NGROUP)()
         ln = (C.c_int * NGROUP)()

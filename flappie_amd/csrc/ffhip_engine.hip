@@ -312,6 +312,7 @@ struct ffhip_batch {
     unsigned last_flags = 0;
     int ran = 0, finished = 0;
     int final_act = 0;                  // which act[] holds the last recurrent layer's output
+    int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel
     hipEvent_t ev[FFHIP_NGROUP + 1];
     int have_ev = 0;
     int launches[FFHIP_NGROUP];
@@ -673,8 +674,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             if (prof) hipEventRecord(b->lev[l][1], s);
             const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
             void *outS = b->actS[cur ^ 1];
-            // the output doubles as the hand-off flag: pre-fill with the sentinel (two bf16 NaNs per dword)
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)outS, (int)0xFFFFFFFF, split_bytes((size_t)Tb * B16, Hp) / 4, s), FFHIP_EHIP);
+            // (the output doubles as the hand-off flag; the kernel arms it itself a few steps ahead of its stores -- no fill)
             // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
             float *out_f32 = (l == 4 || keep) ? out : nullptr;
             for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
@@ -735,6 +735,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     }
     b->profiled = prof;
     b->final_act = cur;
+    b->rnn_path = use_split ? 3 : (use_persist ? (use_fused ? 2 : 1) : 0);
     mark(b, 3);
     const bool rle = (m->kind == FFHIP_NET_LSTM5_RLE);
     if (rle) {
@@ -881,6 +882,8 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
     for (int t = 0; t < b->Tb; t++) memcpy(out + (size_t)t * m->H, tmp.data() + (size_t)t * m->Hp, (size_t)m->H * 4);
     return FFHIP_OK;
 }
+
+extern "C" int ffhip_batch_rnn_path(const ffhip_batch *b) { return b ? b->rnn_path : -1; }
 
 extern "C" int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden) {
     if (!eng || !in || !out || ntile == 0 || hidden <= 0 || hidden % 128 != 0) return set_err(FFHIP_EINVAL, "split round trip: bad arguments");

@@ -129,22 +129,47 @@ k_lstm_split(SplitArgs a) {
     const int ut0 = m * N;
     if (threadIdx.x == 0) lds_abort = 0;
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4);
+    const int q = lane >> 4, rl = lane & 15;
+    auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
+    // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
+    // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
+    // the hardware on one SIMD run in ~2500 cycles, two tiles back to back in one wave in ~3300).
+    const int g6 = xw ? 4 + wave : kw;
+    const bool gate_wave = (xw ? wave < 2 : true) && g6 < ntl * N;
+    const int my_gts = g6 / N, my_gj = g6 % N;
+    // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
+    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
+    auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
+    auto store_wt = [&](unsigned char *tile, unsigned off, v2u v) {      // write-through: visible to every XCD
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(v, wr, off, 0, 16 /*sc1*/);
+    };
+    // The output doubles as the hand-off flag, and the kernel arms it itself: every producer lane writes the sentinel
+    // to ITS slots of steps 0..AHEAD-1 here -- before the group's start barrier below -- and to step i+AHEAD when it
+    // publishes step i.  Stores of one lane to one address stay in order, so its sentinel can never overtake or
+    // undercut its own data; a consumer looks at step i+AHEAD only after it has seen every producer's step i+AHEAD-1,
+    // i.e. at least AHEAD-1 whole steps after that sentinel was written.  No host-side fill of the (reused) buffer.
+    constexpr int AHEAD = 3;
+    const v2u sentinel2 = { kSplitSentinel, kSplitSentinel };
+    if (gate_wave && q < 3)
+        for (int k = 0; k < AHEAD && k < Tb; k++) store_wt(out_tile(step_t(k), my_gts), out_off(my_gj), sentinel2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my sentinels are in L2 ...
+    __syncthreads();                          // ... and so are those of the other waves, before this member checks in
     if (threadIdx.x < 64) {
-        int fast_l = 0;
-        if (a.mode == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc = (xcc & 0xfu) + 1u;
-            unsigned *ids = a.flags + (size_t)g * G;
-            if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
-            unsigned v = xcc;
-            for (unsigned spin = 0; spin < 2000000u; spin++) {
-                v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
-                if (__all(v != 0u)) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            fast_l = __all(v == xcc) ? 1 : 0;
+        // start barrier of the group (also tells whether all 32 members share one XCD, i.e. one L2)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 0xfu) + 1u;
+        unsigned *ids = a.flags + (size_t)g * G;
+        if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
+        unsigned v = xcc;
+        for (unsigned spin = 0; spin < 2000000u; spin++) {
+            v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
+            if (__all(v != 0u)) break;
+            __builtin_amdgcn_s_sleep(2);
         }
+        if (!__all(v != 0u) && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }      // a member never arrived
+        const int fast_l = (a.mode == 0 && __all(v == xcc)) ? 1 : 0;
         if (lane == 0) lds_fast = fast_l;
     }
     // resident weights of this wave: rows of my N unit tiles, chunks kw*N .. kw*N+N-1, three slices
@@ -159,14 +184,13 @@ k_lstm_split(SplitArgs a) {
                 for (int s = 0; s < 3; s++)
                     wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + (kw * N + cc)) * 3 + s) * 64 + lane];
     }
-    const int q = lane >> 4, rl = lane & 15;
     __syncthreads();
+    if (lds_abort) return;
     const bool fast = lds_fast != 0;
     if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
 
     const unsigned lane_off = (unsigned)lane * 16u;
     auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
-    auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     auto raw_barrier = [&]() {               // LDS-only barrier: no vmcnt drain, prefetches stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -198,27 +222,22 @@ k_lstm_split(SplitArgs a) {
         hv.y = __shfl(h, rl + 16);
         hv.z = __shfl(h, rl + 32);
         hv.w = __shfl(h, rl + 48);
-        // quarter-wave q stores slice q of the 4 units of read rl: 8 bytes at k = 4*ut .. 4*ut+3
         const int ut = ut0 + gj;
         const v2u sl = split4(hv, q);
-        const unsigned off = (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8);
-        unsigned char *tp_out = a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB;
+        const unsigned off = out_off(gj);
         if (q < 3) {
-            if (fast) *(v2u *)(tp_out + off) = sl;
-            else {
-                __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tp_out, 0, (int)tileB, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b64(sl, wr, off, 0, 16 /*sc1*/);
+            unsigned char *tp_out = out_tile(t, gts);
+            if (fast) {                                    // the group shares one L2: plain stores
+                if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
+                *(v2u *)(tp_out + off) = sl;
+            } else {
+                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
+                store_wt(tp_out, off, sl);
             }
         } else if (a.hout_f32) {
             *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
         }
     };
-    // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
-    // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
-    // the hardware on one SIMD run in ~2500 cycles, two tiles back to back in one wave in ~3300).
-    const int g6 = xw ? 4 + wave : kw;
-    const bool gate_wave = (xw ? wave < 2 : true) && g6 < ntl * N;
-    const int my_gts = g6 / N, my_gj = g6 % N;
     int my_tb = 0;
     if (gate_wave) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
     float c = 0.0f;

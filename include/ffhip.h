@@ -135,6 +135,9 @@ int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][ns
 /* debug taps used by the parity tests: activations after conv stack (layer -1) or after RNN layer l
  * (0..4) as dense [nblock][hidden] */
 int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
+/* which recurrent implementation the last ffhip_batch_run used: 0 = one launch per step, 1 = persistent recurrence behind a
+ * projection GEMM, 2 = fused f32-MFMA layer kernel, 3 = split-bf16 layer kernel (LSTM, hidden 128/256/384) */
+int ffhip_batch_rnn_path(const ffhip_batch *b);
 /* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split-bf16 activation layout of
  * the recurrent layer kernel and back; out == in bit for bit (three bf16 slices hold any fp32 exactly) */
 int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden);

@@ -44,15 +44,23 @@ def main():
 
 if __name__ == "__main__":
     res = main()
-    dom = [k for k in res if "k_lstm_fused" in k] or [k for k in res if "k_rnn_persist" in k]
+    dom = [k for k in res if "k_lstm_split" in k] or [k for k in res if "k_lstm_fused" in k] or [k for k in res if "k_rnn_persist" in k]
     if dom:
         k = dom[0]
         H, nread, T, Tb = 384, 256, 4000, 800
-        fused = "fused" in k
-        alg = Tb * nread * H * 4 * (2 if fused else 5)      # fused: read x + write h; unfused: read Xa (4H) + write h
-        json.dump({"hidden": H, "nread": nread, "nsample": T, "fused": fused, "kernel": k,
-                   "recurrent_layer_hbm_bytes_per_launch": int(res[k][0] + res[k][1]),
-                   "read_bytes_corrected": int(res[k][0]), "write_bytes": int(res[k][1]),
-                   "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % sys.argv[1]},
-                  open("profiles/r01_traffic.json", "w"), indent=1)
-        print(open("profiles/r01_traffic.json").read())
+        rnn_path = 3 if "split" in k else (2 if "fused" in k else 1)
+        # algorithmic bytes: split kernel reads x and writes h at 6 B per value (three bf16 slices); fused f32 kernel 4 + 4;
+        # unfused: read Xa (4H floats) + write h
+        alg = Tb * nread * H * {3: 12, 2: 8, 1: 20}[rnn_path]
+        entry = {"hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path >= 2, "kernel": k,
+                 "recurrent_layer_hbm_bytes_per_launch": int(res[k][0] + res[k][1]),
+                 "read_bytes_corrected": int(res[k][0]), "write_bytes": int(res[k][1]),
+                 "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % sys.argv[1]}
+        try:
+            old = json.load(open("profiles/r01_traffic.json"))
+            old = old if isinstance(old, list) else [old]
+        except (OSError, ValueError):
+            old = []
+        old = [e for e in old if e.get("rnn_path", 2 if e.get("fused") else 1) != rnn_path] + [entry]
+        json.dump(old, open("profiles/r01_traffic.json", "w"), indent=1)
+        print(json.dumps(entry, indent=1))
