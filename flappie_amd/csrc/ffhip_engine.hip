@@ -885,6 +885,19 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
 
 extern "C" int ffhip_batch_rnn_path(const ffhip_batch *b) { return b ? b->rnn_path : -1; }
 
+extern "C" int ffhip_debug_lean_math_check(ffhip_engine *eng, int exponent, int steps, unsigned long long *mismatches) {
+    if (!eng || !mismatches || exponent < 0 || exponent > 125 || steps < 0 || steps > 2) return set_err(FFHIP_EINVAL, "lean math check: bad arguments");
+    hipSetDevice(eng->device);
+    TmpDev tmp;
+    unsigned long long *d = (unsigned long long *)tmp.get(8);
+    if (!d) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemset(d, 0, 8), FFHIP_EHIP);
+    launch_lean_math_check(nullptr, exponent, steps, d);
+    HIP_TRY(hipDeviceSynchronize(), FFHIP_EHIP);
+    HIP_TRY(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden) {
     if (!eng || !in || !out || ntile == 0 || hidden <= 0 || hidden % 128 != 0) return set_err(FFHIP_EINVAL, "split round trip: bad arguments");
     hipSetDevice(eng->device);

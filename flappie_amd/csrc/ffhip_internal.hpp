@@ -90,6 +90,7 @@ bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const v
                        const int *tbs = nullptr, const int *tbt = nullptr);
 void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H);      // tile-interleaved fp32 -> split
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H);
+void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad);      // adds the mismatch count to *bad
 
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,

@@ -134,6 +134,74 @@ __device__ __forceinline__ ffv4 logistic_ref4(ffv4 x) {
     return r;
 }
 
+// ---- the same results with fewer instructions, for the gate phase of the persistent layer kernels -------------------
+// 1 / d for 1 <= d <= 2^126, correctly rounded (= the IEEE quotient 1.0f / d, bit for bit): hardware reciprocal, one
+// Newton step, and the closing fused step q + (1 - d q) q of the standard division expansion.  What the compiler's
+// expansion adds on top -- v_div_scale x2, v_div_fmas, v_div_fixup -- only serves operands outside this range.
+// Checked exhaustively over every mantissa at several exponents by ffhip_debug_recip_check (tests/test_split_gpu.py).
+template <int STEPS = 1>
+__device__ __forceinline__ float recip_1_to_2p126(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+        const float e = __builtin_fmaf(-d, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+    }
+    const float e2 = __builtin_fmaf(-d, r, 1.0f);      // exact: r is within an ulp of 1/d
+    return __builtin_fmaf(e2, r, r);
+}
+
+// exp_cephes4 with the reference's truncate / compare / subtract floor written as floor (the same value for every
+// input: |fx| <= 128 here) -- 1 instruction instead of 5 per component
+__device__ __forceinline__ ffv4 exp_cephes4_floor(ffv4 x) {
+    const ffv4 hi = { 88.3762626647949f, 88.3762626647949f, 88.3762626647949f, 88.3762626647949f };
+    x = __builtin_elementwise_min(x, hi);
+    x = __builtin_elementwise_max(x, -hi);
+    ffv4 fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    fx = __builtin_elementwise_floor(fx);
+    ffv4 tmp = fx * 0.693359375f;
+    ffv4 z = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - z;
+    z = x * x;
+    ffv4 y = { 1.9875691500E-4f, 1.9875691500E-4f, 1.9875691500E-4f, 1.9875691500E-4f };
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z;
+    y = y + x;
+    y = y + 1.0f;
+    ffv4 p2;
+    p2.x = __int_as_float((__float2int_rz(fx.x) + 0x7f) << 23);
+    p2.y = __int_as_float((__float2int_rz(fx.y) + 0x7f) << 23);
+    p2.z = __int_as_float((__float2int_rz(fx.z) + 0x7f) << 23);
+    p2.w = __int_as_float((__float2int_rz(fx.w) + 0x7f) << 23);
+    return y * p2;
+}
+
+// logistic_ref4, bit for bit, through the two functions above; a lane whose denominator 1 + exp(-x) exceeds 2^126
+// (x < -87.3) sends the wave through the general division
+__device__ __forceinline__ ffv4 logistic_ref4_lean(ffv4 x) {
+    const ffv4 e = exp_cephes4_floor(-x);
+    const ffv4 d = e + 1.0f;
+    ffv4 r;
+    const float big = 8.5070592e37f;      // 2^126
+    if (__builtin_expect(__any(d.x > big || d.y > big || d.z > big || d.w > big), 0)) {
+        r.x = 1.0f / d.x; r.y = 1.0f / d.y; r.z = 1.0f / d.z; r.w = 1.0f / d.w;
+    } else {
+        r.x = recip_1_to_2p126<>(d.x); r.y = recip_1_to_2p126<>(d.y); r.z = recip_1_to_2p126<>(d.z); r.w = recip_1_to_2p126<>(d.w);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float tanh_ref_lean(float x) {
+    const ffv4 L = logistic_ref4_lean((ffv4){ x + x, 0.0f, 0.0f, 0.0f });
+    return (L.x + L.x) - 1.0f;
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? swish_ref(x) : (act == 2 ? tanh_ref(x) : x);
 }

@@ -260,12 +260,12 @@ k_rnn_persist(PersistArgs a) {
                 c = forget + update;
                 h = logistic_ref(s.w) * tanh_ref(c);
 #else
-                const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });      // bit-identical to logistic_ref4, fewer instructions (ffhip_math.hpp)
                 const float tanh_g = (L.z + L.z) - 1.0f;
                 const float forget = L.y * c;
                 const float update = L.x * tanh_g;
                 c = forget + update;
-                h = L.w * tanh_ref(c);
+                h = L.w * tanh_ref_lean(c);
 #endif
             } else {
                 // layers.c:690-714: x added to z,r before the logistic; candidate = tanh(r*u + x_c)
@@ -520,12 +520,12 @@ k_lstm_fused(PersistArgs a) {
                 h = so * (2.0f * sg(c + c) - 1.0f);
             } else {
                 s = s + bias;
-                const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });      // bit-identical to logistic_ref4, fewer instructions (ffhip_math.hpp)
                 const float tanh_g = (L.z + L.z) - 1.0f;
                 const float forget = L.y * c;
                 const float update = L.x * tanh_g;
                 c = forget + update;
-                h = L.w * tanh_ref(c);
+                h = L.w * tanh_ref_lean(c);
             }
             if (t >= my_tb) { h = 0.0f; c = 0.0f; hprev_own = 0.0f; }      // beyond this read's end (ragged batch)
             v4f hv;

@@ -187,7 +187,9 @@ k_lstm_split(SplitArgs a) {
     __syncthreads();
     if (lds_abort) return;
     const bool fast = lds_fast != 0;
+#ifndef FFHIP_SPLIT_NOPRIO
     if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+#endif
 
     const unsigned lane_off = (unsigned)lane * 16u;
     auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
@@ -210,12 +212,13 @@ k_lstm_split(SplitArgs a) {
         v4f s = sbias[gj][q];
 #pragma unroll
         for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
-        const ffv4 L = logistic_ref4((ffv4){ s.x, s.y, s.z + s.z, s.w });
+        // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
+        const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
         const float tanh_g = (L.z + L.z) - 1.0f;
         const float forget = L.y * c;
         const float update = L.x * tanh_g;
         c = forget + update;
-        float h = L.w * tanh_ref(c);
+        float h = L.w * tanh_ref_lean(c);
         if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
         v4f hv;
         hv.x = __shfl(h, rl);
@@ -281,6 +284,10 @@ k_lstm_split(SplitArgs a) {
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
             TL(0);
+#ifdef FFHIP_TIMELINE
+            if (a.mode & 2) { if (i + 2 < Tb) load_x(i + 2); } else            // experiment: x waves issue no MFMAs
+            if (a.mode & 8) { if (i + 1 < Tb) project(i + 1); } else           // experiment: no prefetch of x (stale operands)
+#endif
             if (i + 1 < Tb) {
                 project(i + 1);
                 if (i + 2 < Tb) load_x(i + 2);
@@ -458,6 +465,29 @@ void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t nti
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H) {
     const size_t npair = ntile * (size_t)(H / 8) * 16;
     hipLaunchKernelGGL(k_f32_from_split, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (const unsigned char *)in, out, npair, H / 4);
+}
+
+// ---- exhaustive check of the lean gate math (debug entry point) -----------------------------------
+// every fp32 mantissa at the given binary exponent: recip_1_to_2p126 against the IEEE division, logistic_ref4_lean against
+// logistic_ref4 on the same bit patterns read as gate pre-activations in [-128, 128)
+__global__ void __launch_bounds__(256)
+k_lean_math_check(int exponent, int steps, unsigned long long *bad) {
+    const unsigned mant = blockIdx.x * 256 + threadIdx.x;       // 2^23 threads
+    const float d = __uint_as_float(((unsigned)(127 + exponent) << 23) | mant);
+    const float want = 1.0f / d;
+    const float got = steps == 0 ? recip_1_to_2p126<0>(d) : (steps == 1 ? recip_1_to_2p126<1>(d) : recip_1_to_2p126<2>(d));
+    unsigned nbad = (__float_as_uint(want) != __float_as_uint(got)) ? 1u : 0u;
+    // gate pre-activations: sign and magnitude patterns derived from the same counter
+    const float x = (exponent & 1 ? -1.0f : 1.0f) * __uint_as_float(((unsigned)(127 + (exponent % 7)) << 23) | mant) * 1.0f;
+    const ffv4 a = logistic_ref4((ffv4){ x, -x, x * 0.03125f, x * 61.0f });
+    const ffv4 b = logistic_ref4_lean((ffv4){ x, -x, x * 0.03125f, x * 61.0f });
+    nbad += (__float_as_uint(a.x) != __float_as_uint(b.x)) + (__float_as_uint(a.y) != __float_as_uint(b.y)) +
+            (__float_as_uint(a.z) != __float_as_uint(b.z)) + (__float_as_uint(a.w) != __float_as_uint(b.w));
+    nbad += (__float_as_uint(tanh_ref(x)) != __float_as_uint(tanh_ref_lean(x)));
+    if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad) {
+    hipLaunchKernelGGL(k_lean_math_check, dim3(1u << 15), dim3(256), 0, s, exponent, steps, bad);
 }
 
 // ---- host side ---------------------------------------------------------------------------------

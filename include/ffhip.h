@@ -141,6 +141,11 @@ int ffhip_batch_rnn_path(const ffhip_batch *b);
 /* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split-bf16 activation layout of
  * the recurrent layer kernel and back; out == in bit for bit (three bf16 slices hold any fp32 exactly) */
 int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden);
+/* debug tap: the gate math of the persistent layer kernels (reciprocal by Newton steps instead of the division expansion,
+ * floor instead of truncate/compare/subtract) against the reference-order arithmetic, on every fp32 mantissa at binary
+ * exponent `exponent` (0..125); `steps` = Newton steps before the closing step (the kernels use 1).  Counts mismatching bit
+ * patterns: 0 means bit-identical */
+int ffhip_debug_lean_math_check(ffhip_engine *eng, int exponent, int steps, unsigned long long *mismatches);
 
 /* ---- single-matrix decode entry points -------------------------------------------------------
  * Used by the reference-compatible wrappers in include/decode.h.  `trans` / `scores` / `post` are
