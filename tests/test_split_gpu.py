@@ -113,3 +113,17 @@ def test_split_layout_round_trip(B, engine):
     L.ffhip_debug_split_round_trip.restype = C.c_int
     assert L.ffhip_debug_split_round_trip(engine.h, x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)), 3, 128) == 0
     assert np.array_equal(x, y)
+
+
+def test_lean_gate_math_is_bit_identical(B, engine):
+    """the gate phase of the layer kernels evaluates 1 / (1 + exp(-x)) with a Newton reciprocal and floor() where the
+    reference-order code divides and truncates/compares/subtracts (ffhip_math.hpp, *_lean): every fp32 mantissa at
+    several binary exponents must give the same bits, for the reciprocal, the logistic and tanh"""
+    import ctypes as C
+    L = B.lib()
+    L.ffhip_debug_lean_math_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.ffhip_debug_lean_math_check.restype = C.c_int
+    for ex in (0, 1, 2, 3, 4, 5, 6, 7, 23, 100, 125):
+        n = C.c_ulonglong(1)
+        assert L.ffhip_debug_lean_math_check(engine.h, ex, 1, C.byref(n)) == 0
+        assert n.value == 0, ex
