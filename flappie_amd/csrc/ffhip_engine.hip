@@ -628,6 +628,18 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         return FFHIP_OK;
     };
 
+    // split-bf16 layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM, H = 128/256/384)
+    const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
+    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
+    const bool use_split = use_persist && use_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+                           split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
+    if (use_split) {
+        const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
+        for (int i = 0; i < 2; i++)
+            if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
+    }
+    // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
+    const bool conv_split = use_split && !keep && m->conv[m->nconv - 1].Mpad == Hp;
     mark(b, 0);
     // ---- convolutions (layers.c:189-276, activations :24-49)
     for (int l = 0; l < m->nconv; l++) {
@@ -638,7 +650,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                               b->ragged ? b->rag_tin[l] : nullptr);
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
-                             b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0);
+                             b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0,
+                             conv_split ? b->actS[0] : nullptr);
         }
         b->launches[0]++;
     }
@@ -649,18 +662,10 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // whole stack and the split is measured with per-layer events when profiling is on.
     int cur = 0;
     const bool prof = b->eng->profiling != 0;
-    const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
     if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
-    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
-    // split-bf16 layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM, H = 128/256/384)
-    const bool use_split = use_persist && use_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
-                           split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
-    if (use_split) {
-        const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
-        for (int i = 0; i < 2; i++)
-            if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
+    if (use_split && !conv_split) {
         launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp);
         b->launches[0]++;
     }

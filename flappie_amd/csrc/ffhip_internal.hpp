@@ -54,7 +54,8 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
-                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0);
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0,
+                      void *out_split = nullptr);      // != nullptr: write the split-bf16 layout of ffhip_rnn_split.hip INSTEAD of `out` (M % 128 == 0)
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
