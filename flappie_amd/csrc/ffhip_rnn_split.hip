@@ -26,16 +26,27 @@
 //   * one GROUP of 32 workgroups per PAIR of read tiles (32 reads); 256 CUs = 8 groups = 256 reads per launch, one
 //     workgroup of 8 waves per CU (the weights of a CU, 48 rows x 768 k x 6 B = 221 KiB, live in VGPRs: 108 per
 //     lane).  Member m owns N unit tiles (4N hidden units x 4 gates);
-//   * waves 0-3 ("x waves") hold the input weights of the member's rows, K split four ways, and compute the
-//     projection Wi x(t+1) one step AHEAD, under the hand-off latency of step t;
-//     waves 4-7 ("h waves") hold the recurrent weights, poll their K slice of h(t-1) and compute sW h(t-1);
-//   * partial tiles meet in LDS; six of the eight waves then do the gate math of one 16 x 16 tile each (4 gates of
-//     one unit of one read per lane, cell state in a register), split h(t) and store it.
-//   * hand-off: the payload is the flag, as in ffhip_rnn_persist.hip: the output is pre-filled with 0xFFFFFFFF
-//     (two bf16 NaNs -- never a pair of slices of a finite value) and consumers re-sweep until no dword is the
-//     sentinel; plain stores when the 32 members verifiably share one XCD (= one L2), write-through otherwise.
-//   * a second barrier closes the gate phase so that no x wave starts its MFMAs next to a gate wave on the same
-//     SIMD (a dependent VALU chain beside a saturated MFMA stream runs ~3x slower).
+//   * waves 0-3 ("x waves", low priority) hold the input weights of the member's rows, K split four ways, and compute
+//     the projection Wi x(t+1) one step AHEAD, under the hand-off latency of step t; x(t+2) is prefetched into
+//     registers right behind those MFMAs (it comes from HBM: a whole step of latency to hide);
+//     waves 4-7 ("h waves", high priority) hold the recurrent weights and START their accumulators from the projection
+//     partials of their K quarter (LDS), wait for h(t-1), add sW h(t-1), and leave the gate pre-activations in LDS;
+//   * after one LDS-only barrier six waves (the h waves and x waves 0, 1) do the gate math of one 16 x 16 tile each
+//     (4 gates of one unit of one read per lane, cell state in a register; ffhip_math.hpp *_lean forms, bit-identical
+//     to the reference-order arithmetic), split h(t) and store it; a second barrier closes the gate phase, so that no
+//     MFMA stream starts next to a gate wave on its SIMD (a dependent VALU chain beside one runs ~3x slower);
+//   * hand-off: the payload is the flag.  A producer lane writes the sentinel 0xFFFFFFFF (two bf16 NaNs -- never a
+//     pair of slices of a finite value) to ITS slots of step t+3 when it publishes step t (and of steps 0..2 before
+//     the group's start barrier): no host-side fill of the reused buffer.  A consumer wave first polls ONE dword per
+//     producing gate wave of its K slice (a full sweep is 18 KiB per wave and the CU's path to L2 takes 64 B/clk),
+//     then issues its sweep once; the sweep's chunks feed the MFMAs as they land (counted vmcnt waits) with the
+//     sentinel check riding along, and only a failed check (a producer's store became visible line by line) falls
+//     back to re-sweeping.  Plain stores when the 32 members verifiably share one XCD (= one L2), write-through
+//     otherwise; every spin is bounded (abort word -> FFHIP_ETIMEOUT).
+//
+// Measured (MI355X, 256 reads x 800 blocks, H = 384): 3.2 ms per layer = 150 TFLOP/s of fp32-equivalent work (the f32
+// MFMA kernel: 4.7 ms, 102 TFLOP/s).  Per step ~9700 cycles: hand-off poll ~1000, sweep + MFMAs ~4500 (the matrix
+// pipes carry 216 MFMAs = 3700 cycles per SIMD), gate phase ~2500, barriers ~300 -- DESIGN.md section 5.1.
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
 #include <stdlib.h>

@@ -19,7 +19,10 @@ nread = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = B.Engine(0)
 tot = dict(reads=0, bases=0, base_mismatch=0, qual_mismatch=0, path_mismatch=0, qual_chars_diff=0, worst=0.0)
 t0 = time.time()
-for kind, H, seed in ((M.NET_LSTM5, 96, 1), (M.NET_LSTM5, 64, 2), (M.NET_GRUMOD5, 64, 3), (M.NET_LSTM5, 128, 4)):
+models = ((M.NET_LSTM5, 96, 1), (M.NET_LSTM5, 64, 2), (M.NET_GRUMOD5, 64, 3), (M.NET_LSTM5, 128, 4))
+if len(sys.argv) > 2 and sys.argv[2] == "split":        # only shapes the split-bf16 layer kernel takes (H = 128, 256)
+    models = ((M.NET_LSTM5, 128, 4), (M.NET_LSTM5, 128, 5), (M.NET_LSTM5, 256, 6))
+for kind, H, seed in models:
     mdl = M.synthetic_model(kind, H, seed=seed)
     om = ffo.OracleModel(mdl)
     dm = B.DeviceModel(eng, mdl)
