@@ -688,7 +688,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 // one workgroup per CU: two such launches are co-resident only if together they need no more CUs than there are
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
-                if (!launch_lstm_split(s, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
+                if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
                                        backward, persist_mode, tbs, tbt))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }

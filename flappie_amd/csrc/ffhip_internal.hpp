@@ -86,7 +86,7 @@ bool split_supported(int kind, int H);
 int split_max_tiles(int ncu);                              // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU
 size_t split_flag_words(int nrt);
 inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 96; }      // 16 reads x H x 6 B
-bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
+bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
                        const int *tbs = nullptr, const int *tbt = nullptr);
 void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H);      // tile-interleaved fp32 -> split

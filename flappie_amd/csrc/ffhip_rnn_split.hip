@@ -109,7 +109,8 @@ __device__ __forceinline__ void mm6(const v4u (&w)[N][N][3], int cc, const v4u (
         for (int j = 0; j < N; j++) acc[j] = mm(w[j][cc][WS[term]], x[XS[term]], acc[j]);
 }
 
-template <int N>
+// KIND 0 = LSTM (gate rows i, f, g, o), 1 = GRUmod (gate rows z, r, candidate, -; layers.c:571-715)
+template <int KIND, int N>
 __global__ void __launch_bounds__(512, 1)
 k_lstm_split(SplitArgs a) {
     __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
@@ -220,16 +221,32 @@ k_lstm_split(SplitArgs a) {
     // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
         const int t = step_t(i);
-        v4f s = sbias[gj][q];
+        float h;
+        if (KIND == 1) {
+            // GRUmod (layers.c:690-714).  The accumulator rows are {z: x + h parts, r: x + h parts, u = (sW h)_c, x_c = (Wi x)_c}:
+            // the candidate's two halves must stay apart (r multiplies only the recurrent one), and a unit's fourth row is free.
+            // `c` carries this lane's own h(t-1).
+            v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
-        // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
-        const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
-        const float tanh_g = (L.z + L.z) - 1.0f;
-        const float forget = L.y * c;
-        const float update = L.x * tanh_g;
-        c = forget + update;
-        float h = L.w * tanh_ref_lean(c);
+            for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            const v4f b = sbias[gj][q];
+            const ffv4 L = logistic_ref4_lean((ffv4){ s.x + b.x, s.y + b.y, 0.0f, 0.0f });
+            float hbar = L.y * s.z + (s.w + b.z);
+            hbar = tanh_ref_lean(hbar);
+            h = L.x * c + (1.0f - L.x) * hbar;
+            c = h;
+        } else {
+            v4f s = sbias[gj][q];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
+            const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
+            const float tanh_g = (L.z + L.z) - 1.0f;
+            const float forget = L.y * c;
+            const float update = L.x * tanh_g;
+            c = forget + update;
+            h = L.w * tanh_ref_lean(c);
+        }
         if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
         v4f hv;
         hv.x = __shfl(h, rl);
@@ -329,7 +346,10 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                 for (int ts = 0; ts < 2; ts++)
 #pragma unroll
-                    for (int j = 0; j < N; j++) acc[ts][j] = px[i & 1][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+                    for (int j = 0; j < N; j++) {
+                        const v4f p = px[i & 1][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+                        acc[ts][j] = KIND == 1 ? (v4f){ p.x, p.y, 0.0f, p.z } : p;      // GRUmod: the projection's candidate row moves to the free row
+                    }
             };
             init_acc();
             if (i > 0) {
@@ -502,14 +522,14 @@ void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned lon
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-bool split_supported(int kind, int H) { return kind == 0 && H % 128 == 0 && H >= 128 && H <= 384; }
+bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 384; }
 // read tiles (of 16) one launch takes: one workgroup per CU, 32 per pair of tiles
 int split_max_tiles(int ncu) { return 2 * (ncu / 32); }
 size_t split_flag_words(int nrt) { return (size_t)((nrt + 1) / 2) * 32; }
 
 unsigned long long *g_split_dbg = nullptr;
 
-bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
+bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
                        const int *tbs, const int *tbt) {
     SplitArgs a;
@@ -518,11 +538,10 @@ bool launch_lstm_split(hipStream_t s, const void *Wp, const float *bias, const v
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
     const int ngroup = (nrt + 1) / 2;
-    switch (H / 128) {
-    case 1: hipLaunchKernelGGL(k_lstm_split<1>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
-    case 2: hipLaunchKernelGGL(k_lstm_split<2>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
-    case 3: hipLaunchKernelGGL(k_lstm_split<3>, dim3(ngroup * 32), dim3(512), 0, s, a); return true;
-    }
+#define SPLIT_LAUNCH(K, NN) hipLaunchKernelGGL((k_lstm_split<K, NN>), dim3(ngroup * 32), dim3(512), 0, s, a); return true
+    if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
+    if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
+#undef SPLIT_LAUNCH
     return false;
 }
 

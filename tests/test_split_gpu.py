@@ -51,6 +51,32 @@ def test_split_kernel_against_oracle_odd_tile_count(B, engine):
     dm.close()
 
 
+def test_split_kernel_grumod_against_oracle(B, engine):
+    """the GRUmod variant (r941_5mC family: gate rows z, r, candidate; the candidate's projection half rides in the free
+    fourth row), uniform and ragged, against the oracle"""
+    mdl = M.synthetic_model(M.NET_GRUMOD5, 128, seed=21)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(77)
+    sig = rng.standard_normal((20, 1000)).astype(np.float32)
+    b = B.Batch(dm, 20, 1000)
+    b.set_signals(sig)
+    b.run(); b.finish()
+    assert b.rnn_path() == 3
+    for r in range(20):
+        check_read(b, r, om.basecall(sig[r]))
+    lens = [1000, 999, 400, 37, 19, 640, 1000, 12 * 50, 333] + [0] * 8 + [777, 1000, 5]
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    lens[-1] = 0; sigs[-1] = np.zeros(0, dtype=np.float32)          # (5 samples would be shorter than the window)
+    b.set_signals_ragged(sigs)
+    b.run(); b.finish()
+    for r, x in enumerate(sigs):
+        if x.size:
+            check_read(b, r, om.basecall(x))
+    b.close()
+    dm.close()
+
+
 def test_split_kernel_ragged_and_empty_slots(B, engine):
     """per-read lengths, tiles whose block counts differ inside a pair, a tile of empty slots, and bitwise independence
     of a read's result from its slot and its neighbours"""
@@ -77,10 +103,12 @@ def test_split_kernel_ragged_and_empty_slots(B, engine):
     dm.close()
 
 
-@pytest.mark.parametrize("hidden,nread,T", [(256, 48, 2000), (384, 32, 1500), (128, 272, 500)])
-def test_split_kernel_agrees_with_f32_kernel(B, engine, hidden, nread, T):
-    """H = 256 and 384 (two and three unit tiles per workgroup); 272 reads = 17 read tiles, one more than a launch takes"""
-    mdl = M.synthetic_model(M.NET_LSTM5, hidden, seed=hidden)
+@pytest.mark.parametrize("kind,hidden,nread,T", [(M.NET_LSTM5, 256, 48, 2000), (M.NET_LSTM5, 384, 32, 1500), (M.NET_LSTM5, 128, 272, 500),
+                                                 (M.NET_GRUMOD5, 256, 40, 1200), (M.NET_GRUMOD5, 384, 16, 800)])
+def test_split_kernel_agrees_with_f32_kernel(B, engine, kind, hidden, nread, T):
+    """H = 256 and 384 (two and three unit tiles per workgroup), LSTM and GRUmod; 272 reads = 17 read tiles, one more than a
+    launch takes"""
+    mdl = M.synthetic_model(kind, hidden, seed=hidden)
     dm = B.DeviceModel(engine, mdl)
     rng = np.random.default_rng(nread)
     sig = rng.standard_normal((nread, T)).astype(np.float32)

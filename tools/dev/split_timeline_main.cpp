@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
         hipMemset(flags, 0, 4096 * 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        launch_lstm_split(0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode);   // mode & 2: x waves skip their MFMAs (timing experiment)
+        launch_lstm_split(0, 0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode);   // mode & 2: x waves skip their MFMAs (timing experiment)
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("layer %.3f ms = %.3f us/step = %.0f cycles/step\n", ms, ms * 1e3 / Tb, ms * 1e3 / Tb * 2400);
