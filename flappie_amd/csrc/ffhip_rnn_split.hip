@@ -51,6 +51,10 @@
 #include "ffhip_math.hpp"
 #include <stdlib.h>
 
+#ifndef FFHIP_SPLIT_ABLATE
+#define FFHIP_SPLIT_ABLATE 0      // development builds only (tools/dev/ablate.py): leave parts of the step out to time the rest
+#endif
+
 namespace ffhip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -218,7 +222,11 @@ k_lstm_split(SplitArgs a) {
     };
 
 #ifdef FFHIP_TIMELINE
-#define TL(k) do { if (a.dbg && i >= 100 && i < 132 && lane == 0) a.dbg[((((size_t)blockIdx.x * 8 + wave) * 32 + (i - 100)) * 16 + (k))] = __builtin_readcyclecounter(); } while (0)
+    // phase stamps go to LDS and are copied out after the loop: a global store per stamp would sit on the same counter as the
+    // loads and turn the kernel's counted vmcnt waits into vmcnt(0) -- the instrumented kernel would not be the kernel.
+    // (Even so the timeline build runs ~35 % slower than the product; tools/dev/ablate.py times the real thing.)
+    __shared__ unsigned long long tl_lds[8][32][8];
+#define TL(k) do { if (i >= 100 && i < 132 && lane == 0) tl_lds[wave][i - 100][(k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TL(k) do { } while (0)
 #endif
@@ -228,6 +236,10 @@ k_lstm_split(SplitArgs a) {
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
         const int t = step_t(i);
         float h;
+#if FFHIP_SPLIT_ABLATE & 4              // 4 = no gate math (one LDS read stands in for it)
+        h = ph[0][gts][gj][lane].x * 1e-3f;
+        if (false)
+#endif
         if (KIND == 1) {
             // GRUmod (layers.c:690-714).  The accumulator rows are {z: x + h parts, r: x + h parts, u = (sW h)_c, x_c = (Wi x)_c}:
             // the candidate's two halves must stay apart (r multiplies only the recurrent one), and a unit's fourth row is free.
@@ -322,8 +334,10 @@ k_lstm_split(SplitArgs a) {
         unsigned touched = 0, sink = 0;
         auto touch_x = [&](int i) {
             const int line = m * LPM + lane;
+            unsigned t = 0;                               // (not `touched` itself: keeping the old value would make this a use of the old load)
             if (wave == 3 && lane < LPM && line < ntl * Hc * 24 && i < Tb)
-                touched = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
+                t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
+            touched = t;
         };
         load_x(0);
         project(0);
@@ -332,13 +346,13 @@ k_lstm_split(SplitArgs a) {
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
             TL(0);
-#ifdef FFHIP_TIMELINE
-            if (a.mode & 2) { if (i + 2 < Tb) load_x(i + 2); } else            // experiment: x waves issue no MFMAs
-            if (a.mode & 8) { if (i + 1 < Tb) project(i + 1); } else           // experiment: no prefetch of x (stale operands)
-#endif
             if (i + 1 < Tb) {
+#if !(FFHIP_SPLIT_ABLATE & 1)      // compile-time timing experiments (results wrong by construction): 1 = x waves issue no MFMAs
                 project(i + 1);
+#endif
+#if !(FFHIP_SPLIT_ABLATE & 16)     // 16 = no prefetch of x (stale operands)
                 if (i + 2 < Tb) load_x(i + 2);
+#endif
             }
             sink ^= touched;                                 // (keeps the touch a real load; it landed a step ago)
             touch_x(i + WARM);
@@ -385,9 +399,7 @@ k_lstm_split(SplitArgs a) {
                     const int put = ((kw + m) & 3) * NPROD + ul;
                     const bool act = pts < ntl;
                     const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * 3 * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
-#ifdef FFHIP_TIMELINE
-                    if (!(a.mode & 16))                    // experiment: no hand-off wait at all (timing of the compute pipeline alone)
-#endif
+#if !(FFHIP_SPLIT_ABLATE & 2)          // 2 = no hand-off wait at all (timing of the compute pipeline alone)
                     for (unsigned spin = 0;; spin++) {
                         const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
                         if (__all(v != kSplitSentinel)) break;
@@ -396,6 +408,7 @@ k_lstm_split(SplitArgs a) {
                             if (ab != 0u || spin > 6000000u) { timed_out = true; break; }
                         }
                     }
+#endif
                 }
                 TL(1);
                 v4u raw[NCH][3];
@@ -405,6 +418,9 @@ k_lstm_split(SplitArgs a) {
                 const int offB = (ntl > 1) ? (int)tileB : 0;
                 auto load_chunk = [&](int k) {          // k = ts*N + cc
                     const int ts = k / N, cc = k % N;
+#if FFHIP_SPLIT_ABLATE & 8              // 8 = no sweep: operands are whatever the registers hold
+                    if (i > 1) return;
+#endif
 #pragma unroll
                     for (int s = 0; s < 3; s++)
                         raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
@@ -426,8 +442,8 @@ k_lstm_split(SplitArgs a) {
                         mm6<N>(wf, k % N, raw[k], acc[k / N]);
                         __builtin_amdgcn_sched_barrier(0);      // keep each chunk's check and MFMAs behind ITS loads only: the sweep streams under the MFMAs
                     }
-#ifdef FFHIP_TIMELINE
-                    if (a.mode & 16) return true;
+#if FFHIP_SPLIT_ABLATE & 2
+                    return true;
 #endif
                     return __all(ok) != 0;
                 };
@@ -468,6 +484,10 @@ k_lstm_split(SplitArgs a) {
             TL(5);
         }
     }
+#ifdef FFHIP_TIMELINE
+    if (a.dbg && Tb >= 132)
+        for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)blockIdx.x * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
+#endif
 }
 
 // ---- layout converters -------------------------------------------------------------------------

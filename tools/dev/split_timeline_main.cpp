@@ -22,7 +22,8 @@ int main(int argc, char **argv) {
     hipMalloc(&dbg, ndbg * 8); hipMemset(dbg, 0, ndbg * 8);
     g_split_dbg = dbg;
     const int mode = argc > 3 ? atoi(argv[3]) : 0;
-    for (int rep = 0; rep < 2; rep++) {
+    const int nrep = argc > 4 ? atoi(argv[4]) : 40;      // enough launches for the clocks to settle: the first ones run ~40 % slower
+    for (int rep = 0; rep < nrep; rep++) {
         hipMemsetD32((hipDeviceptr_t)hout, 0xFFFFFFFF, abytes / 4);
         hipMemset(flags, 0, 4096 * 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -30,7 +31,7 @@ int main(int argc, char **argv) {
         launch_lstm_split(0, 0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode);   // mode & 2: x waves skip their MFMAs (timing experiment)
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("layer %.3f ms = %.3f us/step = %.0f cycles/step\n", ms, ms * 1e3 / Tb, ms * 1e3 / Tb * 2400);
+        if (rep < 2 || rep >= nrep - 2) printf("rep %d: layer %.3f ms = %.3f us/step = %.0f cycles/step\n", rep, ms, ms * 1e3 / Tb, ms * 1e3 / Tb * 2400);
     }
     unsigned abv = 0; hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost);
     printf("abort word %u\n", abv);
