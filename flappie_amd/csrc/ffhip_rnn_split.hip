@@ -209,9 +209,8 @@ k_lstm_split(SplitArgs a) {
     __syncthreads();
     if (lds_abort) return;
     const bool fast = lds_fast != 0;
-#ifndef FFHIP_SPLIT_NOPRIO
+    // the h waves are the critical path: their MFMAs go first, the projection fills the gaps (without priorities: +9 %)
     if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-#endif
 
     const unsigned lane_off = (unsigned)lane * 16u;
     auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
