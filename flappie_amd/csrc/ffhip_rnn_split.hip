@@ -120,6 +120,8 @@ k_lstm_split(SplitArgs a) {
     __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
     __shared__ v4f ph[4][2][N][64];         // gate pre-activations by K quarter: projection partial + recurrent partial
     __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
+    __shared__ unsigned short gsl[8][3][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
+    __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
     __shared__ int lds_abort;
     __shared__ int lds_fast;
     constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
@@ -265,15 +267,25 @@ k_lstm_split(SplitArgs a) {
             h = L.w * tanh_ref_lean(c);
         }
         if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
-        v4f hv;
-        hv.x = __shfl(h, rl);
-        hv.y = __shfl(h, rl + 16);
-        hv.z = __shfl(h, rl + 32);
-        hv.w = __shfl(h, rl + 48);
+#if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
+        if (h == 123.0f) a.flags[0] = 1; else return;
+#endif
+        // Split h ONCE, in the lane that owns it, and transpose through a wave-private LDS patch: lane (unit q, read rl) writes its
+        // three bf16 slices to [slice][read][unit]; quarter-wave q then reads the 8 bytes [slice q][read rl][units 0..3] -- the
+        // packed operand piece it stores.  (Four ds_bpermute + a 4-value split in every lane cost ~3x the VALU work.)
+        const unsigned b0 = bf16_bits(h);
+        const float r1 = h - bf16_val(b0);
+        const unsigned b1 = bf16_bits(r1);
+        const unsigned b2 = bf16_bits(r1 - bf16_val(b1));
+        gsl[wave][0][rl][q] = (unsigned short)b0;
+        gsl[wave][1][rl][q] = (unsigned short)b1;
+        gsl[wave][2][rl][q] = (unsigned short)b2;
+        if (a.hout_f32) gf32[wave][rl][q] = h;
+        asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
         const int ut = ut0 + gj;
-        const v2u sl = split4(hv, q);
         const unsigned off = out_off(gj);
         if (q < 3) {
+            const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
                 if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
@@ -283,6 +295,7 @@ k_lstm_split(SplitArgs a) {
                 store_wt(tp_out, off, sl);
             }
         } else if (a.hout_f32) {
+            const v4f hv = *(const v4f *)&gf32[wave][rl][0];
             *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
         }
     };
