@@ -197,9 +197,49 @@ __device__ __forceinline__ ffv4 logistic_ref4_lean(ffv4 x) {
     return r;
 }
 
+// the same for one value and for two (a 4-vector with idle components costs its full instruction count)
+__device__ __forceinline__ float exp_cephes_floor1(float x) {
+    x = __builtin_fminf(x, 88.3762626647949f);
+    x = __builtin_fmaxf(x, -88.3762626647949f);
+    float fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    fx = __builtin_floorf(fx);
+    const float tmp = fx * 0.693359375f;
+    float z = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - z;
+    z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z;
+    y = y + x;
+    y = y + 1.0f;
+    return y * __int_as_float((__float2int_rz(fx) + 0x7f) << 23);
+}
+
+__device__ __forceinline__ float logistic_ref_lean(float x) {
+    const float d = exp_cephes_floor1(-x) + 1.0f;
+    if (__builtin_expect(__any(d > 8.5070592e37f), 0)) return 1.0f / d;
+    return recip_1_to_2p126<>(d);
+}
+
+typedef float ffv2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ffv2 logistic_ref2_lean(ffv2 x) {
+    ffv2 r;
+    // two independent scalar chains: the compiler packs the multiplies and adds of the pair (v_pk_mul_f32 / v_pk_add_f32)
+    const float d0 = exp_cephes_floor1(-x.x) + 1.0f, d1 = exp_cephes_floor1(-x.y) + 1.0f;
+    if (__builtin_expect(__any(d0 > 8.5070592e37f || d1 > 8.5070592e37f), 0)) { r.x = 1.0f / d0; r.y = 1.0f / d1; }
+    else { r.x = recip_1_to_2p126<>(d0); r.y = recip_1_to_2p126<>(d1); }
+    return r;
+}
+
 __device__ __forceinline__ float tanh_ref_lean(float x) {
-    const ffv4 L = logistic_ref4_lean((ffv4){ x + x, 0.0f, 0.0f, 0.0f });
-    return (L.x + L.x) - 1.0f;
+    const float y = logistic_ref_lean(x + x);
+    return (y + y) - 1.0f;
 }
 
 __device__ __forceinline__ float apply_act(float x, int act) {

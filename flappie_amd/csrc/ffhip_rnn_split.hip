@@ -249,7 +249,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
             const v4f b = sbias[gj][q];
-            const ffv4 L = logistic_ref4_lean((ffv4){ s.x + b.x, s.y + b.y, 0.0f, 0.0f });
+            const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
             float hbar = L.y * s.z + (s.w + b.z);
             hbar = tanh_ref_lean(hbar);
             h = L.x * c + (1.0f - L.x) * hbar;
@@ -576,6 +576,8 @@ k_lean_math_check(int exponent, int steps, unsigned long long *bad) {
     nbad += (__float_as_uint(a.x) != __float_as_uint(b.x)) + (__float_as_uint(a.y) != __float_as_uint(b.y)) +
             (__float_as_uint(a.z) != __float_as_uint(b.z)) + (__float_as_uint(a.w) != __float_as_uint(b.w));
     nbad += (__float_as_uint(tanh_ref(x)) != __float_as_uint(tanh_ref_lean(x)));
+    const ffv2 b2 = logistic_ref2_lean((ffv2){ x, x * -0.5f });
+    nbad += (__float_as_uint(logistic_ref(x)) != __float_as_uint(b2.x)) + (__float_as_uint(logistic_ref(x * -0.5f)) != __float_as_uint(b2.y));
     if (nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad) {
