@@ -864,23 +864,53 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
     const int st = lane & 7;
     const float NEG = -INFINITY;
 
+    // The two recursions are chains of ~200 cycles of work per block; nothing on them may wait for memory.  Their
+    // forward / backward vectors therefore go to an LDS stage and leave in rows of 64 blocks (a global store per block
+    // shares the wave's memory counter with the loads: the compiler then waits for the store's acknowledgement, ~700
+    // cycles, before it may use the next block's scores), and the scores of the next kDepth blocks are in flight while
+    // kDepth blocks are processed (clamped addresses, never predicated loads: counted waits need branch-free queues).
+    __shared__ float stage[2][64][kMaxState];
+    constexpr int kDepth = 8;
+    const int lane_c = valid ? lane : P - 1;
+    auto flush = [&](int w, float *dst0, long long dstep, int cnt) {      // row r of the stage -> dst0 + r*dstep (kMaxState floats each)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const float4 *src = (const float4 *)&stage[w][lane][0];
+            float4 *dst = (float4 *)(dst0 + (long long)lane * dstep);
+            dst[0] = src[0]; dst[1] = src[1];                              // ns = 8 states
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     if (wave == 0) {
         // forwards: pv = fwd[blk][lane & 7]
         float pv = 0.0f;
         if (lane < ns) F[lane] = 0.0f;
-        float s_next = valid ? T[lane] : 0.0f;
-        for (int blk = 0; blk < Tb; blk++) {
-            const float s = s_next;
-            if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-            const float term = valid ? s + pv : NEG;
-            float m = fmaxf(term, xor4_f(term));
-            if (flip) { m = fmaxf(m, xor1_f(m)); m = fmaxf(m, xor2_f(m)); }
-            float e = valid ? expf(term - m) : 0.0f;
-            e += xor4_f(e);
-            if (flip) { e += xor1_f(e); e += xor2_f(e); }
-            const float val = m + logf(e);
-            pv = __shfl(val, ff8_src_lane(st));
-            if (lane < ns) F[(size_t)(blk + 1) * kMaxState + lane] = pv;
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + lane_c]; };
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
+        for (int b0 = 0; b0 < Tb; b0 += kDepth) {
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int blk = b0 + k;
+                if (blk >= Tb) break;
+                const float term = valid ? cur[k] + pv : NEG;
+                float m = fmaxf(term, xor4_f(term));
+                if (flip) { m = fmaxf(m, xor1_f(m)); m = fmaxf(m, xor2_f(m)); }
+                float e = valid ? expf(term - m) : 0.0f;
+                e += xor4_f(e);
+                if (flip) { e += xor1_f(e); e += xor2_f(e); }
+                const float val = m + logf(e);
+                pv = __shfl(val, ff8_src_lane(st));
+                if (lane < ns) stage[0][blk & 63][lane] = pv;              // fwd[blk + 1]
+                if ((blk & 63) == 63 || blk == Tb - 1) flush(0, F + (size_t)((blk & ~63) + 1) * kMaxState, kMaxState, (blk & 63) + 1);
+            }
         }
     } else if (wave == 1) {
         // backwards: pb = bwd[blk][lane & 7]; Bw[blk] is the vector that multiplies block blk-1's transitions
@@ -888,24 +918,37 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
         if (lane < 32) to = lane >> 3;
         else { const int idx = lane - 32; to = (idx < 4) ? idx + 4 : idx; }
         float pb = 0.0f;
-        float s_next = valid ? T[(size_t)(Tb - 1) * Ps + lane] : 0.0f;
-        for (int blk = Tb; blk > 0; blk--) {
-            const float s = s_next;
-            if (blk > 1) s_next = valid ? T[(size_t)(blk - 2) * Ps + lane] : 0.0f;
-            if (lane < ns) Bw[(size_t)blk * kMaxState + lane] = pb;
-            const float pb_to = __shfl(pb, to & 7);
-            const float t2 = valid ? s + pb_to : NEG;
-            // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
-            const float f5 = __shfl(t2, 32 + st);
-            float m = fmaxf(t2, xor8_f(t2));
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, f5);
-            float e = flip ? expf(t2 - m) : 0.0f;
-            e += xor8_f(e);
-            e += __shfl_xor(e, 16);
-            e += expf(f5 - m);
-            const float cur = m + logf(e);
-            pb = __shfl(cur, st);
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + lane_c]; };       // blk counts down
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - k);
+        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                          // j = Tb - blk: 0, 1, ...
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - (j0 + kDepth + k));
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int j = j0 + k, blk = Tb - j;
+                if (j >= Tb) break;
+                if (lane < ns) stage[1][j & 63][lane] = pb;                // bwd[blk]
+                if ((j & 63) == 63 || j == Tb - 1) flush(1, Bw + (size_t)(Tb - (j & ~63)) * kMaxState, -(long long)kMaxState, (j & 63) + 1);
+                const float pb_to = __shfl(pb, to & 7);
+                const float t2 = valid ? cur[k] + pb_to : NEG;
+                // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
+                const float f5 = __shfl(t2, 32 + st);
+                float m = fmaxf(t2, xor8_f(t2));
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, f5);
+                float e = flip ? expf(t2 - m) : 0.0f;
+                e += xor8_f(e);
+                e += __shfl_xor(e, 16);
+                e += expf(f5 - m);
+                const float cur_v = m + logf(e);
+                pb = __shfl(cur_v, st);
+                (void)blk;
+            }
         }
     }
     __syncthreads();
@@ -948,6 +991,8 @@ __global__ void __launch_bounds__(256)
 k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf,
                 int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
     __shared__ float term[2][64];
+    __shared__ float texp[2][64];
+    __shared__ float smax[2][kMaxState];
     __shared__ float svec[2][kMaxState];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ns = 2 * nbase, off = nbase * ns;
@@ -971,29 +1016,43 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
         float *tm = term[0], *sv = svec[0];
         if (is_state) { F[lane] = 0.0f; sv[lane] = 0.0f; }
         WAVE_SYNC();
+        // Per block: every entry's term in parallel, the maximum per destination state (exact, order-free), ONE expf per
+        // lane in parallel, then the sums in the reference's order (flip: from-state 0..ns-1; flop: stay, move) -- the same
+        // values as a serial logsumexp per state, without ten dependent expf on the chain.
+        float *mx = smax[0], *te = texp[0];
         float s_next = valid ? T[lane] : 0.0f;
         for (int blk = 0; blk < Tb; blk++) {
             const float s = s_next;
             if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-            tm[lane] = valid ? s + sv[src] : -INFINITY;
+            const float term_l = valid ? s + sv[src] : -INFINITY;
+            tm[lane] = term_l;
+            WAVE_SYNC();
+            float m = 0.0f;
+            if (is_state) {
+                if (is_flip) {
+                    m = tm[lane * ns];
+                    for (int f = 1; f < ns; f++) m = fmaxf(m, tm[lane * ns + f]);
+                } else {
+                    m = fmaxf(tm[off + lane], tm[off + lane - nbase]);
+                }
+                mx[lane] = m;
+            }
+            WAVE_SYNC();
+            te[lane] = valid ? expf(term_l - mx[dst]) : 0.0f;
             WAVE_SYNC();
             float val = 0.0f;
             if (is_state) {
+                float e;
                 if (is_flip) {
-                    float m = tm[lane * ns];
-                    for (int f = 1; f < ns; f++) m = fmaxf(m, tm[lane * ns + f]);
-                    float e = 0.0f;
-                    for (int f = 0; f < ns; f++) e += expf(tm[lane * ns + f] - m);
-                    val = m + logf(e);
+                    e = 0.0f;
+                    for (int f = 0; f < ns; f++) e += te[lane * ns + f];
                 } else {
-                    const float a = tm[off + lane], b = tm[off + lane - nbase];
-                    const float m = fmaxf(a, b);
-                    val = m + logf(expf(a - m) + expf(b - m));
+                    e = te[off + lane] + te[off + lane - nbase];
                 }
+                val = m + logf(e);
                 F[(size_t)(blk + 1) * kMaxState + lane] = val;
+                sv[lane] = val;
             }
-            WAVE_SYNC();
-            if (is_state) sv[lane] = val;
             WAVE_SYNC();
         }
     } else if (wave == 1) {
@@ -1001,22 +1060,30 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
         float *tm = term[1], *sv = svec[1];
         if (is_state) sv[lane] = 0.0f;
         WAVE_SYNC();
+        float *mx = smax[1], *te = texp[1];
+        float s_next = valid ? T[(size_t)(Tb - 1) * Ps + lane] : 0.0f;
         for (int blk = Tb; blk > 0; blk--) {
-            const float s = valid ? T[(size_t)(blk - 1) * Ps + lane] : 0.0f;
+            const float s = s_next;
+            if (blk > 1) s_next = valid ? T[(size_t)(blk - 2) * Ps + lane] : 0.0f;
             if (is_state) Bw[(size_t)blk * kMaxState + lane] = sv[lane];
-            const float pb_to = sv[dst];
-            tm[lane] = valid ? s + pb_to : -INFINITY;
+            const float term_l = valid ? s + sv[dst] : -INFINITY;
+            tm[lane] = term_l;
             WAVE_SYNC();
-            float cur = 0.0f;
+            // state `lane` as a SOURCE: its flop exit (entry off + lane) and its nbase flip exits (entries b1*ns + lane)
+            float m = 0.0f;
             if (is_state) {
-                float m = tm[off + lane];
+                m = tm[off + lane];
                 for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, tm[b1 * ns + lane]);
-                float e = expf(tm[off + lane] - m);
-                for (int b1 = 0; b1 < nbase; b1++) e += expf(tm[b1 * ns + lane] - m);
-                cur = m + logf(e);
+                mx[lane] = m;
             }
             WAVE_SYNC();
-            if (is_state) sv[lane] = cur;
+            te[lane] = valid ? expf(term_l - mx[src]) : 0.0f;
+            WAVE_SYNC();
+            if (is_state) {
+                float e = te[off + lane];
+                for (int b1 = 0; b1 < nbase; b1++) e += te[b1 * ns + lane];
+                sv[lane] = m + logf(e);
+            }
             WAVE_SYNC();
         }
     }
@@ -1150,30 +1217,58 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
     const int st = lane & 7;
     const float NEG = -INFINITY;
 
+    // Forward recursion.  The chain is ~150 cycles of work per block, so nothing on it may wait for memory:
+    //  * the traceback bytes go to LDS (a chunk of kTbChunk blocks; earlier chunks of longer reads are flushed to HBM with wide
+    //    stores) -- a global store per block shares the wave's memory counter with the loads, and the compiler then waits for
+    //    the store's acknowledgement (~700 cycles) before it may use the next block's scores;
+    //  * the scores of the next kDepth blocks are in flight while kDepth blocks are processed.
+    constexpr int kDepth = 8;
+    float ring[kDepth];
+    // (clamped, never predicated: a branch around a load makes the compiler drain the whole queue before the next use)
+    const int lane_c = valid ? lane : P - 1;
+    auto fetch = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + lane_c]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
     float pv = 0.0f;
-    float s_next = valid ? T[lane] : 0.0f;
-    for (int blk = 0; blk < Tb; blk++) {
-        const float s = s_next;
-        if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-        float v = valid ? s + pv : NEG;
-        int a = st;
-        // flop pair (lanes 32..39): partner = lane ^ 4; stay = idx >= 4
-        const float o4 = xor4_f(v);
-        if (!flip) {
-            const bool i_am_stay = (lane & 4) != 0;
-            const float stay = i_am_stay ? v : o4, move = i_am_stay ? o4 : v;
-            const int b2 = 4 + (lane & 3);
-            if (move > stay) { v = move; a = b2 - nbase; } else { v = stay; a = b2; }
-        } else {
-            // flip groups: argmax over from-state, lowest index on ties
-            { const int oa = a ^ 4; if (o4 > v || (o4 == v && oa < a)) { v = o4; a = oa; } }
-            { const float ov = xor1_f(v); const int oa = xor1_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
-            { const float ov = xor2_f(v); const int oa = xor2_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+    const int nchunk = (Tb + kTbChunk - 1) / kTbChunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0);
+        for (int b0 = 0; b0 < n; b0 += kDepth) {
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(c0 + b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                if (b0 + k >= n) break;
+                float v = valid ? cur[k] + pv : NEG;
+                int a = st;
+                // flop pair (lanes 32..39): partner = lane ^ 4; stay = idx >= 4
+                const float o4 = xor4_f(v);
+                if (!flip) {
+                    const bool i_am_stay = (lane & 4) != 0;
+                    const float stay = i_am_stay ? v : o4, move = i_am_stay ? o4 : v;
+                    const int b2 = 4 + (lane & 3);
+                    if (move > stay) { v = move; a = b2 - nbase; } else { v = stay; a = b2; }
+                } else {
+                    // flip groups: argmax over from-state, lowest index on ties
+                    { const int oa = a ^ 4; if (o4 > v || (o4 == v && oa < a)) { v = o4; a = oa; } }
+                    { const float ov = xor1_f(v); const int oa = xor1_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+                    { const float ov = xor2_f(v); const int oa = xor2_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+                }
+                const int src = ff8_src_lane(st);
+                pv = __shfl(v, src);
+                const int arg = __shfl(a, src);
+                if (lane < ns) tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg;
+            }
         }
-        const int src = ff8_src_lane(st);
-        pv = __shfl(v, src);
-        const int arg = __shfl(a, src);
-        if (lane < ns) tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg;
+        if (c + 1 < nchunk) {             // a longer read: this chunk's bytes leave LDS (kTbChunk is a multiple of kDepth: the ring stays aligned)
+            __syncthreads();
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)(tb + (size_t)c0 * kMaxState))[i] = ((const uint32_t *)tb_lds)[i];
+            __syncthreads();
+        }
     }
     float score = __shfl(pv, 0);
     int last = 0;
@@ -1183,11 +1278,14 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
     }
     if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
     __syncthreads();
-    for (int c1 = Tb; c1 > 0; c1 -= kTbChunk) {
-        const int c0 = max(0, c1 - kTbChunk), n = c1 - c0;
-        for (int i = lane; i < n * (kMaxState / 4); i += 64)
-            ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
-        __syncthreads();
+    // traceback, last chunk first (it is still in LDS)
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0), c1 = c0 + n;
+        if (c != nchunk - 1) {
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
+            __syncthreads();
+        }
         if (lane == 0) {
             int p = last;
             path_lds[n] = p;
