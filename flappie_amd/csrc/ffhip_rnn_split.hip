@@ -434,16 +434,21 @@ k_lstm_split(SplitArgs a) {
                     if (i > 1) return;
 #endif
 #pragma unroll
-                    for (int s = 0; s < 3; s++)
+                    for (int s = 0; s < 3; s++) {
                         raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                    }
                 };
-                // acc += sW h over my K slice; false if a sentinel was among the operands.  The four h waves share one
-                // 64 B/clk path to L2: a wave that issued its whole sweep at once would get its first chunk behind the other
-                // waves' 54 KiB; two chunks in flight per wave keep the queue round-robin and every wave's MFMAs fed.
+                // acc += sW h over my K slice; false if a sentinel was among the operands
                 auto recur = [&]() -> bool {
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < NCH; k++) load_chunk(k);
+                    for (int k = 0; k < NCH; k++) {
+                        load_chunk(k);
+                        // a short pause between the chunks: the CU's memory pipe takes the four h waves' requests in issue order,
+                        // and a wave that fires its 18 loads back to back gets its data as one burst -- the last wave's first
+                        // chunk would wait behind 54 KiB of the others' (layer time -3 %; sleep 2: -1.5 %, 3: 0)
+                        if (k + 1 < NCH) __builtin_amdgcn_s_sleep(1);
+                    }
 #pragma unroll
                     for (int k = 0; k < NCH; k++) {
 #pragma unroll
