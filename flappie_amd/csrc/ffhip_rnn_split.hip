@@ -318,9 +318,12 @@ k_lstm_split(SplitArgs a) {
                 if (ts >= ntl) continue;
                 const v4u *p = (const v4u *)(tile_ptr(a.xin, t, ts) + lane_off);
 #pragma unroll
-                for (int cc = 0; cc < N; cc++)
+                for (int cc = 0; cc < N; cc++) {
 #pragma unroll
                     for (int s = 0; s < 3; s++) xb[ts][cc][s] = p[(chunk[cc] * 3 + s) * 64];
+                    __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
+                                                       // occupying it with an 18 KiB burst per wave (A/B on one device: -0.2 %, i.e. nothing)
+                }
             }
         };
         auto project = [&](int i) {           // xb holds x(step i): partial Wi x -> px[i & 1]
@@ -446,7 +449,9 @@ k_lstm_split(SplitArgs a) {
                         load_chunk(k);
                         // a short pause between the chunks: the CU's memory pipe takes the four h waves' requests in issue order,
                         // and a wave that fires its 18 loads back to back gets its data as one burst -- the last wave's first
-                        // chunk would wait behind 54 KiB of the others' (layer time -3 %; sleep 2: -1.5 %, 3: 0)
+                        // chunk would wait behind 54 KiB of the others'.  (Interleaved A/B on one device: -0.2 % of the layer
+                        // time; the -3 % first seen came from comparing runs on different devices of the pool, which differ by
+                        // up to 4 % on this kernel.)
                         if (k + 1 < NCH) __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
