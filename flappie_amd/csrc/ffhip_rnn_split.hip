@@ -322,7 +322,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                     for (int s = 0; s < 3; s++) xb[ts][cc][s] = p[(chunk[cc] * 3 + s) * 64];
                     __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
-                                                       // occupying it with an 18 KiB burst per wave (A/B on one device: -0.2 %, i.e. nothing)
+                                                       // occupying it with an 18 KiB burst per wave
                 }
             }
         };
@@ -449,9 +449,9 @@ k_lstm_split(SplitArgs a) {
                         load_chunk(k);
                         // a short pause between the chunks: the CU's memory pipe takes the four h waves' requests in issue order,
                         // and a wave that fires its 18 loads back to back gets its data as one burst -- the last wave's first
-                        // chunk would wait behind 54 KiB of the others'.  (Interleaved A/B on one device: -0.2 % of the layer
-                        // time; the -3 % first seen came from comparing runs on different devices of the pool, which differ by
-                        // up to 4 % on this kernel.)
+                        // chunk would wait behind 54 KiB of the others'.  With this and the pause in the x waves' prefetch the
+                        // layer takes 14.31 instead of 14.85 ms (same device, interleaved runs; `s_sleep 0` does the same: what
+                        // counts is that the burst is broken, not the length of the pause).
                         if (k + 1 < NCH) __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
