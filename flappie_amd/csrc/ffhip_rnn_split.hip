@@ -44,8 +44,8 @@
 //     back to re-sweeping.  Plain stores when the 32 members verifiably share one XCD (= one L2), write-through
 //     otherwise; every spin is bounded (abort word -> FFHIP_ETIMEOUT).
 //
-// Measured (MI355X, 256 reads x 800 blocks, H = 384): 2.97 ms per layer = 163 TFLOP/s of fp32-equivalent work (the f32
-// MFMA kernel: 4.7 ms, 102 TFLOP/s).  Per step ~8900 cycles: hand-off poll ~1000, sweep + MFMAs ~4000 (the matrix
+// Measured (MI355X, 256 reads x 800 blocks, H = 384): 2.84 ms per layer = 170 TFLOP/s of fp32-equivalent work (the f32
+// MFMA kernel: 4.7 ms, 102 TFLOP/s).  Per step ~8500 cycles: hand-off poll ~1000, sweep + MFMAs ~4000 (the matrix
 // pipes carry 216 MFMAs = 3700 cycles per SIMD), gate phase ~2500, barriers ~300 -- DESIGN.md section 5.1.1.
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
