@@ -428,7 +428,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->lens = (int *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
     if (!(b->trace = (int32_t *)dalloc(b, (size_t)nread * (Tb + 1) * ns * 4, true))) BFAIL();
     if (!(b->pflags = (unsigned *)dalloc(b, persist_flag_words((int)Hp, b->B16) * sizeof(unsigned), true))) BFAIL();
-    if (!(b->pabort = (unsigned *)dalloc(b, sizeof(unsigned), true))) BFAIL();
+    if (!(b->pabort = (unsigned *)dalloc(b, 4 * sizeof(unsigned), true))) BFAIL();      // [0] abort word, [1] development counter
     if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
     *b->h_abort = 0;
     if (persist_supported(m->cell, (int)Hp, eng->prop.multiProcessorCount)) {
@@ -889,6 +889,13 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
 }
 
 extern "C" int ffhip_batch_rnn_path(const ffhip_batch *b) { return b ? b->rnn_path : -1; }
+
+// development counter next to the abort word (e.g. re-sweeps of the split layer kernel in builds that count them)
+extern "C" unsigned ffhip_debug_batch_counter(ffhip_batch *b) {
+    unsigned v = 0;
+    if (b) { hipSetDevice(b->eng->device); hipMemcpy(&v, b->pabort + 1, 4, hipMemcpyDeviceToHost); }
+    return v;
+}
 
 extern "C" int ffhip_debug_lean_math_check(ffhip_engine *eng, int exponent, int steps, unsigned long long *mismatches) {
     if (!eng || !mismatches || exponent < 0 || exponent > 125 || steps < 0 || steps > 2) return set_err(FFHIP_EINVAL, "lean math check: bad arguments");

@@ -288,11 +288,11 @@ k_lstm_split(SplitArgs a) {
             const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
+                *(v2u *)(tp_out + off) = sl;               // (the data first: it is what the consumers wait for)
                 if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
-                *(v2u *)(tp_out + off) = sl;
             } else {
-                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
                 store_wt(tp_out, off, sl);
+                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
             }
         } else if (a.hout_f32) {
             const v4f hv = *(const v4f *)&gf32[wave][rl][0];
@@ -475,6 +475,9 @@ k_lstm_split(SplitArgs a) {
                     // They completed long ago (the poll above outlasts them) -- say so, and the sweep gets counted waits.
                     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
                     if (!recur()) {
+#ifdef FFHIP_COUNT_FALLBACK
+                        if (lane == 0) atomicAdd(a.abort_word + 1, 1u);
+#endif
                         for (unsigned spin = 0;; spin++) {
                             if (spin > 3000000u || (spin & 255u) == 255u) {
                                 const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
