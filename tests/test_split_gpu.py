@@ -155,3 +155,23 @@ def test_lean_gate_math_is_bit_identical(B, engine):
         n = C.c_ulonglong(1)
         assert L.ffhip_debug_lean_math_check(engine.h, ex, 1, C.byref(n)) == 0
         assert n.value == 0, ex
+
+
+@pytest.mark.parametrize("kind", [M.NET_LSTM5, M.NET_GRUMOD5])
+def test_split_kernel_very_short_reads(B, engine, kind):
+    """batches whose reads have fewer blocks than the kernel looks ahead (sentinels three steps, L2 warming three steps, the
+    projection one step): 1 to 7 blocks"""
+    mdl = M.synthetic_model(kind, 128, seed=31)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(3)
+    for T in (19, 20, 24, 26, 31, 37):
+        sig = rng.standard_normal((18, T)).astype(np.float32)
+        b = B.Batch(dm, 18, T)
+        b.set_signals(sig)
+        b.run(); b.finish()
+        assert b.rnn_path() == 3
+        for r in (0, 15, 16, 17):
+            check_read(b, r, om.basecall(sig[r]))
+        b.close()
+    dm.close()
