@@ -1011,6 +1011,20 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
     // one wave: LDS executes its instructions in order; only the compiler has to be kept from reordering
 #define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+    // As in k_transpost8: the forward / backward vectors leave through an LDS stage in rows of 64 blocks (no global store on
+    // the per-block chain) and the scores of the next kDepth blocks are in flight (clamped, branch-free loads).
+    __shared__ float stage[2][64][kMaxState];
+    constexpr int kDepth = 8;
+    const int lane_c = valid ? lane : P - 1;
+    auto flush = [&](int w, float *dst0, long long dstep, int cnt) {      // row r of the stage -> dst0 + r*dstep (kMaxState floats each)
+        WAVE_SYNC();
+        if (lane < cnt) {
+            const float4 *src4 = (const float4 *)&stage[w][lane][0];
+            float4 *dst = (float4 *)(dst0 + (long long)lane * dstep);
+            dst[0] = src4[0]; dst[1] = src4[1]; dst[2] = src4[2]; dst[3] = src4[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     if (wave == 0) {
         // forwards
         float *tm = term[0], *sv = svec[0];
@@ -1020,40 +1034,51 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
         // lane in parallel, then the sums in the reference's order (flip: from-state 0..ns-1; flop: stay, move) -- the same
         // values as a serial logsumexp per state, without ten dependent expf on the chain.
         float *mx = smax[0], *te = texp[0];
-        float s_next = valid ? T[lane] : 0.0f;
-        for (int blk = 0; blk < Tb; blk++) {
-            const float s = s_next;
-            if (blk + 1 < Tb) s_next = valid ? T[(size_t)(blk + 1) * Ps + lane] : 0.0f;
-            const float term_l = valid ? s + sv[src] : -INFINITY;
-            tm[lane] = term_l;
-            WAVE_SYNC();
-            float m = 0.0f;
-            if (is_state) {
-                if (is_flip) {
-                    m = tm[lane * ns];
-                    for (int f = 1; f < ns; f++) m = fmaxf(m, tm[lane * ns + f]);
-                } else {
-                    m = fmaxf(tm[off + lane], tm[off + lane - nbase]);
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + lane_c]; };
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
+        for (int b0 = 0; b0 < Tb; b0 += kDepth) {
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int blk = b0 + k;
+                if (blk >= Tb) break;
+                const float term_l = valid ? cur[k] + sv[src] : -INFINITY;
+                tm[lane] = term_l;
+                WAVE_SYNC();
+                float m = 0.0f;
+                if (is_state) {
+                    if (is_flip) {
+                        m = tm[lane * ns];
+                        for (int f = 1; f < ns; f++) m = fmaxf(m, tm[lane * ns + f]);
+                    } else {
+                        m = fmaxf(tm[off + lane], tm[off + lane - nbase]);
+                    }
+                    mx[lane] = m;
                 }
-                mx[lane] = m;
-            }
-            WAVE_SYNC();
-            te[lane] = valid ? expf(term_l - mx[dst]) : 0.0f;
-            WAVE_SYNC();
-            float val = 0.0f;
-            if (is_state) {
-                float e;
-                if (is_flip) {
-                    e = 0.0f;
-                    for (int f = 0; f < ns; f++) e += te[lane * ns + f];
-                } else {
-                    e = te[off + lane] + te[off + lane - nbase];
+                WAVE_SYNC();
+                te[lane] = valid ? expf(term_l - mx[dst]) : 0.0f;
+                WAVE_SYNC();
+                if (is_state) {
+                    float e;
+                    if (is_flip) {
+                        e = 0.0f;
+                        for (int f = 0; f < ns; f++) e += te[lane * ns + f];
+                    } else {
+                        e = te[off + lane] + te[off + lane - nbase];
+                    }
+                    const float val = m + logf(e);
+                    stage[0][blk & 63][lane] = val;                        // fwd[blk + 1]
+                    sv[lane] = val;
                 }
-                val = m + logf(e);
-                F[(size_t)(blk + 1) * kMaxState + lane] = val;
-                sv[lane] = val;
+                if ((blk & 63) == 63 || blk == Tb - 1) flush(0, F + (size_t)((blk & ~63) + 1) * kMaxState, kMaxState, (blk & 63) + 1);
+                else WAVE_SYNC();
             }
-            WAVE_SYNC();
         }
     } else if (wave == 1) {
         // backwards; Bw[blk] is the vector that meets block blk-1's transitions
@@ -1061,30 +1086,42 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
         if (is_state) sv[lane] = 0.0f;
         WAVE_SYNC();
         float *mx = smax[1], *te = texp[1];
-        float s_next = valid ? T[(size_t)(Tb - 1) * Ps + lane] : 0.0f;
-        for (int blk = Tb; blk > 0; blk--) {
-            const float s = s_next;
-            if (blk > 1) s_next = valid ? T[(size_t)(blk - 2) * Ps + lane] : 0.0f;
-            if (is_state) Bw[(size_t)blk * kMaxState + lane] = sv[lane];
-            const float term_l = valid ? s + sv[dst] : -INFINITY;
-            tm[lane] = term_l;
-            WAVE_SYNC();
-            // state `lane` as a SOURCE: its flop exit (entry off + lane) and its nbase flip exits (entries b1*ns + lane)
-            float m = 0.0f;
-            if (is_state) {
-                m = tm[off + lane];
-                for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, tm[b1 * ns + lane]);
-                mx[lane] = m;
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + lane_c]; };       // blk counts down
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - k);
+        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                          // j = Tb - blk: 0, 1, ...
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - (j0 + kDepth + k));
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int j = j0 + k;
+                if (j >= Tb) break;
+                if (is_state) stage[1][j & 63][lane] = sv[lane];           // bwd[blk], blk = Tb - j
+                if ((j & 63) == 63 || j == Tb - 1) flush(1, Bw + (size_t)(Tb - (j & ~63)) * kMaxState, -(long long)kMaxState, (j & 63) + 1);
+                const float term_l = valid ? cur[k] + sv[dst] : -INFINITY;
+                tm[lane] = term_l;
+                WAVE_SYNC();
+                // state `lane` as a SOURCE: its flop exit (entry off + lane) and its nbase flip exits (entries b1*ns + lane)
+                float m = 0.0f;
+                if (is_state) {
+                    m = tm[off + lane];
+                    for (int b1 = 0; b1 < nbase; b1++) m = fmaxf(m, tm[b1 * ns + lane]);
+                    mx[lane] = m;
+                }
+                WAVE_SYNC();
+                te[lane] = valid ? expf(term_l - mx[src]) : 0.0f;
+                WAVE_SYNC();
+                if (is_state) {
+                    float e = te[off + lane];
+                    for (int b1 = 0; b1 < nbase; b1++) e += te[b1 * ns + lane];
+                    sv[lane] = m + logf(e);
+                }
+                WAVE_SYNC();
             }
-            WAVE_SYNC();
-            te[lane] = valid ? expf(term_l - mx[src]) : 0.0f;
-            WAVE_SYNC();
-            if (is_state) {
-                float e = te[off + lane];
-                for (int b1 = 0; b1 < nbase; b1++) e += te[b1 * ns + lane];
-                sv[lane] = m + logf(e);
-            }
-            WAVE_SYNC();
         }
     }
 #undef WAVE_SYNC
@@ -1140,43 +1177,84 @@ k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restr
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     const bool is_state = lane < ns, is_flip = lane < nbase;
+    const bool valid = lane < P;
+    const int src = lane % ns;                      // source state of entry `lane` (off is a multiple of ns)
+    __shared__ float cand[64];
+    __shared__ float pvs[kMaxState];
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-    float prev = 0.0f;
-    for (int blk = 0; blk < Tb; blk++) {
-        const float s = (lane < P) ? T[(size_t)blk * Ps + lane] : 0.0f;
-        const int base = is_flip ? lane * ns : 0;
-        float best = __shfl(s, base) + __shfl(prev, 0);
-        int arg = 0;
-        for (int f = 1; f < ns; f++) {
-            const float sc = __shfl(s, base + f) + __shfl(prev, f);
-            if (sc > best) { best = sc; arg = f; }
+    // Forward recursion, one wave.  Every entry's candidate s + prev[from] in parallel; each state then scans its entries in
+    // the reference's order (flip: from-state 0..ns-1, first maximum; flop: stay unless move is strictly greater) -- the
+    // same comparisons on the same values as a lane-exchange chain, without 2*ns+4 dependent exchanges per block.  As in
+    // k_viterbi8 the traceback bytes stay in LDS (earlier chunks of longer reads are flushed) and the scores of the next
+    // kDepth blocks are in flight: nothing on the chain waits for memory.
+    constexpr int kDepth = 8;
+    float ring[kDepth];
+    const int lane_c = valid ? lane : P - 1;
+    auto fetch = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + lane_c]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
+    if (is_state) pvs[lane] = 0.0f;
+    WAVE_SYNC();
+    const int nchunk = (Tb + kTbChunk - 1) / kTbChunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0);
+        for (int b0 = 0; b0 < n; b0 += kDepth) {
+            float cur[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(c0 + b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                if (b0 + k >= n) break;
+                cand[lane] = valid ? cur[k] + pvs[src] : -INFINITY;
+                WAVE_SYNC();
+                if (is_state) {
+                    float best;
+                    int arg;
+                    if (is_flip) {
+                        best = cand[lane * ns]; arg = 0;
+                        for (int f = 1; f < ns; f++) {
+                            const float sc = cand[lane * ns + f];
+                            if (sc > best) { best = sc; arg = f; }
+                        }
+                    } else {
+                        const float stay = cand[off + lane], move = cand[off + lane - nbase];
+                        best = stay; arg = lane;
+                        if (move > stay) { best = move; arg = lane - nbase; }
+                    }
+                    pvs[lane] = best;
+                    tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg;
+                }
+                WAVE_SYNC();
+            }
         }
-        const int b2 = (is_state && !is_flip) ? lane : nbase;
-        const float stay = __shfl(prev, b2) + __shfl(s, off + b2);
-        const float move = __shfl(prev, b2 - nbase) + __shfl(s, off + b2 - nbase);
-        if (!is_flip) {
-            best = stay; arg = b2;
-            if (move > stay) { best = move; arg = b2 - nbase; }
+        if (c + 1 < nchunk) {             // a longer read: this chunk's bytes leave LDS (kTbChunk is a multiple of kDepth: the ring stays aligned)
+            __syncthreads();
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)(tb + (size_t)c0 * kMaxState))[i] = ((const uint32_t *)tb_lds)[i];
+            __syncthreads();
         }
-        prev = best;
-        if (is_state) tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg;
     }
+#undef WAVE_SYNC
     // final score and state: first maximum
-    float score = __shfl(prev, 0);
+    float score = pvs[0];
     int last = 0;
     for (int st = 1; st < ns; st++) {
-        const float v = __shfl(prev, st);
+        const float v = pvs[st];
         if (v > score) { score = v; last = st; }
     }
     if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
-    __syncthreads();     // this wave's tb stores are complete and visible to its own loads below
-
-    // traceback, chunk by chunk from the end; `last` = path[c1]
-    for (int c1 = Tb; c1 > 0; c1 -= kTbChunk) {
-        const int c0 = max(0, c1 - kTbChunk), n = c1 - c0;
-        for (int i = lane; i < n * (kMaxState / 4); i += 64)
-            ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
-        __syncthreads();
+    __syncthreads();
+    // traceback, last chunk first (it is still in LDS); `last` = path[c1]
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0), c1 = c0 + n;
+        if (c != nchunk - 1) {
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
+            __syncthreads();
+        }
         if (lane == 0) {
             int p = last;
             path_lds[n] = p;
@@ -1192,7 +1270,6 @@ k_viterbi(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restr
             qp[c0 + i + 1] = T[(size_t)(c0 + i) * Ps + idx];
         }
         last = path_lds[0];
-        last = __shfl(last, 0);
         __syncthreads();
     }
 }
