@@ -438,7 +438,12 @@ k_lstm_split(SplitArgs a) {
 #endif
 #pragma unroll
                     for (int s = 0; s < 3; s++) {
+#if FFHIP_SPLIT_ABLATE & 64             // 64 = the second tile's operands are the first tile's lines again (L2 traffic of the sweep halved)
+                        if (ts) raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 0);
+                        else raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16);
+#else
                         raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+#endif
                     }
                 };
                 // acc += sW h over my K slice; false if a sentinel was among the operands
