@@ -52,28 +52,51 @@ k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, dou
     if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     if (lane < ns) st[0][lane] = 0.0;
     __syncthreads();
+    // The chain is serial by definition (pairwise logsumexp in the reference's order); what it must not do is wait for
+    // memory: the transition rows of the next kDepth blocks are in flight (clamped, branch-free loads) and each block's row
+    // is handed to the state lanes through LDS.
+    __shared__ float srow[64];
+    constexpr int kDepth = 8;
+    const int nrow = 2 * nbase * nbase, lane_c = lane < nrow ? lane : nrow - 1;
+    float ring[kDepth];
+    auto fetch = [&](int c) { return C[(size_t)(c < Tb ? c : Tb - 1) * Ps + lane_c]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
     int cur = 0;
-    for (int c = 0; c < Tb; c++) {
-        const float *S = C + (size_t)c * Ps;
-        const double *prev = st[cur];
-        double v = 0.0;
-        if (lane < nbase) {
-            const int b1 = lane;
-            v = -HUGE_VAL;
-            for (int b2 = 0; b2 < nbase; b2++) {
-                if (b1 == b2) continue;
-                v = lse64(v, prev[b2] + (double)S[rle_idx(b2, 0, b1, nbase)]);
-                v = lse64(v, prev[b2 + nbase] + (double)S[rle_idx(b2, 1, b1, nbase)]);
+    for (int c0 = 0; c0 < Tb; c0 += kDepth) {
+        float curv[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) curv[k] = ring[k];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(c0 + kDepth + k);
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            if (c0 + k >= Tb) break;
+            srow[lane] = curv[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float *S = srow;
+            const double *prev = st[cur];
+            double v = 0.0;
+            if (lane < nbase) {
+                const int b1 = lane;
+                v = -HUGE_VAL;
+                for (int b2 = 0; b2 < nbase; b2++) {
+                    if (b1 == b2) continue;
+                    v = lse64(v, prev[b2] + (double)S[rle_idx(b2, 0, b1, nbase)]);
+                    v = lse64(v, prev[b2 + nbase] + (double)S[rle_idx(b2, 1, b1, nbase)]);
+                }
+            } else if (lane < ns) {
+                const int b = lane - nbase;
+                const float x = (float)(prev[b] + (double)S[rle_idx(b, 0, b, nbase)]);
+                const float y = (float)(prev[b + nbase] + (double)S[rle_idx(b, 1, b, nbase)]);
+                v = (double)logsumexpf_ref(x, y);
             }
-        } else if (lane < ns) {
-            const int b = lane - nbase;
-            const float x = (float)(prev[b] + (double)S[rle_idx(b, 0, b, nbase)]);
-            const float y = (float)(prev[b + nbase] + (double)S[rle_idx(b, 1, b, nbase)]);
-            v = (double)logsumexpf_ref(x, y);
+            if (lane < ns) st[cur ^ 1][lane] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
         }
-        if (lane < ns) st[cur ^ 1][lane] = v;
-        __syncthreads();
-        cur ^= 1;
     }
     if (lane == 0) {
         double z = st[cur][0];
@@ -107,66 +130,115 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
     float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
+    // As in the flip-flop posterior: transition rows prefetched kDepth blocks ahead and handed over through LDS, forward /
+    // backward vectors staged in LDS and written out in rows of 64 blocks -- no global load or store on the per-block chains.
+    __shared__ float srow[2][64];
+    __shared__ float stage[2][64][kMaxState];
+    constexpr int kDepth = 8;
+    const int nrow = 2 * nbase * nbase, lane_c = lane < nrow ? lane : nrow - 1;
+#define RLE_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+    auto flush = [&](int w, float *dst0, long long dstep, int cnt) {      // row r of the stage -> dst0 + r*dstep (kMaxState floats each)
+        RLE_WAVE_SYNC();
+        if (lane < cnt) {
+            const float4 *src4 = (const float4 *)&stage[w][lane][0];
+            float4 *dst = (float4 *)(dst0 + (long long)lane * dstep);
+            dst[0] = src4[0]; dst[1] = src4[1]; dst[2] = src4[2]; dst[3] = src4[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     if (wave == 0) {
         if (lane < ns) { fs[0][lane] = 0.0f; F[lane] = 0.0f; }
         __builtin_amdgcn_wave_barrier();
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)(blk < Tb ? blk : Tb - 1) * Ps + ns + lane_c]; };
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
         int cur = 0;
-        for (int blk = 0; blk < Tb; blk++) {
-            const float *S = T + (size_t)blk * Ps + ns;
-            const float *prev = fs[cur];
-            float v = 0.0f;
-            if (lane < nbase) {
-                const int b1 = lane;
-                v = -HUGE_VALF;
-                for (int b2 = 0; b2 < nbase; b2++) {
-                    if (b1 == b2) continue;
-                    const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
-                    const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
-                    v = logsumexpf_ref(v, logsumexpf_ref(stay_score, move_score));
+        for (int b0 = 0; b0 < Tb; b0 += kDepth) {
+            float curv[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int blk = b0 + k;
+                if (blk >= Tb) break;
+                srow[0][lane] = curv[k];
+                RLE_WAVE_SYNC();
+                const float *S = srow[0];
+                const float *prev = fs[cur];
+                float v = 0.0f;
+                if (lane < nbase) {
+                    const int b1 = lane;
+                    v = -HUGE_VALF;
+                    for (int b2 = 0; b2 < nbase; b2++) {
+                        if (b1 == b2) continue;
+                        const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
+                        const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
+                        v = logsumexpf_ref(v, logsumexpf_ref(stay_score, move_score));
+                    }
+                } else if (lane < ns) {
+                    const int b = lane - nbase;
+                    const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
+                    const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
+                    v = logsumexpf_ref(stay_score, move_score);
                 }
-            } else if (lane < ns) {
-                const int b = lane - nbase;
-                const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
-                const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
-                v = logsumexpf_ref(stay_score, move_score);
+                if (lane < ns) { fs[cur ^ 1][lane] = v; stage[0][blk & 63][lane] = v; }      // fwd[blk + 1]
+                if ((blk & 63) == 63 || blk == Tb - 1) flush(0, F + (size_t)((blk & ~63) + 1) * kMaxState, kMaxState, (blk & 63) + 1);
+                else RLE_WAVE_SYNC();
+                cur ^= 1;
             }
-            if (lane < ns) { fs[cur ^ 1][lane] = v; F[(size_t)(blk + 1) * kMaxState + lane] = v; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            cur ^= 1;
         }
     } else if (wave == 1) {
         if (lane < ns) bs[0][lane] = 0.0f;
         __builtin_amdgcn_wave_barrier();
+        float ring[kDepth];
+        auto fetch = [&](int blk) { return T[(size_t)(blk > 0 ? blk : 0) * Ps + ns + lane_c]; };      // blk counts down
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - k);
         int cur = 0;
-        for (int blk = Tb; blk > 0; blk--) {
-            const float *S = T + (size_t)(blk - 1) * Ps + ns;
-            const float *prev = bs[cur];
-            if (lane < ns) Bw[(size_t)blk * kMaxState + lane] = prev[lane];      // the vector that meets block blk-1's transitions
-            float v = 0.0f;
-            if (lane < nbase) {
-                const int b1 = lane;
-                v = -HUGE_VALF;
-                for (int b2 = 0; b2 < nbase; b2++) {
-                    if (b1 == b2) continue;
-                    v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 0, b2, nbase)]);
+        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                                    // j = Tb - blk
+            float curv[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - (j0 + kDepth + k));
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int j = j0 + k;
+                if (j >= Tb) break;
+                srow[1][lane] = curv[k];
+                const float *prev = bs[cur];
+                if (lane < ns) stage[1][j & 63][lane] = prev[lane];       // bwd[blk], blk = Tb - j: the vector that meets block blk-1's transitions
+                if ((j & 63) == 63 || j == Tb - 1) flush(1, Bw + (size_t)(Tb - (j & ~63)) * kMaxState, -(long long)kMaxState, (j & 63) + 1);
+                else RLE_WAVE_SYNC();
+                const float *S = srow[1];
+                float v = 0.0f;
+                if (lane < nbase) {
+                    const int b1 = lane;
+                    v = -HUGE_VALF;
+                    for (int b2 = 0; b2 < nbase; b2++) {
+                        if (b1 == b2) continue;
+                        v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 0, b2, nbase)]);
+                    }
+                    v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 0, b1, nbase)]);
+                } else if (lane < ns) {
+                    const int b1 = lane - nbase;
+                    v = -HUGE_VALF;
+                    for (int b2 = 0; b2 < nbase; b2++) {
+                        if (b1 == b2) continue;
+                        v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 1, b2, nbase)]);
+                    }
+                    v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 1, b1, nbase)]);
                 }
-                v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 0, b1, nbase)]);
-            } else if (lane < ns) {
-                const int b1 = lane - nbase;
-                v = -HUGE_VALF;
-                for (int b2 = 0; b2 < nbase; b2++) {
-                    if (b1 == b2) continue;
-                    v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 1, b2, nbase)]);
-                }
-                v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 1, b1, nbase)]);
+                if (lane < ns) bs[cur ^ 1][lane] = v;
+                RLE_WAVE_SYNC();
+                cur ^= 1;
             }
-            if (lane < ns) bs[cur ^ 1][lane] = v;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            cur ^= 1;
         }
     }
+#undef RLE_WAVE_SYNC
     __syncthreads();
     for (int blk = threadIdx.x; blk < Tb; blk += 256) {
         const float *x = T + (size_t)blk * Ps;
@@ -204,44 +276,90 @@ k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int 
     if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     if (lane < ns) vs[0][lane] = 0.0f;
     __syncthreads();
+    // No memory on the chain: transition rows prefetched kDepth blocks ahead and handed over through LDS, traceback bytes kept in
+    // LDS (a chunk of kRleChunk blocks; earlier chunks of longer reads are flushed to HBM and read back for the traceback).
+    constexpr int kRleChunk = 2048, kDepth = 8;
+    __shared__ uint8_t tb_lds[kRleChunk * kMaxState];
+    __shared__ float srow[64];
+    const int nrow = 2 * nbase * nbase, lane_c = lane < nrow ? lane : nrow - 1;
+    float ring[kDepth];
+    auto fetch = [&](int blk) { return T[(size_t)(blk < Tb ? blk : Tb - 1) * Ps + ns + lane_c]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
     int cur = 0;
-    for (int blk = 0; blk < Tb; blk++) {
-        const float *S = T + (size_t)blk * Ps + ns;
-        const float *prev = vs[cur];
-        float v = -HUGE_VALF;
-        int arg = 0;
-        if (lane < nbase) {
-            const int b1 = lane;
-            for (int b2 = 0; b2 < nbase; b2++) {
-                if (b1 == b2) continue;
-                const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
-                if (move_score > v) { v = move_score; arg = b2; }
-                const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
-                if (stay_score > v) { v = stay_score; arg = b2 + nbase; }
+    const int nchunk = (Tb + kRleChunk - 1) / kRleChunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int c0 = c * kRleChunk, n = min(kRleChunk, Tb - c0);
+        for (int b0 = 0; b0 < n; b0 += kDepth) {
+            float curv[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) ring[k] = fetch(c0 + b0 + kDepth + k);
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                if (b0 + k >= n) break;
+                srow[lane] = curv[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const float *S = srow;
+                const float *prev = vs[cur];
+                float v = -HUGE_VALF;
+                int arg = 0;
+                if (lane < nbase) {
+                    const int b1 = lane;
+                    for (int b2 = 0; b2 < nbase; b2++) {
+                        if (b1 == b2) continue;
+                        const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
+                        if (move_score > v) { v = move_score; arg = b2; }
+                        const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
+                        if (stay_score > v) { v = stay_score; arg = b2 + nbase; }
+                    }
+                } else if (lane < ns) {
+                    const int b = lane - nbase;
+                    const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
+                    const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
+                    if (stay_score > move_score) { v = stay_score; arg = b + nbase; }
+                    else { v = move_score; arg = b; }
+                }
+                if (lane < ns) { vs[cur ^ 1][lane] = v; tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                cur ^= 1;
             }
-        } else if (lane < ns) {
-            const int b = lane - nbase;
-            const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
-            const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
-            if (stay_score > move_score) { v = stay_score; arg = b + nbase; }
-            else { v = move_score; arg = b; }
         }
-        if (lane < ns) { vs[cur ^ 1][lane] = v; tb[(size_t)blk * kMaxState + lane] = (uint8_t)arg; }
-        __syncthreads();
-        cur ^= 1;
+        if (c + 1 < nchunk) {             // a longer read: this chunk's bytes leave LDS (kRleChunk is a multiple of kDepth)
+            __syncthreads();
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)(tb + (size_t)c0 * kMaxState))[i] = ((const uint32_t *)tb_lds)[i];
+            __syncthreads();
+        }
     }
-    if (lane == 0) {
-        int last = 0;
-        for (int s = 1; s < ns; s++) if (vs[cur][s] > vs[cur][last]) last = s;     // argmaxf: first maximum
-        score_out[blockIdx.x] = vs[cur][last];
-        pth[Tb] = 0;
-        qp[Tb] = NAN;
-        for (int blk = Tb; blk > 0; blk--) {
-            const int state = tb[(size_t)(blk - 1) * kMaxState + last];
-            pth[blk - 1] = last;
-            qp[blk - 1] = NAN;
-            last = state;
+    __syncthreads();
+    int last = 0;
+    for (int st = 1; st < ns; st++) if (vs[cur][st] > vs[cur][last]) last = st;     // argmaxf: first maximum
+    if (lane == 0) { score_out[blockIdx.x] = vs[cur][last]; pth[Tb] = 0; qp[Tb] = NAN; }
+    // traceback, last chunk first (it is still in LDS)
+    __shared__ int pl[kRleChunk];
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int c0 = c * kRleChunk, n = min(kRleChunk, Tb - c0);
+        if (c != nchunk - 1) {
+            __syncthreads();
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
         }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = n; i > 0; i--) {
+                const int state = tb_lds[(i - 1) * kMaxState + last];
+                pl[i - 1] = last;
+                last = state;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) { pth[c0 + i] = pl[i]; qp[c0 + i] = NAN; }
+        // `last` for the next (earlier) chunk lives in lane 0: broadcast
+        last = __shfl(last, 0);
     }
 }
 
