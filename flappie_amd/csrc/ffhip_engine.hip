@@ -215,7 +215,7 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
         r.sWp = (float4 *)dev_upload(m, sp.data(), sp.size() * 4);
         r.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
         if (!r.iWp || !r.sWp || !r.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
-        if (split_supported(m->cell, Hp) && H == Hp) {
+        if (H == Hp && Hp % 128 == 0) {      // layer kernel shapes (H <= 384) and the split projection GEMM of the unfused path
             // W = w0 + w1 + w2 exactly, each a bf16 (round to nearest even): [mat][ut][k/32][slice][lane][8]
             const int Ut = Hp / 4, Hc = Hp / 32;
             std::vector<uint16_t> sp3((size_t)2 * Ut * Hc * 3 * 64 * 8);
@@ -701,8 +701,17 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         }
         if (!fuse) {
             if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
-            launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
-            b->launches[1]++;
+            if (r.Wsplit && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT")) {
+                // projection on the bf16 pipes over split operands (fp32-exact products): the layer input is
+                // converted to the split layout first
+                if (!b->actS[0] && !(b->actS[0] = dalloc(b, split_bytes((size_t)Tb * B16, Hp), false))) return FFHIP_ENOMEM;
+                launch_split_from_f32(s, in, b->actS[0], (size_t)Tb * B16, Hp);
+                launch_inproj_split(s, b->actS[0], b->xa, r.Wsplit, r.bias, Tb * B16, Hp);
+                b->launches[1] += 2;
+            } else {
+                launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
+                b->launches[1]++;
+            }
         }
         if (prof) hipEventRecord(b->lev[l][1], s);
         const size_t xa_step = (size_t)Bp * Hp * 4, h_step = (size_t)Bp * Hp;

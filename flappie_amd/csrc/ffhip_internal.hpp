@@ -89,6 +89,9 @@ inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 96; 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
                        const int *tbs = nullptr, const int *tbt = nullptr);
+// input projection GEMM on split operands: in_split = activations in the split layout, Wp = the split weight pack (its first
+// matrix is Wi), xa = D-fragment order like launch_inproj
+void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H);
 void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H);      // tile-interleaved fp32 -> split
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H);
 void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad);      // adds the mismatch count to *bad

@@ -520,6 +520,76 @@ k_lstm_split(SplitArgs a) {
 #endif
 }
 
+// ---- input projection as a plain GEMM on split operands (shapes the layer kernel does not take, e.g. H = 512) -----
+// Xa[nt][mt] = Wi[mt] . x[nt] + b, D-fragment order like k_inproj (ffhip_kernels.hip), products as six bf16 MFMA terms.
+// A workgroup = 4 waves 2 (M) x 2 (N), each wave 4 x 4 tiles of 16 x 16; per K chunk of 32 a wave loads 12 + 12 KiB and
+// issues 96 MFMAs: the CU's 64 B/clk load path and the matrix pipes are about balanced, occupancy hides the latency.
+__global__ void __launch_bounds__(256)
+k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, const v4u *__restrict__ Wp, const float *__restrict__ bias,
+               int ntile, int Mt, int Hc) {
+    constexpr int TM = 4, TN = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
+    const int nNblk = (ntile + 2 * TN - 1) / (2 * TN);
+    // neighbouring workgroups share the activation tiles: walk M fastest
+    const int L = blockIdx.x;
+    const int mblk = L % nMblk, nblk = L / nMblk;
+    if (nblk >= nNblk) return;
+    const int mt0 = (mblk * 2 + wm) * TM, nt0 = (nblk * 2 + wn) * TN;
+    const int kq = lane >> 4;
+    v4f acc[TM][TN];
+    const v4u *ap[TM], *bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(mt0 + i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * Hc * 3 * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int nt = min(nt0 + j, ntile - 1);
+        bp[j] = (const v4u *)(in + (size_t)nt * Hc * 3 * 1024) + lane;
+    }
+    constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
+    for (int c = 0; c < Hc; c++) {
+        v4u A[TM][3], B[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) A[i][s] = ap[i][(size_t)(c * 3 + s) * 64];
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) B[j][s] = bp[j][(size_t)(c * 3 + s) * 64];
+#pragma unroll
+        for (int term = 0; term < 6; term++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = mm(A[i][WS[term]], B[j][XS[term]], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = mt0 + i;
+        if (mt >= Mt) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            *(v4f *)(xa + ((size_t)nt * Mt + mt) * 256 + lane * 4) = acc[i][j];
+        }
+    }
+}
+
+void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H) {
+    const int Mt = H / 4, Hc = H / 32;
+    const int nMblk = (Mt + 7) / 8, nNblk = (ntile + 7) / 8;
+    hipLaunchKernelGGL(k_inproj_split, dim3(nMblk * nNblk), dim3(256), 0, s, (const unsigned char *)in_split, xa, (const v4u *)Wp, bias, ntile, Mt, Hc);
+}
+
 // ---- layout converters -------------------------------------------------------------------------
 // fp32 tile-interleaved [tile][Ut][16 reads][4] <-> split [tile][Hc][3][64][8 bf16]; one thread per (tile, pair of unit tiles, read)
 __global__ void __launch_bounds__(256)

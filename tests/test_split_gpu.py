@@ -175,3 +175,22 @@ def test_split_kernel_very_short_reads(B, engine, kind):
             check_read(b, r, om.basecall(sig[r]))
         b.close()
     dm.close()
+
+
+@pytest.mark.parametrize("kind", [M.NET_LSTM5, M.NET_GRUMOD5])
+def test_split_projection_gemm_on_the_unfused_path(B, engine, kind):
+    """FFHIP_RUN_UNFUSED_RNN at H % 128 == 0 (what H = 512 models always take): the input projection is a GEMM on split
+    operands in front of the f32 persistent recurrence"""
+    mdl = M.synthetic_model(kind, 128, seed=41)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(8)
+    sig = rng.standard_normal((20, 900)).astype(np.float32)
+    b = B.Batch(dm, 20, 900)
+    b.set_signals(sig)
+    b.run(1.0, B.RUN_UNFUSED_RNN); b.finish()
+    assert b.rnn_path() == 1
+    for r in (0, 7, 16, 19):
+        check_read(b, r, om.basecall(sig[r]))
+    b.close()
+    dm.close()
