@@ -312,7 +312,7 @@ struct ffhip_batch {
     unsigned last_flags = 0;
     int ran = 0, finished = 0;
     int final_act = 0;                  // which act[] holds the last recurrent layer's output
-    int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel
+    int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel, 4 split-bf16 projection GEMM + recurrence-only layer kernel
     hipEvent_t ev[FFHIP_NGROUP + 1];
     int have_ev = 0;
     int launches[FFHIP_NGROUP];
@@ -633,13 +633,17 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
     const bool use_split = use_persist && use_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
                            split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
-    if (use_split) {
+    // shapes whose two weight matrices do not fit a CU's registers (H = 512): projection GEMM + recurrence-only layer kernel, both
+    // on split operands (also what FFHIP_RUN_UNFUSED_RNN selects at H = 256)
+    const bool use_split2 = !use_split && use_persist && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+                            rnn_split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
+    if (use_split || use_split2) {
         const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
         for (int i = 0; i < 2; i++)
             if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
     }
     // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
-    const bool conv_split = use_split && !keep && m->conv[m->nconv - 1].Mpad == Hp;
+    const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
     mark(b, 0);
     // ---- convolutions (layers.c:189-276, activations :24-49)
     for (int l = 0; l < m->nconv; l++) {
@@ -665,7 +669,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
-    if (use_split && !conv_split) {
+    if ((use_split || use_split2) && !conv_split) {
         launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp);
         b->launches[0]++;
     }
@@ -675,6 +679,29 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         float *in = b->act[cur], *out = b->act[cur ^ 1];
         const bool fuse = use_persist && use_fused;
         if (prof) hipEventRecord(b->lev[l][0], s);
+        if (use_split2) {
+            if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
+            launch_inproj_split(s, b->actS[cur], b->xa, r.Wsplit, r.bias, Tb * B16, Hp);
+            b->launches[1]++;
+            if (prof) hipEventRecord(b->lev[l][1], s);
+            const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
+            float *out_f32 = (l == 4 || keep) ? out : nullptr;
+            for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
+                const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
+                HIP_TRY(hipMemsetAsync(b->pflags, 0, split_flag_words(nrt) * sizeof(unsigned), s), FFHIP_EHIP);
+                const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
+                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (!launch_rnn_split(s, r.Wsplit, b->xa, b->actS[cur ^ 1], out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
+                                      backward, persist_mode, tbs, tbt))
+                    return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
+                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
+                b->launches[2]++;
+            }
+            if (prof) hipEventRecord(b->lev[l][2], s);
+            cur ^= 1;
+            if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
+            continue;
+        }
         if (use_split) {
             if (prof) hipEventRecord(b->lev[l][1], s);
             const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
@@ -749,7 +776,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     }
     b->profiled = prof;
     b->final_act = cur;
-    b->rnn_path = use_split ? 3 : (use_persist ? (use_fused ? 2 : 1) : 0);
+    b->rnn_path = use_split ? 3 : (use_split2 ? 4 : (use_persist ? (use_fused ? 2 : 1) : 0));
     mark(b, 3);
     const bool rle = (m->kind == FFHIP_NET_LSTM5_RLE);
     if (rle) {

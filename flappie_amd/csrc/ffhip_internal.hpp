@@ -89,6 +89,10 @@ inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 96; 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
                        const int *tbs = nullptr, const int *tbt = nullptr);
+// recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
+bool rnn_split_supported(int kind, int H);
+bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,
+                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, const int *tbs = nullptr, const int *tbt = nullptr);
 // input projection GEMM on split operands: in_split = activations in the split layout, Wp = the split weight pack (its first
 // matrix is Wi), xa = D-fragment order like launch_inproj
 void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H);

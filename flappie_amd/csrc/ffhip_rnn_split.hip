@@ -104,8 +104,8 @@ __device__ __forceinline__ v4f mm(v4u a, v4u b, v4f c) {
 // The six kept products of one K chunk for the N row tiles of a wave, smallest terms first.  Issue order is term-major,
 // row tile minor: consecutive MFMAs write DIFFERENT accumulators, so the matrix pipe never waits for its own result
 // (a dependent v_mfma_f32_16x16x32_bf16 issues every ~28 cycles, an independent one every 16).
-template <int N>
-__device__ __forceinline__ void mm6(const v4u (&w)[N][N][3], int cc, const v4u (&x)[3], v4f (&acc)[N]) {
+template <int N, int NC = N>
+__device__ __forceinline__ void mm6(const v4u (&w)[N][NC][3], int cc, const v4u (&x)[3], v4f (&acc)[N]) {
     constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
 #pragma unroll
     for (int term = 0; term < 6; term++)
@@ -518,6 +518,240 @@ k_lstm_split(SplitArgs a) {
     if (a.dbg && Tb >= 132)
         for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)blockIdx.x * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
 #endif
+}
+
+// ---- recurrence only, behind the projection GEMM: shapes whose two weight matrices do not fit a CU's registers ------
+// H = 256 * CPW (H = 512: CPW = 2).  The same group / hand-off / gate scheme as k_lstm_split, but all eight waves hold
+// recurrent weights (K split eight ways, N = H/128 unit tiles of rows per member: 197 KiB per CU at H = 512) and every wave
+// gates one of the pair's 2N <= 8 tiles; the gate pre-activations start from Xa = Wi x + b (k_inproj_split), one D-fragment
+// per gate wave and step, prefetched a step ahead.  LSTM only.
+struct RnnSplitArgs {
+    const v4u *Wp;            // recurrent weights [Ut][Hc][3][64] 16 B (the second matrix of the split pack)
+    const v4f *xa;            // [Tb][B16][Ut][64] float4, D-fragment order, bias included
+    unsigned char *hout;      // split layout
+    float *hout_f32;
+    unsigned *flags, *abort_word;
+    int Tb, B16, rt0, nrt, backward, mode;
+    const int *tbs, *tbt;
+};
+
+template <int N, int CPW>
+__global__ void __launch_bounds__(512, 1)
+k_rnn_split(RnnSplitArgs a) {
+    constexpr int G = 32, Hc = 8 * CPW, Ut = 32 * N, NCH = 2 * CPW, NPROD = 8 * CPW;
+    constexpr size_t tileB = (size_t)Hc * 3 * 1024;
+    __shared__ v4f ph[8][2][N][64];                  // recurrent partials by K eighth
+    __shared__ unsigned short gsl[8][3][16][4];
+    __shared__ float gf32[8][16][4];
+    __shared__ int lds_abort;
+    __shared__ int lds_fast;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroup = (a.nrt + 1) >> 1;
+    int g, m;
+    {
+        const int b = blockIdx.x;
+        if ((ngroup & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
+        else { g = b / G; m = b % G; }
+    }
+    const int rtA = a.rt0 + 2 * g;
+    const bool haveB = (2 * g + 1 < a.nrt);
+    const int TbA = a.tbt ? a.tbt[rtA] : a.Tb;
+    const int TbB = haveB ? (a.tbt ? a.tbt[rtA + 1] : a.Tb) : 0;
+    const int Tb = TbA > TbB ? TbA : TbB;
+    if (Tb <= 0) return;
+    const int ntl = (TbB > 0) ? 2 : 1;
+    const int ut0 = m * N;
+    if (threadIdx.x == 0) lds_abort = 0;
+    const int q = lane >> 4, rl = lane & 15;
+    auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
+    const bool gate_wave = wave < ntl * N;
+    const int my_gts = wave / N, my_gj = wave % N;
+    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
+    auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
+    auto store_wt = [&](unsigned char *tile, unsigned off, v2u v) {
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(v, wr, off, 0, 16 /*sc1*/);
+    };
+    constexpr int AHEAD = 3;
+    const v2u sentinel2 = { kSplitSentinel, kSplitSentinel };
+    if (gate_wave && q < 3)
+        for (int k = 0; k < AHEAD && k < Tb; k++) store_wt(out_tile(step_t(k), my_gts), out_off(my_gj), sentinel2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 0xfu) + 1u;
+        unsigned *ids = a.flags + (size_t)g * G;
+        if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
+        unsigned v = xcc;
+        for (unsigned spin = 0; spin < 2000000u; spin++) {
+            v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
+            if (__all(v != 0u)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!__all(v != 0u) && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
+        const int fast_l = (a.mode == 0 && __all(v == xcc)) ? 1 : 0;
+        if (lane == 0) lds_fast = fast_l;
+    }
+    const int cbase = ((wave + m) & 7) * CPW;            // my K eighth: chunks cbase .. cbase+CPW-1
+    v4u wf[N][CPW][3];
+#pragma unroll
+    for (int j = 0; j < N; j++)
+#pragma unroll
+        for (int cc = 0; cc < CPW; cc++)
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+                wf[j][cc][s] = a.Wp[(((size_t)(ut0 + j) * Hc + (cbase + cc)) * 3 + s) * 64 + lane];
+    __syncthreads();
+    if (lds_abort) return;
+    const bool fast = lds_fast != 0;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto raw_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int my_tb = 0;
+    if (gate_wave) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
+    float c = 0.0f;
+    auto xa_tile = [&](int i) { return a.xa[(((size_t)step_t(i) * a.B16 + (rtA + my_gts)) * Ut + ut0 + my_gj) * 64 + lane]; };
+    v4f xa_next = gate_wave ? xa_tile(0) : (v4f){ 0.f, 0.f, 0.f, 0.f };
+    for (int i = 0; i < Tb; i++) {
+        v4f acc[2][N];
+#pragma unroll
+        for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+            for (int j = 0; j < N; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        const v4f xa_cur = xa_next;
+        if (i > 0) {
+            const int tp = step_t(i - 1);
+            const unsigned char *hp = a.hout + ((size_t)tp * a.B16 + rtA) * tileB;
+            __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(2 * tileB), 0x00020000);
+            bool timed_out = false;
+            {
+                const int ul = lane % NPROD, pts = lane / NPROD;
+                const int put = cbase * 8 + ul;
+                const bool act = pts < ntl;
+                const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * 3 * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
+                for (unsigned spin = 0;; spin++) {
+                    const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
+                    if (__all(v != kSplitSentinel)) break;
+                    if (spin > 6000000u || (spin & 511u) == 511u) {
+                        const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                        if (ab != 0u || spin > 6000000u) { timed_out = true; break; }
+                    }
+                }
+            }
+            v4u raw[NCH][3];
+            const int offB = (ntl > 1) ? (int)tileB : 0;
+            auto recur = [&]() -> bool {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+#pragma unroll
+                    for (int s = 0; s < 3; s++)
+                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (k / CPW) * offB + (((cbase + k % CPW) * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                    if (k + 1 < NCH) __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+#pragma unroll
+                    for (int s = 0; s < 3; s++) {
+                        const v4u r = raw[k][s];
+                        ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
+                    }
+                    mm6<N, CPW>(wf, k % CPW, raw[k], acc[k / CPW]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return __all(ok) != 0;
+            };
+            if (!timed_out) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see k_lstm_split
+                if (!recur()) {
+                    for (unsigned spin = 0;; spin++) {
+                        if (spin > 3000000u || (spin & 255u) == 255u) {
+                            const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
+                            if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+                            for (int j = 0; j < N; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+                        if (recur()) break;
+                    }
+                }
+            }
+            if (timed_out && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
+        }
+        if (gate_wave && i + 1 < Tb) xa_next = xa_tile(i + 1);      // behind the sweep in the memory pipe, a step ahead of its use
+#pragma unroll
+        for (int ts = 0; ts < 2; ts++) {
+            if (ts >= ntl) continue;
+#pragma unroll
+            for (int j = 0; j < N; j++) ph[wave][ts][j][lane] = acc[ts][j];
+        }
+        raw_barrier();
+        if (lds_abort) return;
+        if (gate_wave) {
+            const int t = step_t(i);
+            v4f s = xa_cur;
+            if (i > 0) {
+#pragma unroll
+                for (int w2 = 0; w2 < 8; w2++) s = s + ph[w2][my_gts][my_gj][lane];
+            }
+            const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
+            const float tanh_g = (L.z + L.z) - 1.0f;
+            const float forget = L.y * c;
+            const float update = L.x * tanh_g;
+            c = forget + update;
+            float h = L.w * tanh_ref_lean(c);
+            if (t >= my_tb) { h = 0.0f; c = 0.0f; }
+            const unsigned b0 = bf16_bits(h);
+            const float r1 = h - bf16_val(b0);
+            const unsigned b1 = bf16_bits(r1);
+            const unsigned b2 = bf16_bits(r1 - bf16_val(b1));
+            gsl[wave][0][rl][q] = (unsigned short)b0;
+            gsl[wave][1][rl][q] = (unsigned short)b1;
+            gsl[wave][2][rl][q] = (unsigned short)b2;
+            if (a.hout_f32) gf32[wave][rl][q] = h;
+            asm volatile("" ::: "memory");
+            const int ut = ut0 + my_gj;
+            const unsigned off = out_off(my_gj);
+            if (q < 3) {
+                const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
+                unsigned char *tp_out = out_tile(t, my_gts);
+                if (fast) {
+                    *(v2u *)(tp_out + off) = sl;
+                    if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), my_gts) + off) = sentinel2;
+                } else {
+                    store_wt(tp_out, off, sl);
+                    if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), my_gts), off, sentinel2);
+                }
+            } else if (a.hout_f32) {
+                const v4f hv = *(const v4f *)&gf32[wave][rl][0];
+                *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + my_gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+bool rnn_split_supported(int kind, int H) { return kind == 0 && (H == 256 || H == 512); }
+bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,
+                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, const int *tbs, const int *tbt) {
+    RnnSplitArgs a;
+    const int Ut = H / 4, Hc = H / 32;
+    a.Wp = (const v4u *)Wsplit + (size_t)Ut * Hc * 3 * 64;      // second matrix of the pack = recurrent weights
+    a.xa = (const v4f *)xa; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32; a.flags = flags; a.abort_word = abort_word;
+    a.Tb = Tb; a.B16 = B16; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode; a.tbs = tbs; a.tbt = tbt;
+    const int ngroup = (nrt + 1) / 2;
+    if (H == 512) { hipLaunchKernelGGL((k_rnn_split<4, 2>), dim3(ngroup * 32), dim3(512), 0, s, a); return true; }
+    if (H == 256) { hipLaunchKernelGGL((k_rnn_split<2, 1>), dim3(ngroup * 32), dim3(512), 0, s, a); return true; }
+    return false;
 }
 
 // ---- input projection as a plain GEMM on split operands (shapes the layer kernel does not take, e.g. H = 512) -----

@@ -136,7 +136,8 @@ int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][ns
  * (0..4) as dense [nblock][hidden] */
 int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
 /* which recurrent implementation the last ffhip_batch_run used: 0 = one launch per step, 1 = persistent recurrence behind a
- * projection GEMM, 2 = fused f32-MFMA layer kernel, 3 = split-bf16 layer kernel (LSTM, hidden 128/256/384) */
+ * projection GEMM, 2 = fused f32-MFMA layer kernel, 3 = split-bf16 layer kernel (hidden 128/256/384), 4 = split-bf16 projection GEMM +
+ * recurrence-only split-bf16 layer kernel (LSTM, hidden 512; hidden 256 under FFHIP_RUN_UNFUSED_RNN) */
 int ffhip_batch_rnn_path(const ffhip_batch *b);
 /* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split-bf16 activation layout of
  * the recurrent layer kernel and back; out == in bit for bit (three bf16 slices hold any fp32 exactly) */

@@ -194,3 +194,28 @@ def test_split_projection_gemm_on_the_unfused_path(B, engine, kind):
         check_read(b, r, om.basecall(sig[r]))
     b.close()
     dm.close()
+
+
+def test_recurrence_only_split_kernel(B, engine):
+    """the H = 512 arrangement (projection GEMM on split operands + recurrence-only split layer kernel, rnn_path 4), exercised
+    at H = 256 where the oracle is quick: uniform with an odd tile count, then ragged with empty slots"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 256, seed=51)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(12)
+    sig = rng.standard_normal((40, 700)).astype(np.float32)
+    b = B.Batch(dm, 40, 700)
+    b.set_signals(sig)
+    b.run(1.0, B.RUN_UNFUSED_RNN); b.finish()
+    assert b.rnn_path() == 4
+    for r in (0, 15, 16, 31, 32, 39):
+        check_read(b, r, om.basecall(sig[r]))
+    lens = [700, 699, 300, 37, 19, 640] + [0] * 11 + [555, 700, 21] + [0] * 20
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    b.set_signals_ragged(sigs)
+    b.run(1.0, B.RUN_UNFUSED_RNN); b.finish()
+    for r, x in enumerate(sigs):
+        if x.size:
+            check_read(b, r, om.basecall(x))
+    b.close()
+    dm.close()
