@@ -788,8 +788,9 @@ k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, con
         bp[j] = (const v4u *)(in + (size_t)nt * Hc * 3 * 1024) + lane;
     }
     constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
-    for (int c = 0; c < Hc; c++) {
-        v4u A[TM][3], B[TN][3];
+    // the operands of chunk c+1 are in flight while the 96 MFMAs of chunk c issue (two register sets, K loop unrolled by two)
+    v4u A0[TM][3], B0[TN][3], A1[TM][3], B1[TN][3];
+    auto load = [&](v4u (&A)[TM][3], v4u (&B)[TN][3], int c) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -798,12 +799,23 @@ k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, con
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int s = 0; s < 3; s++) B[j][s] = bp[j][(size_t)(c * 3 + s) * 64];
+    };
+    auto mma = [&](v4u (&A)[TM][3], v4u (&B)[TN][3]) {
 #pragma unroll
         for (int term = 0; term < 6; term++)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = mm(A[i][WS[term]], B[j][XS[term]], acc[i][j]);
+    };
+    load(A0, B0, 0);
+    for (int c = 0; c < Hc; c += 2) {
+        if (c + 1 < Hc) load(A1, B1, c + 1);
+        mma(A0, B0);
+        if (c + 1 < Hc) {
+            if (c + 2 < Hc) load(A0, B0, c + 2);
+            mma(A1, B1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
