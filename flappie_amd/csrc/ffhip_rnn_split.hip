@@ -756,12 +756,12 @@ bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *
 
 // ---- input projection as a plain GEMM on split operands (shapes the layer kernel does not take, e.g. H = 512) -----
 // Xa[nt][mt] = Wi[mt] . x[nt] + b, D-fragment order like k_inproj (ffhip_kernels.hip), products as six bf16 MFMA terms.
-// A workgroup = 4 waves 2 (M) x 2 (N), each wave 4 x 4 tiles of 16 x 16; per K chunk of 32 a wave loads 12 + 12 KiB and
-// issues 96 MFMAs: the CU's 64 B/clk load path and the matrix pipes are about balanced, occupancy hides the latency.
+// A workgroup = 4 waves 2 (M) x 2 (N), each wave 4 x 6 tiles of 16 x 16; per K chunk of 32 a wave loads 12 + 18 KiB and
+// issues 144 MFMAs (4 x 4 tiles: 24 KiB per 96 MFMAs sits right at the CU's 64 B/clk load path and measured 10 % slower).
 __global__ void __launch_bounds__(256)
 k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, const v4u *__restrict__ Wp, const float *__restrict__ bias,
                int ntile, int Mt, int Hc) {
-    constexpr int TM = 4, TN = 4;
+    constexpr int TM = 4, TN = 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
@@ -832,7 +832,7 @@ k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, con
 
 void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H) {
     const int Mt = H / 4, Hc = H / 32;
-    const int nMblk = (Mt + 7) / 8, nNblk = (ntile + 7) / 8;
+    const int nMblk = (Mt + 7) / 8, nNblk = (ntile + 11) / 12;
     hipLaunchKernelGGL(k_inproj_split, dim3(nMblk * nNblk), dim3(256), 0, s, (const unsigned char *)in_split, xa, (const v4u *)Wp, bias, ntile, Mt, Hc);
 }
 
