@@ -219,3 +219,14 @@ def test_recurrence_only_split_kernel(B, engine):
             check_read(b, r, om.basecall(x))
     b.close()
     dm.close()
+
+
+def test_differential_fuzz_is_deterministic(B):
+    """a few seconds of tools/dev/diff_fuzz.py: random shapes through the split path twice and the f32 path once; the script
+    asserts bit-for-bit determinism of the split path (differing strings between the two paths are reported, not asserted:
+    DESIGN.md section 3)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "diff_fuzz.py"), "6", "7"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "diff fuzz:" in out.stdout

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: the split-bf16 recurrent path against the f32-MFMA path on random shapes
+(model family, hidden size, batch size, ragged lengths, empty slots).  Base and quality strings must be equal, transition
+scores within 1e-4."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from flappie_amd import binding as B, model as M
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+eng = B.Engine(0)
+t0 = time.time()
+ncase = nread_tot = ndiff = 0
+wo_split = wo_f32 = 0.0
+worst = 0.0
+models = {}
+while time.time() - t0 < budget:
+    kind = int(rng.choice([M.NET_LSTM5, M.NET_LSTM5, M.NET_GRUMOD5]))
+    H = int(rng.choice([128, 256, 384, 512] if kind == M.NET_LSTM5 else [128, 256]))
+    key = (kind, H)
+    if key not in models:
+        models[key] = B.DeviceModel(eng, M.synthetic_model(kind, H, seed=100 + len(models)))
+    dm = models[key]
+    nread = int(rng.choice([1, 5, 16, 17, 33, 48, 64, 100, 256, 290]))
+    cap = int(rng.choice([19, 40, 333, 1000, 2500]))
+    if rng.random() < 0.5:
+        lens = np.full(nread, cap)
+    else:
+        lens = rng.integers(19, cap + 1, nread)
+        lens[rng.random(nread) < 0.15] = 0
+        if not (lens > 0).any():
+            lens[0] = cap
+    sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
+    res = []
+    for flags in (0, B.RUN_F32_RNN, 0):
+        b = B.Batch(dm, nread, cap)
+        b.set_signals_ragged(sigs)
+        b.run(1.0, flags); b.finish()
+        res.append([(b.basecall(r), b.quality(r), b.transitions(r)) if lens[r] > 0 else None for r in range(nread)])
+        path = b.rnn_path()
+        b.close()
+    for r in range(nread):
+        if res[0][r] is None:
+            continue
+        a, c = res[0][r], res[1][r]
+        # the split path twice: bit-identical (a race in the hand-off would show here)
+        assert a[0] == res[2][r][0] and a[1] == res[2][r][1] and np.array_equal(a[2], res[2][r][2]), ("nondeterministic", kind, H, nread, cap, r)
+        d = float(np.abs(a[2] - c[2]).max())
+        worst = max(worst, d)
+        if not (a[0] == c[0] and a[1] == c[1] and d <= 1e-4):
+            from oracle import ffo
+            ref = ffo.OracleModel(M.synthetic_model(kind, H, seed=100 + list(models).index(key))).basecall(sigs[r])
+            nb = sum(x != y for x, y in zip(a[0], c[0])) + abs(len(a[0]) - len(c[0]))
+            nq = sum(x != y for x, y in zip(a[1], c[1]))
+            print("DIFF kind %d H %d nread %d cap %d read %d len %d: |dtrans| %.2e, bases differ %d, quality chars differ %d; vs oracle: split bases %s qual %s (%d chars), f32 bases %s qual %s (%d chars)" % (
+                kind, H, nread, cap, r, lens[r], d, nb, nq, a[0] == ref["basecall"], a[1] == ref["quality"], sum(x != y for x, y in zip(a[1], ref["quality"])),
+                c[0] == ref["basecall"], c[1] == ref["quality"], sum(x != y for x, y in zip(c[1], ref["quality"]))), flush=True)
+            ndiff += 1
+            wo_split = max(wo_split, float(np.abs(a[2] - ref["trans"]).max())); wo_f32 = max(wo_f32, float(np.abs(c[2] - ref["trans"]).max()))
+        nread_tot += 1
+    ncase += 1
+print("flagged reads vs oracle: worst |dtrans| split %.2e, f32 %.2e" % (wo_split, wo_f32))
+print("diff fuzz: %d cases, %d reads, %d reads with a differing string, worst |dtrans| %.2e, %.0f s" % (ncase, nread_tot, ndiff, worst, time.time() - t0))
