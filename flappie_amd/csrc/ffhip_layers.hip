@@ -566,3 +566,184 @@ extern "C" int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *
     if (score) *score = sc;
     return FFHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------ sloika GRU layers and the first run-length head
+// gru_forward/backward/step (layers.c:412-568) and gru_relu_* (layers.c:718-874): the GRU of the sloika networks
+// (networks.c:403, :492).  No model in the reference's registry uses them (networks.c:85-99), so this is a
+// correctness-level operator, not a throughput path: ONE workgroup walks the steps of the one read, the two weight
+// matrices are read from L2 every step, one wave per output row with a lane-strided dot product.
+//   z, r = sigma(x[0:2H] + sW^T h) ; hbar = act(x[2H:3H] + sW2^T (r * h)) ; h' = z h + (1 - z) hbar
+namespace {
+
+template <int RELU>
+__global__ void __launch_bounds__(1024)
+k_gru_sloika(const float *__restrict__ X, size_t xs, const float *__restrict__ sW, size_t ws, const float *__restrict__ sW2, size_t w2s,
+             const float *__restrict__ h0, int H, int T, int backward, float *__restrict__ out, size_t os) {
+    extern __shared__ float gru_sm[];
+    float *h = gru_sm, *rh = gru_sm + H, *g = gru_sm + 2 * H;                 // state, r * h, the two gates
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int u = tid; u < H; u += blockDim.x) h[u] = h0 ? h0[u] : 0.0f;       // layers.c:437: the first state is zero
+    __syncthreads();
+    for (int i = 0; i < T; i++) {
+        const int t = backward ? T - 1 - i : i;
+        const float *x = X + (size_t)t * xs;
+        for (int j = wave; j < 2 * H; j += nw) {                              // layers.c:545-549
+            const float *w = sW + (size_t)j * ws;
+            float acc = 0.0f;
+            for (int k = lane; k < H; k += 64) acc += w[k] * h[k];
+            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+            if (lane == 0) g[j] = logistic_ref(x[j] + acc);
+        }
+        __syncthreads();
+        for (int u = tid; u < H; u += blockDim.x) rh[u] = g[H + u] * h[u];    // layers.c:554-556
+        __syncthreads();
+        for (int u = wave; u < H; u += nw) {                                  // layers.c:557-566
+            const float *w = sW2 + (size_t)u * w2s;
+            float acc = 0.0f;
+            for (int k = lane; k < H; k += 64) acc += w[k] * rh[k];
+            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+            if (lane == 0) {
+                const float pre = x[2 * H + u] + acc;
+                const float hbar = RELU ? fmaxf(pre, 0.0f) : tanh_ref(pre);
+                const float z = g[u];
+                const float hn = z * h[u] + (1.0f - z) * hbar;
+                out[(size_t)t * os + u] = hn;
+                h[u] = hn;                                                    // every read of h for this step is done
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double lse64_l(double x, double y) { return fmax(x, y) + log1p(exp(-fabs(x - y))); }
+__device__ __forceinline__ float softplus_l(float x) { return log1pf(expf(-fabsf(x))) + ((x >= 0.0f) ? x : 0.f); }
+
+// globalnorm_runlength (layers.c:1197-1228), rows after the affine map: shape, scale, move, stay (nbase each)
+__global__ void k_rle1_activate(float *__restrict__ C, size_t n, int nbase, int Ps, float temperature) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = (int)(i % Ps);
+    if (p >= 4 * nbase) return;
+    const float x = C[i];
+    C[i] = p < nbase ? 1.0f + softplus_l(x) : (p < 2 * nbase ? 1e-1f + softplus_l(x) : 5.0f * tanhf(x) / temperature);
+}
+
+// runlength_partition_function (layers.c:1127-1174): one wave, lane = base, fp64 chain in the reference's order
+__global__ void __launch_bounds__(64)
+k_rle1_partition(const float *__restrict__ C, int nc, int nbase, int Ps, double *__restrict__ logz) {
+    __shared__ double st[2][64];
+    const int lane = threadIdx.x;
+    if (lane < nbase) st[0][lane] = 0.0;
+    __syncthreads();
+    int cur = 0;
+    for (int c = 0; c < nc; c++) {
+        const float *move = C + (size_t)c * Ps + 2 * nbase, *stay = move + nbase;
+        if (lane < nbase) {
+            const double *prev = st[cur];
+            double v = -HUGE_VAL;
+            for (int b2 = 0; b2 < nbase; b2++)
+                if (b2 != lane) v = lse64_l(v, prev[b2]);
+            v += (double)move[lane];
+            v = lse64_l(v, prev[lane] + (double)stay[lane]);
+            st[cur ^ 1][lane] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (lane == 0) {
+        double z = st[cur][0];
+        for (int b = 1; b < nbase; b++) z = lse64_l(z, st[cur][b]);
+        *logz = z;
+    }
+}
+
+__global__ void k_rle1_sub(float *__restrict__ C, size_t n, int nbase, int Ps, int nc, const double *__restrict__ logz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = (int)(i % Ps);
+    if (p < 2 * nbase || p >= 4 * nbase) return;
+    C[i] -= (float)(*logz / (double)(float)nc);              // layers.c:1216: `float logZ = partition / (float)C->nc`
+}
+
+}  // namespace
+
+// gru_forward / gru_backward (relu = 0) and gru_relu_forward / gru_relu_backward (relu = 1): X [3H x T], sW [H x 2H], sW2 [H x H]
+extern "C" int ffhip_op_gru(ffhip_engine *eng, int relu, ffhip_mat X, ffhip_mat sW, ffhip_mat sW2, int backward, ffhip_mat out) {
+    OP_ENTER(eng);
+    if (!view_ok(X) || !view_ok(sW) || !view_ok(sW2) || !view_ok(out)) return set_err(FFHIP_EINVAL, "bad GRU-layer arguments");
+    const size_t H = sW2.nc;
+    if (H % 4 != 0 || X.nr != 3 * H || sW.nr != H || sW2.nr != H || sW.nc != 2 * H || out.nr != H || out.nc != X.nc)
+        return set_err(FFHIP_EINVAL, "GRU layer: shapes do not agree (layers.c:419-425)");
+    if (5 * H * sizeof(float) > 64 * 1024) return set_err(FFHIP_EINVAL, "GRU layer: size %zu is beyond this operator (<= 3276)", H);
+    float *d_x = upload_img(tmp, X, s), *d_w = upload_img(tmp, sW, s), *d_w2 = upload_img(tmp, sW2, s);
+    float *d_o = (float *)tmp.get(out.nc * out.stride * 4);
+    if (!d_x || !d_w || !d_w2 || !d_o) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, out.nc * out.stride * 4, s), FFHIP_EHIP);
+    if (relu) hipLaunchKernelGGL(k_gru_sloika<1>, dim3(1), dim3(1024), 5 * H * sizeof(float), s, d_x, X.stride, d_w, sW.stride, d_w2, sW2.stride, (const float *)nullptr, (int)H, (int)X.nc, backward, d_o, out.stride);
+    else hipLaunchKernelGGL(k_gru_sloika<0>, dim3(1), dim3(1024), 5 * H * sizeof(float), s, d_x, X.stride, d_w, sW.stride, d_w2, sW2.stride, (const float *)nullptr, (int)H, (int)X.nc, backward, d_o, out.stride);
+    HIP_TRY(hipMemcpyAsync(out.data, d_o, out.nc * out.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// gru_step (layers.c:513-568) / gru_relu_step (layers.c:819-874): x [3H x 1], istate and ostate [H x 1]
+extern "C" int ffhip_op_gru_step(ffhip_engine *eng, int relu, ffhip_mat x, ffhip_mat istate, ffhip_mat sW, ffhip_mat sW2, ffhip_mat ostate) {
+    OP_ENTER(eng);
+    if (!view_ok(x) || !view_ok(istate) || !view_ok(sW) || !view_ok(sW2) || !view_ok(ostate)) return set_err(FFHIP_EINVAL, "bad GRU-step arguments");
+    const size_t H = istate.nr;
+    if (H % 4 != 0 || x.nr != 3 * H || sW.nr != H || sW.nc != 2 * H || sW2.nr != H || sW2.nc != H || ostate.nr != H)
+        return set_err(FFHIP_EINVAL, "GRU step: shapes do not agree (layers.c:529-538)");
+    if (5 * H * sizeof(float) > 64 * 1024) return set_err(FFHIP_EINVAL, "GRU step: size %zu is beyond this operator (<= 3276)", H);
+    float *d_x = (float *)tmp.upload(x.data, x.stride * 4, s), *d_h = (float *)tmp.upload(istate.data, istate.stride * 4, s);
+    float *d_w = upload_img(tmp, sW, s), *d_w2 = upload_img(tmp, sW2, s), *d_o = (float *)tmp.get(ostate.stride * 4);
+    if (!d_x || !d_h || !d_w || !d_w2 || !d_o) OP_NOMEM();
+    if (relu) hipLaunchKernelGGL(k_gru_sloika<1>, dim3(1), dim3(1024), 5 * H * sizeof(float), s, d_x, x.stride, d_w, sW.stride, d_w2, sW2.stride, (const float *)d_h, (int)H, 1, 0, d_o, ostate.stride);
+    else hipLaunchKernelGGL(k_gru_sloika<0>, dim3(1), dim3(1024), 5 * H * sizeof(float), s, d_x, x.stride, d_w, sW.stride, d_w2, sW2.stride, (const float *)d_h, (int)H, 1, 0, d_o, ostate.stride);
+    HIP_TRY(hipMemcpyAsync(ostate.data, d_o, H * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// globalnorm_runlength (layers.c:1197-1228), the first-generation run-length head: C is [4*nbase x T]
+extern "C" int ffhip_op_globalnorm_runlength_v1(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
+    OP_ENTER(eng);
+    if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C)) return set_err(FFHIP_EINVAL, "bad globalnorm arguments");
+    if (W.nr != X.nr || b.nr != W.nc || C.nr != W.nc || C.nc != X.nc) return set_err(FFHIP_EINVAL, "globalnorm: shapes do not agree");
+    if (W.nc % 4 != 0 || W.nc / 4 > 64) return set_err(FFHIP_EINVAL, "globalnorm_runlength: %zu rows is not 4*nbase with nbase <= 64 (layers.c:1115-1119)", W.nc);
+    const int nbase = (int)(W.nc / 4);
+    const int H = (int)X.nr, Hp = round_up(H, 16), K16 = Hp / 16, P = (int)W.nc, Mt = (P + 15) / 16, T = (int)X.nc;
+    std::vector<float> wp = pack_weight_T(W, Mt, K16);
+    std::vector<float> bias((size_t)Mt * 16, 0.0f);
+    for (int p = 0; p < P; p++) bias[p] = b.data[p];
+    float *d_x = upload_img(tmp, X, s);
+    float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
+    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d_x || !d_w || !d_b || !d_in || !d_c || !d_z) OP_NOMEM();
+    const size_t n = C.nc * C.stride;
+    HIP_TRY(hipMemsetAsync(d_c, 0, n * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
+    launch_head(s, d_in, d_c, (const float4 *)d_w, d_b, T, 1, 1, P, (int)C.stride, K16, 1.0f, 1);
+    hipLaunchKernelGGL(k_rle1_activate, dim3(nblk(n)), dim3(256), 0, s, d_c, n, nbase, (int)C.stride, temperature);
+    hipLaunchKernelGGL(k_rle1_partition, dim3(1), dim3(64), 0, s, (const float *)d_c, T, nbase, (int)C.stride, d_z);
+    hipLaunchKernelGGL(k_rle1_sub, dim3(nblk(n)), dim3(256), 0, s, d_c, n, nbase, (int)C.stride, T, (const double *)d_z);
+    HIP_TRY(hipMemcpyAsync(C.data, d_c, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    HIP_TRY(hipGetLastError(), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// runlength_partition_function (layers.c:1127-1174)
+extern "C" int ffhip_op_runlength_partition_function_v1(ffhip_engine *eng, ffhip_mat S, double *logZ) {
+    OP_ENTER(eng);
+    if (!view_ok(S) || !logZ || S.nr % 4 != 0 || S.nr / 4 > 64) return set_err(FFHIP_EINVAL, "bad partition-function arguments");
+    float *d = upload_img(tmp, S, s);
+    double *d_z = (double *)tmp.get(sizeof(double));
+    if (!d || !d_z) OP_NOMEM();
+    hipLaunchKernelGGL(k_rle1_partition, dim3(1), dim3(64), 0, s, (const float *)d, (int)S.nc, (int)(S.nr / 4), (int)S.stride, d_z);
+    HIP_TRY(hipMemcpyAsync(logZ, d_z, sizeof(double), hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}

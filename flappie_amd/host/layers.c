@@ -204,6 +204,49 @@ flappie_matrix grumod_backward(const_flappie_matrix X, const_flappie_matrix sW, 
     return recurrent(FFHIP_NET_GRUMOD5, X, sW, 1, res, __func__);
 }
 
+/* layers.c:412-510, 718-816 */
+static flappie_matrix gru_layer(int relu, const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, int backward,
+                                flappie_matrix out, const char *what) {
+    if (NULL == X) return NULL;
+    if (NULL == sW || NULL == sW2) { warnx("%s: missing recurrent weights", what); return NULL; }
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    out = remake_flappie_matrix(out, sW2->nc, X->nc);
+    if (NULL == out) return NULL;
+    if (0 != check(ffhip_op_gru(eng, relu, view(X), view(sW), view(sW2), backward, view(out)), what)) return free_flappie_matrix(out);
+    return out;
+}
+flappie_matrix gru_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res) {
+    return gru_layer(0, X, sW, sW2, 0, res, __func__);
+}
+flappie_matrix gru_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res) {
+    return gru_layer(0, X, sW, sW2, 1, res, __func__);
+}
+flappie_matrix gru_relu_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res) {
+    return gru_layer(1, X, sW, sW2, 0, res, __func__);
+}
+flappie_matrix gru_relu_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res) {
+    return gru_layer(1, X, sW, sW2, 1, res, __func__);
+}
+
+/* layers.c:513-568, 819-874; xF (the reference's scratch) is left untouched */
+static void gru_one_step(int relu, const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2,
+                         flappie_matrix ostate, const char *what) {
+    if (NULL == x || NULL == istate || NULL == sW || NULL == sW2 || NULL == ostate) return;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL != eng) (void)check(ffhip_op_gru_step(eng, relu, view(x), view(istate), view(sW), view(sW2), view(ostate)), what);
+}
+void gru_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix xF,
+              flappie_matrix ostate) {
+    (void)xF;
+    gru_one_step(0, x, istate, sW, sW2, ostate, __func__);
+}
+void gru_relu_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix xF,
+                   flappie_matrix ostate) {
+    (void)xF;
+    gru_one_step(1, x, istate, sW, sW2, ostate, __func__);
+}
+
 /* layers.c:979-1026.  xF is the reference's scratch for the gate pre-activations; it is left untouched. */
 void lstm_step(const_flappie_matrix x, const_flappie_matrix out_prev, const_flappie_matrix sW, flappie_matrix xF,
                flappie_matrix state, flappie_matrix output) {
@@ -249,6 +292,28 @@ flappie_matrix globalnorm_manystay(const_flappie_matrix X, const_flappie_matrix 
 
 flappie_matrix globalnorm_flipflop(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature, flappie_matrix C) {
     return globalnorm_manystay(X, W, b, temperature, C);
+}
+
+/* ---- first-generation run-length head (layers.c:1115-1228) ---- */
+size_t nbase_from_runlength_nparam(size_t nparam) { return nparam / 4; }
+
+double runlength_partition_function(const_flappie_matrix C) {
+    if (NULL == C) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    double logZ = NAN;
+    if (NULL == eng || 0 != check(ffhip_op_runlength_partition_function_v1(eng, view(C), &logZ), __func__)) return NAN;
+    return logZ;
+}
+
+flappie_matrix globalnorm_runlength(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature, flappie_matrix C) {
+    if (NULL == X) return NULL;
+    if (NULL == W || NULL == b) { warnx("globalnorm_runlength: missing weights or bias"); return NULL; }
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    C = remake_flappie_matrix(C, W->nc, X->nc);
+    if (NULL == C) return NULL;
+    if (0 != check(ffhip_op_globalnorm_runlength_v1(eng, view(X), view(W), view(b), temperature, view(C)), __func__)) return free_flappie_matrix(C);
+    return C;
 }
 
 /* ---- run-length head (layers.c:1230-1358) ---- */

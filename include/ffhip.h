@@ -193,6 +193,11 @@ int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ffhip_mat Xb,
 int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffhip_mat sW, int backward, ffhip_mat out);
 /* lstm_step (layers.c:979-1026) / grumod_step (layers.c:664-715); `state` = LSTM cell state, updated in place */
 int ffhip_op_recurrent_step(ffhip_engine *eng, int kind, ffhip_mat x, ffhip_mat h_prev, ffhip_mat sW, ffhip_mat state, ffhip_mat h_out);
+/* sloika GRU: gru_forward/backward (layers.c:412-510; relu = 0) and gru_relu_forward/backward (layers.c:718-816; relu = 1);
+ * X [3H x T] projected input, sW [H x 2H], sW2 [H x H].  One workgroup per call: no registered model uses these layers. */
+int ffhip_op_gru(ffhip_engine *eng, int relu, ffhip_mat X, ffhip_mat sW, ffhip_mat sW2, int backward, ffhip_mat out);
+/* gru_step (layers.c:513-568) / gru_relu_step (layers.c:819-874) */
+int ffhip_op_gru_step(ffhip_engine *eng, int relu, ffhip_mat x, ffhip_mat istate, ffhip_mat sW, ffhip_mat sW2, ffhip_mat ostate);
 /* crf_manystay_partition_function (layers.c:1035-1079) */
 int ffhip_op_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
 /* the same quantity by the batched pipeline's scaled linear-space recursion; requires |S| <= bound everywhere */
@@ -205,6 +210,9 @@ int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ff
  * transpost_crf_runlength (decode.c:1037-1159), decode_crf_runlength (decode.c:927-1013). */
 int ffhip_op_globalnorm_runlength(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
 int ffhip_op_runlength_partition_function(ffhip_engine *eng, ffhip_mat S, double *logZ);
+/* first-generation head: globalnorm_runlength (layers.c:1197-1228), runlength_partition_function (layers.c:1127-1174) */
+int ffhip_op_globalnorm_runlength_v1(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C);
+int ffhip_op_runlength_partition_function_v1(ffhip_engine *eng, ffhip_mat S, double *logZ);
 int ffhip_runlength_transpost(ffhip_engine *eng, ffhip_mat param, ffhip_mat post);
 int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *path /* nblock */, float *score);
 

@@ -7,9 +7,8 @@
  *  batch-of-one form of the kernels behind calculate_transitions (ffhip_op_*, include/ffhip.h) and is
  *  synchronous.  On a machine without a usable gfx950 device the functions warn and return NULL.
  *
- *  Not provided (outside the flip-flop hot path): gru_forward/backward/step and
- *  gru_relu_* (sloika GRU, unused by any shipped model), and the first-generation globalnorm_runlength head
- *  (layers.c:1115-1228; the shipped runnie model uses V2, which is provided).
+ *  The sloika GRU layers (gru_*, gru_relu_*) and the first-generation globalnorm_runlength head, which no model in the
+ *  reference's registry uses (networks.c:85-99), are provided as correctness-level operators (one workgroup per call).
  */
 #ifndef FFHIP_LAYERS_H
 #define FFHIP_LAYERS_H
@@ -50,6 +49,16 @@ flappie_matrix softmax_with_temperature(flappie_matrix X, const_flappie_matrix W
 flappie_matrix feedforward2_tanh(const_flappie_matrix Xf, const_flappie_matrix Xb, const_flappie_matrix Wf,
                                  const_flappie_matrix Wb, const_flappie_matrix b, flappie_matrix C);
 
+/* layers.c:412-568 and 718-874: the sloika GRU; X is the projected input [3H x T], sW [H x 2H], sW2 [H x H] */
+flappie_matrix gru_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
+flappie_matrix gru_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
+void gru_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2,
+              flappie_matrix xF, flappie_matrix ostate);
+flappie_matrix gru_relu_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
+flappie_matrix gru_relu_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
+void gru_relu_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2,
+                   flappie_matrix xF, flappie_matrix ostate);
+
 /* layers.c:571-715: X is the projected input [3H x T], sW [H x 3H] */
 flappie_matrix grumod_forward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix res);
 flappie_matrix grumod_backward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix res);
@@ -69,6 +78,11 @@ flappie_matrix globalnorm_manystay(const_flappie_matrix X, const_flappie_matrix 
 size_t nbase_from_flipflop_nparam(size_t nparam);
 flappie_matrix globalnorm_flipflop(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
                                    flappie_matrix C);
+/* layers.c:1115-1228: the first-generation run-length head (rows shape, scale, move, stay; scale = 0.1 + softplus) */
+size_t nbase_from_runlength_nparam(size_t nparam);
+double runlength_partition_function(const_flappie_matrix C);
+flappie_matrix globalnorm_runlength(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
+                                    flappie_matrix C);
 /* layers.c:1230-1358: the run-length head of runnie's model (shape = 1 + softplus, scale = 1e-8 + softplus,
  * transitions 5 tanh / temperature, globally normalised) and its fp64 partition function */
 size_t nbase_from_crf_runlength_nparam(size_t nparam);

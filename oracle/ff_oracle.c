@@ -414,6 +414,41 @@ fo_mat *fo_grumod(const fo_mat *X, const fo_mat *sW, int backward) {
     return out;
 }
 
+/* layers.c:513-568 gru_step and layers.c:819-874 gru_relu_step -- the sloika GRU (gate order z, r, candidate; used only by
+ * networks.c:403/:492, which no registered model reaches):
+ *   xF = x ; xF[0:2H] += sW^T h ; z, r = sigma ; hbar = act(x[2H:3H] + sW2^T (r*h)) ; h' = z*h + (1-z)*hbar */
+static void gru_step(const float *x, const float *hprev, const fo_mat *sW, const fo_mat *sW2, int relu, float *xF, float *hout) {
+    const size_t size = sW2->nc;
+    memcpy(xF, x, 3 * size * sizeof(float));
+    window_accumulate(xF, sW, 0, size, hprev);
+    for (size_t i = 0; i < 2 * size; i++) xF[i] = fo_logisticf(xF[i]);
+    const float *z = xF;
+    float *r = xF + size, *hbar = xF + 2 * size;
+    for (size_t i = 0; i < size; i++) r[i] *= hprev[i];
+    window_accumulate(hbar, sW2, 0, size, r);
+    for (size_t i = 0; i < size; i++) hbar[i] = relu ? fmaxf(hbar[i], 0.0f) : fo_tanhf(hbar[i]);
+    for (size_t i = 0; i < size; i++) hout[i] = z[i] * hprev[i] + (1.0f - z[i]) * hbar[i];
+}
+
+/* layers.c:412-510 gru_forward / gru_backward, layers.c:718-816 gru_relu_forward / gru_relu_backward.
+ * h0 (nullable) replaces the zero start state: with n = 1 this is gru_step / gru_relu_step itself. */
+fo_mat *fo_gru(const fo_mat *X, const fo_mat *sW, const fo_mat *sW2, int backward, int relu, const float *h0) {
+    if (!X || !sW || !sW2) return NULL;
+    const size_t size = sW2->nc, n = X->nc;
+    if (X->nr != 3 * size || sW->nr != size || sW2->nr != size || sW->nc != 2 * size || size % 4 != 0) return NULL;
+    fo_mat *out = fo_make_mat(size, n);
+    float *xF = calloc(3 * size, sizeof(float));
+    float *zero = calloc(size, sizeof(float));
+    if (!out || !xF || !zero) { free(xF); free(zero); return fo_free_mat(out); }
+    for (size_t i = 0; i < n; i++) {
+        const size_t t = backward ? n - 1 - i : i;
+        const float *hprev = (i == 0) ? (h0 ? h0 : zero) : out->f + (backward ? t + 1 : t - 1) * out->stride;
+        gru_step(X->f + t * X->stride, hprev, sW, sW2, relu, xF, out->f + t * out->stride);
+    }
+    free(xF); free(zero);
+    return out;
+}
+
 /* layers.c:1029-1032 */
 size_t fo_nbase_from_nparam(size_t nparam) {
     return (size_t)roundf((-1.0f + sqrtf(1 + 2 * nparam)) / 2.0f);
@@ -795,6 +830,50 @@ int fo_trim_and_segment_raw(const float *raw, size_t n, size_t *start, size_t *e
 
 /* util.h:83-85 */
 float fo_softplusf(float x) { return log1pf(expf(-fabsf(x))) + ((x >= 0.0f) ? x : 0.f); }
+
+/* layers.c:1127-1174  first-generation run-length model: rows shape, scale, move, stay (nbase each); fp64 recursion over
+ * the nbase states: a move into b1 from every other base, or a stay */
+double fo_runlength_partition_function(const fo_mat *C) {
+    if (!C || C->nr % 4 != 0 || C->nr / 4 > 64) return NAN;
+    const size_t nbase = C->nr / 4;
+    double mem[2 * 64] = { 0 };
+    double *curr = mem, *prev = mem + nbase;
+    for (size_t c = 0; c < C->nc; c++) {
+        const float *move = C->f + c * C->stride + 2 * nbase, *stay = move + nbase;
+        { double *tmp = curr; curr = prev; prev = tmp; }
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++)
+                if (b1 != b2) curr[b1] = fo_logsumexp(curr[b1], prev[b2]);
+            curr[b1] += move[b1];
+        }
+        for (size_t b = 0; b < nbase; b++) curr[b] = fo_logsumexp(curr[b], prev[b] + stay[b]);
+    }
+    double logZ = curr[0];
+    for (size_t st = 1; st < nbase; st++) logZ = fo_logsumexp(logZ, curr[st]);
+    return logZ;
+}
+
+/* layers.c:1197-1228 */
+fo_mat *fo_globalnorm_runlength(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature) {
+    fo_mat *C = fo_affine_map(X, W, b);
+    if (!C) return NULL;
+    if (C->nr % 4 != 0) return fo_free_mat(C);
+    const size_t nbase = C->nr / 4;
+    for (size_t c = 0; c < C->nc; c++) {
+        float *x = C->f + c * C->stride;
+        for (size_t k = 0; k < nbase; k++) {
+            x[k] = 1.0f + fo_softplusf(x[k]);
+            x[nbase + k] = 1e-1f + fo_softplusf(x[nbase + k]);
+            x[2 * nbase + k] = 5.0f * tanhf(x[2 * nbase + k]) / temperature;
+            x[3 * nbase + k] = 5.0f * tanhf(x[3 * nbase + k]) / temperature;
+        }
+    }
+    const float logZ = fo_runlength_partition_function(C) / (float)C->nc;
+    for (size_t c = 0; c < C->nc; c++)
+        for (size_t r = 2 * nbase; r < 4 * nbase; r++) C->f[c * C->stride + r] -= logZ;
+    return C;
+}
 
 /* layers.c:1241-1246 */
 static size_t rle_trans_lookup(size_t base_from, int stay_from, size_t base_to, int stay_to, size_t nbase) {

@@ -89,6 +89,9 @@ fo_mat *fo_convolution(const fo_mat *X, const fo_mat *W, const fo_mat *b, size_t
 fo_mat *fo_affine_map(const fo_mat *X, const fo_mat *W, const fo_mat *b);
 fo_mat *fo_lstm(const fo_mat *Xaffine, const fo_mat *sW, int backward);
 fo_mat *fo_grumod(const fo_mat *X, const fo_mat *sW, int backward);
+fo_mat *fo_gru(const fo_mat *X, const fo_mat *sW, const fo_mat *sW2, int backward, int relu, const float *h0);
+double fo_runlength_partition_function(const fo_mat *C);
+fo_mat *fo_globalnorm_runlength(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature);
 double fo_partition_function(const fo_mat *C);
 fo_mat *fo_globalnorm_flipflop(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature);
 fo_mat *fo_transitions(const float *raw, size_t start, size_t end, float temperature,

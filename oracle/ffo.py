@@ -82,6 +82,12 @@ def lib():
     L.fo_lstm.argtypes = [P(FoMat), P(FoMat), C.c_int]
     L.fo_grumod.restype = P(FoMat)
     L.fo_grumod.argtypes = [P(FoMat), P(FoMat), C.c_int]
+    L.fo_gru.restype = P(FoMat)
+    L.fo_gru.argtypes = [P(FoMat), P(FoMat), P(FoMat), C.c_int, C.c_int, P(C.c_float)]
+    L.fo_runlength_partition_function.restype = C.c_double
+    L.fo_runlength_partition_function.argtypes = [P(FoMat)]
+    L.fo_globalnorm_runlength.restype = P(FoMat)
+    L.fo_globalnorm_runlength.argtypes = [P(FoMat), P(FoMat), P(FoMat), C.c_float]
     L.fo_partition_function.restype = C.c_double
     L.fo_partition_function.argtypes = [P(FoMat)]
     L.fo_globalnorm_flipflop.restype = P(FoMat)

@@ -57,6 +57,12 @@ def L():
     lib.lstm_step.restype = None
     lib.grumod_step.argtypes = [PM] * 5
     lib.grumod_step.restype = None
+    for name in ("gru_forward", "gru_backward", "gru_relu_forward", "gru_relu_backward"):
+        getattr(lib, name).restype = PM
+        getattr(lib, name).argtypes = [PM, PM, PM, PM]
+    for name in ("gru_step", "gru_relu_step"):
+        getattr(lib, name).argtypes = [PM] * 6
+        getattr(lib, name).restype = None
     lib.crf_manystay_partition_function.restype = C.c_double
     lib.crf_manystay_partition_function.argtypes = [PM]
     for name in ("globalnorm_flipflop", "globalnorm_manystay"):
@@ -375,6 +381,81 @@ def test_recurrent_steps_chain_to_the_layer(L, kind):
             L.grumod_step(x, h, S, xF, out)
         np.testing.assert_allclose(dense(out)[0], want[t], rtol=0, atol=2e-5)
         np.testing.assert_allclose(dense(out)[0], layer[t], rtol=0, atol=2e-5)
+        L.free_flappie_matrix(h)
+        L.free_flappie_matrix(x)
+        h = out
+
+
+def _gru_numpy(xa, sw, sw2, backward, relu):
+    """the sloika GRU in float64 numpy, written from the equations (an independent check of the oracle's restatement)"""
+    T, H = xa.shape[0], sw2.shape[0]
+    x, w, w2 = xa.astype(np.float64), sw.astype(np.float64), sw2.astype(np.float64)
+    out, h = np.zeros((T, H)), np.zeros(H)
+    for i in range(T):
+        t = T - 1 - i if backward else i
+        zr = 1.0 / (1.0 + np.exp(-(x[t, :2 * H] + w @ h)))
+        z, r = zr[:H], zr[H:]
+        pre = x[t, 2 * H:] + w2 @ (r * h)
+        hbar = np.maximum(pre, 0.0) if relu else np.tanh(pre)
+        h = z * h + (1.0 - z) * hbar
+        out[t] = h
+    return out
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_oracle_sloika_gru_against_numpy(relu):
+    """fo_gru (layers.c:412-568, 718-874) against the equations in float64"""
+    H, T = 24, 40
+    rng = np.random.default_rng(5 + relu)
+    xa = rng.standard_normal((T, 3 * H)).astype(np.float32)
+    sw = (rng.standard_normal((2 * H, H)) / np.sqrt(H)).astype(np.float32)
+    sw2 = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)
+    for backward in (0, 1):
+        got = ffo.take(ffo.lib().fo_gru(omat(xa).ptr, omat(sw).ptr, omat(sw2).ptr, backward, relu, None))
+        np.testing.assert_allclose(got, _gru_numpy(xa, sw, sw2, backward, relu), rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,T", [(32, 50), (96, 77), (36, 23), (256, 40)])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_sloika_gru_layers_match_oracle(L, relu, H, T):
+    """gru_forward/backward (layers.c:412-510), gru_relu_forward/backward (layers.c:718-816)"""
+    rng = np.random.default_rng(H * 3 + T + relu)
+    xa = rng.standard_normal((T, 3 * H)).astype(np.float32)
+    sw = (rng.standard_normal((2 * H, H)) / np.sqrt(H)).astype(np.float32)
+    sw2 = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)
+    X, S, S2 = mk(L, xa), mk(L, sw), mk(L, sw2)
+    stem = "gru_relu" if relu else "gru"
+    for direction, backward in (("forward", 0), ("backward", 1)):
+        want = ffo.take(ffo.lib().fo_gru(omat(xa).ptr, omat(sw).ptr, omat(sw2).ptr, backward, relu, None))
+        out = getattr(L, "%s_%s" % (stem, direction))(X, S, S2, None)
+        assert out, "%s_%s returned NULL" % (stem, direction)
+        got = dense(out)
+        assert got.shape == (T, H)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+        L.free_flappie_matrix(out)
+    assert not L.gru_forward(None, S, S2, None)
+    assert not L.gru_forward(X, S, mk(L, sw), None)          # sW2 of the wrong shape: refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relu", [0, 1])
+def test_sloika_gru_steps_chain_to_the_layer(L, relu):
+    """gru_step (layers.c:513-568) / gru_relu_step (layers.c:819-874) applied T times from a zero state"""
+    H, T = 48, 9
+    rng = np.random.default_rng(77 + relu)
+    xa = rng.standard_normal((T, 3 * H)).astype(np.float32)
+    sw = (rng.standard_normal((2 * H, H)) / np.sqrt(H)).astype(np.float32)
+    sw2 = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)
+    S, S2 = mk(L, sw), mk(L, sw2)
+    want = ffo.take(ffo.lib().fo_gru(omat(xa).ptr, omat(sw).ptr, omat(sw2).ptr, 0, relu, None))
+    h = mk(L, np.zeros((1, H), np.float32))
+    xF = L.make_flappie_matrix(3 * H, 1)
+    for t in range(T):
+        x = mk(L, xa[t:t + 1])
+        out = L.make_flappie_matrix(H, 1)
+        (L.gru_relu_step if relu else L.gru_step)(x, h, S, S2, xF, out)
+        np.testing.assert_allclose(dense(out)[0], want[t], rtol=0, atol=2e-5)
         L.free_flappie_matrix(h)
         L.free_flappie_matrix(x)
         h = out

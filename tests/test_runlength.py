@@ -199,3 +199,80 @@ def test_runlength_host_api(B):
     sw = lib.fo_decode_crf_runlength(pm.ptr, ref_path.ctypes.data_as(ip))
     assert np.array_equal(path, ref_path) and abs(s - sw) <= 1e-3
     assert np.isnan(L.decode_crf_runlength(None, path.ctypes.data_as(ip))) and not L.transpost_crf_runlength(None)
+
+
+# ------------------------------------------------------------------------------------ the first-generation head (layers.c:1115-1228)
+def _brute_force_v1(param, nbase):
+    """log-sum over every state path s_-1, s_0 .. s_T-1 of: move[s_t] when the base changes, stay[s_t] when it does not
+    (the start state s_-1 is free and costs nothing: runlength_partition_function starts from zeros)"""
+    import itertools
+    T = param.shape[0]
+    move, stay = param[:, 2 * nbase:3 * nbase].astype(np.float64), param[:, 3 * nbase:4 * nbase].astype(np.float64)
+    logz = -np.inf
+    for path in itertools.product(range(nbase), repeat=T + 1):
+        sc = sum(stay[t, path[t + 1]] if path[t + 1] == path[t] else move[t, path[t + 1]] for t in range(T))
+        logz = np.logaddexp(logz, sc)
+    return logz
+
+
+def test_oracle_first_generation_head():
+    lib = ffo.lib()
+    rng = np.random.default_rng(12)
+    for nbase, T in ((2, 5), (3, 4), (4, 3)):
+        param = rng.standard_normal((T, 4 * nbase)).astype(np.float32)
+        want = _brute_force_v1(param, nbase)
+        got = lib.fo_runlength_partition_function(ffo.HostMat.from_dense(param).ptr)
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want))
+    nbase, H, T = 4, 24, 30
+    x = np.tanh(rng.standard_normal((T, H))).astype(np.float32)
+    w = (rng.standard_normal((4 * nbase, H)) / np.sqrt(H) * 2).astype(np.float32)
+    b = rng.standard_normal((1, 4 * nbase)).astype(np.float32)
+    for temperature in (1.0, 0.6):
+        got = ffo.take(lib.fo_globalnorm_runlength(ffo.HostMat.from_dense(x).ptr, ffo.HostMat.from_dense(w).ptr, ffo.HostMat.from_dense(b).ptr, temperature))
+        a = x.astype(np.float64) @ w.T.astype(np.float64) + b
+        np.testing.assert_allclose(got[:, :nbase], 1 + np.log1p(np.exp(a[:, :nbase])), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(got[:, nbase:2 * nbase], 0.1 + np.log1p(np.exp(a[:, nbase:2 * nbase])), rtol=2e-6, atol=2e-6)
+        assert abs(lib.fo_runlength_partition_function(ffo.HostMat.from_dense(got).ptr)) <= 1e-3     # globally normalised
+        assert np.ptp(5 * np.tanh(a[:, 2 * nbase:]) / temperature - got[:, 2 * nbase:]) <= 1e-4       # one constant subtracted
+
+
+@pytest.mark.gpu
+def test_first_generation_head_host_api(B):
+    """globalnorm_runlength, runlength_partition_function, nbase_from_runlength_nparam through the reference-named C calls"""
+    from test_host_layer import CMat, HOSTLIB, _f
+    PM = C.POINTER(CMat)
+    L = C.CDLL(HOSTLIB)
+    L.mat_from_array.restype = PM
+    L.mat_from_array.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t]
+    L.globalnorm_runlength.restype = PM
+    L.globalnorm_runlength.argtypes = [PM, PM, PM, C.c_float, PM]
+    L.runlength_partition_function.restype = C.c_double
+    L.runlength_partition_function.argtypes = [PM]
+    L.nbase_from_runlength_nparam.restype = C.c_size_t
+    L.nbase_from_runlength_nparam.argtypes = [C.c_size_t]
+
+    def mk(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return L.mat_from_array(_f(a), a.shape[1], a.shape[0])
+
+    def dense(pm):
+        m = pm.contents
+        return np.ctypeslib.as_array(m.f, shape=(m.nc, m.stride))[:, : m.nr].copy()
+
+    lib = ffo.lib()
+    rng = np.random.default_rng(9)
+    assert L.nbase_from_runlength_nparam(16) == 4
+    for nbase, H, T in ((4, 96, 150), (5, 64, 33), (4, 256, 1)):
+        P = 4 * nbase
+        x = np.tanh(rng.standard_normal((T, H))).astype(np.float32)
+        w = (rng.standard_normal((P, H)) / np.sqrt(H) * 3).astype(np.float32)
+        bias = rng.standard_normal((1, P)).astype(np.float32)
+        want = ffo.take(lib.fo_globalnorm_runlength(ffo.HostMat.from_dense(x).ptr, ffo.HostMat.from_dense(w).ptr, ffo.HostMat.from_dense(bias).ptr, 0.9))
+        c = L.globalnorm_runlength(mk(x), mk(w), mk(bias), 0.9, None)
+        assert c
+        np.testing.assert_allclose(dense(c), want, rtol=0, atol=5e-5)
+        param = (rng.standard_normal((T, P)) * 2).astype(np.float32)
+        z = L.runlength_partition_function(mk(param))
+        zw = lib.fo_runlength_partition_function(ffo.HostMat.from_dense(param).ptr)
+        assert abs(z - zw) <= 1e-9 * max(1.0, abs(zw))
+    assert not L.globalnorm_runlength(None, None, None, 1.0, None)
