@@ -1319,24 +1319,31 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
 #pragma unroll
             for (int k = 0; k < kDepth; k++) {
                 if (b0 + k >= n) break;
-                float v = valid ? cur[k] + pv : NEG;
-                int a = st;
-                // flop pair (lanes 32..39): partner = lane ^ 4; stay = idx >= 4
+                // The chain carries the VALUE only: max is exact, so the winner can be identified afterwards as the lowest
+                // from-state whose candidate equals the maximum (= the reference's scan with its strict >), from a ballot, off
+                // the critical path.  Chain per block: one add, three max over DPP partners, one ds_bpermute.
+                const float cand = valid ? cur[k] + pv : NEG;
+                float v = cand;
                 const float o4 = xor4_f(v);
+                bool moved = false;
                 if (!flip) {
+                    // flop pair (lanes 32..39): partner = lane ^ 4; the stay entry is the one with from >= 4; stay unless move is strictly greater
                     const bool i_am_stay = (lane & 4) != 0;
                     const float stay = i_am_stay ? v : o4, move = i_am_stay ? o4 : v;
-                    const int b2 = 4 + (lane & 3);
-                    if (move > stay) { v = move; a = b2 - nbase; } else { v = stay; a = b2; }
+                    moved = move > stay;
+                    v = moved ? move : stay;
                 } else {
-                    // flip groups: argmax over from-state, lowest index on ties
-                    { const int oa = a ^ 4; if (o4 > v || (o4 == v && oa < a)) { v = o4; a = oa; } }
-                    { const float ov = xor1_f(v); const int oa = xor1_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
-                    { const float ov = xor2_f(v); const int oa = xor2_i(a); if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; } }
+                    v = fmaxf(v, o4);
+                    v = fmaxf(v, xor1_f(v));
+                    v = fmaxf(v, xor2_f(v));
                 }
+                const unsigned eq = (unsigned)__ballot(flip && cand == v);                  // bit 8*to + from
+                const unsigned mv = (unsigned)(__ballot(!flip && valid && moved) >> 32);    // bit (b2 - 4) [and bit b2] of flop state b2
                 const int src = ff8_src_lane(st);
                 pv = __shfl(v, src);
-                const int arg = __shfl(a, src);
+                int arg = 0;
+                if (lane < nbase) arg = __builtin_ctz(((eq >> (8 * lane)) & 0xffu) | 0x100u);
+                else if (lane < ns) arg = ((mv >> (lane - nbase)) & 1u) ? lane - nbase : lane;
                 if (lane < ns) tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg;
             }
         }
