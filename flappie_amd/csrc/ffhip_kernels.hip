@@ -548,6 +548,8 @@ __device__ __forceinline__ double xor4_d(double x) { return __hiloint2double(xor
 // lane holding the new value of state s after the grouped reductions of the 8-state kernels: flip state s < 4 in
 // lanes 8s..8s+7, flop state s in lanes 32+s-4 and 32+s
 __device__ __forceinline__ int ff8_src_lane(int s) { return s < 4 ? 8 * s : 32 + s; }
+// the same for the 10-state kernels: flip state s < 5 in lanes 8s..8s+7, flop state s in lane 40 + s - 5
+__device__ __forceinline__ int ff10_src_lane(int s) { return s < 5 ? 8 * s : 40 + (s - 5); }
 
 // ---- CRF partition function, linear-space form (the pipeline's default) -----------------------------
 // The log-space recursion above spends an fp64 exp and log per state per block ON the dependent chain
@@ -1147,10 +1149,149 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
     }
 }
 
+// ---- nstate == 10 (the 5-base models): the butterfly scheme of k_transpost8 with two entries per lane -------------------
+// Forward (wave 0): flip destination g owns lanes 8g..8g+7, lane j holding its entries from states j and j+8 (j < 2); lanes
+// 40..44 hold the stay / move entries of flop state 5+j.  Backward (wave 1): SOURCE states g and g+5 own lanes 8g..8g+7, lane j
+// holding their exits to flip state j (j < 5) or into the flop state (j = 5; for source g the move to flop g+5, for source g+5
+// the stay) -- so each recursion needs only in-group DPP reductions and one or two ds_bpermute per block to hand the new
+// vector out.  Every per-state logsumexp is max + log(sum exp) as in k_transpost8 (same value up to fp32 rounding of the
+// association); k_transpost_lds keeps the reference's order of the sums (FFHIP_EXACT_ORDER, other nstate).
+__global__ void __launch_bounds__(256)
+k_transpost10(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int TbS,
+              int Ps, const int *__restrict__ tbs) {
+    constexpr int P = 60, ns = 10, nbase = 5, off = 50;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
+    float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
+    float *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    float *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * kMaxState;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    if (Tb <= 0) return;
+    const int g = lane >> 3, j = lane & 7;
+    const float NEG = -INFINITY;
+    __shared__ float stage[2][64][kMaxState];
+    constexpr int kDepth = 8;
+    auto flush = [&](int w, float *dst0, long long dstep, int cnt) {      // row r of the stage -> dst0 + r*dstep (kMaxState floats each)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const float4 *src = (const float4 *)&stage[w][lane][0];
+            float4 *dst = (float4 *)(dst0 + (long long)lane * dstep);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];             // ns = 10 states
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (wave == 0) {
+        const bool flip = g < nbase, flop = (g == nbase && j < nbase);
+        const bool valid0 = flip || flop, valid1 = (flip && j < 2) || flop;
+        const int e0 = flip ? g * ns + j : (flop ? off + nbase + j : 0);                  // flop: stay, from = 5 + j
+        const int e1 = flip ? (j < 2 ? g * ns + 8 + j : e0) : (flop ? off + j : 0);      // flop: move, from = j
+        const int src0 = flip ? ff10_src_lane(j) : (flop ? ff10_src_lane(nbase + j) : 0);
+        const int src1 = flip ? ff10_src_lane(j < 2 ? j + 8 : j) : (flop ? ff10_src_lane(j) : 0);
+        float pv0 = 0.0f, pv1 = 0.0f;
+        if (lane < ns) F[lane] = 0.0f;
+        float ring0[kDepth], ring1[kDepth];
+        auto fetch0 = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + e0]; };
+        auto fetch1 = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + e1]; };
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(k); ring1[k] = fetch1(k); }
+        for (int b0 = 0; b0 < Tb; b0 += kDepth) {
+            float cur0[kDepth], cur1[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { cur0[k] = ring0[k]; cur1[k] = ring1[k]; }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(b0 + kDepth + k); ring1[k] = fetch1(b0 + kDepth + k); }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int blk = b0 + k;
+                if (blk >= Tb) break;
+                const float t0 = valid0 ? cur0[k] + pv0 : NEG, t1 = valid1 ? cur1[k] + pv1 : NEG;
+                float m = fmaxf(t0, t1);
+                if (flip) { m = fmaxf(m, xor4_f(m)); m = fmaxf(m, xor1_f(m)); m = fmaxf(m, xor2_f(m)); }
+                float e = (valid0 ? expf(t0 - m) : 0.0f) + (valid1 ? expf(t1 - m) : 0.0f);
+                if (flip) { e += xor4_f(e); e += xor1_f(e); e += xor2_f(e); }
+                const float val = m + logf(e);
+                pv0 = __shfl(val, src0);
+                pv1 = __shfl(val, src1);
+                if (lane < 8) stage[0][blk & 63][lane] = pv0;              // fwd[blk + 1], states 0..7 (lane j of group 0 reads state j)
+                if (lane < 2) stage[0][blk & 63][8 + lane] = pv1;          // states 8, 9
+                if ((blk & 63) == 63 || blk == Tb - 1) flush(0, F + (size_t)((blk & ~63) + 1) * kMaxState, kMaxState, (blk & 63) + 1);
+            }
+        }
+    } else if (wave == 1) {
+        // lane (g, j), g < 5, j < 6: slot 0 = source state g, slot 1 = source state g + 5; exit j < 5 -> flip state j, j = 5 -> flop state g + 5
+        const bool act = g < nbase && j <= nbase;
+        const int e0 = act ? (j < nbase ? j * ns + g : off + g) : 0;
+        const int e1 = act ? (j < nbase ? j * ns + g + nbase : off + g + nbase) : 0;
+        const int srcl = 8 * min(j, nbase - 1);        // new value of flip state j: slot 0 of group j (used by lanes j < 5)
+        float pb_to0 = 0.0f;                           // bwd[to] for this lane's exits: flip state j, or the group's own flop state
+        float n0 = 0.0f, n1 = 0.0f;                    // bwd of the group's two source states (replicated over the group)
+        float ring0[kDepth], ring1[kDepth];
+        auto fetch0 = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + e0]; };       // blk counts down
+        auto fetch1 = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + e1]; };
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(Tb - 1 - k); ring1[k] = fetch1(Tb - 1 - k); }
+        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                          // jj = Tb - blk: 0, 1, ...
+            float cur0[kDepth], cur1[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { cur0[k] = ring0[k]; cur1[k] = ring1[k]; }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(Tb - 1 - (j0 + kDepth + k)); ring1[k] = fetch1(Tb - 1 - (j0 + kDepth + k)); }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                const int jj = j0 + k;
+                if (jj >= Tb) break;
+                if (j == 0 && g < nbase) { stage[1][jj & 63][g] = n0; stage[1][jj & 63][g + nbase] = n1; }      // bwd[blk], blk = Tb - jj
+                if ((jj & 63) == 63 || jj == Tb - 1) flush(1, Bw + (size_t)(Tb - (jj & ~63)) * kMaxState, -(long long)kMaxState, (jj & 63) + 1);
+                const float t0 = act ? cur0[k] + pb_to0 : NEG, t1 = act ? cur1[k] + pb_to0 : NEG;
+                float m0 = t0, m1 = t1;
+                m0 = fmaxf(m0, xor4_f(m0)); m1 = fmaxf(m1, xor4_f(m1));
+                m0 = fmaxf(m0, xor1_f(m0)); m1 = fmaxf(m1, xor1_f(m1));
+                m0 = fmaxf(m0, xor2_f(m0)); m1 = fmaxf(m1, xor2_f(m1));
+                float x0 = act ? expf(t0 - m0) : 0.0f, x1 = act ? expf(t1 - m1) : 0.0f;
+                x0 += xor4_f(x0); x1 += xor4_f(x1);
+                x0 += xor1_f(x0); x1 += xor1_f(x1);
+                x0 += xor2_f(x0); x1 += xor2_f(x1);
+                n0 = m0 + logf(x0);
+                n1 = m1 + logf(x1);
+                const float flipv = __shfl(n0, srcl);
+                pb_to0 = (j < nbase) ? flipv : n1;         // exits into flip state j; or into the group's flop state g + 5
+            }
+        }
+    }
+    __syncthreads();
+    // posterior of transition r of block blk = (fwd[blk][from] + bwd[blk+1][to]) + trans (decode.c:451-461), then the per-block
+    // log-normalisation over the P entries (flappie_matrix.c:450-467); one block per thread
+    for (int blk = threadIdx.x; blk < Tb; blk += 256) {
+        const float *x = T + (size_t)blk * Ps;
+        float *o = Pp + (size_t)blk * Ps;
+        float f[ns], bb[ns];
+#pragma unroll
+        for (int k = 0; k < ns; k++) { f[k] = F[(size_t)blk * kMaxState + k]; bb[k] = Bw[(size_t)(blk + 1) * kMaxState + k]; }
+        float v[P];
+        float m = NEG;
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            const int from = r % ns;
+            const int to = (r < off) ? (r / ns) : ((r - off < nbase) ? r - off + nbase : r - off);
+            v[r] = (f[from] + bb[to]) + x[r];
+            m = fmaxf(m, v[r]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < P; r++) sum += expf(v[r] - m);
+        const float lse = m + logf(sum);
+#pragma unroll
+        for (int r = 0; r < P; r++) o[r] = v[r] - lse;
+    }
+}
+
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs);
+    else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_CRF_GENERIC"))
+        hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs);
     else if (!getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps, tbs);
     else
@@ -1388,11 +1529,129 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
     }
 }
 
+// Viterbi for nstate == 10 (the 5-base models, r941_5mC): the scheme of k_viterbi8 with two candidates per lane.  Flip
+// destination g (0..4) owns lanes 8g..8g+7, lane j holding its candidates from states j and j+8 (j < 2); lanes 40..44 hold
+// the stay / move pair of flop state 5+j.  The chain carries the value only (local max, three DPP exchanges, two
+// ds_bpermute to hand the new vector out); the winner -- lowest from-state among equals for a flip, stay unless the move is
+// strictly greater for a flop, exactly decode.c:119-204 -- comes from ballots off the chain.
+
+__global__ void __launch_bounds__(64)
+k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path,
+            float *__restrict__ qpath, float *__restrict__ score_out, int TbS, int Ps, const int *__restrict__ tbs) {
+    constexpr int ns = 10, nbase = 5, off = 50;
+    __shared__ uint8_t tb_lds[kTbChunk * kMaxState];
+    __shared__ int path_lds[kTbChunk + 1];
+    const int lane = threadIdx.x;
+    const float *T = M + (size_t)blockIdx.x * TbS * Ps;
+    uint8_t *tb = tbbuf + (size_t)blockIdx.x * TbS * kMaxState;
+    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
+    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    if (Tb <= 0) return;
+    const int g = lane >> 3, j = lane & 7;
+    const bool flip = g < nbase, flop = (g == nbase && j < nbase);
+    const bool valid0 = flip || flop, valid1 = (flip && j < 2) || flop;
+    // entries (trans_lookup, decode.c:104-114) and source states of this lane's two candidates
+    const int e0 = flip ? g * ns + j : (flop ? off + nbase + j : 0);          // flop: stay, from = 5 + j
+    const int e1 = flip ? (j < 2 ? g * ns + 8 + j : e0) : (flop ? off + j : 0);      // flop: move, from = j
+    const int src0 = flip ? ff10_src_lane(j) : (flop ? ff10_src_lane(nbase + j) : 0);
+    const int src1 = flip ? ff10_src_lane(j < 2 ? j + 8 : j) : (flop ? ff10_src_lane(j) : 0);
+    const float NEG = -INFINITY;
+
+    constexpr int kDepth = 8;
+    float ring0[kDepth], ring1[kDepth];
+    auto fetch0 = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + e0]; };
+    auto fetch1 = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + e1]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(k); ring1[k] = fetch1(k); }
+    float pv0 = 0.0f, pv1 = 0.0f;
+    const int nchunk = (Tb + kTbChunk - 1) / kTbChunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0);
+        for (int b0 = 0; b0 < n; b0 += kDepth) {
+            float cur0[kDepth], cur1[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { cur0[k] = ring0[k]; cur1[k] = ring1[k]; }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) { ring0[k] = fetch0(c0 + b0 + kDepth + k); ring1[k] = fetch1(c0 + b0 + kDepth + k); }
+#pragma unroll
+            for (int k = 0; k < kDepth; k++) {
+                if (b0 + k >= n) break;
+                const float a0 = valid0 ? cur0[k] + pv0 : NEG, a1 = valid1 ? cur1[k] + pv1 : NEG;
+                float v;
+                bool moved = false;
+                if (flip) {
+                    v = fmaxf(a0, a1);
+                    v = fmaxf(v, xor4_f(v));
+                    v = fmaxf(v, xor1_f(v));
+                    v = fmaxf(v, xor2_f(v));
+                } else {
+                    moved = a1 > a0;                              // stay unless the move is strictly greater
+                    v = moved ? a1 : a0;
+                }
+                const unsigned long long eq0 = __ballot(flip && a0 == v);                    // bit 8*to + from, from < 8
+                const unsigned long long eq1 = __ballot(flip && valid1 && a1 == v);          // bit 8*to + (from - 8)
+                const unsigned mv = (unsigned)(__ballot(flop && moved) >> 40);               // bit j: flop state 5 + j moved
+                pv0 = __shfl(v, src0);
+                pv1 = __shfl(v, src1);
+                int arg = 0;
+                if (lane < nbase) {
+                    const unsigned lo = (unsigned)(eq0 >> (8 * lane)) & 0xffu, hi = (unsigned)(eq1 >> (8 * lane)) & 0x3u;
+                    arg = lo ? __builtin_ctz(lo) : 8 + __builtin_ctz(hi | 0x4u);
+                } else if (lane < ns) {
+                    arg = ((mv >> (lane - nbase)) & 1u) ? lane - nbase : lane;
+                }
+                if (lane < ns) tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg;
+            }
+        }
+        if (c + 1 < nchunk) {             // a longer read: this chunk's bytes leave LDS
+            __syncthreads();
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)(tb + (size_t)c0 * kMaxState))[i] = ((const uint32_t *)tb_lds)[i];
+            __syncthreads();
+        }
+    }
+    // final score and state: first maximum (state s < 8 is pv0 of lane s, states 8 and 9 are pv1 of lanes 0 and 1)
+    float score = __shfl(pv0, 0);
+    int last = 0;
+    for (int s2 = 1; s2 < ns; s2++) {
+        const float v = s2 < 8 ? __shfl(pv0, s2) : __shfl(pv1, s2 - 8);
+        if (v > score) { score = v; last = s2; }
+    }
+    if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
+    __syncthreads();
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int c0 = c * kTbChunk, n = min(kTbChunk, Tb - c0), c1 = c0 + n;
+        if (c != nchunk - 1) {
+            for (int i = lane; i < n * (kMaxState / 4); i += 64)
+                ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tb + (size_t)c0 * kMaxState))[i];
+            __syncthreads();
+        }
+        if (lane == 0) {
+            int p = last;
+            path_lds[n] = p;
+            for (int i = n; i > 0; i--) { p = tb_lds[(i - 1) * kMaxState + p]; path_lds[i - 1] = p; }
+        }
+        __syncthreads();
+        if (c1 == Tb && lane == 0) pth[Tb] = path_lds[n];
+        for (int i = lane; i < n; i += 64) {
+            const int from = path_lds[i], to = path_lds[i + 1];
+            pth[c0 + i] = from;
+            const int idx = (to < nbase) ? (to * ns + from) : (off + from);
+            qp[c0 + i + 1] = T[(size_t)(c0 + i) * Ps + idx];
+        }
+        last = path_lds[0];
+        __syncthreads();
+    }
+}
+
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
                     int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40)
         hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+    else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER"))
+        hipLaunchKernelGGL(k_viterbi10, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, Ps, tbs);
     else
         hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps, tbs);
 }

@@ -266,3 +266,39 @@ def test_other_baseline_configs_properties(B, engine, label, kind, H, nread, T, 
             assert len(b.basecall(r)) == len(b.quality(r)) > 0
     finally:
         b.close(); dm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,hidden", [(M.NET_GRUMOD5, 64), (M.NET_LSTM5, 64)])
+def test_decode_kernels_agree_with_their_chain_order_forms(B, engine, kind, hidden):
+    """The butterfly decode kernels (k_transpost8/10, k_viterbi8/10) against the chain-order / generic forms selected by
+    FFHIP_EXACT_ORDER=1: the same Viterbi paths, qualities and calls; posteriors equal up to the rounding of the summation order."""
+    mdl = M.synthetic_model(kind, hidden, seed=21)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(77)
+    lens = [2500, 19, 777, 0, 1234, 2499, 300, 1500, 64, 2000]
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    out = {}
+    for mode in ("fast", "exact"):
+        if mode == "exact":
+            os.environ["FFHIP_EXACT_ORDER"] = "1"
+        try:
+            b = B.Batch(dm, len(sigs), max(lens))
+            b.set_signals_ragged(sigs)
+            b.run()
+            b.finish()
+            out[mode] = [(b.basecall(r), b.quality(r), b.path(r), b.posterior(r), b.score(r)) if lens[r] else None for r in range(len(sigs))]
+            b.close()
+        finally:
+            os.environ.pop("FFHIP_EXACT_ORDER", None)
+    for r, n in enumerate(lens):
+        if not n:
+            continue
+        f, e = out["fast"][r], out["exact"][r]
+        assert f[0] == e[0] and f[1] == e[1], r
+        assert np.array_equal(f[2][0], e[2][0]), r                                   # Viterbi path
+        assert np.abs(f[2][1][1:] - e[2][1][1:]).max() <= 2e-5                       # its per-block scores are posteriors
+        # log posteriors: improbable transitions sit at -100 and below, where one ulp is 1e-5
+        assert np.all(np.abs(f[3] - e[3]) <= 2e-5 + 2e-6 * np.abs(e[3])), (r, float(np.abs(f[3] - e[3]).max()))
+        assert abs(f[4] - e[4]) <= 1e-3 * max(1.0, abs(e[4]))
+    dm.close()
