@@ -748,6 +748,83 @@ k_crf_chain8(const double *__restrict__ E, int TbS, int Pd, int R, double *__res
     if (lane == 0) logz_out[blockIdx.x] = logZ;
 }
 
+// nstate = 10 (ACGTZ): two entries per lane as in k_viterbi10 / the forward half of k_transpost10 -- flip destination g in
+// lanes 8g..8g+7 (lane j: sources j and j+8), flop state 5+j in lane 40+j (stay, move); alpha of the two source states per lane.
+__global__ void __launch_bounds__(64)
+k_crf_chain10(const double *__restrict__ E, int TbS, int Pd, int R, double *__restrict__ logz_out, const int *__restrict__ tbs) {
+    constexpr int P = 60, ns = 10, nbase = 5, off = 50, kMaxPd = 64;
+    __shared__ double ebuf[2][kCrfChunk * kMaxPd];
+    const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
+    const bool flip = g < nbase, flop = (g == nbase && j < nbase);
+    const bool valid0 = flip || flop, valid1 = (flip && j < 2) || flop;
+    const int e0 = flip ? g * ns + j : (flop ? off + nbase + j : 0);
+    const int e1 = flip ? (j < 2 ? g * ns + 8 + j : e0) : (flop ? off + j : 0);
+    const int src0 = flip ? ff10_src_lane(j) : (flop ? ff10_src_lane(nbase + j) : 0);
+    const int src1 = flip ? ff10_src_lane(j < 2 ? j + 8 : j) : (flop ? ff10_src_lane(j) : 0);
+    const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    if (Tb <= 0) return;                                 // an empty slot
+    const int per_chunk = kCrfChunk * Pd;
+    constexpr int kStage = (kCrfChunk * kMaxPd + 63) / 64;      // 32 doubles per lane
+    double stage[kStage];
+    const int nchunk = (Tb + kCrfChunk - 1) / kCrfChunk;
+    auto fetch = [&](int c) {
+        const size_t base = (size_t)c * per_chunk, lim = (size_t)Tb * Pd;
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int i = k * 64 + lane;
+            stage[k] = (i < per_chunk && base + i < lim) ? Er[base + i] : 0.0;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < kStage; k++) {
+            const int i = k * 64 + lane;
+            if (i < per_chunk) ebuf[buf][i] = stage[k];
+        }
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    double a0 = 1.0, a1 = 1.0, msum = 0.0;
+    long long K = 0;
+    int since = 0;
+    for (int c = 0; c < nchunk; c++) {
+        if (c + 1 < nchunk) fetch(c + 1);
+        const double *eb = ebuf[c & 1];
+        const int t0 = c * kCrfChunk, t1 = min(Tb, t0 + kCrfChunk);
+        double x0 = valid0 ? eb[e0] : 0.0, x1 = valid1 ? eb[e1] : 0.0, m_next = eb[P];
+        for (int t = t0; t < t1; t++) {
+            const double f0 = x0, f1 = x1, mt = m_next;
+            if (t + 1 < t1) { const double *row = eb + (t + 1 - t0) * Pd; x0 = valid0 ? row[e0] : 0.0; x1 = valid1 ? row[e1] : 0.0; m_next = row[P]; }
+            double val = f0 * a0 + f1 * a1;                       // flop states: stay + move
+            if (flip) { val = val + xor4_d(val); val = val + xor1_d(val); val = val + xor2_d(val); }
+            a0 = __shfl(val, src0);
+            a1 = __shfl(val, src1);
+            msum = msum + mt;
+            if (++since == R || t + 1 == Tb) {
+                since = 0;
+                double mx = (lane < 2) ? fmax(a0, a1) : a0;       // lanes 0..7: alpha of states 0..7 (a0) and 8, 9 (a1 of lanes 0, 1)
+                mx = fmax(mx, xor4_d(mx));
+                mx = fmax(mx, xor1_d(mx));
+                mx = fmax(mx, xor2_d(mx));
+                const int ex = __builtin_amdgcn_readfirstlane((mx > 0.0) ? ilogb(mx) : 0);
+                a0 = ldexp(a0, -ex);
+                a1 = ldexp(a1, -ex);
+                K += ex;
+            }
+        }
+        if (c + 1 < nchunk) commit((c + 1) & 1);
+        __syncthreads();
+    }
+    double total = (lane < 2) ? a0 + a1 : a0;
+    total = total + xor4_d(total);
+    total = total + xor1_d(total);
+    total = total + xor2_d(total);
+    const double logZ = log(total) + 0.693147180559945309417232121458 * (double)K + msum;
+    if (lane == 0) logz_out[blockIdx.x] = logZ;
+}
+
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
                             double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
@@ -756,6 +833,8 @@ void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, i
     const int Rr = R < 1 ? 1 : R;
     if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
         hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
+    } else if (nbase == 5 && Pd <= 64 && !getenv("FFHIP_CRF_GENERIC")) {
+        hipLaunchKernelGGL(k_crf_chain10, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
     } else
     switch (2 * nbase) {
 #define CHAIN_CASE(NS) case NS: hipLaunchKernelGGL(k_crf_chain<NS>, dim3(nread), dim3(64), 0, s, E, Tb, P, Pd, Rr, logz, tbs); break;
