@@ -994,16 +994,20 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
             }
         }
     } else if (wave == 1) {
-        // backwards: pb = bwd[blk][lane & 7]; Bw[blk] is the vector that multiplies block blk-1's transitions
-        int to;
-        if (lane < 32) to = lane >> 3;
-        else { const int idx = lane - 32; to = (idx < 4) ? idx + 4 : idx; }
-        float pb = 0.0f;
+        // backwards, lanes grouped by SOURCE state: lane (g = lane >> 3, j = lane & 7) holds the exit of state g to flip state j (j < 4)
+        // or into its flop state (j = 4: flip g -> flop g+4, flop g stays) -- the new bwd[g] is an in-group DPP reduction and each
+        // lane then needs one value of the new vector (one ds_bpermute per block).
+        const int g = lane >> 3, j = lane & 7;
+        const bool act = j <= 4;
+        const int fdst = g < 4 ? g + 4 : g;                              // flop destination of source g
+        const int e = act ? (j < 4 ? j * ns + g : 32 + g) : 0;
+        const int srcl = 8 * (j < 4 ? j : fdst);                         // where the new bwd of this exit's destination lives
+        float pb_to = 0.0f, nb = 0.0f;                                   // bwd[destination of my exit], bwd[g] (replicated over the group)
         float ring[kDepth];
-        auto fetch = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + lane_c]; };       // blk counts down
+        auto fetch = [&](int blk) { return T[(size_t)max(blk, 0) * Ps + e]; };           // blk counts down
 #pragma unroll
         for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - k);
-        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                          // j = Tb - blk: 0, 1, ...
+        for (int j0 = 0; j0 < Tb; j0 += kDepth) {                                          // jj = Tb - blk: 0, 1, ...
             float cur[kDepth];
 #pragma unroll
             for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
@@ -1011,24 +1015,20 @@ k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *_
             for (int k = 0; k < kDepth; k++) ring[k] = fetch(Tb - 1 - (j0 + kDepth + k));
 #pragma unroll
             for (int k = 0; k < kDepth; k++) {
-                const int j = j0 + k, blk = Tb - j;
-                if (j >= Tb) break;
-                if (lane < ns) stage[1][j & 63][lane] = pb;                // bwd[blk]
-                if ((j & 63) == 63 || j == Tb - 1) flush(1, Bw + (size_t)(Tb - (j & ~63)) * kMaxState, -(long long)kMaxState, (j & 63) + 1);
-                const float pb_to = __shfl(pb, to & 7);
-                const float t2 = valid ? cur[k] + pb_to : NEG;
-                // sources: entries {st, 8+st, 16+st, 24+st} (flip destinations) and 32+st (flop destination)
-                const float f5 = __shfl(t2, 32 + st);
-                float m = fmaxf(t2, xor8_f(t2));
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, f5);
-                float e = flip ? expf(t2 - m) : 0.0f;
-                e += xor8_f(e);
-                e += __shfl_xor(e, 16);
-                e += expf(f5 - m);
-                const float cur_v = m + logf(e);
-                pb = __shfl(cur_v, st);
-                (void)blk;
+                const int jj = j0 + k;
+                if (jj >= Tb) break;
+                if (j == 0) stage[1][jj & 63][g] = nb;                     // bwd[blk], blk = Tb - jj
+                if ((jj & 63) == 63 || jj == Tb - 1) flush(1, Bw + (size_t)(Tb - (jj & ~63)) * kMaxState, -(long long)kMaxState, (jj & 63) + 1);
+                const float t2 = act ? cur[k] + pb_to : NEG;
+                float m = fmaxf(t2, xor4_f(t2));
+                m = fmaxf(m, xor1_f(m));
+                m = fmaxf(m, xor2_f(m));
+                float x = act ? expf(t2 - m) : 0.0f;
+                x += xor4_f(x);
+                x += xor1_f(x);
+                x += xor2_f(x);
+                nb = m + logf(x);
+                pb_to = __shfl(nb, srcl);
             }
         }
     }
