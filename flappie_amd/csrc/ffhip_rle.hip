@@ -46,6 +46,7 @@ k_rle_activate(float *__restrict__ param, size_t n /*nread*Tb*Ps*/, int nbase, i
 __global__ void __launch_bounds__(64)
 k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, double *__restrict__ logz, const int *__restrict__ tbs) {
     __shared__ double st[2][kMaxState];
+    __shared__ double cand[2 * 8 * 8], cmax[8];          // nbase <= 8
     const int lane = threadIdx.x, ns = 2 * nbase;
     const float *C = param + (size_t)blockIdx.x * TbS * Ps + ns;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
@@ -77,20 +78,39 @@ k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, dou
             __builtin_amdgcn_wave_barrier();
             const float *S = srow;
             const double *prev = st[cur];
+            // layers.c:1271-1290.  A move state's value is the log of a sum of 2 (nbase - 1) exponentials, which the reference folds
+            // with pairwise fp64 logsumexp -- ten dependent exp / log1p per block.  Here: all candidates side by side (lanes ns..),
+            // their exact maximum, ONE exp per candidate lane, the sum in the reference's order, one log: the same number up to
+            // fp64 rounding of the association (1e-16 relative; the result is rounded to fp32 after / nblock).  The stay states
+            // keep the reference's FLOAT logsumexpf.
+            const int ncand = 2 * nbase * nbase;
+            for (int pi = lane - ns; pi >= 0 && pi < ncand; pi += 64 - ns) {
+                const int b1 = pi / ns, r = pi % ns, b2 = r >> 1, sf = r & 1;           // candidate order within b1: b2 ascending, move then stay
+                cand[pi] = (b1 != b2) ? prev[b2 + sf * nbase] + (double)S[rle_idx(b2, sf, b1, nbase)] : -HUGE_VAL;
+            }
             double v = 0.0;
-            if (lane < nbase) {
-                const int b1 = lane;
-                v = -HUGE_VAL;
-                for (int b2 = 0; b2 < nbase; b2++) {
-                    if (b1 == b2) continue;
-                    v = lse64(v, prev[b2] + (double)S[rle_idx(b2, 0, b1, nbase)]);
-                    v = lse64(v, prev[b2 + nbase] + (double)S[rle_idx(b2, 1, b1, nbase)]);
-                }
-            } else if (lane < ns) {
+            if (lane >= nbase && lane < ns) {
                 const int b = lane - nbase;
                 const float x = (float)(prev[b] + (double)S[rle_idx(b, 0, b, nbase)]);
                 const float y = (float)(prev[b + nbase] + (double)S[rle_idx(b, 1, b, nbase)]);
                 v = (double)logsumexpf_ref(x, y);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            double m = -HUGE_VAL;
+            if (lane < nbase) {
+                for (int r = 0; r < ns; r++) m = fmax(m, cand[lane * ns + r]);
+                cmax[lane] = m;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (int pi = lane - ns; pi >= 0 && pi < ncand; pi += 64 - ns) cand[pi] = exp(cand[pi] - cmax[pi / ns]);      // exp(-inf) = 0 for the b2 = b1 slots
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nbase) {
+                double e = 0.0;
+                for (int r = 0; r < ns; r++) e += cand[lane * ns + r];
+                v = m + log(e);
             }
             if (lane < ns) st[cur ^ 1][lane] = v;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -133,6 +153,7 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
     // As in the flip-flop posterior: transition rows prefetched kDepth blocks ahead and handed over through LDS, forward /
     // backward vectors staged in LDS and written out in rows of 64 blocks -- no global load or store on the per-block chains.
     __shared__ float srow[2][64];
+    __shared__ float inner[64];            // forward recursion: lse(stay, move) of every (destination, source) pair of a block
     __shared__ float stage[2][64][kMaxState];
     constexpr int kDepth = 8;
     const int nrow = 2 * nbase * nbase, lane_c = lane < nrow ? lane : nrow - 1;
@@ -168,21 +189,36 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
                 RLE_WAVE_SYNC();
                 const float *S = srow[0];
                 const float *prev = fs[cur];
-                float v = 0.0f;
-                if (lane < nbase) {
-                    const int b1 = lane;
-                    v = -HUGE_VALF;
-                    for (int b2 = 0; b2 < nbase; b2++) {
-                        if (b1 == b2) continue;
+                // decode.c:1064-1083.  The reference chains, per move state b1, lse(v, lse(stay_b2, move_b2)) over b2 != b1 in ascending b2.
+                // The INNER logsumexp of every (b1, b2) pair is independent of the chain: lanes 16.. compute them side by side, the
+                // state lanes then run the outer chain in the reference's order on the same values (bit-identical; the first outer
+                // step, lse(-inf, x) = x exactly, is a copy) -- three logsumexp latencies per block instead of six.
+                for (int pi = lane - 16; pi >= 0 && pi < nbase * nbase; pi += 48) {       // (one pass for nbase <= 6)
+                    const int b1 = pi / nbase, b2 = pi % nbase;
+                    if (b1 != b2) {
                         const float stay_score = prev[b2 + nbase] + S[rle_idx(b2, 1, b1, nbase)];
                         const float move_score = prev[b2] + S[rle_idx(b2, 0, b1, nbase)];
-                        v = logsumexpf_ref(v, logsumexpf_ref(stay_score, move_score));
+                        inner[b1 * nbase + b2] = logsumexpf_ref(stay_score, move_score);
                     }
-                } else if (lane < ns) {
+                }
+                float v = 0.0f;
+                if (lane >= nbase && lane < ns) {
                     const int b = lane - nbase;
                     const float stay_score = prev[b + nbase] + S[rle_idx(b, 1, b, nbase)];
                     const float move_score = prev[b] + S[rle_idx(b, 0, b, nbase)];
                     v = logsumexpf_ref(stay_score, move_score);
+                }
+                RLE_WAVE_SYNC();
+                if (lane < nbase) {
+                    const int b1 = lane;
+                    bool first = true;
+                    for (int b2 = 0; b2 < nbase; b2++) {
+                        if (b1 == b2) continue;
+                        const float in = inner[b1 * nbase + b2];
+                        v = first ? in : logsumexpf_ref(v, in);
+                        first = false;
+                    }
+                    if (first) v = -HUGE_VALF;
                 }
                 if (lane < ns) { fs[cur ^ 1][lane] = v; stage[0][blk & 63][lane] = v; }      // fwd[blk + 1]
                 if ((blk & 63) == 63 || blk == Tb - 1) flush(0, F + (size_t)((blk & ~63) + 1) * kMaxState, kMaxState, (blk & 63) + 1);
@@ -215,22 +251,19 @@ k_rle_transpost(const float *__restrict__ param, float *__restrict__ post, float
                 else RLE_WAVE_SYNC();
                 const float *S = srow[1];
                 float v = 0.0f;
-                if (lane < nbase) {
-                    const int b1 = lane;
-                    v = -HUGE_VALF;
+                if (lane < ns) {
+                    // source state (b1, stay = lane >= nbase): chain over its moves to b2 != b1 in ascending b2, then its stay exit
+                    // (decode.c:1085-1100; the first step, lse(-inf, x) = x exactly, is a copy)
+                    const int b1 = lane < nbase ? lane : lane - nbase, st1 = lane < nbase ? 0 : 1;
+                    bool first = true;
                     for (int b2 = 0; b2 < nbase; b2++) {
                         if (b1 == b2) continue;
-                        v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 0, b2, nbase)]);
+                        const float c = prev[b2] + S[rle_idx(b1, st1, b2, nbase)];
+                        v = first ? c : logsumexpf_ref(v, c);
+                        first = false;
                     }
-                    v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 0, b1, nbase)]);
-                } else if (lane < ns) {
-                    const int b1 = lane - nbase;
-                    v = -HUGE_VALF;
-                    for (int b2 = 0; b2 < nbase; b2++) {
-                        if (b1 == b2) continue;
-                        v = logsumexpf_ref(v, prev[b2] + S[rle_idx(b1, 1, b2, nbase)]);
-                    }
-                    v = logsumexpf_ref(v, prev[b1 + nbase] + S[rle_idx(b1, 1, b1, nbase)]);
+                    const float cs = prev[b1 + nbase] + S[rle_idx(b1, st1, b1, nbase)];
+                    v = first ? cs : logsumexpf_ref(v, cs);
                 }
                 if (lane < ns) bs[cur ^ 1][lane] = v;
                 RLE_WAVE_SYNC();
