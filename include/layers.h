@@ -19,76 +19,76 @@
 extern "C" {
 #endif
 
-/* layers.c:24-124 */
-void swish_activation_inplace(flappie_matrix C);
-void tanh_activation_inplace(flappie_matrix C);
-void exp_activation_inplace(flappie_matrix C);
-void log_activation_inplace(flappie_matrix C);
-void elu_activation_inplace(flappie_matrix C);
-void robustlog_activation_inplace(flappie_matrix C, float min_prob);
+/* A shorthand for this header only: every operand below is a read-only matrix handle. */
+#define FM_IN const_flappie_matrix
 
-/* layers.c:127-187: pure data movement, done on the host */
-flappie_matrix embedding(int const *index, size_t n, const_flappie_matrix E, flappie_matrix C);
-flappie_matrix window(const_flappie_matrix input, size_t w, size_t stride);
+/* ---- element-wise, in place, pad lanes included (layers.c:24-124) ---- */
+void swish_activation_inplace(flappie_matrix acts);
+void tanh_activation_inplace(flappie_matrix acts);
+void exp_activation_inplace(flappie_matrix acts);
+void log_activation_inplace(flappie_matrix acts);
+void elu_activation_inplace(flappie_matrix acts);
+void robustlog_activation_inplace(flappie_matrix probs, float min_prob);
 
-/* layers.c:189-276 */
-flappie_matrix convolution(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, size_t stride,
-                           flappie_matrix C);
-/* layers.c:279-310 */
-flappie_matrix feedforward_linear(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, flappie_matrix C);
-flappie_matrix feedforward_tanh(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, flappie_matrix C);
-flappie_matrix feedforward_exp(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, flappie_matrix C);
-/* layers.c:313-353 */
-flappie_matrix residual(const_flappie_matrix X, const_flappie_matrix fX, flappie_matrix C);
-void residual_inplace(const_flappie_matrix X, flappie_matrix fX);
-/* layers.c:356-395 */
-flappie_matrix softmax(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, flappie_matrix C);
-flappie_matrix softmax_with_temperature(flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float tempW,
-                                        float tempb, flappie_matrix C);
-/* layers.c:398-410 */
-flappie_matrix feedforward2_tanh(const_flappie_matrix Xf, const_flappie_matrix Xb, const_flappie_matrix Wf,
-                                 const_flappie_matrix Wb, const_flappie_matrix b, flappie_matrix C);
+/* ---- pure data movement, done on the host (layers.c:127-187) ---- */
+flappie_matrix embedding(int const *index, size_t nindex, FM_IN table, flappie_matrix out);
+flappie_matrix window(FM_IN signal, size_t winlen, size_t stride);
 
-/* layers.c:412-568 and 718-874: the sloika GRU; X is the projected input [3H x T], sW [H x 2H], sW2 [H x H] */
-flappie_matrix gru_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
-flappie_matrix gru_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
-void gru_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2,
-              flappie_matrix xF, flappie_matrix ostate);
-flappie_matrix gru_relu_forward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
-flappie_matrix gru_relu_backward(const_flappie_matrix X, const_flappie_matrix sW, const_flappie_matrix sW2, flappie_matrix res);
-void gru_relu_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, const_flappie_matrix sW2,
-                   flappie_matrix xF, flappie_matrix ostate);
+/* ---- strided convolution with the reference's edge behaviour (layers.c:189-276); out is [nfilter x ceil(T / stride)] ---- */
+flappie_matrix convolution(FM_IN signal, FM_IN filters, FM_IN bias, size_t stride, flappie_matrix out);
 
-/* layers.c:571-715: X is the projected input [3H x T], sW [H x 3H] */
-flappie_matrix grumod_forward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix res);
-flappie_matrix grumod_backward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix res);
-void grumod_step(const_flappie_matrix x, const_flappie_matrix istate, const_flappie_matrix sW, flappie_matrix xF,
-                 flappie_matrix ostate);
+/* ---- out = weights^T input + bias, then nothing / tanh / exp (layers.c:279-310) ---- */
+flappie_matrix feedforward_linear(FM_IN input, FM_IN weights, FM_IN bias, flappie_matrix out);
+flappie_matrix feedforward_tanh(FM_IN input, FM_IN weights, FM_IN bias, flappie_matrix out);
+flappie_matrix feedforward_exp(FM_IN input, FM_IN weights, FM_IN bias, flappie_matrix out);
+/* two inputs, two weight matrices, one bias (layers.c:398-410) */
+flappie_matrix feedforward2_tanh(FM_IN input_f, FM_IN input_b, FM_IN weights_f, FM_IN weights_b, FM_IN bias, flappie_matrix out);
 
-/* layers.c:877-1026: X is the projected input [4H x T], sW [H x 4H] */
-flappie_matrix lstm_forward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix output);
-flappie_matrix lstm_backward(const_flappie_matrix X, const_flappie_matrix sW, flappie_matrix output);
-void lstm_step(const_flappie_matrix x, const_flappie_matrix out_prev, const_flappie_matrix sW, flappie_matrix xF,
-               flappie_matrix state, flappie_matrix output);
+/* ---- out = skip + branch (layers.c:313-353) ---- */
+flappie_matrix residual(FM_IN skip, FM_IN branch, flappie_matrix out);
+void residual_inplace(FM_IN skip, flappie_matrix branch);
 
-/* layers.c:1029-1106 */
-double crf_manystay_partition_function(const_flappie_matrix C);
-flappie_matrix globalnorm_manystay(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
-                                   flappie_matrix C);
+/* ---- affine map, exp, row normalisation (layers.c:356-395) ---- */
+flappie_matrix softmax(FM_IN input, FM_IN weights, FM_IN bias, flappie_matrix out);
+flappie_matrix softmax_with_temperature(flappie_matrix input, FM_IN weights, FM_IN bias, float temp_weights, float temp_bias,
+                                        flappie_matrix out);
+
+/* ---- recurrent layers: `projected` is the already-projected input [G*H x T], `recurrent` the state weights [H x G*H], the result is
+ *      [H x T].  `scratch` of the step functions is the reference's gate buffer; it is not touched here. ---- */
+/* sloika GRU (layers.c:412-568) and its ReLU variant (layers.c:718-874): G = 3, recurrent [H x 2H], recurrent2 [H x H] */
+flappie_matrix gru_forward(FM_IN projected, FM_IN recurrent, FM_IN recurrent2, flappie_matrix out);
+flappie_matrix gru_backward(FM_IN projected, FM_IN recurrent, FM_IN recurrent2, flappie_matrix out);
+void gru_step(FM_IN projected_t, FM_IN state_in, FM_IN recurrent, FM_IN recurrent2, flappie_matrix scratch, flappie_matrix state_out);
+flappie_matrix gru_relu_forward(FM_IN projected, FM_IN recurrent, FM_IN recurrent2, flappie_matrix out);
+flappie_matrix gru_relu_backward(FM_IN projected, FM_IN recurrent, FM_IN recurrent2, flappie_matrix out);
+void gru_relu_step(FM_IN projected_t, FM_IN state_in, FM_IN recurrent, FM_IN recurrent2, flappie_matrix scratch,
+                   flappie_matrix state_out);
+/* GRUmod of the 5mC model (layers.c:571-715): G = 3 */
+flappie_matrix grumod_forward(FM_IN projected, FM_IN recurrent, flappie_matrix out);
+flappie_matrix grumod_backward(FM_IN projected, FM_IN recurrent, flappie_matrix out);
+void grumod_step(FM_IN projected_t, FM_IN state_in, FM_IN recurrent, flappie_matrix scratch, flappie_matrix state_out);
+/* LSTM (layers.c:877-1026): G = 4; `cell` is the cell state, updated in place */
+flappie_matrix lstm_forward(FM_IN projected, FM_IN recurrent, flappie_matrix out);
+flappie_matrix lstm_backward(FM_IN projected, FM_IN recurrent, flappie_matrix out);
+void lstm_step(FM_IN projected_t, FM_IN hidden_in, FM_IN recurrent, flappie_matrix scratch, flappie_matrix cell, flappie_matrix hidden_out);
+
+/* ---- flip-flop CRF head: tanh, scale by 5 / temperature, global normalisation (layers.c:1029-1106) ---- */
 size_t nbase_from_flipflop_nparam(size_t nparam);
-flappie_matrix globalnorm_flipflop(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
-                                   flappie_matrix C);
-/* layers.c:1115-1228: the first-generation run-length head (rows shape, scale, move, stay; scale = 0.1 + softplus) */
+double crf_manystay_partition_function(FM_IN scores);
+flappie_matrix globalnorm_manystay(FM_IN input, FM_IN weights, FM_IN bias, float temperature, flappie_matrix out);
+flappie_matrix globalnorm_flipflop(FM_IN input, FM_IN weights, FM_IN bias, float temperature, flappie_matrix out);
+
+/* ---- run-length heads.  First generation (layers.c:1115-1228): rows shape, scale, move, stay; scale = 0.1 + softplus ---- */
 size_t nbase_from_runlength_nparam(size_t nparam);
-double runlength_partition_function(const_flappie_matrix C);
-flappie_matrix globalnorm_runlength(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
-                                    flappie_matrix C);
-/* layers.c:1230-1358: the run-length head of runnie's model (shape = 1 + softplus, scale = 1e-8 + softplus,
- * transitions 5 tanh / temperature, globally normalised) and its fp64 partition function */
+double runlength_partition_function(FM_IN params);
+flappie_matrix globalnorm_runlength(FM_IN input, FM_IN weights, FM_IN bias, float temperature, flappie_matrix out);
+/* runnie's model (layers.c:1230-1358): shape = 1 + softplus, scale = 1e-8 + softplus, transitions 5 tanh / temperature,
+ * globally normalised with the fp64 partition function below */
 size_t nbase_from_crf_runlength_nparam(size_t nparam);
-double runlengthV2_partition_function(const_flappie_matrix C);
-flappie_matrix globalnorm_runlengthV2(const_flappie_matrix X, const_flappie_matrix W, const_flappie_matrix b, float temperature,
-                                      flappie_matrix C);
+double runlengthV2_partition_function(FM_IN params);
+flappie_matrix globalnorm_runlengthV2(FM_IN input, FM_IN weights, FM_IN bias, float temperature, flappie_matrix out);
+
+#undef FM_IN
 
 #ifdef __cplusplus
 }
