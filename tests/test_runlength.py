@@ -190,7 +190,7 @@ def test_runlength_host_api(B):
     pm = ffo.HostMat.from_dense(param)
     z = L.runlengthV2_partition_function(mk(param))
     zw = lib.fo_runlengthV2_partition_function(pm.ptr)
-    assert abs(z - zw) <= 1e-6 * max(1.0, abs(zw))
+    assert abs(z - zw) <= 1e-9 * max(1.0, abs(zw))          # fp64 re-association only (the stay updates are the same float logsumexpf)
     post = L.transpost_crf_runlength(mk(param))
     np.testing.assert_allclose(dense(post), ffo.take(lib.fo_transpost_crf_runlength(pm.ptr)), rtol=0, atol=2e-4)
     path, ref_path = np.zeros(T, dtype=np.int32), np.zeros(T, dtype=np.int32)
