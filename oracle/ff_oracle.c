@@ -121,6 +121,31 @@ char fo_phredf(float p) {
     return (ph < 126) ? ph : 126;
 }
 
+/* Array forms of the scalar functions above, for the bit-for-bit sweeps against the reference's header-inline code
+ * (oracle/ref_inline.c, tests/test_ref_pins.py).  kind: 0 exp, 1 log, 2 logistic, 3 tanh, 4 elu. */
+int fo_map_array(int kind, const float *in, float *out, size_t n) {
+    float (*fn)(float) = NULL;
+    switch (kind) {
+    case 0: fn = fo_expf_cephes; break;
+    case 1: fn = fo_logf_cephes; break;
+    case 2: fn = fo_logisticf; break;
+    case 3: fn = fo_tanhf; break;
+    case 4: fn = fo_eluf; break;
+    default: return -1;
+    }
+    for (size_t i = 0; i < n; i++) out[i] = fn(in[i]);
+    return 0;
+}
+void fo_logsumexpf_array(const float *x, const float *y, float *out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = fo_logsumexpf(x[i], y[i]);
+}
+void fo_logsumexp_array(const double *x, const double *y, double *out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = fo_logsumexp(x[i], y[i]);
+}
+void fo_phredf_array(const float *p, char *out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = fo_phredf(p[i]);
+}
+
 /* layers.c:24-33  applied to every stored element, pad lanes included */
 void fo_swish_inplace(fo_mat *C) {
     if (!C) return;

@@ -73,6 +73,12 @@ float fo_logsumexpf(float x, float y);
 double fo_logsumexp(double x, double y);
 char fo_phredf(float p);
 
+/* array forms for the sweeps against the reference's inline code; kind: 0 exp, 1 log, 2 logistic, 3 tanh, 4 elu */
+int fo_map_array(int kind, const float *in, float *out, size_t n);
+void fo_logsumexpf_array(const float *x, const float *y, float *out, size_t n);
+void fo_logsumexp_array(const double *x, const double *y, double *out, size_t n);
+void fo_phredf_array(const float *p, char *out, size_t n);
+
 /* layers */
 void fo_swish_inplace(fo_mat *C);
 void fo_tanh_inplace(fo_mat *C);
