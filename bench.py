@@ -26,37 +26,67 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 SPLIT_PRODUCTS = 6                # bf16 MFMA products the split-bf16 layer kernel issues per fp32-exact product (ffhip_rnn_split.hip)
 HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size inferred from the model's size
-NREAD, NSAMPLE = int(os.environ.get('FFHIP_BENCH_NREAD', '256')), 4000
+
+# Workloads.  c2 is the headline (BASELINE.json configs[1], the configuration the metric is quoted on) and the default;
+# the others let the driver or a reader reproduce the figures DESIGN.md quotes for configs[3] / configs[4] and the
+# smaller r941_native file with the same JSON line (own roofline, own CPU leg).  kind: 0 LSTM5, 1 GRUmod5, 2 LSTM5 + run-length head.
+CONFIGS = {
+    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, ident="r941native",
+                 metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
+                 label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
+    "h256": dict(kind=0, hidden=256, nread=256, nsample=4000, steps=200, warmup=5, ident="r941native",
+                 metric="Msamples/s basecalled (r941_native 20200220-size model, 4k-sample chunks)",
+                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace"),
+    "c4":   dict(kind=1, hidden=256, nread=256, nsample=4000, steps=100, warmup=3, ident="r941_5mC",
+                 metric="Msamples/s basecalled (r941_5mC, 4k-sample chunks)",
+                 label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=256 synthetic 4000-sample reads per GPU, "
+                       "posterior decode + trace (BASELINE.json configs[3])"),
+    "c5":   dict(kind=0, hidden=512, nread=256, nsample=100000, steps=5, warmup=1, ident="r103native",
+                 metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",
+                 label="r103_native-shape LSTM5 H=512 (SURVEY.md section 0.3: there is no r10C_pcr model), batch=256 synthetic 100000-sample reads per GPU, "
+                       "posterior decode + trace (BASELINE.json configs[4])"),
+    "rle":  dict(kind=2, hidden=384, nread=256, nsample=4000, steps=100, warmup=3, ident="rle_r941native",
+                 metric="Msamples/s run-length called (rle_r941_native, 4k-sample chunks)",
+                 label="rle_r941_native-shape LSTM5 H=384 + run-length head (runnie), batch=256 synthetic 4000-sample reads per GPU"),
+}
+SURVEY_OPENBLAS_PER_CORE = {(0, 384): 0.010, (0, 256): 0.035, (0, 512): 0.0046, (1, 256): 0.0185}   # Msamples/s/core, SURVEY.md section 6 [probe]
 
 
 def _cpu_worker(job):
     """One host core: the oracle's whole path over its own reads until the time budget is spent."""
-    hidden, seed, nread, budget_s, max_reads = job
+    kind, hidden, ident, nsample, seed, budget_s, max_reads, mode = job
     from flappie_amd import model as M
     from oracle import ffo
-    mdl = M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native")
+    mdl = M.synthetic_model(kind, hidden, seed=1, ident=ident)
     om = ffo.OracleModel(mdl)
-    sig = np.random.default_rng(seed).standard_normal((max_reads, NSAMPLE)).astype(np.float32)
+    ffo.lib().fo_set_dot_mode(mode)
+    sig = np.random.default_rng(seed).standard_normal((max_reads, nsample)).astype(np.float32)
+    call = om.runlength_call if kind == M.NET_LSTM5_RLE else (lambda x: om.basecall(x, want_trans=False))
     t0 = time.time()
     n = 0
     while n < max_reads and (n == 0 or time.time() - t0 < budget_s):
-        om.basecall(sig[n], want_trans=False)
+        call(sig[n])
         n += 1
     return n, time.time() - t0
 
 
-def cpu_baseline(hidden, budget_s=12.0, max_reads=6):
-    """The oracle (a scalar C port of the reference's algorithm, NOT the OpenBLAS reference itself, which cannot
-    be built in this image) timed on the host cores of the GPU box: one single-threaded process per core, each
-    over its own bounded sample of synthetic reads of the benchmark's shape, as the reference's README runs it
-    (one flappie process per core under GNU parallel)."""
+def cpu_baseline(cfg, budget_s=12.0):
+    """The oracle's algorithm (a C port of the reference's, NOT the OpenBLAS reference itself, which cannot be built in this
+    image) timed on the host cores of the GPU box, the way the reference's README runs flappie: one single-threaded process
+    per core under GNU parallel, each over its own bounded sample of synthetic reads of the benchmark's shape.  Dot products
+    run through oracle/cpu_ref.c's vectorised kernels (AVX-512 / AVX2 clones: sgemv for the recurrent steps, a register-tiled
+    sgemm for projections and convolutions) -- the shapes OpenBLAS would run, within ~1.5-2x of the survey's OpenBLAS probe
+    on one core; the reference-order scalar oracle that the parity tests use is ~5x slower and is not what is timed."""
     import multiprocessing as mp
     try:
         ncore = len(os.sched_getaffinity(0))
     except AttributeError:
         ncore = os.cpu_count() or 1
     ncore = max(1, min(ncore, 64))
-    jobs = [(hidden, 777 + k, NREAD, budget_s, max_reads) for k in range(ncore)]
+    nsample = min(cfg["nsample"], 20000)        # long-read configs: a 20 000-sample prefix per read keeps the sample bounded
+    max_reads = max(2, int(400000 // nsample))
+    jobs = [(cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 777 + k, budget_s, max_reads, 2) for k in range(ncore)]
+    one = _cpu_worker((cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 776, 3.0, 2, 2))      # one core alone, nothing competing for memory bandwidth
     t0 = time.time()
     if ncore == 1:
         res = [_cpu_worker(jobs[0])]
@@ -66,39 +96,58 @@ def cpu_baseline(hidden, budget_s=12.0, max_reads=6):
     wall = time.time() - t0
     nread = sum(r[0] for r in res)
     dt = max(r[1] for r in res)
-    return dict(value=round(nread * NSAMPLE / dt / 1e6, 6), unit="Msamples/s", cores=ncore, kind="port",
-                sample="%d synthetic reads of %d samples over %d single-threaded processes (whole path), slowest worker %.1f s, %.1f s wall"
-                       % (nread, NSAMPLE, ncore, dt, wall),
-                per_core=round(nread * NSAMPLE / dt / 1e6 / ncore, 6))
+    return dict(value=round(nread * nsample / dt / 1e6, 6), unit="Msamples/s", cores=ncore, kind="port",
+                sample="%d synthetic reads of %d samples over %d single-threaded processes (whole path, oracle algorithm on the vectorised "
+                       "kernels of oracle/cpu_ref.c), slowest worker %.1f s, %.1f s wall" % (nread, nsample, ncore, dt, wall),
+                per_core=round(nread * nsample / dt / 1e6 / ncore, 6),
+                one_core_alone=round(one[0] * nsample / one[1] / 1e6, 6),
+                reference_openblas_per_core_survey=SURVEY_OPENBLAS_PER_CORE.get((cfg["kind"] % 2, cfg["hidden"])),
+                note="kind=port: the reference's OpenBLAS build cannot be made in this image; reference_openblas_per_core_survey is the "
+                     "survey container's probe of it (SURVEY.md section 6, other host), for scale")
 
 
-def measured_traffic(hidden, rnn_path):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus
-    WRITE_SIZE, separate passes).  Counters cannot be read inside this process, so the value is the
-    profile's, keyed by shape and kernel; null when no profile of this shape and kernel is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh)
+def measured_traffic(name, cfg, rnn_path):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*traffic*.json:
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE, separate passes).  Counters cannot
+    be read inside this process, so the value is the profile's, keyed by shape and kernel; null when no profile of this
+    shape and kernel is committed.  The newest round's file wins."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            with open(path) as fh:
+                t = json.load(fh)
+        except (OSError, ValueError):
+            continue
         for e in (t if isinstance(t, list) else [t]):
-            if e.get("hidden") == hidden and e.get("nread") == NREAD and e.get("nsample") == NSAMPLE and e.get("rnn_path", 2 if e.get("fused") else 1) == rnn_path:
-                return e.get("recurrent_layer_hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    return None
+            if (e.get("hidden") == cfg["hidden"] and e.get("nread") == cfg["nread"] and e.get("nsample") == cfg["nsample"]
+                    and e.get("kind", 0) == cfg["kind"] and e.get("rnn_path", 2 if e.get("fused") else 1) == rnn_path):
+                best = e.get("recurrent_layer_hbm_bytes_per_launch")
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="workload: c2 = the headline (default); h256, c4, c5, rle = the other shapes DESIGN.md quotes")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FFHIP_INFLIGHT", "1")),
                     help="batches in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hidden", type=int, default=HIDDEN)
+    ap.add_argument("--no-h2d-leg", action="store_true")
+    ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
+    ap.add_argument("--nread", type=int, default=int(os.environ.get("FFHIP_BENCH_NREAD", "0")) or None, help="override the config's reads per batch")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.hidden:
+        cfg["hidden"] = args.hidden
+    if args.nread:
+        cfg["nread"] = args.nread
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    warmup = args.warmup if args.warmup is not None else cfg["warmup"]
+    NREAD, NSAMPLE, H = cfg["nread"], cfg["nsample"], cfg["hidden"]
 
     # Only the JSON line may reach stdout: RCCL prints a version banner there at init, so fd 1 is pointed at
     # stderr for the duration of the run and the result is written to the saved descriptor.
@@ -127,7 +176,7 @@ def main():
     from flappie_amd import model as M
 
     eng = B.Engine(local_rank)
-    mdl = M.synthetic_model(M.NET_LSTM5, args.hidden, seed=1, ident="r941native")
+    mdl = M.synthetic_model(cfg["kind"], H, seed=1, ident=cfg["ident"])
     dm = B.DeviceModel(eng, mdl)
     rng = np.random.default_rng(20260928 + rank)
     sig = rng.standard_normal((NREAD, NSAMPLE)).astype(np.float32)
@@ -143,50 +192,70 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    def run_steps(n):
+    def run_steps(n, upload=False):
         pending = []
         for i in range(n):
             b = batches[i % nfl]
             if len(pending) == nfl:
                 pending.pop(0).finish()
+            if upload:
+                b.set_signals(sig)       # host buffer -> HBM inside the step (the PCIe-inclusive leg)
             b.run(1.0, 0)
             pending.append(b)
         for b in pending:
             b.finish()
 
-    run_steps(args.warmup)
+    run_steps(warmup)
     eng.set_profiling(True)              # HIP events on the kernels' own stream; no host synchronisation added
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(steps)
     barrier()
     dt = time.perf_counter() - t0
     prof = [b.profile() for b in batches]
     eng.set_profiling(False)
 
+    # second leg, reported beside `value`, never as it: the same steps with the batch's signal handed over as a HOST buffer
+    # every step (SURVEY.md section 8d counts "from first H2D")
+    dt_h2d, steps_h2d = None, 0
+    if not args.no_h2d_leg:
+        steps_h2d = max(1, min(steps, 50))
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(steps_h2d, upload=True)
+        barrier()
+        dt_h2d = time.perf_counter() - t1
+
     if dist_on:       # MAX over ranks of the timed region (flappie_amd/shard.py::max_over_ranks, inlined so that it also runs at world 1)
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt, dt_h2d or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        dt_h2d = float(tmax[1].item()) if dt_h2d is not None else None
 
     if rank == 0:
         nblock = batches[0].nblock
-        value = world * args.steps * NREAD * NSAMPLE / dt / 1e6
+        value = world * steps * NREAD * NSAMPLE / dt / 1e6
         # dominant kernel: one recurrent layer.  Algorithmic work per read per block:
-        # 2*H*4H FLOP for the recurrence, and the same again for the input projection when the layer
-        # runs fused (projection and recurrence in one persistent launch; `inproj` then has 0 launches).
+        # 2*H*G*H FLOP for the recurrence (G = 4 gates for LSTM, 3 for GRUmod), and the same again for the input
+        # projection when the layer runs fused (projection and recurrence in one persistent launch; `inproj` then has 0 launches).
+        G = 3 if cfg["kind"] == M.NET_GRUMOD5 else 4
         rec = prof[-1]["recurrent"]
         fused = prof[-1]["inproj"]["launches"] == 0
         rnn_path = batches[-1].rnn_path()
-        flop_layer = (2.0 if fused else 1.0) * 2.0 * args.hidden * 4 * args.hidden * NREAD * nblock
+        flop_layer = (2.0 if fused else 1.0) * 2.0 * H * G * H * NREAD * nblock
         launches_per_layer = rec["launches"] / 5.0
         ms_layer = rec["ms"] / 5.0
         achieved = flop_layer / (ms_layer * 1e-3) / 1e12
-        if rnn_path == 3:
+        cell = "GRUmod" if G == 3 else "LSTM"
+        if rnn_path in (3, 4):
             # fp32-exact products out of bf16 MFMAs: each algorithmic (fp32) multiply-add is six bf16 MFMA products
             # (three-way split of both operands, the three smallest cross terms dropped).  `achieved` counts the
             # ALGORITHMIC fp32 FLOPs; the ceiling of this formulation is the dense bf16 peak / 6.
-            kname = "k_lstm_split<%d> (input projection + recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps)" % (args.hidden // 128, nblock)
+            if rnn_path == 3:
+                kname = "k_lstm_split<%d,%d> (%s input projection + recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps)" % (
+                    1 if G == 3 else 0, H // 128, cell, nblock)
+            else:
+                kname = "k_rnn_split (%s recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps; its projection GEMM k_inproj_split is a separate launch)" % (cell, nblock)
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
             peak_note = ("dense bf16 MFMA peak %.0f TFLOP/s / %d products per fp32-exact product; the kernel issues %.1f TFLOP/s of bf16 MFMA work "
                          "= %.3f of the bf16 peak; against the f32-input MFMA peak (%.1f) the algorithmic rate is %.3f"
@@ -194,39 +263,48 @@ def main():
                             PEAK_F32_MFMA_TFLOPS, achieved / PEAK_F32_MFMA_TFLOPS))
             dtype = "f32 (products as 6 bf16 MFMA terms over 3-way split operands, f32 accumulate; gate math f32)"
         else:
-            kname = ("k_lstm_fused (input projection + recurrence of one layer, %d dependent steps)" if fused
-                     else "k_rnn_persist (recurrence of one layer, %d dependent steps)") % nblock
+            kname = ("k_lstm_fused (%s input projection + recurrence of one layer, %d dependent steps)" if fused
+                     else "k_rnn_persist (%s recurrence of one layer, %d dependent steps)") % (cell, nblock)
             peak = PEAK_F32_MFMA_TFLOPS
             peak_note = "f32-input MFMA peak (v_mfma_f32_16x16x4_f32)"
             dtype = "f32"
+        roof = {"bound": "mfma", "kernel": kname,
+                "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.config, cfg, rnn_path),
+                "peak_note": peak_note,
+                "flop_per_launch": flop_layer / launches_per_layer,
+                "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
+                "launches_per_layer": launches_per_layer}
+        if not fused and prof[-1]["inproj"]["ms"] > 0:
+            ip = prof[-1]["inproj"]
+            ip_flop = 2.0 * H * G * H * NREAD * nblock
+            roof["inproj_gemm"] = {"achieved": round(ip_flop / (ip["ms"] / 5.0 * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                   "frac": round(ip_flop / (ip["ms"] / 5.0 * 1e-3) / 1e12 / peak, 4), "avg_ms_per_layer": round(ip["ms"] / 5.0, 4)}
+        bytes_per_block = 12 * mdl.nparam + mdl.nstate + 8
+        dec_ms = prof[-1]["posterior"]["ms"] + prof[-1]["viterbi_assembly"]["ms"]
         out = {
-            "metric": "Msamples/s basecalled (r941_native, 4k-sample chunks)",
-            "value": round(value, 4), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "metric": cfg["metric"],
+            "value": round(value, 4), "unit": "Msamples/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the r941_native architecture)",
-            "config": {"workload": "r941_native-shape LSTM5 H=%d, batch=256 synthetic 4000-sample reads per GPU, "
-                                   "posterior decode + trace (BASELINE.json configs[1])" % args.hidden,
+            "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the %s architecture)" % cfg["ident"],
+            "config": {"workload": cfg["label"].replace("H=%d" % CONFIGS[args.config]["hidden"], "H=%d" % H), "name": args.config,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.hidden, rnn_path),
-                         "peak_note": peak_note,
-                         "flop_per_launch": flop_layer / launches_per_layer,
-                         "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
-                         "launches_per_layer": launches_per_layer},
+            "roofline": roof,
             "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in prof[-1].items()},
             # decode side (posterior + Viterbi + assembly + trace): algorithmic bytes per block (SURVEY.md section 8d:
             # 4P read + nstate traceback + 8 path/qpath, plus 4P read + 4P write for the posterior) against HBM peak.
             # At 256 reads these kernels are latency-bound chains, not bandwidth-bound.
-            "decode_hbm": (lambda ms, nbytes: {"achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                                               "bytes_per_block": 12 * mdl.nparam + mdl.nstate + 8})(
-                prof[-1]["posterior"]["ms"] + prof[-1]["viterbi_assembly"]["ms"],
-                float(NREAD) * nblock * (12 * mdl.nparam + mdl.nstate + 8)),
+            "decode_hbm": {"achieved": round(float(NREAD) * nblock * bytes_per_block / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else None,
+                           "peak": 8000.0, "unit": "GB/s", "bytes_per_block": bytes_per_block, "ms": round(dec_ms, 4)},
         }
+        if dt_h2d is not None:
+            out["h2d_inclusive"] = {"value": round(world * steps_h2d * NREAD * NSAMPLE / dt_h2d / 1e6, 4), "unit": "Msamples/s",
+                                    "ms_per_step": round(dt_h2d / steps_h2d * 1e3, 4), "steps": steps_h2d,
+                                    "note": "the same step with the batch's %.1f MB of signal copied from a host buffer inside it (never `value`)" % (NREAD * NSAMPLE * 4 / 1e6)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.hidden)
+            out["cpu_baseline"] = cpu_baseline(cfg)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     for b in batches:

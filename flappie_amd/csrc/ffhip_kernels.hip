@@ -1557,12 +1557,19 @@ k_viterbi8(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__rest
                     v = fmaxf(v, xor1_f(v));
                     v = fmaxf(v, xor2_f(v));
                 }
+                // NaN scores (never produced by the network, possible through ffhip_viterbi): the reference's scan starts from
+                // the from-state-0 candidate and replaces it only on a strict >, so a NaN there stays the maximum while NaNs
+                // elsewhere are skipped; fmaxf skips them all.  Rare and wave-uniform, so the chain pays one scalar branch.
+                if (__builtin_expect(__ballot(cand != cand) != 0ull, 0)) {
+                    const float c0 = __shfl(cand, lane & ~7);
+                    if (flip && c0 != c0) v = c0;
+                }
                 const unsigned eq = (unsigned)__ballot(flip && cand == v);                  // bit 8*to + from
                 const unsigned mv = (unsigned)(__ballot(!flip && valid && moved) >> 32);    // bit (b2 - 4) [and bit b2] of flop state b2
                 const int src = ff8_src_lane(st);
                 pv = __shfl(v, src);
                 int arg = 0;
-                if (lane < nbase) arg = __builtin_ctz(((eq >> (8 * lane)) & 0xffu) | 0x100u);
+                if (lane < nbase) { const unsigned m = (eq >> (8 * lane)) & 0xffu; arg = m ? __builtin_ctz(m) : 0; }    // empty (NaN maximum): state 0, as the reference's scan
                 else if (lane < ns) arg = ((mv >> (lane - nbase)) & 1u) ? lane - nbase : lane;
                 if (lane < ns) tb_lds[(b0 + k) * kMaxState + lane] = (uint8_t)arg;
             }
@@ -1668,6 +1675,10 @@ k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
                     moved = a1 > a0;                              // stay unless the move is strictly greater
                     v = moved ? a1 : a0;
                 }
+                if (__builtin_expect(__ballot(a0 != a0 || a1 != a1) != 0ull, 0)) {      // NaN scores: see k_viterbi8
+                    const float c0 = __shfl(a0, lane & ~7);
+                    if (flip && c0 != c0) v = c0;
+                }
                 const unsigned long long eq0 = __ballot(flip && a0 == v);                    // bit 8*to + from, from < 8
                 const unsigned long long eq1 = __ballot(flip && valid1 && a1 == v);          // bit 8*to + (from - 8)
                 const unsigned mv = (unsigned)(__ballot(flop && moved) >> 40);               // bit j: flop state 5 + j moved
@@ -1676,7 +1687,7 @@ k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
                 int arg = 0;
                 if (lane < nbase) {
                     const unsigned lo = (unsigned)(eq0 >> (8 * lane)) & 0xffu, hi = (unsigned)(eq1 >> (8 * lane)) & 0x3u;
-                    arg = lo ? __builtin_ctz(lo) : 8 + __builtin_ctz(hi | 0x4u);
+                    arg = lo ? __builtin_ctz(lo) : (hi ? 8 + __builtin_ctz(hi) : 0);      // none (NaN maximum): state 0, as the reference's scan
                 } else if (lane < ns) {
                     arg = ((mv >> (lane - nbase)) & 1u) ? lane - nbase : lane;
                 }

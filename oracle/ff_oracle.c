@@ -284,8 +284,34 @@ fo_mat *fo_features_from_raw(const float *raw, size_t start, size_t end) {
     return m;
 }
 
+/* How dot products are summed.  0 (default, THE oracle): float, term by term in index order.  1: the same terms in a double
+ * accumulator, rounded to float once per dot product -- "what the float32 network would give without summation error", the
+ * yardstick tests use to tell the GPU's rounding from the oracle's own (tests/test_fuzz_tail_gpu.py).  2: vectorised kernels
+ * (cpu_ref.c; 16 interleaved partial sums), the shapes a BLAS would run -- only for bench.py's cpu_baseline leg. */
+static int g_dot_mode = 0;
+void fo_set_dot_mode(int mode) { g_dot_mode = mode; }
+int fo_get_dot_mode(void) { return g_dot_mode; }
+void fo_fast_gemv_t(float *y, const float *W, size_t ldW, size_t nout, size_t len, const float *x);
+void fo_fast_gemm_tn(float *Y, size_t ldY, const float *W, size_t ldW, size_t nout, size_t len,
+                     const float *X, size_t ldX, size_t ncol);
+void fo_fast_lstm_gates(const float *xF, float *state, float *hout, size_t size);
+void fo_fast_grumod_gates(float *xF, const float *x, const float *hprev, float *hout, size_t size);
+
 /* y[f] += sum_{i<len} W[woff + i + f*ldW] * x[i]     (the reference's sgemv(T) shape) */
 static void window_accumulate(float *y, const fo_mat *W, size_t woff, size_t len, const float *x) {
+    if (g_dot_mode == 2) {
+        fo_fast_gemv_t(y, W->f + woff, W->stride, W->nc, len, x);
+        return;
+    }
+    if (g_dot_mode == 1) {
+        for (size_t f = 0; f < W->nc; f++) {
+            const float *w = W->f + f * W->stride + woff;
+            double acc = 0.0;
+            for (size_t i = 0; i < len; i++) acc += (double)w[i] * (double)x[i];
+            y[f] = (float)((double)y[f] + acc);
+        }
+        return;
+    }
     for (size_t f = 0; f < W->nc; f++) {
         const float *w = W->f + f * W->stride + woff;
         float acc = y[f];
@@ -333,6 +359,11 @@ fo_mat *fo_convolution(const fo_mat *X, const fo_mat *W, const fo_mat *b, size_t
     for (long w = 0; w < winlen; w += s) {                    /* body */
         const long ncol = (T - shiftX - w) / nstepX;          /* ifloor, :248 */
         const long col0 = ncolsL + w / s;
+        if (g_dot_mode == 2 && ncol > 0) {                    /* the reference's one sgemm per family, :250 */
+            fo_fast_gemm_tn(C->f + ldC * col0, (size_t)(ldC * nstepC), W->f, W->stride, W->nc, W->nr,
+                            X->f + ldX * (shiftX + w), (size_t)(ldX * nstepX), (size_t)ncol);
+            continue;
+        }
         for (long k = 0; k < ncol; k++) {
             const long xstart = shiftX + w + nstepX * k;
             window_accumulate(C->f + ldC * (col0 + nstepC * k), W, 0, W->nr, X->f + ldX * xstart);
@@ -360,11 +391,12 @@ fo_mat *fo_affine_map(const fo_mat *X, const fo_mat *W, const fo_mat *b) {
     if (!X || !W || !b || W->nr != X->nr) return NULL;
     fo_mat *C = fo_make_mat(W->nc, X->nc);
     if (!C) return NULL;
-    for (size_t c = 0; c < X->nc; c++) {
-        float *y = C->f + c * C->stride;
-        memcpy(y, b->f, C->stride * sizeof(float));
-        window_accumulate(y, W, 0, W->nr, X->f + c * X->stride);
+    for (size_t c = 0; c < X->nc; c++) memcpy(C->f + c * C->stride, b->f, C->stride * sizeof(float));
+    if (g_dot_mode == 2) {
+        fo_fast_gemm_tn(C->f, C->stride, W->f, W->stride, W->nc, W->nr, X->f, X->stride, X->nc);
+        return C;
     }
+    for (size_t c = 0; c < X->nc; c++) window_accumulate(C->f + c * C->stride, W, 0, W->nr, X->f + c * X->stride);
     return C;
 }
 
@@ -375,6 +407,7 @@ static void lstm_step(const float *xaff, const float *hprev, const fo_mat *sW,
     const size_t size = sW->nr;
     memcpy(xF, xaff, 4 * size * sizeof(float));
     window_accumulate(xF, sW, 0, size, hprev);
+    if (g_dot_mode == 2) { fo_fast_lstm_gates(xF, state, hout, size); return; }
     for (size_t i = 0; i < size; i++) {
         const float forget = fo_logisticf(xF[size + i]) * state[i];
         const float update = fo_logisticf(xF[i]) * fo_tanhf(xF[2 * size + i]);
@@ -412,6 +445,7 @@ static void grumod_step(const float *x, const float *hprev, const fo_mat *sW, fl
     memcpy(xF, x, 3 * size * sizeof(float));
     memset(xF + 2 * size, 0, size * sizeof(float));
     window_accumulate(xF, sW, 0, size, hprev);
+    if (g_dot_mode == 2) { fo_fast_grumod_gates(xF, x, hprev, hout, size); return; }
     for (size_t i = 0; i < 2 * size; i++) xF[i] = fo_logisticf(xF[i]);
     const float *z = xF, *r = xF + size;
     float *hbar = xF + 2 * size;

@@ -79,6 +79,11 @@ void fo_logsumexpf_array(const float *x, const float *y, float *out, size_t n);
 void fo_logsumexp_array(const double *x, const double *y, double *out, size_t n);
 void fo_phredf_array(const float *p, char *out, size_t n);
 
+/* summation of dot products: 0 reference order in float (default, the oracle), 1 double accumulator (yardstick),
+ * 2 vectorised kernels of cpu_ref.c (cpu_baseline timing only) */
+void fo_set_dot_mode(int mode);
+int fo_get_dot_mode(void);
+
 /* layers */
 void fo_swish_inplace(fo_mat *C);
 void fo_tanh_inplace(fo_mat *C);

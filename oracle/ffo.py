@@ -41,8 +41,8 @@ class FoReadResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libff_oracle.so")
-    src = os.path.join(_HERE, "ff_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ff_oracle.c", "ff_oracle.h", "cpu_ref.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _HERE, "libff_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -53,6 +53,8 @@ def lib():
         return _LIB
     L = C.CDLL(build())
     P = C.POINTER
+    L.fo_set_dot_mode.restype = None
+    L.fo_set_dot_mode.argtypes = [C.c_int]
     L.fo_make_mat.restype = P(FoMat)
     L.fo_make_mat.argtypes = [C.c_size_t, C.c_size_t]
     L.fo_free_mat.restype = P(FoMat)
@@ -133,6 +135,20 @@ def lib():
                                           C.c_size_t, C.c_size_t, C.c_size_t, C.c_float]
     _LIB = L
     return L
+
+
+class dot_mode:
+    """with ffo.dot_mode(1): ...  -- how the oracle sums dot products inside the block (ff_oracle.c: 0 reference order in
+    float = the oracle, 1 double accumulator = yardstick, 2 vectorised kernels = cpu_baseline timing)."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        lib().fo_set_dot_mode(self.mode)
+
+    def __exit__(self, *exc):
+        lib().fo_set_dot_mode(0)
 
 
 def _fptr(a: np.ndarray):

@@ -340,3 +340,20 @@ def test_oracle_regression_vectors(tag, golden_dir):
         assert np.array_equal(res["trace"], g["trace%d" % i].astype(np.int32))
         # invariants: trace columns are probabilities x 255
         assert res["trace"].min() >= 0 and res["trace"].max() <= 255
+
+
+def test_dot_modes_stay_within_rounding_of_the_oracle():
+    """ff_oracle.c's other summation modes (1: double accumulator, the yardstick of tests/test_fuzz_tail_gpu.py; 2: the
+    vectorised kernels of cpu_ref.c that bench.py's cpu_baseline times) evaluate the same network: identical calls and
+    transition scores within a few 1e-5 of the reference-order oracle on both model families."""
+    for kind, hidden, T in ((M.NET_LSTM5, 96, 1505), (M.NET_GRUMOD5, 64, 1200), (M.NET_LSTM5, 36, 600)):
+        mdl = M.synthetic_model(kind, hidden, seed=3)
+        om = ffo.OracleModel(mdl)
+        sig = np.random.default_rng(hidden).standard_normal(T).astype(np.float32)
+        ref = om.basecall(sig)
+        for mode in (1, 2):
+            with ffo.dot_mode(mode):
+                alt = om.basecall(sig)
+            assert np.abs(alt["trans"] - ref["trans"]).max() <= 5e-5, (kind, hidden, mode)
+            assert alt["basecall"] == ref["basecall"]
+        assert np.array_equal(om.basecall(sig)["trans"], ref["trans"])      # mode restored

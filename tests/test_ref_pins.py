@@ -152,12 +152,17 @@ def _scores(rng, nparam, nblock, style):
         s = rng.integers(-2, 3, (nblock, nparam)).astype(np.float64)
     elif style == "flat":
         s = np.zeros((nblock, nparam))
+    elif style == "nan":                         # every score NaN: strict-> scans keep their first candidate
+        s = np.full((nblock, nparam), np.nan)
+    elif style == "some_nan":
+        s = rng.standard_normal((nblock, nparam)) * 2
+        s[rng.random((nblock, nparam)) < 0.05] = np.nan
     else:
         raise ValueError(style)
     return s.astype(np.float32)
 
 
-CASES = [(nb, nblock, style) for nb in (4, 5) for nblock in (1, 2, 3, 17, 800) for style in ("normal", "tanh5", "ties", "flat")]
+CASES = [(nb, nblock, style) for nb in (4, 5) for nblock in (1, 2, 3, 17, 800) for style in ("normal", "tanh5", "ties", "flat", "nan", "some_nan")]
 
 
 @pytest.mark.parametrize("nbase,nblock,style", CASES)
