@@ -113,7 +113,7 @@ def measured_traffic(name, cfg, rnn_path):
     shape and kernel is committed.  The newest round's file wins."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*traffic.json"))):
         try:
             with open(path) as fh:
                 t = json.load(fh)

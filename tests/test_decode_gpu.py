@@ -1,0 +1,147 @@
+"""GPU decode operators through the reference-named C functions (include/decode.h -> libflappie_host.so -> ffhip_viterbi /
+ffhip_transpost / ffhip_trace) on score matrices the network would never emit but a caller of decode.h may pass: ties
+everywhere, constant scores, NaNs.  The oracle these are held to is itself bit-for-bit the reference's compiled decode.c on
+the same inputs (tests/test_ref_pins.py).
+
+Integer results (path, change positions) must be EQUAL.  Float results: Viterbi qpath/score are sums of the input scores along
+the path -> equal bits; posteriors within 2e-5 + 2e-6 |x| (log-sum-exp association differs), trace within one count, with the
+measured fraction of differing trace cells printed (run pytest -s / -rP to see it)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_host_layer import CIMat, CMat, _dense, _f, host  # noqa: F401  (host is a fixture)
+
+pytestmark = pytest.mark.gpu
+P = C.POINTER
+
+
+def _scores(rng, nparam, nblock, style):
+    if style == "normal":
+        s = rng.standard_normal((nblock, nparam)) * 2
+    elif style == "tanh5":
+        s = 5 * np.tanh(rng.standard_normal((nblock, nparam)) * 2) - 3.0
+    elif style == "ties":
+        s = rng.integers(-2, 3, (nblock, nparam)).astype(np.float64)
+    elif style == "flat":
+        s = np.zeros((nblock, nparam))
+    elif style == "nan":
+        s = np.full((nblock, nparam), np.nan)
+    elif style == "some_nan":
+        s = rng.standard_normal((nblock, nparam)) * 2
+        s[rng.random((nblock, nparam)) < 0.05] = np.nan
+    elif style == "nan_block":                   # one all-NaN block in the middle of an ordinary read
+        s = rng.standard_normal((nblock, nparam)) * 2
+        s[nblock // 2] = np.nan
+    return s.astype(np.float32)
+
+
+def _same_bits(a, b):
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("nbase", [4, 5])
+@pytest.mark.parametrize("style", ["normal", "tanh5", "ties", "flat", "nan", "some_nan", "nan_block"])
+def test_viterbi_any_scores_equal_the_oracle(host, nbase, style):
+    """decode_crf_flipflop (decode.c:119-204) incl. the cases ADVICE r1 named: an all-NaN matrix must give state 0 everywhere
+    (the reference's strict-> scans keep their first candidate), never an out-of-range state or an out-of-bounds read."""
+    from oracle import ffo
+    L = ffo.lib()
+    nstate = 2 * nbase
+    nparam = nstate * (nbase + 1)
+    rng = np.random.default_rng(nbase * 100 + len(style))
+    try:
+        for nblock in (1, 7, 300, 2500):         # 2500 > one traceback chunk of the kernels
+            dense = _scores(rng, nparam, nblock, style)
+            m = host.mat_from_array(_f(np.ascontiguousarray(dense)), nparam, nblock)
+            hm = ffo.HostMat.from_dense(dense)
+            for combine in (False, True):
+                pa, pb = np.full(nblock + 1, -7, np.int32), np.full(nblock + 1, -7, np.int32)
+                qa, qb = np.zeros(nblock + 1, np.float32), np.zeros(nblock + 1, np.float32)
+                sa = host.decode_crf_flipflop(m, combine, pa.ctypes.data_as(P(C.c_int)), _f(qa))
+                sb = L.fo_decode_viterbi(hm.ptr, int(combine), pb.ctypes.data_as(P(C.c_int)), _f(qb))
+                lo = -1 if combine else 0
+                assert pa.min() >= lo and pa.max() < nstate, (style, nblock, pa.min(), pa.max())
+                assert np.array_equal(pa, pb), (style, nblock, combine)
+                assert _same_bits(qa, qb), (style, nblock)
+                assert _same_bits(np.float32([sa]), np.float32([sb])), (style, nblock, sa, sb)
+            host.free_flappie_matrix(m)
+    finally:
+        host.flappie_hip_shutdown()
+
+
+@pytest.mark.parametrize("nbase", [4, 5])
+def test_posterior_and_trace_tolerances_with_hit_rates(host, nbase):
+    """transpost_crf_flipflop + exp + trace_from_posterior against the oracle, counting how often the tolerated differences
+    actually occur: fraction of trace cells off by one count, largest log-posterior difference."""
+    from oracle import ffo
+    L = ffo.lib()
+    nstate = 2 * nbase
+    nparam = nstate * (nbase + 1)
+    rng = np.random.default_rng(nbase)
+    ncell = noff = 0
+    worst = 0.0
+    try:
+        for nblock in (3, 800, 2000):
+            for style in ("tanh5", "normal", "ties"):
+                dense = _scores(rng, nparam, nblock, style)
+                m = host.mat_from_array(_f(np.ascontiguousarray(dense)), nparam, nblock)
+                hm = ffo.HostMat.from_dense(dense)
+                post = host.transpost_crf_flipflop(m, True)
+                ref = L.fo_transpost(hm.ptr, 1)
+                a, b = _dense(post), ffo.take(ref, free=False)
+                assert np.all(np.abs(a - b) <= 2e-5 + 2e-6 * np.abs(b)), (style, nblock, float(np.abs(a - b).max()))
+                worst = max(worst, float(np.abs(a - b).max()))
+                host.exp_activation_inplace(post)
+                L.fo_exp_inplace(ref)
+                tr = host.trace_from_posterior(post)
+                t = np.ctypeslib.as_array(tr.contents.f, shape=(nblock + 1, tr.contents.stride))[:, : tr.contents.nr].copy()
+                tref = ffo.take_i(L.fo_trace_from_posterior(ref))
+                d = np.abs(t - tref)
+                assert d.max() <= 1
+                ncell += d.size
+                noff += int((d == 1).sum())
+                host.free_flappie_imatrix(tr)
+                host.free_flappie_matrix(post)
+                host.free_flappie_matrix(m)
+                L.fo_free_mat(ref)
+    finally:
+        host.flappie_hip_shutdown()
+    print("nbase %d: trace cells off by one count: %d of %d (%.4f %%); largest |dlogpost| %.2e" % (nbase, noff, ncell, 100.0 * noff / ncell, worst))
+    assert noff <= 0.01 * ncell          # the +-1 tolerance is a rounding-boundary effect, not a licence
+
+
+def test_constant_signal_read_in_a_batch(engine):
+    """A read whose signal is NaN throughout (what med-MAD normalisation makes of a constant signal: 0/0) next to ordinary
+    reads: results of the ordinary reads are unaffected, the NaN read's path stays in range and equals the oracle's (the
+    reference's exp_ps clamps NaN away inside the gates, so its scores are finite after the first recurrent layer)."""
+    from flappie_amd import binding as B, model as M
+    from oracle import ffo
+    mdl = M.synthetic_model(M.NET_LSTM5, 64, seed=7)
+    om = ffo.OracleModel(mdl)
+    rng = np.random.default_rng(4)
+    sig = rng.standard_normal((3, 1000)).astype(np.float32)
+    sig[1] = np.nan
+    dm = B.DeviceModel(engine, mdl)
+    b = B.Batch(dm, 3, 1000)
+    try:
+        b.set_signals(sig)
+        b.run()
+        b.finish()
+        for r in (0, 2):
+            ref = om.basecall(sig[r])
+            assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
+            assert np.abs(b.transitions(r) - ref["trans"]).max() <= 1e-4
+        ref = om.basecall(sig[1])
+        path, _ = b.path(1)
+        assert path.min() >= 0 and path.max() < 8
+        tr, rt = b.transitions(1), ref["trans"]
+        assert np.array_equal(np.isnan(tr), np.isnan(rt))
+        if not np.isnan(rt).any():
+            assert np.abs(tr - rt).max() <= 1e-4
+            assert np.array_equal(path, ref["path"])
+            assert b.basecall(1) == ref["basecall"]
+    finally:
+        b.close()
+        dm.close()

@@ -15,6 +15,7 @@ ncase = nread_tot = ndiff = 0
 wo_split = wo_f32 = 0.0
 worst = 0.0
 models = {}
+dump = []          # flagged reads, for tests/golden/fuzz_tail.npz (tests/test_fuzz_tail_gpu.py re-runs them against the oracle)
 while time.time() - t0 < budget:
     kind = int(rng.choice([M.NET_LSTM5, M.NET_LSTM5, M.NET_GRUMOD5]))
     H = int(rng.choice([128, 256, 384, 512] if kind == M.NET_LSTM5 else [128, 256]))
@@ -57,8 +58,14 @@ while time.time() - t0 < budget:
                 kind, H, nread, cap, r, lens[r], d, nb, nq, a[0] == ref["basecall"], a[1] == ref["quality"], sum(x != y for x, y in zip(a[1], ref["quality"])),
                 c[0] == ref["basecall"], c[1] == ref["quality"], sum(x != y for x, y in zip(c[1], ref["quality"]))), flush=True)
             ndiff += 1
+            if len(dump) < 24:
+                dump.append(dict(kind=kind, hidden=H, model_seed=100 + list(models).index(key), signal=sigs[r].copy(),
+                                 d_split_oracle=float(np.abs(a[2] - ref["trans"]).max()), d_f32_oracle=float(np.abs(c[2] - ref["trans"]).max())))
             wo_split = max(wo_split, float(np.abs(a[2] - ref["trans"]).max())); wo_f32 = max(wo_f32, float(np.abs(c[2] - ref["trans"]).max()))
         nread_tot += 1
     ncase += 1
+if dump:
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez_compressed("gpurun_out/fuzz_tail_seed%d.npz" % seed, n=len(dump), **{"%s%d" % (k, i): np.asarray(v) for i, e in enumerate(dump) for k, v in e.items()})
 print("flagged reads vs oracle: worst |dtrans| split %.2e, f32 %.2e" % (wo_split, wo_f32))
 print("diff fuzz: %d cases, %d reads, %d reads with a differing string, worst |dtrans| %.2e, %.0f s" % (ncase, nread_tot, ndiff, worst, time.time() - t0))

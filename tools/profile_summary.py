@@ -1,66 +1,116 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 CSV outputs (kernel trace + separate FETCH_SIZE / WRITE_SIZE PMC passes) into the
-summaries committed under profiles/.  usage: profile_summary.py TAG trace.csv fetch_counters.csv write_counters.csv"""
+"""Turn the rocprofv3 CSV outputs of tools/profile_config.sh (kernel trace, separate FETCH_SIZE / WRITE_SIZE passes, SQ counter
+passes) into the summaries committed under profiles/.   usage: profile_summary.py TAG CONFIG SCRATCH_DIR OUT_DIR"""
 import collections
 import csv
+import glob
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+RECURRENT = ("k_lstm_split", "k_rnn_split", "k_lstm_fused", "k_rnn_persist")
+
+
+def find(scratch, tag, leg, suffix):
+    hits = sorted(glob.glob(os.path.join(scratch, "prof_%s_%s" % (tag, leg), "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("ffhip::", "")
 
 
 def main():
-    tag, trace, fetch, write = sys.argv[1:5]
+    tag, cfgname, scratch, outdir = sys.argv[1:5]
+    import bench
+    cfg = bench.CONFIGS[cfgname]
+    cmd = "python bench.py --config %s --steps 4 --warmup 1 --no-cpu-baseline --no-h2d-leg" % cfgname
+    trace = find(scratch, tag, "trace", "kernel_trace.csv")
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
-        d[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     tot = sum(sum(v) for v in d.values())
     lines = ["kernel,calls,total_ms,avg_us,min_us,max_us,percent"]
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-        lines.append("%s,%d,%.3f,%.3f,%.3f,%.3f,%.2f" % (k, len(v), sum(v) / 1e3, sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
-    open("profiles/%s_kernel_stats.csv" % tag, "w").write(
-        "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline\n" + "\n".join(lines) + "\n")
-    print("\n".join(lines[:10]))
+        lines.append("\"%s\",%d,%.3f,%.3f,%.3f,%.3f,%.2f" % (k, len(v), sum(v) / 1e3, sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
+    open(os.path.join(outdir, "%s_kernel_stats.csv" % tag), "w").write(
+        "# rocprofv3 --kernel-trace --stats --output-format csv -- %s\n" % cmd + "\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+    rec = [k for k in d if any(n in k for n in RECURRENT)]
+    dom = max(rec, key=lambda k: sum(d[k])) if rec else None
 
-    def pmc(path, name):
-        out = collections.defaultdict(list)
+    def pmc(leg, names):
+        path = find(scratch, tag, leg, "counter_collection.csv")
+        out = {n: collections.defaultdict(list) for n in names}
+        meta = {}
+        if not path:
+            return out, meta
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == name:
-                out[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-        return out
-    f, w = pmc(fetch, "FETCH_SIZE"), pmc(write, "WRITE_SIZE")
+            if r["Counter_Name"] in out:
+                k = short(r["Kernel_Name"])
+                out[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
+                meta[k] = {c: r.get(c) for c in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if c in r}
+        return out, meta
+
+    f = pmc("fetch", ["FETCH_SIZE"])[0]["FETCH_SIZE"]
+    w = pmc("write", ["WRITE_SIZE"])[0]["WRITE_SIZE"]
     out = ["kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_read_MB_corrected(2xFETCH),hbm_write_MB"]
     res = {}
     for k in f:
         fa = sum(f[k]) / len(f[k])
         wa = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
-        out.append("%s,%d,%.1f,%.1f,%.2f,%.2f" % (k, len(f[k]), fa, wa, 2 * fa * 1024 / 1e6, wa * 1024 / 1e6))
+        out.append("\"%s\",%d,%.1f,%.1f,%.2f,%.2f" % (k, len(f[k]), fa, wa, 2 * fa * 1024 / 1e6, wa * 1024 / 1e6))
         res[k] = (2 * fa * 1024, wa * 1024)
-    open("profiles/%s_hbm_traffic_pmc.csv" % tag, "w").write(
-        "# separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python bench.py --steps 4 --warmup 1\n"
-        "# FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)\n"
+    open(os.path.join(outdir, "%s_hbm_traffic_pmc.csv" % tag), "w").write(
+        "# separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE -- %s\n"
+        "# FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)\n" % cmd
         + "\n".join(out) + "\n")
-    print("\n".join(out))
-    return res
+    print("\n".join(out[:14]))
+
+    # SQ counters of the recurrent kernels
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
+             "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"]
+    vals, meta = {}, {}
+    for leg, ns in (("sq1", names[0:3]), ("sq2", names[3:6]), ("sq3", names[6:9])):
+        o, m = pmc(leg, ns)
+        vals.update(o)
+        meta.update(m)
+    sq = ["kernel,launches,avg_us," + ",".join(names) + ",mfma_busy_frac,grid,workgroup,lds,vgpr,agpr,sgpr"]
+    for k in rec:
+        row = []
+        for n in names:
+            v = vals.get(n, {}).get(k, [])
+            row.append(sum(v) / len(v) if v else float("nan"))
+        busy, gui = row[0], row[2]
+        # SQ_VALU_MFMA_BUSY_CYCLES sums over the chip's SIMDs (x4 per CU on gfx950's counter: cycles with the matrix pipe busy);
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles -> busy fraction = busy / (GUI/8 * 1024 SIMDs)
+        frac = busy / (gui / 8.0 * 1024.0) if gui == gui and gui > 0 else float("nan")
+        m = meta.get(k, {})
+        sq.append("\"%s\",%d,%.3f,%s,%.4f,%s" % (k, len(d[k]), sum(d[k]) / len(d[k]), ",".join("%.0f" % x for x in row), frac,
+                                                  ",".join(str(m.get(c, "")) for c in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"))))
+    open(os.path.join(outdir, "%s_sq_pmc.csv" % tag), "w").write(
+        "# three separate passes (counter slots): rocprofv3 --kernel-trace --pmc {SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES} -- %s\n"
+        "# per-launch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)\n" % cmd + "\n".join(sq) + "\n")
+    print("\n".join(sq))
+
+    if dom and dom in res:
+        H, nread, T = cfg["hidden"], cfg["nread"], cfg["nsample"]
+        from flappie_amd import model as M
+        Tb = M.synthetic_model(cfg["kind"], 128, seed=1).nblock(T)
+        rnn_path = 3 if "k_lstm_split" in dom else (4 if "k_rnn_split" in dom else (2 if "fused" in dom else 1))
+        G = 3 if cfg["kind"] == 1 else 4
+        # algorithmic bytes per launch: split layer kernel reads x and writes h at 6 B per value (three bf16 slices); f32 fused 4 + 4;
+        # recurrence-only kernels read the projected gates (G*H floats) and write h
+        alg = Tb * nread * H * {3: 12, 2: 8, 1: 4 * G + 4, 4: 4 * G + 6}[rnn_path]
+        entry = {"config": cfgname, "kind": cfg["kind"], "hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path in (2, 3), "kernel": dom,
+                 "recurrent_layer_hbm_bytes_per_launch": int(res[dom][0] + res[dom][1]),
+                 "read_bytes_corrected": int(res[dom][0]), "write_bytes": int(res[dom][1]),
+                 "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % tag}
+        json.dump([entry], open(os.path.join(outdir, "%s_traffic.json" % tag), "w"), indent=1)
+        print(json.dumps(entry, indent=1))
 
 
 if __name__ == "__main__":
-    res = main()
-    dom = [k for k in res if "k_lstm_split" in k] or [k for k in res if "k_lstm_fused" in k] or [k for k in res if "k_rnn_persist" in k]
-    if dom:
-        k = dom[0]
-        H, nread, T, Tb = 384, 256, 4000, 800
-        rnn_path = 3 if "split" in k else (2 if "fused" in k else 1)
-        # algorithmic bytes: split kernel reads x and writes h at 6 B per value (three bf16 slices); fused f32 kernel 4 + 4;
-        # unfused: read Xa (4H floats) + write h
-        alg = Tb * nread * H * {3: 12, 2: 8, 1: 20}[rnn_path]
-        entry = {"hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path >= 2, "kernel": k,
-                 "recurrent_layer_hbm_bytes_per_launch": int(res[k][0] + res[k][1]),
-                 "read_bytes_corrected": int(res[k][0]), "write_bytes": int(res[k][1]),
-                 "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % sys.argv[1]}
-        try:
-            old = json.load(open("profiles/r01_traffic.json"))
-            old = old if isinstance(old, list) else [old]
-        except (OSError, ValueError):
-            old = []
-        old = [e for e in old if e.get("rnn_path", 2 if e.get("fused") else 1) != rnn_path] + [entry]
-        json.dump(old, open("profiles/r01_traffic.json", "w"), indent=1)
-        print(json.dumps(entry, indent=1))
+    main()
