@@ -93,7 +93,8 @@ struct RnnDev {
     float4 *iWp = nullptr, *sWp = nullptr;
     float *bias = nullptr;      // [4*Hp] permuted rows
     int Kin16 = 0;
-    void *Wsplit = nullptr;     // both matrices as three bf16 slices in MFMA 16x16x32 A order (ffhip_rnn_split.hip), or nullptr
+    void *Wsplit = nullptr;     // both matrices as 16-bit slices in MFMA 16x16x32 A order (ffhip_rnn_split.hip, ffhip_split.hpp), or nullptr
+    int split_S = 0;            // the power-of-two exponent both products of this layer carry: sw(Wi) + e(x) = sw(sW) + e(h)
 };
 
 struct ffhip_model {
@@ -216,23 +217,30 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
         r.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
         if (!r.iWp || !r.sWp || !r.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
         if (H == Hp && Hp % 128 == 0) {      // layer kernel shapes (H <= 384) and the split projection GEMM of the unfused path
-            // W = w0 + w1 + w2 exactly, each a bf16 (round to nearest even): [mat][ut][k/32][slice][lane][8]
+            // [mat][ut][k/32][slice][lane][8] 16-bit slices of w * 2^sw (ffhip_split.hpp).  The layer's input arrives scaled by
+            // 2^ex (the swish convolution's output by 2^kSplitExpX, everything bounded by 1 by 2^kSplitExpH), h by
+            // 2^kSplitExpH; each matrix could take the exponent that brings its largest entry to [2^14, 2^15), and the two
+            // products must carry the same total S: the matrix with headroom gives some of it up.
             const int Ut = Hp / 4, Hc = Hp / 32;
-            std::vector<uint16_t> sp3((size_t)2 * Ut * Hc * 3 * 64 * 8);
-            auto rne = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-            auto val = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            const int ex = (l == 0 && m->act == ACT_SWISH) ? kSplitExpX : kSplitExpH, eh = kSplitExpH;
+            float mx[2] = { 0.0f, 0.0f };
+            for (int mat = 0; mat < 2; mat++)
+                for (int row = 0; row < 4 * Hp; row++)
+                    for (int k = 0; k < Hp; k++) mx[mat] = fmaxf(mx[mat], fabsf(rowcol(mat == 0 ? iW : sW, row, k)));
+            const int S = (split_weight_exp(mx[0]) + ex < split_weight_exp(mx[1]) + eh) ? split_weight_exp(mx[0]) + ex : split_weight_exp(mx[1]) + eh;
+            const int sw[2] = { S - ex, S - eh };
+            r.split_S = kSplitF16 ? S : 0;
+            std::vector<uint16_t> sp3((size_t)2 * Ut * Hc * kSplitNS * 64 * 8);
             for (int mat = 0; mat < 2; mat++)
                 for (int ut = 0; ut < Ut; ut++)
                     for (int c = 0; c < Hc; c++)
                         for (int lane = 0; lane < 64; lane++)
                             for (int e = 0; e < 8; e++) {
                                 const float w = rowcol(mat == 0 ? iW : sW, ut * 16 + (lane & 15), c * 32 + (lane >> 4) * 8 + e);
-                                const uint16_t b0 = rne(w);
-                                const float r1 = w - val(b0);
-                                const uint16_t b1 = rne(r1);
-                                const uint16_t b2 = rne(r1 - val(b1));
-                                const size_t base = ((((size_t)mat * Ut + ut) * Hc + c) * 3) * 64 * 8 + (size_t)lane * 8 + e;
-                                sp3[base] = b0; sp3[base + 64 * 8] = b1; sp3[base + 2 * 64 * 8] = b2;
+                                uint16_t sl[kSplitNS];
+                                split_host_slices(w, sw[mat], sl);
+                                const size_t base = ((((size_t)mat * Ut + ut) * Hc + c) * kSplitNS) * 64 * 8 + (size_t)lane * 8 + e;
+                                for (int k = 0; k < kSplitNS; k++) sp3[base + (size_t)k * 64 * 8] = sl[k];
                             }
             r.Wsplit = dev_upload(m, sp3.data(), sp3.size() * 2);
             if (!r.Wsplit) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
@@ -655,7 +663,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0,
-                             conv_split ? b->actS[0] : nullptr);
+                             conv_split ? b->actS[0] : nullptr, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH);
         }
         b->launches[0]++;
     }
@@ -670,7 +678,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     if ((use_split || use_split2) && !conv_split) {
-        launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp);
+        launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH);
         b->launches[0]++;
     }
     for (int l = 0; l < 5; l++) {
@@ -681,7 +689,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         if (prof) hipEventRecord(b->lev[l][0], s);
         if (use_split2) {
             if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
-            launch_inproj_split(s, b->actS[cur], b->xa, r.Wsplit, r.bias, Tb * B16, Hp);
+            launch_inproj_split(s, b->actS[cur], b->xa, r.Wsplit, r.bias, Tb * B16, Hp, r.split_S);
             b->launches[1]++;
             if (prof) hipEventRecord(b->lev[l][1], s);
             const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
@@ -692,7 +700,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (!launch_rnn_split(s, r.Wsplit, b->xa, b->actS[cur ^ 1], out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                      backward, persist_mode, tbs, tbt))
+                                      backward, persist_mode, r.split_S, tbs, tbt))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -716,7 +724,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, tbs, tbt))
+                                       backward, persist_mode, r.split_S, tbs, tbt))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -732,8 +740,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 // projection on the bf16 pipes over split operands (fp32-exact products): the layer input is
                 // converted to the split layout first
                 if (!b->actS[0] && !(b->actS[0] = dalloc(b, split_bytes((size_t)Tb * B16, Hp), false))) return FFHIP_ENOMEM;
-                launch_split_from_f32(s, in, b->actS[0], (size_t)Tb * B16, Hp);
-                launch_inproj_split(s, b->actS[0], b->xa, r.Wsplit, r.bias, Tb * B16, Hp);
+                launch_split_from_f32(s, in, b->actS[0], (size_t)Tb * B16, Hp, (l == 0 && m->act == ACT_SWISH) ? kSplitExpX : kSplitExpH);
+                launch_inproj_split(s, b->actS[0], b->xa, r.Wsplit, r.bias, Tb * B16, Hp, r.split_S);
                 b->launches[1] += 2;
             } else {
                 launch_inproj(s, in, b->xa, r.iWp, r.bias, Tb * B16, 4 * Hp, r.Kin16);
@@ -955,8 +963,8 @@ extern "C" int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, 
     void *d_split = tmp.get(split_bytes(ntile, hidden));
     if (!d_in || !d_out || !d_split) return set_err(FFHIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpy(d_in, in, nf * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
-    launch_split_from_f32(nullptr, d_in, d_split, ntile, hidden);
-    launch_f32_from_split(nullptr, d_split, d_out, ntile, hidden);
+    launch_split_from_f32(nullptr, d_in, d_split, ntile, hidden, kSplitExpH);
+    launch_f32_from_split(nullptr, d_split, d_out, ntile, hidden, kSplitExpH);
     HIP_TRY(hipDeviceSynchronize(), FFHIP_EHIP);
     HIP_TRY(hipMemcpy(out, d_out, nf * 4, hipMemcpyDeviceToHost), FFHIP_EHIP);
     return FFHIP_OK;

@@ -1,6 +1,7 @@
 // ffhip_internal.hpp -- shared declarations between the HIP kernels and the host engine.
 // gfx950 (MI355X) only.  Not part of the public boundary (include/ffhip.h is).
 #pragma once
+#include "ffhip_split.hpp"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -55,7 +56,7 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
                       const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0,
-                      void *out_split = nullptr);      // != nullptr: write the split-bf16 layout of ffhip_rnn_split.hip INSTEAD of `out` (M % 128 == 0)
+                      void *out_split = nullptr, int split_exp = 0);      // != nullptr: write the split layout of ffhip_rnn_split.hip (values * 2^split_exp) INSTEAD of `out` (M % 128 == 0)
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
@@ -85,19 +86,19 @@ int persist_blocks_per_cu(int kind, int H);
 bool split_supported(int kind, int H);
 int split_max_tiles(int ncu);                              // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU
 size_t split_flag_words(int nrt);
-inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 96; }      // 16 reads x H x 6 B
+inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 * kSplitNS; }      // 16 reads x H x 2 B x slices
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       const int *tbs = nullptr, const int *tbt = nullptr);
+                       int scale_exp, const int *tbs = nullptr, const int *tbt = nullptr);      // scale_exp: the exponent S both products carry
 // recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
 bool rnn_split_supported(int kind, int H);
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,
-                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, const int *tbs = nullptr, const int *tbt = nullptr);
+                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, int scale_exp, const int *tbs = nullptr, const int *tbt = nullptr);
 // input projection GEMM on split operands: in_split = activations in the split layout, Wp = the split weight pack (its first
 // matrix is Wi), xa = D-fragment order like launch_inproj
-void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H);
-void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H);      // tile-interleaved fp32 -> split
-void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H);
+void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H, int scale_exp);
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp);      // tile-interleaved fp32 -> split of in * 2^act_exp
+void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H, int act_exp);
 void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad);      // adds the mismatch count to *bad
 
 // head: trans = tanh(W^T h + b) / (temperature/5)

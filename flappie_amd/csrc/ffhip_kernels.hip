@@ -153,7 +153,7 @@ template <bool BVEC>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, const float *__restrict__ bias,
             const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act, int ldp,
-            unsigned char *__restrict__ out_split) {
+            unsigned char *__restrict__ out_split, float split_scale) {
     constexpr int TM = 4, TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -206,27 +206,17 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
             v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
             v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
             if (out_split) {
-                // split-bf16 layout of the recurrent layer kernel (ffhip_rnn_split.hip): three exact bf16 slices per value,
-                // [k/32][slice][(k%32)/8 * 16 + read][8]; this lane holds k = 16 mt + 4 kq + 0..3 of read rl
-                unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 96) +
-                                     (size_t)(((mt >> 1) * 3 * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);
-                unsigned lo[3], hi[3];
-                const float f[4] = { v.x, v.y, v.z, v.w };
-                unsigned sb[4][3];
+                // split layout of the recurrent layer kernel (ffhip_rnn_split.hip, ffhip_split.hpp): kSplitNS 16-bit slices of
+                // value * 2^split_exp, [k/32][slice][(k%32)/8 * 16 + read][8]; this lane holds k = 16 mt + 4 kq + 0..3 of read rl
+                unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 32 * kSplitNS) +
+                                     (size_t)(((mt >> 1) * kSplitNS * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);
+                const float f[4] = { v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale };
+                unsigned sb[4][kSplitNS];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const unsigned b0 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f[e]);
-                    const float r1 = f[e] - __uint_as_float(b0 << 16);
-                    const unsigned b1 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r1);
-                    const float r2 = r1 - __uint_as_float(b1 << 16);
-                    const unsigned b2 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r2);
-                    sb[e][0] = b0; sb[e][1] = b1; sb[e][2] = b2;
-                }
+                for (int e = 0; e < 4; e++) split_slices<true>(f[e], sb[e]);
 #pragma unroll
-                for (int sl = 0; sl < 3; sl++) {
-                    lo[sl] = sb[0][sl] | (sb[1][sl] << 16); hi[sl] = sb[2][sl] | (sb[3][sl] << 16);
-                    *(uint2 *)(dst + (size_t)sl * 1024) = make_uint2(lo[sl], hi[sl]);
-                }
+                for (int sl = 0; sl < kSplitNS; sl++)
+                    *(uint2 *)(dst + (size_t)sl * 1024) = make_uint2(sb[0][sl] | (sb[1][sl] << 16), sb[2][sl] | (sb[3][sl] << 16));
             } else
                 *(v4f *)(out + ((size_t)nt * Mt + mt) * 256 + lane * 4) = v;
         }
@@ -234,16 +224,16 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
 }
 
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
-                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp, void *out_split) {
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp, void *out_split, int split_exp) {
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
     if (vec)
         hipLaunchKernelGGL(k_conv_mfma<true>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split);
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp));
     else
         hipLaunchKernelGGL(k_conv_mfma<false>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split);
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp));
 }
 
 // ---- input projection: Xa[nt][mt] = Wp[mt] . act[nt] + b ----------------------------------

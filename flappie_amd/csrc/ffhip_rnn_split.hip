@@ -49,6 +49,7 @@
 // pipes carry 216 MFMAs = 3700 cycles per SIMD), gate phase ~2500, barriers ~300 -- DESIGN.md section 5.1.1.
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
+#include "ffhip_split.hpp"
 #include <stdlib.h>
 
 #ifndef FFHIP_SPLIT_ABLATE
@@ -61,9 +62,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+constexpr int NS = kSplitNS;
 
 struct SplitArgs {
-    const v4u *Wp;            // [2][Ut][Hc][3][64] 16 B; mat 0 = input weights, 1 = recurrent weights
+    const v4u *Wp;            // [2][Ut][Hc][NS][64] 16 B; mat 0 = input weights, 1 = recurrent weights
     const float *bias;        // [16*Ut] permuted (4u + g)
     const unsigned char *xin; // layer input, split layout
     unsigned char *hout;      // layer output, split layout, pre-filled with the sentinel
@@ -71,44 +74,45 @@ struct SplitArgs {
     unsigned *flags;          // [ngroup][32] XCC ids (zeroed before launch)
     unsigned *abort_word;
     int Tb, B16, H, rt0, nrt, backward, mode;
+    float acc_scale;          // 2^S: the exponent both products of this layer carry (ffhip_split.hpp); the bias is added in that space
     const int *tbs, *tbt;     // ragged batch (see PersistArgs)
     unsigned long long *dbg;
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr unsigned kSplitSentinel = 0xFFFFFFFFu;
 
-__device__ __forceinline__ unsigned bf16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }
-__device__ __forceinline__ float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
-
-// three-way split of 4 values; returns the packed slice `which` (0..2) as two dwords
+// slice `which` of 4 values (each already multiplied by its power of two), packed as two dwords
+template <bool CLAMP>
 __device__ __forceinline__ v2u split4(v4f v, int which) {
     unsigned s[4];
     const float f[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        const unsigned b0 = bf16_bits(f[e]);
-        const float r1 = f[e] - bf16_val(b0);
-        const unsigned b1 = bf16_bits(r1);
-        const float r2 = r1 - bf16_val(b1);
-        const unsigned b2 = bf16_bits(r2);
-        s[e] = which == 0 ? b0 : (which == 1 ? b1 : b2);
+        unsigned sl[NS];
+        split_slices<CLAMP>(f[e], sl);
+        s[e] = sl[0];
+#pragma unroll
+        for (int k = 1; k < NS; k++) s[e] = (which == k) ? sl[k] : s[e];
     }
     return (v2u){ s[0] | (s[1] << 16), s[2] | (s[3] << 16) };
 }
 
 __device__ __forceinline__ v4f mm(v4u a, v4u b, v4f c) {
+#ifdef FFHIP_SPLIT_BF16X3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+#endif
 }
 
-// The six kept products of one K chunk for the N row tiles of a wave, smallest terms first.  Issue order is term-major,
-// row tile minor: consecutive MFMAs write DIFFERENT accumulators, so the matrix pipe never waits for its own result
-// (a dependent v_mfma_f32_16x16x32_bf16 issues every ~28 cycles, an independent one every 16).
+// The kept products of one K chunk (ffhip_split.hpp) for the N row tiles of a wave, smallest terms first.  Issue order is
+// term-major, row tile minor: consecutive MFMAs write DIFFERENT accumulators, so the matrix pipe never waits for its own
+// result (a dependent 16x16x32 MFMA issues every ~28 cycles, an independent one every 16).
 template <int N, int NC = N>
-__device__ __forceinline__ void mm6(const v4u (&w)[N][NC][3], int cc, const v4u (&x)[3], v4f (&acc)[N]) {
-    constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
+__device__ __forceinline__ void mm6(const v4u (&w)[N][NC][NS], int cc, const v4u (&x)[NS], v4f (&acc)[N]) {
+    constexpr int WS[kSplitNT] = FFHIP_SPLIT_TERMS_W, XS[kSplitNT] = FFHIP_SPLIT_TERMS_X;
 #pragma unroll
-    for (int term = 0; term < 6; term++)
+    for (int term = 0; term < kSplitNT; term++)
 #pragma unroll
         for (int j = 0; j < N; j++) acc[j] = mm(w[j][cc][WS[term]], x[XS[term]], acc[j]);
 }
@@ -120,12 +124,12 @@ k_lstm_split(SplitArgs a) {
     __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
     __shared__ v4f ph[4][2][N][64];         // gate pre-activations by K quarter: projection partial + recurrent partial
     __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
-    __shared__ unsigned short gsl[8][3][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
+    __shared__ unsigned short gsl[8][NS][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
     __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
     __shared__ int lds_abort;
     __shared__ int lds_fast;
     constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
-    constexpr size_t tileB = (size_t)Hc * 3 * 1024;      // bytes of one (t, read tile) in the split layout
+    constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool xw = wave < 4;
@@ -146,17 +150,17 @@ k_lstm_split(SplitArgs a) {
     const int ntl = (TbB > 0) ? 2 : 1;
     const int ut0 = m * N;
     if (threadIdx.x == 0) lds_abort = 0;
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
     const int q = lane >> 4, rl = lane & 15;
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
     // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
     // the hardware on one SIMD run in ~2500 cycles, two tiles back to back in one wave in ~3300).
     const int g6 = xw ? 4 + wave : kw;
-    const bool gate_wave = (xw ? wave < 2 : true) && g6 < ntl * N;
+    const bool gate_wave = g6 < ntl * N;
     const int my_gts = g6 / N, my_gj = g6 % N;
     // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
-    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
+    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * NS + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
     auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
     auto store_wt = [&](unsigned char *tile, unsigned off, v2u v) {      // write-through: visible to every XCD
         __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
@@ -169,7 +173,7 @@ k_lstm_split(SplitArgs a) {
     // i.e. at least AHEAD-1 whole steps after that sentinel was written.  No host-side fill of the (reused) buffer.
     constexpr int AHEAD = 3;
     const v2u sentinel2 = { kSplitSentinel, kSplitSentinel };
-    if (gate_wave && q < 3)
+    if (gate_wave && q < NS)
         for (int k = 0; k < AHEAD && k < Tb; k++) store_wt(out_tile(step_t(k), my_gts), out_off(my_gj), sentinel2);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my sentinels are in L2 ...
     __syncthreads();                          // ... and so are those of the other waves, before this member checks in
@@ -197,16 +201,16 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
     for (int cc = 0; cc < N; cc++) chunk[cc] = ((kw + m) & 3) * N + (cc + (m >> 2)) % N;
     // resident weights of this wave: rows of my N unit tiles, my N chunks, three slices
-    v4u wf[N][N][3];
+    v4u wf[N][N][NS];
     {
-        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * Ut * Hc * 3 * 64;
+        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * Ut * Hc * NS * 64;
 #pragma unroll
         for (int j = 0; j < N; j++)
 #pragma unroll
             for (int cc = 0; cc < N; cc++)
 #pragma unroll
-                for (int s = 0; s < 3; s++)
-                    wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + chunk[cc]) * 3 + s) * 64 + lane];
+                for (int s = 0; s < NS; s++)
+                    wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + chunk[cc]) * NS + s) * 64 + lane];
     }
     __syncthreads();
     if (lds_abort) return;
@@ -234,6 +238,7 @@ k_lstm_split(SplitArgs a) {
 
     // ---- gate math of one 16 x 16 tile (4 units x 4 gates x 16 reads; layers.c:1005-1025) and the store of its h(t), already
     // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
+    const float inv_scale = 1.0f / a.acc_scale;
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
         const int t = step_t(i);
         float h;
@@ -248,6 +253,7 @@ k_lstm_split(SplitArgs a) {
             v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
             const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
             float hbar = L.y * s.z + (s.w + b.z);
@@ -258,6 +264,7 @@ k_lstm_split(SplitArgs a) {
             v4f s = sbias[gj][q];
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
             const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
             const float tanh_g = (L.z + L.z) - 1.0f;
@@ -273,18 +280,17 @@ k_lstm_split(SplitArgs a) {
         // Split h ONCE, in the lane that owns it, and transpose through a wave-private LDS patch: lane (unit q, read rl) writes its
         // three bf16 slices to [slice][read][unit]; quarter-wave q then reads the 8 bytes [slice q][read rl][units 0..3] -- the
         // packed operand piece it stores.  (Four ds_bpermute + a 4-value split in every lane cost ~3x the VALU work.)
-        const unsigned b0 = bf16_bits(h);
-        const float r1 = h - bf16_val(b0);
-        const unsigned b1 = bf16_bits(r1);
-        const unsigned b2 = bf16_bits(r1 - bf16_val(b1));
-        gsl[wave][0][rl][q] = (unsigned short)b0;
-        gsl[wave][1][rl][q] = (unsigned short)b1;
-        gsl[wave][2][rl][q] = (unsigned short)b2;
+        {
+            unsigned sl[NS];
+            split_slices(h * split_pow2(kSplitExpH), sl);        // |h| <= 1: in range without a clamp
+#pragma unroll
+            for (int k = 0; k < NS; k++) gsl[wave][k][rl][q] = (unsigned short)sl[k];
+        }
         if (a.hout_f32) gf32[wave][rl][q] = h;
         asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
         const int ut = ut0 + gj;
         const unsigned off = out_off(gj);
-        if (q < 3) {
+        if (q < NS) {
             const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
@@ -310,7 +316,7 @@ k_lstm_split(SplitArgs a) {
         // registers right after the MFMAs that consumed x(step i+1): a whole step ahead of its use (it comes from HBM),
         // and never in the gate phase, where the issue of 18 KiB of loads per wave (the CU's path to L2 takes 64 B/clk)
         // would delay a gating x wave and with it the critical path.
-        v4u xb[2][N][3];
+        v4u xb[2][N][NS];
         auto load_x = [&](int i) {
             const int t = step_t(i);
 #pragma unroll
@@ -320,7 +326,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                 for (int cc = 0; cc < N; cc++) {
 #pragma unroll
-                    for (int s = 0; s < 3; s++) xb[ts][cc][s] = p[(chunk[cc] * 3 + s) * 64];
+                    for (int s = 0; s < NS; s++) xb[ts][cc][s] = p[(chunk[cc] * NS + s) * 64];
                     __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
                                                        // occupying it with an 18 KiB burst per wave
                 }
@@ -345,12 +351,12 @@ k_lstm_split(SplitArgs a) {
         // sweep and the gate waves' stores.  Each member therefore TOUCHES 1/32 of the lines of x(step i+3) -- one dword
         // load of <= 18 lanes per step, issued behind its own prefetch -- so that the prefetches of step i+3 are L2 hits.
         constexpr int WARM = 3;
-        constexpr int LPM = Hc * 24 * 2 / 32;            // 128-byte lines of a pair's x(step) per member
+        constexpr int LPM = Hc * NS * 8 * 2 / 32;            // 128-byte lines of a pair's x(step) per member
         unsigned touched = 0, sink = 0;
         auto touch_x = [&](int i) {
             const int line = m * LPM + lane;
             unsigned t = 0;                               // (not `touched` itself: keeping the old value would make this a use of the old load)
-            if (wave == 3 && lane < LPM && line < ntl * Hc * 24 && i < Tb)
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
@@ -413,7 +419,7 @@ k_lstm_split(SplitArgs a) {
                     const int ul = lane % NPROD, pts = lane / NPROD;
                     const int put = ((kw + m) & 3) * NPROD + ul;
                     const bool act = pts < ntl;
-                    const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * 3 * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
+                    const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * NS * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
 #if !(FFHIP_SPLIT_ABLATE & 2)          // 2 = no hand-off wait at all (timing of the compute pipeline alone)
                     for (unsigned spin = 0;; spin++) {
                         const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
@@ -426,7 +432,7 @@ k_lstm_split(SplitArgs a) {
 #endif
                 }
                 TL(1);
-                v4u raw[NCH][3];
+                v4u raw[NCH][NS];
                 // Both tiles of the pair are always swept and multiplied (an absent second tile re-reads the first one and
                 // its products are dropped): a branch on ntl between the loads makes the outstanding-load count path
                 // dependent, and the compiler then waits vmcnt(0) before the first MFMA instead of counting.
@@ -437,12 +443,12 @@ k_lstm_split(SplitArgs a) {
                     if (i > 1) return;
 #endif
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
+                    for (int s = 0; s < NS; s++) {
 #if FFHIP_SPLIT_ABLATE & 64             // 64 = the second tile's operands are the first tile's lines again (L2 traffic of the sweep halved)
-                        if (ts) raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 0);
-                        else raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16);
+                        if (ts) raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 0);
+                        else raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 16);
 #else
-                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
 #endif
                     }
                 };
@@ -462,7 +468,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                     for (int k = 0; k < NCH; k++) {
 #pragma unroll
-                        for (int s = 0; s < 3; s++) {
+                        for (int s = 0; s < NS; s++) {
                             const v4u r = raw[k][s];
                             ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
                         }
@@ -526,12 +532,13 @@ k_lstm_split(SplitArgs a) {
 // gates one of the pair's 2N <= 8 tiles; the gate pre-activations start from Xa = Wi x + b (k_inproj_split), one D-fragment
 // per gate wave and step, prefetched a step ahead.  LSTM only.
 struct RnnSplitArgs {
-    const v4u *Wp;            // recurrent weights [Ut][Hc][3][64] 16 B (the second matrix of the split pack)
+    const v4u *Wp;            // recurrent weights [Ut][Hc][NS][64] 16 B (the second matrix of the split pack)
     const v4f *xa;            // [Tb][B16][Ut][64] float4, D-fragment order, bias included
     unsigned char *hout;      // split layout
     float *hout_f32;
     unsigned *flags, *abort_word;
     int Tb, B16, rt0, nrt, backward, mode;
+    float acc_scale;          // 2^S of sW h (ffhip_split.hpp); xa arrives unscaled
     const int *tbs, *tbt;
 };
 
@@ -539,9 +546,9 @@ template <int N, int CPW>
 __global__ void __launch_bounds__(512, 1)
 k_rnn_split(RnnSplitArgs a) {
     constexpr int G = 32, Hc = 8 * CPW, Ut = 32 * N, NCH = 2 * CPW, NPROD = 8 * CPW;
-    constexpr size_t tileB = (size_t)Hc * 3 * 1024;
+    constexpr size_t tileB = (size_t)Hc * NS * 1024;
     __shared__ v4f ph[8][2][N][64];                  // recurrent partials by K eighth
-    __shared__ unsigned short gsl[8][3][16][4];
+    __shared__ unsigned short gsl[8][NS][16][4];
     __shared__ float gf32[8][16][4];
     __shared__ int lds_abort;
     __shared__ int lds_fast;
@@ -567,7 +574,7 @@ k_rnn_split(RnnSplitArgs a) {
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     const bool gate_wave = wave < ntl * N;
     const int my_gts = wave / N, my_gj = wave % N;
-    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * 3 + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
+    auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * NS + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
     auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
     auto store_wt = [&](unsigned char *tile, unsigned off, v2u v) {
         __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
@@ -575,7 +582,7 @@ k_rnn_split(RnnSplitArgs a) {
     };
     constexpr int AHEAD = 3;
     const v2u sentinel2 = { kSplitSentinel, kSplitSentinel };
-    if (gate_wave && q < 3)
+    if (gate_wave && q < NS)
         for (int k = 0; k < AHEAD && k < Tb; k++) store_wt(out_tile(step_t(k), my_gts), out_off(my_gj), sentinel2);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
@@ -596,14 +603,14 @@ k_rnn_split(RnnSplitArgs a) {
         if (lane == 0) lds_fast = fast_l;
     }
     const int cbase = ((wave + m) & 7) * CPW;            // my K eighth: chunks cbase .. cbase+CPW-1
-    v4u wf[N][CPW][3];
+    v4u wf[N][CPW][NS];
 #pragma unroll
     for (int j = 0; j < N; j++)
 #pragma unroll
         for (int cc = 0; cc < CPW; cc++)
 #pragma unroll
-            for (int s = 0; s < 3; s++)
-                wf[j][cc][s] = a.Wp[(((size_t)(ut0 + j) * Hc + (cbase + cc)) * 3 + s) * 64 + lane];
+            for (int s = 0; s < NS; s++)
+                wf[j][cc][s] = a.Wp[(((size_t)(ut0 + j) * Hc + (cbase + cc)) * NS + s) * 64 + lane];
     __syncthreads();
     if (lds_abort) return;
     const bool fast = lds_fast != 0;
@@ -634,7 +641,7 @@ k_rnn_split(RnnSplitArgs a) {
                 const int ul = lane % NPROD, pts = lane / NPROD;
                 const int put = cbase * 8 + ul;
                 const bool act = pts < ntl;
-                const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * 3 * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
+                const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * NS * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
                 for (unsigned spin = 0;; spin++) {
                     const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
                     if (__all(v != kSplitSentinel)) break;
@@ -644,21 +651,21 @@ k_rnn_split(RnnSplitArgs a) {
                     }
                 }
             }
-            v4u raw[NCH][3];
+            v4u raw[NCH][NS];
             const int offB = (ntl > 1) ? (int)tileB : 0;
             auto recur = [&]() -> bool {
                 bool ok = true;
 #pragma unroll
                 for (int k = 0; k < NCH; k++) {
 #pragma unroll
-                    for (int s = 0; s < 3; s++)
-                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (k / CPW) * offB + (((cbase + k % CPW) * 3 + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
+                    for (int s = 0; s < NS; s++)
+                        raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (k / CPW) * offB + (((cbase + k % CPW) * NS + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
                     if (k + 1 < NCH) __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; k++) {
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
+                    for (int s = 0; s < NS; s++) {
                         const v4u r = raw[k][s];
                         ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
                     }
@@ -697,11 +704,12 @@ k_rnn_split(RnnSplitArgs a) {
         if (lds_abort) return;
         if (gate_wave) {
             const int t = step_t(i);
-            v4f s = xa_cur;
+            v4f s = xa_cur * a.acc_scale;                    // into the accumulators' scaled space and back: powers of two, exact
             if (i > 0) {
 #pragma unroll
                 for (int w2 = 0; w2 < 8; w2++) s = s + ph[w2][my_gts][my_gj][lane];
             }
+            s = s * (1.0f / a.acc_scale);
             const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
             const float tanh_g = (L.z + L.z) - 1.0f;
             const float forget = L.y * c;
@@ -709,18 +717,17 @@ k_rnn_split(RnnSplitArgs a) {
             c = forget + update;
             float h = L.w * tanh_ref_lean(c);
             if (t >= my_tb) { h = 0.0f; c = 0.0f; }
-            const unsigned b0 = bf16_bits(h);
-            const float r1 = h - bf16_val(b0);
-            const unsigned b1 = bf16_bits(r1);
-            const unsigned b2 = bf16_bits(r1 - bf16_val(b1));
-            gsl[wave][0][rl][q] = (unsigned short)b0;
-            gsl[wave][1][rl][q] = (unsigned short)b1;
-            gsl[wave][2][rl][q] = (unsigned short)b2;
+            {
+                unsigned sl[NS];
+                split_slices(h * split_pow2(kSplitExpH), sl);
+#pragma unroll
+                for (int k = 0; k < NS; k++) gsl[wave][k][rl][q] = (unsigned short)sl[k];
+            }
             if (a.hout_f32) gf32[wave][rl][q] = h;
             asm volatile("" ::: "memory");
             const int ut = ut0 + my_gj;
             const unsigned off = out_off(my_gj);
-            if (q < 3) {
+            if (q < NS) {
                 const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
                 unsigned char *tp_out = out_tile(t, my_gts);
                 if (fast) {
@@ -742,10 +749,11 @@ k_rnn_split(RnnSplitArgs a) {
 
 bool rnn_split_supported(int kind, int H) { return kind == 0 && (H == 256 || H == 512); }
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,
-                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, const int *tbs, const int *tbt) {
+                      int Tb, int B16, int H, int rt0, int nrt, int backward, int mode, int scale_exp, const int *tbs, const int *tbt) {
     RnnSplitArgs a;
+    a.acc_scale = split_pow2(scale_exp);
     const int Ut = H / 4, Hc = H / 32;
-    a.Wp = (const v4u *)Wsplit + (size_t)Ut * Hc * 3 * 64;      // second matrix of the pack = recurrent weights
+    a.Wp = (const v4u *)Wsplit + (size_t)Ut * Hc * NS * 64;      // second matrix of the pack = recurrent weights
     a.xa = (const v4f *)xa; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32; a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode; a.tbs = tbs; a.tbt = tbt;
     const int ngroup = (nrt + 1) / 2;
@@ -760,7 +768,7 @@ bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *
 // issues 144 MFMAs (4 x 4 tiles: 24 KiB per 96 MFMAs sits right at the CU's 64 B/clk load path and measured 10 % slower).
 __global__ void __launch_bounds__(256)
 k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, const v4u *__restrict__ Wp, const float *__restrict__ bias,
-               int ntile, int Mt, int Hc) {
+               int ntile, int Mt, int Hc, float acc_scale) {
     constexpr int TM = 4, TN = 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -777,37 +785,38 @@ k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, con
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int mt = min(mt0 + i, Mt - 1);
-        ap[i] = Wp + (size_t)mt * Hc * 3 * 64 + lane;
-        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4);
+        ap[i] = Wp + (size_t)mt * Hc * NS * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4) * acc_scale;      // the bias joins the products in their scaled space (exact)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = bv;
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int nt = min(nt0 + j, ntile - 1);
-        bp[j] = (const v4u *)(in + (size_t)nt * Hc * 3 * 1024) + lane;
+        bp[j] = (const v4u *)(in + (size_t)nt * Hc * NS * 1024) + lane;
     }
-    constexpr int WS[6] = { 2, 0, 1, 1, 0, 0 }, XS[6] = { 0, 2, 1, 0, 1, 0 };
+    constexpr int WS[kSplitNT] = FFHIP_SPLIT_TERMS_W, XS[kSplitNT] = FFHIP_SPLIT_TERMS_X;
     // the operands of chunk c+1 are in flight while the 96 MFMAs of chunk c issue (two register sets, K loop unrolled by two)
-    v4u A0[TM][3], B0[TN][3], A1[TM][3], B1[TN][3];
-    auto load = [&](v4u (&A)[TM][3], v4u (&B)[TN][3], int c) {
+    v4u A0[TM][NS], B0[TN][NS], A1[TM][NS], B1[TN][NS];
+    auto load = [&](v4u (&A)[TM][NS], v4u (&B)[TN][NS], int c) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) A[i][s] = ap[i][(size_t)(c * 3 + s) * 64];
+            for (int s = 0; s < NS; s++) A[i][s] = ap[i][(size_t)(c * NS + s) * 64];
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) B[j][s] = bp[j][(size_t)(c * 3 + s) * 64];
+            for (int s = 0; s < NS; s++) B[j][s] = bp[j][(size_t)(c * NS + s) * 64];
     };
-    auto mma = [&](v4u (&A)[TM][3], v4u (&B)[TN][3]) {
+    auto mma = [&](v4u (&A)[TM][NS], v4u (&B)[TN][NS]) {
 #pragma unroll
-        for (int term = 0; term < 6; term++)
+        for (int term = 0; term < kSplitNT; term++)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = mm(A[i][WS[term]], B[j][XS[term]], acc[i][j]);
     };
+    const float inv_scale = 1.0f / acc_scale;
     load(A0, B0, 0);
     for (int c = 0; c < Hc; c += 2) {
         if (c + 1 < Hc) load(A1, B1, c + 1);
@@ -825,21 +834,21 @@ k_inproj_split(const unsigned char *__restrict__ in, float *__restrict__ xa, con
         for (int j = 0; j < TN; j++) {
             const int nt = nt0 + j;
             if (nt >= ntile) continue;
-            *(v4f *)(xa + ((size_t)nt * Mt + mt) * 256 + lane * 4) = acc[i][j];
+            *(v4f *)(xa + ((size_t)nt * Mt + mt) * 256 + lane * 4) = acc[i][j] * inv_scale;
         }
     }
 }
 
-void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H) {
+void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H, int scale_exp) {
     const int Mt = H / 4, Hc = H / 32;
     const int nMblk = (Mt + 7) / 8, nNblk = (ntile + 11) / 12;
-    hipLaunchKernelGGL(k_inproj_split, dim3(nMblk * nNblk), dim3(256), 0, s, (const unsigned char *)in_split, xa, (const v4u *)Wp, bias, ntile, Mt, Hc);
+    hipLaunchKernelGGL(k_inproj_split, dim3(nMblk * nNblk), dim3(256), 0, s, (const unsigned char *)in_split, xa, (const v4u *)Wp, bias, ntile, Mt, Hc, split_pow2(scale_exp));
 }
 
 // ---- layout converters -------------------------------------------------------------------------
-// fp32 tile-interleaved [tile][Ut][16 reads][4] <-> split [tile][Hc][3][64][8 bf16]; one thread per (tile, pair of unit tiles, read)
+// fp32 tile-interleaved [tile][Ut][16 reads][4] <-> split [tile][Hc][NS][64][8 bf16]; one thread per (tile, pair of unit tiles, read)
 __global__ void __launch_bounds__(256)
-k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, size_t npair, int Ut) {
+k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, size_t npair, int Ut, float scale) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= npair) return;
     const int rl = (int)(idx & 15);
@@ -847,50 +856,52 @@ k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, 
     const int up = (int)(pr % (Ut / 2));
     const size_t tile = pr / (Ut / 2);
     const float *src = in + (tile * Ut + 2 * up) * 64 + rl * 4;
-    const v4f lo = *(const v4f *)src, hi = *(const v4f *)(src + 64);
-    unsigned char *dst = out + tile * ((size_t)Ut / 8 * 3 * 1024);
+    const v4f lo = *(const v4f *)src * scale, hi = *(const v4f *)(src + 64) * scale;
+    unsigned char *dst = out + tile * ((size_t)Ut / 8 * NS * 1024);
     const int c = up >> 2, kq = up & 3;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const v2u a = split4(lo, s), b = split4(hi, s);
-        *(v4u *)(dst + (size_t)(((c * 3 + s) * 64 + kq * 16 + rl) * 16)) = (v4u){ a.x, a.y, b.x, b.y };
+    for (int s = 0; s < NS; s++) {
+        const v2u a = split4<true>(lo, s), b = split4<true>(hi, s);
+        *(v4u *)(dst + (size_t)(((c * NS + s) * 64 + kq * 16 + rl) * 16)) = (v4u){ a.x, a.y, b.x, b.y };
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_f32_from_split(const unsigned char *__restrict__ in, float *__restrict__ out, size_t npair, int Ut) {
+k_f32_from_split(const unsigned char *__restrict__ in, float *__restrict__ out, size_t npair, int Ut, float inv_scale) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= npair) return;
     const int rl = (int)(idx & 15);
     const size_t pr = idx >> 4;
     const int up = (int)(pr % (Ut / 2));
     const size_t tile = pr / (Ut / 2);
-    const unsigned char *src = in + tile * ((size_t)Ut / 8 * 3 * 1024);
+    const unsigned char *src = in + tile * ((size_t)Ut / 8 * NS * 1024);
     const int c = up >> 2, kq = up & 3;
     float v[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    // smallest slice first: the sum of the three slices is exact in any order (they partition the mantissa)
+    // smallest slice first (bf16 build: the three slices partition the mantissa, the sum is exact in any order)
 #pragma unroll
-    for (int s = 2; s >= 0; s--) {
-        const v4u w = *(const v4u *)(src + (size_t)(((c * 3 + s) * 64 + kq * 16 + rl) * 16));
+    for (int s = NS - 1; s >= 0; s--) {
+        const v4u w = *(const v4u *)(src + (size_t)(((c * NS + s) * 64 + kq * 16 + rl) * 16));
         const unsigned d[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            v[2 * e] += __uint_as_float(d[e] << 16);
-            v[2 * e + 1] += __uint_as_float(d[e] & 0xFFFF0000u);
+            v[2 * e] += split_slice_value(d[e] & 0xFFFFu);
+            v[2 * e + 1] += split_slice_value(d[e] >> 16);
         }
     }
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] *= inv_scale;
     float *dst = out + (tile * Ut + 2 * up) * 64 + rl * 4;
     *(v4f *)dst = (v4f){ v[0], v[1], v[2], v[3] };
     *(v4f *)(dst + 64) = (v4f){ v[4], v[5], v[6], v[7] };
 }
 
-void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H) {
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp) {
     const size_t npair = ntile * (size_t)(H / 8) * 16;
-    hipLaunchKernelGGL(k_split_from_f32, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, in, (unsigned char *)out, npair, H / 4);
+    hipLaunchKernelGGL(k_split_from_f32, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, in, (unsigned char *)out, npair, H / 4, split_pow2(act_exp));
 }
-void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H) {
+void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H, int act_exp) {
     const size_t npair = ntile * (size_t)(H / 8) * 16;
-    hipLaunchKernelGGL(k_f32_from_split, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (const unsigned char *)in, out, npair, H / 4);
+    hipLaunchKernelGGL(k_f32_from_split, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (const unsigned char *)in, out, npair, H / 4, split_pow2(-act_exp));
 }
 
 // ---- exhaustive check of the lean gate math (debug entry point) -----------------------------------
@@ -919,7 +930,14 @@ void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned lon
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 384; }
+// largest H / 128 whose two weight matrices fit one CU's registers: 16N rows x 256N k x 2 B x slices per CU
+// (three bf16 slices: 221 KiB at N = 3; two fp16 slices: 147 KiB at N = 3, 256 KiB at N = 4; the file holds 512 KiB)
+#ifdef FFHIP_SPLIT_BF16X3
+constexpr int kSplitMaxN = 3;
+#else
+constexpr int kSplitMaxN = 4;
+#endif
+bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 128 * (kind == 0 ? kSplitMaxN : 3); }      // GRUmod at N = 4 spills 169 registers; no GRUmod model is that wide
 // read tiles (of 16) one launch takes: one workgroup per CU, 32 per pair of tiles
 int split_max_tiles(int ncu) { return 2 * (ncu / 32); }
 size_t split_flag_words(int nrt) { return (size_t)((nrt + 1) / 2) * 32; }
@@ -928,16 +946,22 @@ unsigned long long *g_split_dbg = nullptr;
 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       const int *tbs, const int *tbt) {
+                       int scale_exp, const int *tbs, const int *tbt) {
     SplitArgs a;
+    a.acc_scale = split_pow2(scale_exp);
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
     const int ngroup = (nrt + 1) / 2;
 #define SPLIT_LAUNCH(K, NN) hipLaunchKernelGGL((k_lstm_split<K, NN>), dim3(ngroup * 32), dim3(512), 0, s, a); return true
+#ifdef FFHIP_SPLIT_BF16X3
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
+#else
+    if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); case 4: SPLIT_LAUNCH(0, 4); }
+    if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
+#endif
 #undef SPLIT_LAUNCH
     return false;
 }

@@ -104,6 +104,12 @@ static error_t parse_arg(int key, char *arg, struct argp_state *state) {
         break;
     case 'l': args.limit = atoi(arg); break;
     case 'm':
+#ifdef BUILD_RUNNIE
+        /* runnie has one model (runnie.c:71); its --model option is commented out in the reference (runnie.c:42-60): a
+         * flip-flop model name here must not reach the run-length record formatter */
+        warnx("--model is ignored by runnie (always %s)", flappie_model_string(DEFAULT_MODEL));
+        break;
+#endif
         if (0 == strcasecmp(arg, "help")) { print_models(stdout); exit(EXIT_SUCCESS); }
         args.model = get_flappie_model_type(arg);
         if (FLAPPIE_MODEL_INVALID == args.model || args.model > FLAPPIE_MODEL_INVALID) {
@@ -276,8 +282,17 @@ static void collect_batch(const struct ffhip_model *mdl, pending_batch *pb) {
                 if (!emit) { dwell += 1; continue; }
                 if (last_blk >= 0) {
                     const int base = path[last_blk];
-                    len += snprintf(text + len, cap - len, "%c\t%f\t%f\t%d\n", basechar(base), mat[(size_t)last_blk * P + base],
-                                    mat[(size_t)last_blk * P + nbase + base], dwell);
+                    /* %f of a huge value prints ~47 characters: grow the buffer instead of trusting the 64-per-block estimate
+                     * (snprintf returns the would-be length, so an unchecked `len +=` walks past `cap` after one truncation) */
+                    for (;;) {
+                        const int ret = snprintf(text + len, cap - len, "%c\t%f\t%f\t%d\n", basechar(base), mat[(size_t)last_blk * P + base],
+                                                 mat[(size_t)last_blk * P + nbase + base], dwell);
+                        if (ret >= 0 && (size_t)ret < cap - len) { len += (size_t)ret; break; }
+                        char *bigger = (ret < 0) ? NULL : realloc(text, 2 * cap + (size_t)ret);
+                        if (NULL == bigger) { text[len] = 0; blk = nblock; break; }      /* out of memory: keep what fits */
+                        text = bigger;
+                        cap = 2 * cap + (size_t)ret;
+                    }
                 }
                 last_blk = (int)blk;
                 dwell = 1;

@@ -148,6 +148,7 @@ flappie_matrix residual(const_flappie_matrix X, const_flappie_matrix fX, flappie
     if (NULL == X || NULL == fX) return NULL;
     if (X->nr != fX->nr || X->nc != fX->nc) { warnx("residual: shapes differ"); return NULL; }
     if (C == fX) { residual_inplace(X, C); return C; }
+    if (C == X) { residual_inplace(fX, C); return C; }          /* output aliases the first input: X += fX (the sum is symmetric) */
     C = remake_flappie_matrix(C, X->nr, X->nc);
     if (NULL == C) return NULL;
     memcpy(C->data.f, fX->data.f, fX->stride * fX->nc * sizeof(float));

@@ -77,12 +77,19 @@ mdl_file *mdl_load(const char *path) {
     }
     mdl_file *m = calloc(1, sizeof(*m));
     size_t cap_t = 64, cap_d = 32;
+    if (NULL == m) { warnx("%s: out of memory", path); free(text); return NULL; }
     m->tensor = calloc(cap_t, sizeof(mdl_tensor));
     m->define = calloc(cap_d, sizeof(mdl_define_t));
+    if (NULL == m->tensor || NULL == m->define) goto oom;
     const char *p = text;
     while (*p) {
         if (0 == strncmp(p, "float __", 8)) {                       /* value array */
-            if (m->ntensor == cap_t) { cap_t *= 2; m->tensor = realloc(m->tensor, cap_t * sizeof(mdl_tensor)); }
+            if (m->ntensor == cap_t) {
+                mdl_tensor *bigger = realloc(m->tensor, 2 * cap_t * sizeof(mdl_tensor));
+                if (NULL == bigger) goto oom;
+                m->tensor = bigger;
+                cap_t *= 2;
+            }
             mdl_tensor *t = &m->tensor[m->ntensor];
             memset(t, 0, sizeof(*t));
             const char *q;
@@ -92,17 +99,23 @@ mdl_file *mdl_load(const char *path) {
             q++;
             size_t cap = 1024;
             t->values = malloc(cap * sizeof(float));
+            m->ntensor++;                                           /* (counted now so that mdl_free releases its values on every exit) */
+            if (NULL == t->values) goto oom;
             while (*q && *q != '}') {
                 while (*q && (isspace((unsigned char)*q) || *q == ',')) q++;
                 if (*q == '}' || !*q) break;
                 char *e;
                 const float v = strtof(q, &e);
                 if (e == q) { q++; continue; }
-                if (t->nvalue == cap) { cap *= 2; t->values = realloc(t->values, cap * sizeof(float)); }
+                if (t->nvalue == cap) {
+                    float *bigger = realloc(t->values, 2 * cap * sizeof(float));
+                    if (NULL == bigger) goto oom;
+                    t->values = bigger;
+                    cap *= 2;
+                }
                 t->values[t->nvalue++] = v;
                 q = e;
             }
-            m->ntensor++;
             p = q;
         } else if (0 == strncmp(p, "_Mat _", 6)) {                  /* matrix header */
             char name[MDL_NAME_MAX];
@@ -129,7 +142,12 @@ mdl_file *mdl_load(const char *path) {
         } else if (0 == strncmp(p, "#define", 7)) {
             const char *q = p + 7;
             while (*q == ' ' || *q == '\t') q++;
-            if (m->ndefine == cap_d) { cap_d *= 2; m->define = realloc(m->define, cap_d * sizeof(mdl_define_t)); }
+            if (m->ndefine == cap_d) {
+                mdl_define_t *bigger = realloc(m->define, 2 * cap_d * sizeof(mdl_define_t));
+                if (NULL == bigger) goto oom;
+                m->define = bigger;
+                cap_d *= 2;
+            }
             mdl_define_t *d = &m->define[m->ndefine];
             copy_ident(d->name, sizeof(d->name), q, &q);
             while (*q == ' ' || *q == '\t') q++;
@@ -143,5 +161,19 @@ mdl_file *mdl_load(const char *path) {
         }
     }
     free(text);
+    /* a value array without a consistent `_Mat` header means a truncated or damaged file: fail the load here, with the
+     * tensor's name, rather than later as "model file lacks tensor" */
+    for (size_t i = 0; i < m->ntensor; i++) {
+        if (!m->tensor[i].have_mat) {
+            warnx("%s: tensor %s has %zu values but no matching _Mat header (truncated file?)", path, m->tensor[i].name, m->tensor[i].nvalue);
+            mdl_free(m);
+            return NULL;
+        }
+    }
     return m;
+oom:
+    warnx("%s: out of memory while parsing", path);
+    free(text);
+    mdl_free(m);
+    return NULL;
 }

@@ -91,3 +91,23 @@ def test_flop_count_matches_baseline_formula():
     for H in (256, 384, 512):
         mdl = M.synthetic_model(M.NET_LSTM5, H, seed=1)
         assert mdl.flop_per_block() == 80 * H * H + 688 * H + 3400
+
+
+def test_split_operand_packer_fp16_rounding(tmp_path):
+    """The host half of the split operand format (flappie_amd/csrc/ffhip_split.hpp packs the weights as fp16 slices): its
+    fp32 -> fp16 conversion must round to nearest even exactly as IEEE does (numpy float16), subnormals and overflow included."""
+    import subprocess
+    src = tmp_path / "h.cpp"
+    src.write_text('#include "ffhip_split.hpp"\n#include <cstdio>\nint main() { float f; while (fread(&f, 4, 1, stdin) == 1) {'
+                   ' uint16_t h = ffhip::split_host_f16_rne(f); float b = ffhip::split_host_f16_value(h); fwrite(&h, 2, 1, stdout); fwrite(&b, 4, 1, stdout); } return 0; }\n')
+    exe = str(tmp_path / "h")
+    subprocess.check_call(["g++", "-O2", "-I", os.path.join(ROOT, "flappie_amd", "csrc"), "-o", exe, str(src)])
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(100000) * rng.choice([1e-8, 1e-6, 1e-4, 1, 100, 30000, 70000], 100000),
+                        [0, -0.0, 65504, 65519.9, 65520, 65536, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 2.99e-8, 6.1e-5, 6.0975e-5, np.inf, -np.inf]]).astype(np.float32)
+    out = subprocess.run([exe], input=x.tobytes(), capture_output=True, check=True).stdout
+    rec = np.frombuffer(out, dtype=np.dtype([("h", "<u2"), ("b", "<f4")]))
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16)
+    assert np.array_equal(rec["h"], ref.view(np.uint16))
+    assert np.array_equal(rec["b"], ref.astype(np.float32))

@@ -51,3 +51,55 @@ def test_six_terms_match_fp32_five_do_not():
     fp32 = float(np.abs(W @ X - exact).max())
     assert six <= fp32                                         # products do not round; the accumulation is fp32 either way
     assert six < 3e-6 and five > 3 * six and three > 10 * six and one > 1e-3
+
+
+# ---- the default operand format: two fp16 slices of the operand scaled into fp16's range (ffhip_split.hpp) -------------------
+def split_f16(x, exp2):
+    v = np.asarray(x, dtype=np.float32) * np.float32(2.0 ** exp2)
+    a = v.astype(np.float16).astype(np.float32)
+    b = (v - a).astype(np.float16).astype(np.float32)
+    return a, b
+
+
+def test_two_fp16_slices_hold_22_bits():
+    rng = np.random.default_rng(2)
+    x = np.concatenate([np.tanh(rng.standard_normal(200000)), rng.uniform(-1, 1, 100000) * 1e-3, rng.uniform(-1, 1, 100000) * 1e-6]).astype(np.float32)
+    a, b = split_f16(x, 12)
+    back = (a.astype(np.float64) + b.astype(np.float64)) / 4096.0
+    err = np.abs(back - x.astype(np.float64))
+    assert np.all(err <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -37))
+    assert np.all(np.abs(a) <= 4096.0)                          # in fp16's range with room to spare
+
+
+def test_three_fp16_products_are_as_good_as_an_fp32_gemm():
+    """the three products the default kernels keep (w0 x0, w0 x1, w1 x0): error against float64 at the level of a plain fp32 GEMM
+    and of the reference's sequential fp32 dot product; the fourth product (w1 x1) buys nothing; one product alone is useless"""
+    rng = np.random.default_rng(1)
+    K, M, N = 768, 512, 16
+    worst = 0.0
+    for trial in range(3):
+        W = (rng.uniform(-1, 1, (M, K)) * 3 / np.sqrt(K)).astype(np.float32)
+        X = np.tanh(rng.standard_normal((K, N))).astype(np.float32)
+        if trial == 1:
+            X = (X * rng.choice([1, 1e-2, 1e-4], (K, N))).astype(np.float32)      # small activations: second slices in fp16's subnormal range
+        exact = W.astype(np.float64) @ X.astype(np.float64)
+        sw = int(np.floor(np.log2(32768 / np.abs(W).max())))
+        w, x = split_f16(W, sw), split_f16(X, 12)
+
+        def err(pairs):
+            acc = np.zeros((M, N), dtype=np.float32)
+            for i, j in pairs:
+                acc = acc + (w[i] @ x[j])
+            return float(np.abs(acc.astype(np.float64) / 2.0 ** (sw + 12) - exact).max())
+        three = err([(1, 0), (0, 1), (0, 0)])
+        four = err([(1, 1), (1, 0), (0, 1), (0, 0)])
+        one = err([(0, 0)])
+        fp32 = float(np.abs(W @ X - exact).max())
+        seq = np.zeros((64, N), dtype=np.float32)                # the reference's order: term by term
+        for k in range(K):
+            seq = seq + W[:64, k:k + 1] * X[k:k + 1, :]
+        seq_err = float(np.abs(seq - exact[:64]).max())
+        assert three <= 1.25 * max(fp32, seq_err), (trial, three, fp32, seq_err)
+        assert four >= 0.8 * three and one > 100 * three
+        worst = max(worst, three)
+    assert worst < 3e-6
