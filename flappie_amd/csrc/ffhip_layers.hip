@@ -747,3 +747,164 @@ extern "C" int ffhip_op_runlength_partition_function_v1(ffhip_engine *eng, ffhip
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------ the other flip-flop decoders of decode.h
+// argmax_decoder (decode.c:17-36), constrained_crf_flipflop (:209-270) and posterior_crf_flipflop (:275-372): entry points of
+// decode.h that flappie.c never calls (its path is transpost_crf_flipflop + decode_crf_flipflop).  They are here so that a
+// caller of the whole header links and gets the reference's results; one wave per call, the recursions in the
+// reference's order -- correctness-level operators, not throughput paths.
+namespace {
+
+// argmaxf (util.c:17-34): first maximum, a NaN is never greater
+__global__ void __launch_bounds__(256)
+k_argmax_cols(const float *__restrict__ X, size_t stride, int nr, int nc, int *__restrict__ seq, float *__restrict__ val) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const float *x = X + (size_t)c * stride;
+    int imax = 0;
+    float vmax = x[0];
+    for (int i = 1; i < nr; i++) if (x[i] > vmax) { vmax = x[i]; imax = i; }
+    seq[c] = (imax == nr - 1) ? -1 : imax;              // decode.c:32: the last state is the blank
+    val[c] = vmax;
+}
+// the reference adds the block maxima one by one in block order (decode.c:31): a float sum, so the order is the result
+__global__ void k_sum_in_order(const float *__restrict__ v, int n, float *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.0f;
+    for (int i = 0; i < n; i++) acc += v[i];
+    out[0] = acc;
+}
+
+// constrained_crf_flipflop (decode.c:209-270): Viterbi over per-state posteriors with the flip-flop transition constraint.
+// One wave, lane st < nstate holds prev[st].  Flop b2 comes from itself if prev[b2] > prev[b2 - nbase], else from the flip of
+// its base (:239-243); every flip comes from the best state of all (argmaxf: first maximum, :246-250).
+__global__ void __launch_bounds__(64)
+k_constrained_flipflop(const float *__restrict__ post, size_t stride, int nstate, int nblk, int *__restrict__ tb /*[nblk][16]*/,
+                       int *__restrict__ path, float *__restrict__ score) {
+    const int lane = threadIdx.x, nbase = nstate / 2;
+    const bool on = lane < nstate;
+    float prev = 0.0f;                                  // calloc'ed (:219)
+    for (int blk = 0; blk < nblk; blk++) {
+        int best = 0;
+        float vbest = __shfl(prev, 0);
+        for (int st = 1; st < nstate; st++) {
+            const float v = __shfl(prev, st);
+            if (v > vbest) { vbest = v; best = st; }
+        }
+        const float flip_of_base = __shfl(prev, lane >= nbase ? lane - nbase : lane);
+        int from;
+        float cur;
+        if (lane >= nbase) { from = (prev > flip_of_base) ? lane : lane - nbase; cur = (prev > flip_of_base) ? prev : flip_of_base; }
+        else { from = best; cur = vbest; }
+        if (on) {
+            tb[(size_t)blk * 16 + lane] = from;
+            cur += post[(size_t)blk * stride + lane];
+        }
+        prev = cur;
+    }
+    // :256-262 valmaxf / argmaxf over the final vector, then the traceback
+    int last = 0;
+    float vlast = __shfl(prev, 0);
+    for (int st = 1; st < nstate; st++) {
+        const float v = __shfl(prev, st);
+        if (v > vlast) { vlast = v; last = st; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        score[0] = vlast;
+        path[nblk] = last;
+        for (int blk = nblk; blk > 0; blk--) path[blk - 1] = tb[(size_t)(blk - 1) * 16 + path[blk]];
+    }
+}
+
+// posterior_crf_flipflop (decode.c:275-372): per-STATE log posteriors [nstate x nblk+1] = forward + backward, every
+// log-sum-exp chain in the reference's order (flip: over from-states ascending; backward: flop terms first, then the flips
+// ascending).  One wave; lane st owns state st in both passes.
+__global__ void __launch_bounds__(64)
+k_posterior_flipflop(const float *__restrict__ trans, size_t tstride, int nbase, int nblk, float *__restrict__ fwd, size_t fstride) {
+    const int lane = threadIdx.x, nstate = 2 * nbase, off = nstate * nbase;
+    const bool on = lane < nstate;
+    __shared__ float pv[16];
+    if (lane < 16) pv[lane] = 0.0f;                     // make_flappie_matrix zero-fills column 0
+    if (on) fwd[lane] = 0.0f;
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk++) {              // forwards, :288-315
+        const float *t = trans + (size_t)blk * tstride;
+        float cur = 0.0f;
+        if (on) {
+            if (lane >= nbase) {
+                cur = pv[lane] + t[off + lane];                                           // stay in flop
+                cur = logsumexpf_ref(cur, pv[lane - nbase] + t[off + lane - nbase]);      // flip -> flop
+            } else {
+                cur = t[lane * nstate] + pv[0];
+                for (int from = 1; from < nstate; from++) cur = logsumexpf_ref(cur, t[lane * nstate + from] + pv[from]);
+            }
+        }
+        __syncthreads();
+        if (on) { pv[lane] = cur; fwd[(size_t)(blk + 1) * fstride + lane] = cur; }
+        __syncthreads();
+    }
+    if (lane < 16) pv[lane] = 0.0f;                     // backwards from zeros (calloc, :317)
+    __syncthreads();
+    for (int blk = nblk; blk > 0; blk--) {              // :326-366
+        const float *t = trans + (size_t)(blk - 1) * tstride;
+        float cur = 0.0f;
+        if (on) {
+            // :339-345  source lane: a flop state stays, a flip state moves to the flop of its base
+            cur = (lane >= nbase) ? pv[lane] + t[off + lane] : pv[lane + nbase] + t[off + lane];
+            for (int b1 = 0; b1 < nbase; b1++) cur = logsumexpf_ref(cur, t[b1 * nstate + lane] + pv[b1]);      // :348-356
+        }
+        __syncthreads();
+        if (on) { pv[lane] = cur; fwd[(size_t)(blk - 1) * fstride + lane] += cur; }      // :358-361
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// argmax_decoder (decode.c:17-36): seq[nc] (index of the column maximum, -1 for the last row), *score = sum of the maxima
+extern "C" int ffhip_op_argmax_decoder(ffhip_engine *eng, ffhip_mat logpost, int *seq, float *score) {
+    OP_ENTER(eng);
+    if (!view_ok(logpost) || !seq || !score) return set_err(FFHIP_EINVAL, "bad argmax_decoder arguments");
+    const int nc = (int)logpost.nc;
+    float *d = upload_img(tmp, logpost, s), *d_v = (float *)tmp.get((size_t)nc * 4), *d_s = (float *)tmp.get(4);
+    int *d_q = (int *)tmp.get((size_t)nc * 4);
+    if (!d || !d_v || !d_s || !d_q) OP_NOMEM();
+    hipLaunchKernelGGL(k_argmax_cols, dim3((nc + 255) / 256), dim3(256), 0, s, d, logpost.stride, (int)logpost.nr, nc, d_q, d_v);
+    hipLaunchKernelGGL(k_sum_in_order, dim3(1), dim3(64), 0, s, d_v, nc, d_s);
+    HIP_TRY(hipMemcpyAsync(seq, d_q, (size_t)nc * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(score, d_s, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// constrained_crf_flipflop (decode.c:209-270): post [nstate x nblk] per-state scores; path[nblk + 1]
+extern "C" int ffhip_op_constrained_flipflop(ffhip_engine *eng, ffhip_mat post, int *path, float *score) {
+    OP_ENTER(eng);
+    if (!view_ok(post) || !path || !score || post.nr % 2 != 0 || post.nr > 16) return set_err(FFHIP_EINVAL, "bad constrained_crf_flipflop arguments");
+    const size_t nblk = post.nc;
+    float *d = upload_img(tmp, post, s), *d_s = (float *)tmp.get(4);
+    int *d_tb = (int *)tmp.get(nblk * 16 * 4), *d_p = (int *)tmp.get((nblk + 1) * 4);
+    if (!d || !d_s || !d_tb || !d_p) OP_NOMEM();
+    hipLaunchKernelGGL(k_constrained_flipflop, dim3(1), dim3(64), 0, s, d, post.stride, (int)post.nr, (int)nblk, d_tb, d_p, d_s);
+    HIP_TRY(hipMemcpyAsync(path, d_p, (nblk + 1) * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(score, d_s, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// posterior_crf_flipflop (decode.c:275-372), log space: out is [nstate x nblk + 1] (column stride out.stride)
+extern "C" int ffhip_op_posterior_flipflop(ffhip_engine *eng, ffhip_mat trans, ffhip_mat out) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!view_ok(trans) || !view_ok(out) || !flipflop_dims(trans.nr, trans.stride, &nbase) || out.nr != (size_t)(2 * nbase) || out.nc != trans.nc + 1)
+        return set_err(FFHIP_EINVAL, "bad posterior_crf_flipflop arguments");
+    const size_t n = out.nc * out.stride;
+    float *d = upload_img(tmp, trans, s), *d_o = (float *)tmp.get(n * 4);
+    if (!d || !d_o) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, n * 4, s), FFHIP_EHIP);
+    hipLaunchKernelGGL(k_posterior_flipflop, dim3(1), dim3(64), 0, s, d, trans.stride, nbase, (int)trans.nc, d_o, out.stride);
+    HIP_TRY(hipMemcpyAsync(out.data, d_o, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}

@@ -9,6 +9,21 @@
 #include "../../include/networks.h"
 #include "../../include/ffhip.h"
 
+static ffhip_mat mview(const_flappie_matrix m) {
+    ffhip_mat v = { m->data.f, m->nr, m->nc, m->stride };
+    return v;
+}
+
+/* decode.c:17-36 */
+float argmax_decoder(const_flappie_matrix logpost, int *seq) {
+    if (NULL == logpost || NULL == seq) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    float score = NAN;
+    if (NULL == eng) return NAN;
+    if (0 != ffhip_op_argmax_decoder(eng, mview(logpost), seq, &score)) { warnx("%s: %s", __func__, ffhip_last_error()); return NAN; }
+    return score;
+}
+
 /* decode.c:39-63 */
 char *collapse_repeats(int const *path, size_t npos, int modbase) {
     if (NULL == path || modbase <= 0 || 0 == npos) return NULL;
@@ -46,6 +61,32 @@ float decode_crf_flipflop(const_flappie_matrix trans, bool combine_stays, int *p
     return score;
 }
 
+/* decode.c:209-270 */
+float constrained_crf_flipflop(const_flappie_matrix post, int *path) {
+    if (NULL == post || NULL == path) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    float score = NAN;
+    if (NULL == eng) return NAN;
+    if (0 != ffhip_op_constrained_flipflop(eng, mview(post), path, &score)) { warnx("%s: %s", __func__, ffhip_last_error()); return NAN; }
+    return score;
+}
+
+/* decode.c:275-372 */
+flappie_matrix posterior_crf_flipflop(const_flappie_matrix trans, bool return_log) {
+    if (NULL == trans) return NULL;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    const size_t nbase = nbase_from_flipflop_nparam(trans->nr);
+    flappie_matrix fwd = make_flappie_matrix(2 * nbase, trans->nc + 1);
+    if (NULL == fwd) return NULL;
+    if (0 != ffhip_op_posterior_flipflop(eng, mview(trans), mview(fwd))) { warnx("%s: %s", __func__, ffhip_last_error()); return free_flappie_matrix(fwd); }
+    if (!return_log) {                                   /* :365-368 */
+        exp_activation_inplace(fwd);
+        row_normalise_inplace(fwd);
+    }
+    return fwd;
+}
+
 /* decode.c:377-497 */
 flappie_matrix transpost_crf_flipflop(const_flappie_matrix trans, bool return_log) {
     if (NULL == trans) return NULL;
@@ -79,10 +120,6 @@ flappie_imatrix trace_from_posterior(flappie_matrix tpost) {
 }
 
 /* ---- run-length decoders (decode.c:927-1159) ---- */
-static ffhip_mat mview(const_flappie_matrix m) {
-    ffhip_mat v = { m->data.f, m->nr, m->nc, m->stride };
-    return v;
-}
 
 float decode_crf_runlength(const_flappie_matrix param, int *path) {
     if (NULL == param || NULL == path) return NAN;

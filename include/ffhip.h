@@ -169,6 +169,14 @@ int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t npar
  * batched pipeline runs. */
 typedef struct { float *data; size_t nr, nc, stride; } ffhip_mat;
 
+/* the flip-flop decoders of decode.h that flappie.c does not use (one wave per call, reference order):
+ * argmax_decoder (decode.c:17-36): seq[nc] = row of the column maximum (-1 for the last row), *score = their sum in block order */
+int ffhip_op_argmax_decoder(ffhip_engine *eng, ffhip_mat logpost, int *seq, float *score);
+/* constrained_crf_flipflop (decode.c:209-270): post [nstate x nblock] per-state scores, path[nblock+1] */
+int ffhip_op_constrained_flipflop(ffhip_engine *eng, ffhip_mat post, int *path, float *score);
+/* posterior_crf_flipflop (decode.c:275-372) in log space: out [nstate x nblock+1] per-state forward + backward */
+int ffhip_op_posterior_flipflop(ffhip_engine *eng, ffhip_mat trans, ffhip_mat out);
+
 enum ffhip_activation {
     FFHIP_ACT_NONE = 0,
     FFHIP_ACT_SWISH = 1,        /* swish_activation_inplace, layers.c:24-33    */

@@ -86,6 +86,9 @@ def test_posterior_and_trace_tolerances_with_hit_rates(host, nbase):
         for nblock in (3, 800, 2000):
             for style in ("tanh5", "normal", "ties"):
                 dense = _scores(rng, nparam, nblock, style)
+                # globally normalised, as globalnorm_flipflop hands them over (layers.c:1089-1096): without that the forward
+                # values grow like nblock * mean score and fp32 cannot hold posteriors to 1e-5 for anybody
+                dense = (dense - np.float32(L.fo_partition_function(ffo.HostMat.from_dense(dense).ptr) / nblock)).astype(np.float32)
                 m = host.mat_from_array(_f(np.ascontiguousarray(dense)), nparam, nblock)
                 hm = ffo.HostMat.from_dense(dense)
                 post = host.transpost_crf_flipflop(m, True)
@@ -145,3 +148,74 @@ def test_constant_signal_read_in_a_batch(engine):
     finally:
         b.close()
         dm.close()
+
+
+def _decref():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "oracle", "_ref", "libflappie_decref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libflappie_decref.so not built (reference sources absent where build() ran)")
+    from oracle import ffo
+    R = C.CDLL(path)
+    M_ = P(ffo.FoMat)
+    R.argmax_decoder.restype = C.c_float
+    R.argmax_decoder.argtypes = [M_, P(C.c_int)]
+    R.constrained_crf_flipflop.restype = C.c_float
+    R.constrained_crf_flipflop.argtypes = [M_, P(C.c_int)]
+    R.posterior_crf_flipflop.restype = M_
+    R.posterior_crf_flipflop.argtypes = [M_, C.c_bool]
+    R.free_flappie_matrix.restype = M_
+    R.free_flappie_matrix.argtypes = [M_]
+    return R
+
+
+@pytest.mark.parametrize("nbase", [4, 5])
+def test_other_flipflop_decoders_against_the_compiled_reference(host, nbase):
+    """argmax_decoder (decode.c:17-36), constrained_crf_flipflop (:209-270), posterior_crf_flipflop (:275-372) -- the entry points of
+    decode.h outside flappie.c's path -- against the REFERENCE's own decode.c object code (oracle/_ref/libflappie_decref.so):
+    integer paths equal, the argmax score (a sum in block order) equal to the bit, log-sum-exp results within 2e-5 + 2e-6 |x|."""
+    from oracle import ffo
+    R = _decref()
+    host.argmax_decoder.restype = C.c_float
+    host.argmax_decoder.argtypes = [P(CMat), P(C.c_int)]
+    host.constrained_crf_flipflop.restype = C.c_float
+    host.constrained_crf_flipflop.argtypes = [P(CMat), P(C.c_int)]
+    host.posterior_crf_flipflop.restype = P(CMat)
+    host.posterior_crf_flipflop.argtypes = [P(CMat), C.c_bool]
+    L = ffo.lib()
+    nstate, nparam = 2 * nbase, 2 * nbase * (nbase + 1)
+    rng = np.random.default_rng(17 + nbase)
+    try:
+        for nblock in (1, 5, 800):
+            for style in ("normal", "ties", "tanh5"):
+                # per-state scores [nstate x nblock]: argmax decoder and constrained Viterbi
+                st = _scores(rng, nstate, nblock, style)
+                m = host.mat_from_array(_f(np.ascontiguousarray(st)), nstate, nblock)
+                hm = ffo.HostMat.from_dense(st)
+                sa, sb = np.zeros(nblock, np.int32), np.zeros(nblock, np.int32)
+                va = host.argmax_decoder(m, sa.ctypes.data_as(P(C.c_int)))
+                vb = R.argmax_decoder(hm.ptr, sb.ctypes.data_as(P(C.c_int)))
+                assert np.array_equal(sa, sb) and _same_bits(np.float32([va]), np.float32([vb])), (style, nblock)
+                pa, pb = np.zeros(nblock + 1, np.int32), np.zeros(nblock + 1, np.int32)
+                va = host.constrained_crf_flipflop(m, pa.ctypes.data_as(P(C.c_int)))
+                vb = R.constrained_crf_flipflop(hm.ptr, pb.ctypes.data_as(P(C.c_int)))
+                assert np.array_equal(pa, pb), (style, nblock)
+                assert _same_bits(np.float32([va]), np.float32([vb])), (style, nblock, va, vb)
+                host.free_flappie_matrix(m)
+                # transition scores [nparam x nblock], globally normalised: per-state posteriors
+                tr = _scores(rng, nparam, nblock, style)
+                tr = (tr - np.float32(L.fo_partition_function(ffo.HostMat.from_dense(tr).ptr) / nblock)).astype(np.float32)
+                m = host.mat_from_array(_f(np.ascontiguousarray(tr)), nparam, nblock)
+                hm = ffo.HostMat.from_dense(tr)
+                for return_log in (True, False):
+                    a = host.posterior_crf_flipflop(m, return_log)
+                    b = R.posterior_crf_flipflop(hm.ptr, return_log)
+                    A, Bm = _dense(a), ffo.take(b, free=False)
+                    assert A.shape == Bm.shape == (nblock + 1, nstate)
+                    assert np.all(np.abs(A - Bm) <= 2e-5 + 2e-6 * np.abs(Bm)), (style, nblock, return_log, float(np.abs(A - Bm).max()))
+                    host.free_flappie_matrix(a)
+                    R.free_flappie_matrix(b)
+                host.free_flappie_matrix(m)
+    finally:
+        host.flappie_hip_shutdown()
