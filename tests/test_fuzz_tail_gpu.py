@@ -1,0 +1,90 @@
+"""The tail of the GPU <-> oracle deviation, as a test the driver runs ("weak" 2).
+
+north_star asks for transition scores within 1e-4 of the reference.  On every model the rest of the suite uses the worst case
+is ~6e-5; the randomised differential test (tools/dev/diff_fuzz.py, seeds 1 and 5) found reads where BOTH GPU paths deviate
+more -- all on one random LSTM5 model (H = 256, synthetic_model(seed=102)), an untrained and barely contractive recurrence
+through which rounding differences of 1e-7 grow over 5 layers x 500 steps.  tests/golden/fuzz_tail.npz holds those reads
+(tests/golden/make_fuzz_tail.py).  This test re-runs them and
+
+  * asserts the DOCUMENTED bound for them: max |dtrans| <= 3.0e-4 against the oracle for the default
+    split-precision path and for the f32-MFMA path;
+  * reports who is off: the oracle with a double accumulator for every dot product (ff_oracle.c dot mode 1 -- the float32
+    network without summation error) is the yardstick; GPU <-> yardstick and oracle <-> yardstick are printed side by side,
+    and the GPU must not be further from it than 1.5x the reference-order oracle is;
+  * counts what the tolerances of the suite let through on these reads: base / quality strings that differ from the
+    oracle's, and the fraction of trace cells off by one count.
+
+Run with -rP (or -s) to see the report."""
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _oracle_job(job):
+    kind, hidden, seed, signal, mode = job
+    from oracle import ffo
+    mdl = M.synthetic_model(kind, hidden, seed=seed)
+    om = ffo.OracleModel(mdl)
+    with ffo.dot_mode(mode):
+        r = om.basecall(signal)
+    return dict(trans=r["trans"], basecall=r["basecall"], quality=r["quality"], trace=r["trace"], path=r["path"])
+
+
+def test_fuzz_tail_reads_stay_within_the_documented_bound(engine):
+    from flappie_amd import binding as B
+    g = np.load(os.path.join(HERE, "golden", "fuzz_tail.npz"))
+    n = int(g["n"])
+    assert n >= 6
+    reads = [(int(g["kind%d" % i]), int(g["hidden%d" % i]), int(g["model_seed%d" % i]), g["signal%d" % i]) for i in range(n)]
+    assert len({r[:3] for r in reads}) == 1          # one model: LSTM5 H = 256 seed 102
+    kind, hidden, seed = reads[0][:3]
+    jobs = [(kind, hidden, seed, r[3], mode) for r in reads for mode in (0, 1)]
+    with ProcessPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:      # ~1 s per read and mode, in parallel
+        res = list(pool.map(_oracle_job, jobs))
+    oracle, yard = res[0::2], res[1::2]
+
+    mdl = M.synthetic_model(kind, hidden, seed=seed)
+    dm = B.DeviceModel(engine, mdl)
+    cap = max(r[3].size for r in reads)
+    out = {}
+    try:
+        for name, flags in (("split", 0), ("f32", B.RUN_F32_RNN)):
+            b = B.Batch(dm, n, cap)
+            b.set_signals_ragged([r[3] for r in reads])
+            b.run(1.0, flags)
+            b.finish()
+            out[name] = [dict(trans=b.transitions(i), basecall=b.basecall(i), quality=b.quality(i), trace=b.trace(i), path=b.path(i)[0]) for i in range(n)]
+            b.close()
+    finally:
+        dm.close()
+
+    def dmax(a, c):
+        return max(float(np.abs(x["trans"].astype(np.float64) - y["trans"]).max()) for x, y in zip(a, c))
+
+    rows = []
+    for name in ("split", "f32"):
+        gpu = out[name]
+        nbase = sum(x["basecall"] != y["basecall"] for x, y in zip(gpu, oracle))
+        nqual = sum(x["quality"] != y["quality"] for x, y in zip(gpu, oracle))
+        npath = sum(not np.array_equal(x["path"], y["path"]) for x, y in zip(gpu, oracle))
+        cells = sum(x["trace"].size for x in gpu)
+        off1 = sum(int((np.abs(x["trace"] - y["trace"]) == 1).sum()) for x, y in zip(gpu, oracle))
+        offn = sum(int((np.abs(x["trace"] - y["trace"]) > 1).sum()) for x, y in zip(gpu, oracle))
+        rows.append((name, dmax(gpu, oracle), dmax(gpu, yard), nbase, nqual, npath, off1, offn, cells))
+    d_oy = dmax(oracle, yard)
+    print("fuzz tail, %d reads of LSTM5 H = %d seed %d (max |dtrans| over all scores):" % (n, hidden, seed))
+    print("  oracle (reference-order float sums)  <-> yardstick (double accumulators): %.2e" % d_oy)
+    for name, d_go, d_gy, nbase, nqual, npath, off1, offn, cells in rows:
+        print("  GPU %-5s <-> oracle %.2e   <-> yardstick %.2e   reads with a different base string %d, quality string %d, Viterbi path %d (of %d);"
+              " trace cells off by one %d, by more %d, of %d (%.4f %%)" % (name, d_go, d_gy, nbase, nqual, npath, n, off1, offn, cells, 100.0 * off1 / cells))
+    for name, d_go, d_gy, nbase, nqual, npath, off1, offn, cells in rows:
+        assert d_go <= 3.0e-4, (name, d_go)                       # the documented bound on these reads (1e-4 holds on every other model of the suite)
+        assert d_gy <= max(1.5 * d_oy, 1.0e-4), (name, d_gy, d_oy)   # the GPU is no further from the float32 network proper than the reference-order sums are
+        assert offn == 0
