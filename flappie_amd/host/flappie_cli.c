@@ -20,6 +20,11 @@
 #include <string.h>
 #include <time.h>
 #include <strings.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "../../include/decode.h"
 #include "../../include/fast5_interface.h"
@@ -59,6 +64,8 @@ static struct argp_option options[] = {
     {"uuid", 14, 0, 0, "Output UUID"},
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default 256)"},
+    {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
+    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 4; 0 reads in this process)"},
     {0}
 };
 
@@ -87,7 +94,9 @@ static struct {
     char **files;
     bool uuid;
     int batch;
-} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 256 };
+    int readers;
+    int shard, nshard;
+} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 256, 4, 0, 0 };      /* nshard 0: --shard not given */
 
 static void print_models(FILE *fh) {
     for (int mdl = 0; mdl < (int)flappie_nmodel; mdl++)
@@ -168,6 +177,14 @@ static error_t parse_arg(int key, char *arg, struct argp_state *state) {
     case 16:
         args.batch = atoi(arg);
         if (args.batch <= 0) errx(EXIT_FAILURE, "--batch must be positive");
+        break;
+    case 17:
+        args.readers = atoi(arg);
+        if (args.readers < 0 || args.readers > 64) errx(EXIT_FAILURE, "--readers must be between 0 and 64");
+        break;
+    case 18:
+        if (2 != sscanf(arg, "%d/%d", &args.shard, &args.nshard) || args.nshard < 1 || args.shard < 0 || args.shard >= args.nshard)
+            errx(EXIT_FAILURE, "--shard takes g/n with 0 <= g < n");
         break;
     case ARGP_KEY_NO_ARGS: argp_usage(state); break;
     case ARGP_KEY_ARG:
@@ -436,8 +453,10 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
 /* ---- input side: the list of files (flappie.c:336-358), read one chunk ahead of the GPU by a reader thread ---- */
 typedef struct { char **path; size_t n, cap; } file_list;
 
+static int by_path(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
+
 static void list_files(file_list *fl) {
-    const int reads_limit = args.limit;
+    const int reads_limit = (args.nshard >= 1) ? 0 : args.limit;      /* a shard is cut from the whole list, then limited */
     for (int fn = 0; args.files && args.files[fn]; fn++) {
         if (reads_limit > 0 && (int)fl->n >= reads_limit) break;
         glob_t globbuf;
@@ -461,6 +480,16 @@ static void list_files(file_list *fl) {
         }
         globfree(&globbuf);
     }
+    if (args.nshard >= 1) {
+        /* every process of a sharded run must see the same order: sort, keep every n-th file starting at g */
+        qsort(fl->path, fl->n, sizeof(char *), by_path);
+        size_t kept = 0;
+        for (size_t f = 0; f < fl->n; f++) {
+            if ((int)(f % (size_t)args.nshard) == args.shard && (args.limit <= 0 || (int)kept < args.limit)) fl->path[kept++] = fl->path[f];
+            else free(fl->path[f]);
+        }
+        fl->n = kept;
+    }
 }
 
 typedef struct {
@@ -471,6 +500,99 @@ typedef struct {
     sem_t filled[2], empty[2];
 } reader_state;
 
+/* ---- reader PROCESSES.  Opening and reading a single-read fast5 costs ~0.1-0.15 ms of CPU in libhdf5 (~6800 files/s on one
+ * core), this libhdf5 is not thread-safe, and one MI355X consumes 15-20 000 reads of 4000 samples per second: one reader
+ * thread caps the binary at less than half of what the kernels deliver.  So the files are read by `--readers` child
+ * processes, forked BEFORE the HIP runtime starts (a fork of a process with a live GPU context is not supported): child k
+ * reads files k, k + R, k + 2R ... in order (read_raw, fast5_interface.c:231-318, with the pA scaling of flappie.c:248) and
+ * streams {nsample, uuid, samples} records down its own pipe; the parent's reader thread takes file f from pipe f % R, so
+ * the input order is kept.  Children run ahead by what a pipe holds (1 MiB: ~50 reads each). */
+typedef struct { pid_t pid; int fd; } reader_proc;
+static reader_proc *rprocs = NULL;
+static int nrproc = 0;
+
+static int write_all(int fd, const void *buf, size_t n) {
+    const char *p = buf;
+    while (n > 0) {
+        const ssize_t w = write(fd, p, n);
+        if (w < 0) { if (EINTR == errno) continue; return -1; }
+        p += w; n -= (size_t)w;
+    }
+    return 0;
+}
+static int read_all(int fd, void *buf, size_t n) {
+    char *p = buf;
+    while (n > 0) {
+        const ssize_t r = read(fd, p, n);
+        if (r < 0) { if (EINTR == errno) continue; return -1; }
+        if (0 == r) return -1;
+        p += r; n -= (size_t)r;
+    }
+    return 0;
+}
+
+static void reader_child(const file_list *fl, int k, int R, int fd) {
+    for (size_t f = (size_t)k; f < fl->n; f += (size_t)R) {
+        raw_table rt = read_raw(fl->path[f], true);
+        uint64_t hdr[2] = { (NULL != rt.raw) ? (uint64_t)rt.n : 0, (NULL != rt.uuid && NULL != rt.raw) ? (uint64_t)strlen(rt.uuid) : 0 };
+        if (0 != write_all(fd, hdr, sizeof(hdr)) || (hdr[1] && 0 != write_all(fd, rt.uuid, hdr[1])) ||
+            (hdr[0] && 0 != write_all(fd, rt.raw, hdr[0] * sizeof(float)))) _exit(1);      /* the parent went away */
+        free(rt.raw);
+        free(rt.uuid);
+    }
+    _exit(0);
+}
+
+static void start_reader_procs(const file_list *fl, int R) {
+    if (R <= 0 || 0 == fl->n) return;
+    if ((size_t)R > fl->n) R = (int)fl->n;
+    rprocs = calloc((size_t)R, sizeof(reader_proc));
+    fflush(NULL);
+    for (int k = 0; k < R; k++) {
+        int pfd[2];
+        if (0 != pipe(pfd)) errx(EXIT_FAILURE, "could not create a pipe for reader %d", k);
+        const pid_t pid = fork();
+        if (pid < 0) errx(EXIT_FAILURE, "could not fork reader %d", k);
+        if (0 == pid) {
+            close(pfd[0]);
+            for (int j = 0; j < k; j++) close(rprocs[j].fd);
+            reader_child(fl, k, R, pfd[1]);
+        }
+        close(pfd[1]);
+#ifdef F_SETPIPE_SZ
+        (void)fcntl(pfd[0], F_SETPIPE_SZ, 1 << 20);
+#endif
+        rprocs[k].pid = pid;
+        rprocs[k].fd = pfd[0];
+        nrproc = k + 1;
+    }
+}
+
+static raw_table read_from_proc(size_t f) {
+    raw_table rt = { NULL, 0, 0, 0, NULL };
+    const int fd = rprocs[f % (size_t)nrproc].fd;
+    uint64_t hdr[2];
+    if (0 != read_all(fd, hdr, sizeof(hdr))) { warnx("reader process %zu ended early", f % (size_t)nrproc); return rt; }
+    char *uuid = hdr[1] ? calloc(hdr[1] + 1, 1) : NULL;
+    if (hdr[1] && (NULL == uuid || 0 != read_all(fd, uuid, hdr[1]))) { free(uuid); return rt; }
+    if (0 == hdr[0]) { free(uuid); return rt; }                        /* the child could not read the file (it said why) */
+    float *raw = malloc(hdr[0] * sizeof(float));
+    if (NULL == raw || 0 != read_all(fd, raw, hdr[0] * sizeof(float))) { free(raw); free(uuid); return rt; }
+    rt = (raw_table){ uuid, hdr[0], 0, hdr[0], raw };
+    return rt;
+}
+
+static void stop_reader_procs(void) {
+    for (int k = 0; k < nrproc; k++) {
+        close(rprocs[k].fd);
+        int st = 0;
+        (void)waitpid(rprocs[k].pid, &st, 0);
+    }
+    free(rprocs);
+    rprocs = NULL;
+    nrproc = 0;
+}
+
 static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *items, int *nitem) {
     int n = 0;
     for (size_t f = first; f < fl->n && n < chunk_cap; f++, n++) {
@@ -478,9 +600,13 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
         memset(it, 0, sizeof(*it));
         it->filename = fl->path[f];                                   /* ownership moves to the item */
         const double tr0 = now_s();
-        pthread_mutex_lock(&hdf5_lock);
-        it->res.rt = read_raw(it->filename, true);                    /* flappie.c:248 */
-        pthread_mutex_unlock(&hdf5_lock);
+        if (nrproc > 0) {
+            it->res.rt = read_from_proc(f);
+        } else {
+            pthread_mutex_lock(&hdf5_lock);
+            it->res.rt = read_raw(it->filename, true);                /* flappie.c:248 */
+            pthread_mutex_unlock(&hdf5_lock);
+        }
         t_phase[0] += now_s() - tr0;
     }
     *nitem = n;
@@ -502,15 +628,16 @@ static void *reader_main(void *arg) {
 int main(int argc, char *argv[]) {
     argp_parse(&argp, argc, argv, 0, 0, NULL);
     if (NULL == args.output) args.output = stdout;
-    const struct ffhip_model *mdl = flappie_hip_model(args.model);
-    if (NULL == mdl) errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model));
-    struct ffhip_engine *eng = flappie_hip_engine();
-    hid_t hdf5out = open_or_create_hdf5(args.trace);
-
     const double t_start = now_s();
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
     const double t_listed = now_s();
+    signal(SIGPIPE, SIG_IGN);
+    start_reader_procs(&fl, getenv("FLAPPIE_NO_READER_THREAD") ? 0 : args.readers);      /* before the HIP runtime and libhdf5 are touched here */
+    const struct ffhip_model *mdl = flappie_hip_model(args.model);
+    if (NULL == mdl) { stop_reader_procs(); errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model)); }
+    struct ffhip_engine *eng = flappie_hip_engine();
+    hid_t hdf5out = open_or_create_hdf5(args.trace);
     reader_state rs;
     memset(&rs, 0, sizeof(rs));
     rs.fl = &fl;
@@ -535,6 +662,7 @@ int main(int argc, char *argv[]) {
         if (threaded) sem_post(&rs.empty[k]);
     }
     if (threaded) pthread_join(reader, NULL);
+    stop_reader_procs();
     for (int k = 0; k < 2; k++) free(rs.items[k]);
     free(fl.path);
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }

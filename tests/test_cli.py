@@ -328,3 +328,51 @@ def test_runnie_records_match_oracle(tmp_path):
             assert sum(int(g[3]) for g in got) <= ref["param"].shape[0]
             for g, rec in zip(got, ref["records"]):
                 assert abs(float(g[1]) - rec[1]) <= 2e-4 and abs(float(g[2]) - rec[2]) <= 2e-4
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_reader_processes_and_multi_gpu_script(cli_inputs, tmp_path):
+    """BASELINE.json configs[2] at the size a 1-GPU box allows: a reads/ directory through (a) the binary with its reader processes
+    (--readers 3: files read by forked children, order kept by the parent), (b) the same in-process (--readers 0), (c)
+    tools/flappie_multi_gpu.sh with one slice -- the three outputs are byte-identical, an unreadable file among the inputs
+    costs one warning and no reordering, and explicit file arguments come out in argument order (README.md:81-83,
+    flappie.c:334-385)."""
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    big = tmp_path / "reads"
+    big.mkdir()
+    rng = np.random.default_rng(5)
+    names = []
+    for i in range(37):                                             # more files than readers x pipe depth matters for; mixed lengths
+        fn = "read_%03d.fast5" % i
+        if i == 11:
+            (big / fn).write_bytes(b"not an hdf5 file")
+        else:
+            write_fast5(big / fn, "uuid-%04d" % i, synth_raw(rng, int(rng.integers(1500, 4200))))
+        names.append(fn)
+    files = [str(big / fn) for fn in names]
+    outs = {}
+    for tag, extra in (("procs", ["--readers", "3"]), ("inproc", ["--readers", "0"]), ("one", ["--readers", "1"])):
+        r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid"] + extra + files, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stderr.count("No basecall returned") == 1 and "read_011.fast5" in r.stderr
+        outs[tag] = r.stdout
+    recs = _parse_fastq(outs["procs"])
+    assert [x[0] for x in recs] == [fn for fn in names if fn != "read_011.fast5"]       # argument order, the bad file skipped
+    assert outs["procs"] == outs["inproc"] == outs["one"]
+    # the per-GPU launcher of configs[2] with one slice: same records as one process over the directory (sorted file order)
+    script = os.path.join(ROOT, "tools", "flappie_multi_gpu.sh")
+    r = subprocess.run([script, "1", str(tmp_path / "shard"), "--batch", "8", "--no-uuid", str(big)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "shard.0.fq").read_text() == outs["procs"]
+    # two slices on the one GPU of this box, run one after the other by the script (FLAPPIE_SERIAL=1): slice g holds files g, g+2, ...
+    r = subprocess.run([script, "2", str(tmp_path / "two"), "--batch", "8", "--no-uuid", str(big)], env=dict(env, FLAPPIE_SERIAL="1", FLAPPIE_DEVICES="0,0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    by_name = {x[0]: x for x in recs}
+    for g in (0, 1):
+        got = _parse_fastq((tmp_path / ("two.%d.fq" % g)).read_text())
+        want = [fn for fn in names[g::2] if fn != "read_011.fast5"]
+        assert [x[0] for x in got] == want
+        assert all(x == by_name[x[0]] for x in got)
