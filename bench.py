@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
-SPLIT_PRODUCTS = 6                # bf16 MFMA products the split-bf16 layer kernel issues per fp32-exact product (ffhip_rnn_split.hip)
+SPLIT_PRODUCTS = 3                # fp16 MFMA products the split layer kernels issue per fp32 multiply-add block (two fp16 slices per operand,
+                                  # w0x0 + w0x1 + w1x0: flappie_amd/csrc/ffhip_split.hpp; the -DFFHIP_SPLIT_BF16X3 build issues 6)
 HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size inferred from the model's size
 
 # Workloads.  c2 is the headline (BASELINE.json configs[1], the configuration the metric is quoted on) and the default;
@@ -248,20 +249,21 @@ def main():
         achieved = flop_layer / (ms_layer * 1e-3) / 1e12
         cell = "GRUmod" if G == 3 else "LSTM"
         if rnn_path in (3, 4):
-            # fp32-exact products out of bf16 MFMAs: each algorithmic (fp32) multiply-add is six bf16 MFMA products
-            # (three-way split of both operands, the three smallest cross terms dropped).  `achieved` counts the
-            # ALGORITHMIC fp32 FLOPs; the ceiling of this formulation is the dense bf16 peak / 6.
+            # fp32-grade products out of 16-bit MFMAs: each algorithmic (fp32) multiply-add is three fp16 MFMA products
+            # (two-way fp16 split of both operands, the smallest cross term dropped; accuracy of an fp32 GEMM:
+            # tests/test_split_numerics.py).  `achieved` counts the ALGORITHMIC fp32 FLOPs; the ceiling of this
+            # formulation is the dense fp16/bf16 MFMA peak / 3.
             if rnn_path == 3:
-                kname = "k_lstm_split<%d,%d> (%s input projection + recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps)" % (
+                kname = "k_lstm_split<%d,%d> (%s input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps)" % (
                     1 if G == 3 else 0, H // 128, cell, nblock)
             else:
-                kname = "k_rnn_split (%s recurrence of one layer on bf16 MFMAs over 3-way split operands, %d dependent steps; its projection GEMM k_inproj_split is a separate launch)" % (cell, nblock)
+                kname = "k_rnn_split (%s recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps; its projection GEMM k_inproj_split is a separate launch)" % (cell, nblock)
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
-            peak_note = ("dense bf16 MFMA peak %.0f TFLOP/s / %d products per fp32-exact product; the kernel issues %.1f TFLOP/s of bf16 MFMA work "
-                         "= %.3f of the bf16 peak; against the f32-input MFMA peak (%.1f) the algorithmic rate is %.3f"
+            peak_note = ("dense fp16/bf16 MFMA peak %.0f TFLOP/s / %d products per fp32 multiply-add; the kernel issues %.1f TFLOP/s of fp16 MFMA work "
+                         "= %.3f of the 16-bit MFMA peak; against the f32-input MFMA peak (%.1f) the algorithmic rate is %.3f"
                          % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS,
                             PEAK_F32_MFMA_TFLOPS, achieved / PEAK_F32_MFMA_TFLOPS))
-            dtype = "f32 (products as 6 bf16 MFMA terms over 3-way split operands, f32 accumulate; gate math f32)"
+            dtype = "f32 (products as 3 fp16 MFMA terms over 2-way split operands, f32 accumulate; gate math f32)"
         else:
             kname = ("k_lstm_fused (%s input projection + recurrence of one layer, %d dependent steps)" if fused
                      else "k_rnn_persist (%s recurrence of one layer, %d dependent steps)") % (cell, nblock)

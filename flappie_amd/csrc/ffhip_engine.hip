@@ -639,7 +639,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // split-bf16 layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM, H = 128/256/384)
     const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
     const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
-    const bool use_split = use_persist && use_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+    const bool want_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE");      // (use_fused also asks whether the f32 layer kernel takes the shape)
+    const bool use_split = use_persist && want_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
                            split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
     // shapes whose two weight matrices do not fit a CU's registers (H = 512): projection GEMM + recurrence-only layer kernel, both
     // on split operands (also what FFHIP_RUN_UNFUSED_RNN selects at H = 256)

@@ -376,3 +376,32 @@ def test_reader_processes_and_multi_gpu_script(cli_inputs, tmp_path):
         want = [fn for fn in names[g::2] if fn != "read_011.fast5"]
         assert [x[0] for x in got] == want
         assert all(x == by_name[x[0]] for x in got)
+
+
+RELINKED = os.path.join(ROOT, "oracle", "_ref", "relink", "flappie_relinked")
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_reference_main_relinked_against_the_engine(cli_inputs):
+    """INTEGRATION.md section 1, executed: the REFERENCE's own flappie.c (compiled unchanged by tools/relink_check.sh in the build
+    container, where /root/reference lies, against include/ and linked with -lflappie_host -lffhip; the binary travels like the
+    other oracle/_ref artefacts) basecalls fast5 files on the GPU through the reference-named functions -- one read per call,
+    flappie.c:245-316 -- and prints the records the oracle expects, in the reference's own format."""
+    if not os.path.exists(RELINKED):
+        pytest.skip("oracle/_ref/relink/flappie_relinked not built (reference sources absent where build() ran)")
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d), LD_LIBRARY_PATH=os.path.join(ROOT, "flappie_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    files = [str(reads / fn) for fn in sorted(raws)]
+    r = subprocess.run([RELINKED, "--model", "r941_native"] + files, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    recs = _parse_fastq(r.stdout)
+    ref = _oracle_calls(mdl, raws)
+    assert [x[0] for x in recs] == [ref[fn]["uuid"] for fn in sorted(raws)]          # the reference's loop: argument order, uuid names
+    for (name, hdr, bases, quals), fn in zip(recs, sorted(raws)):
+        v = ref[fn]
+        assert bases == v["basecall"] and quals == v["quality"], fn
+        assert '"nblock" : %d' % v["nblock"] in hdr and '"trim" : [ %d, %d ]' % (v["start"], v["end"]) in hdr
+    # and our own binary prints the same bytes for the same files
+    ours = subprocess.run([FLAPPIE, "--model", "r941_native"] + files, env=env, capture_output=True, text=True, timeout=300)
+    assert ours.returncode == 0 and ours.stdout == r.stdout

@@ -101,9 +101,9 @@ def main():
         Tb = M.synthetic_model(cfg["kind"], 128, seed=1).nblock(T)
         rnn_path = 3 if "k_lstm_split" in dom else (4 if "k_rnn_split" in dom else (2 if "fused" in dom else 1))
         G = 3 if cfg["kind"] == 1 else 4
-        # algorithmic bytes per launch: split layer kernel reads x and writes h at 6 B per value (three bf16 slices); f32 fused 4 + 4;
+        # algorithmic bytes per launch: split layer kernel reads x and writes h at 4 B per value (two fp16 slices); f32 fused 4 + 4;
         # recurrence-only kernels read the projected gates (G*H floats) and write h
-        alg = Tb * nread * H * {3: 12, 2: 8, 1: 4 * G + 4, 4: 4 * G + 6}[rnn_path]
+        alg = Tb * nread * H * {3: 8, 2: 8, 1: 4 * G + 4, 4: 4 * G + 4}[rnn_path]
         entry = {"config": cfgname, "kind": cfg["kind"], "hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path in (2, 3), "kernel": dom,
                  "recurrent_layer_hbm_bytes_per_launch": int(res[dom][0] + res[dom][1]),
                  "read_bytes_corrected": int(res[dom][0]), "write_bytes": int(res[dom][1]),
