@@ -23,6 +23,7 @@ RUN_STEPWISE_RNN = 8
 RUN_KEEP_ACTS = 16
 RUN_UNFUSED_RNN = 32
 RUN_F32_RNN = 64
+RUN_FAST_GATES = 128
 NGROUP = 6
 GROUP_NAMES = ("conv", "inproj", "recurrent", "head_crf", "posterior", "viterbi_assembly")
 

@@ -318,6 +318,7 @@ struct ffhip_batch {
     char *h_bases = nullptr, *h_quals = nullptr; int *h_lens = nullptr; float *h_score = nullptr;
     std::vector<void *> owned;
     unsigned last_flags = 0;
+    float last_temperature = 1.0f;
     int ran = 0, finished = 0;
     int final_act = 0;                  // which act[] holds the last recurrent layer's output
     int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel, 4 split-bf16 projection GEMM + recurrence-only layer kernel
@@ -626,6 +627,11 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     hipSetDevice(b->eng->device);
     hipStream_t s = b->stream;
     const int Tb = b->Tb, B16 = b->B16, Bp = b->Bp, Hp = m->Hp;
+    if (b->eng->stepwise_batches > 0 && !(flags & FFHIP_RUN_STEPWISE_RNN)) {      // a co-tenant was seen recently (ffhip_batch_finish)
+        flags |= FFHIP_RUN_STEPWISE_RNN;
+        b->eng->stepwise_batches--;
+    }
+    b->last_temperature = temperature;
     const bool keep = (flags & FFHIP_RUN_KEEP_ACTS) != 0;
     memset(b->launches, 0, sizeof(b->launches));
     const int *tbs = b->ragged ? b->d_tbs : nullptr, *tbt = b->ragged ? b->d_tbt : nullptr;      // ragged batch: per-read / per-tile block counts
@@ -675,7 +681,8 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // whole stack and the split is measured with per-layer events when profiling is on.
     int cur = 0;
     const bool prof = b->eng->profiling != 0;
-    if (use_persist) HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->pabort, (use_persist && getenv("FFHIP_DEBUG_FORCE_ABORT")) ? 1 : 0, sizeof(unsigned), s), FFHIP_EHIP);      // (debug: pretend a wait timed out)
+    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     if ((use_split || use_split2) && !conv_split) {
@@ -725,7 +732,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, r.split_S, tbs, tbt))
+                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -854,7 +861,20 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
-    if (*b->h_abort != 0) return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
+    if (*b->h_abort != 0) {
+        if ((b->last_flags & FFHIP_RUN_STEPWISE_RNN) || getenv("FFHIP_NO_FALLBACK"))
+            return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
+        // Not every workgroup of a persistent layer launch became resident -- something else holds part of the GPU.  The
+        // launch-per-step kernels have no such requirement: run this batch again on them, and stay there for a while.
+        static int warned = 0;
+        if (!warned++) fprintf(stderr, "ffhip: a persistent recurrent kernel timed out waiting for its peer workgroups (is the GPU shared?); "
+                                       "falling back to the launch-per-step kernels\n");
+        b->eng->fallbacks++;
+        b->eng->stepwise_batches = 64;
+        const int rc = ffhip_batch_run(b, b->last_temperature, b->last_flags | FFHIP_RUN_STEPWISE_RNN);
+        if (rc != FFHIP_OK) return rc;
+        return ffhip_batch_finish(b);
+    }
     b->finished = 1;
     return FFHIP_OK;
 }
@@ -934,6 +954,8 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
 }
 
 extern "C" int ffhip_batch_rnn_path(const ffhip_batch *b) { return b ? b->rnn_path : -1; }
+
+extern "C" int ffhip_debug_fallback_count(const ffhip_engine *eng) { return eng ? eng->fallbacks : -1; }
 
 // development counter next to the abort word (e.g. re-sweeps of the split layer kernel in builds that count them)
 extern "C" unsigned ffhip_debug_batch_counter(ffhip_batch *b) {

@@ -19,6 +19,12 @@ struct ffhip_engine {
     // launches are chained through this event.
     hipEvent_t persist_done = nullptr;
     int persist_chained = 0;
+    // A persistent layer kernel whose workgroups are not all resident (another tenant on the GPU, e.g. a second flappie
+    // process) gives up through its bounded waits (abort word).  ffhip_batch_finish then re-runs the batch on the
+    // launch-per-step kernels, which need no co-residency, and the next `stepwise_batches` runs go there directly:
+    // co-tenancy becomes a slowdown, not FFHIP_ETIMEOUT.
+    int stepwise_batches = 0;
+    int fallbacks = 0;          // how often that happened (ffhip_debug_fallback_count)
 };
 
 struct ffhip_prep;

@@ -242,6 +242,21 @@ __device__ __forceinline__ float tanh_ref_lean(float x) {
     return (y + y) - 1.0f;
 }
 
+// ---- hardware gate math (opt-in in the layer kernels: FFHIP_RUN_FAST_GATES) -------------------------------------------
+// logistic through v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the cephes replay: 6 instructions instead of ~35.  NOT
+// bit-compatible with exp_ps -- results move by ~1e-7 per activation, a tenth of what the summation order of a dot product
+// moves them.  The clamp keeps the reference's NaN behaviour: min/max return the finite bound for a NaN input, as
+// _mm_min_ps / _mm_max_ps do in exp_ps (sse_mathfun.h:228-229), so a NaN pre-activation gives a finite gate here too.
+__device__ __forceinline__ float logistic_hw(float x) {
+    float v = __builtin_fminf(-x, 88.3762626647949f);
+    v = __builtin_fmaxf(v, -88.3762626647949f);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 1.44269504088896341f));
+}
+__device__ __forceinline__ float tanh_hw(float x) {
+    const float y = logistic_hw(x + x);
+    return (y + y) - 1.0f;
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? swish_ref(x) : (act == 2 ? tanh_ref(x) : x);
 }

@@ -75,6 +75,7 @@ struct SplitArgs {
     unsigned *abort_word;
     int Tb, B16, H, rt0, nrt, backward, mode;
     float acc_scale;          // 2^S: the exponent both products of this layer carry (ffhip_split.hpp); the bias is added in that space
+    int fast_gates;           // FFHIP_RUN_FAST_GATES: hardware exp / reciprocal in the gate phase (ffhip_math.hpp logistic_hw)
     const int *tbs, *tbt;     // ragged batch (see PersistArgs)
     unsigned long long *dbg;
 };
@@ -149,7 +150,7 @@ k_lstm_split(SplitArgs a) {
     if (Tb <= 0) return;                                  // empty slots only (uniform for the whole group)
     const int ntl = (TbB > 0) ? 2 : 1;
     const int ut0 = m * N;
-    if (threadIdx.x == 0) lds_abort = 0;
+    if (threadIdx.x == 0) lds_abort = (__hip_atomic_load(a.abort_word, RLX_AGENT) != 0u) ? 1 : 0;      // an earlier layer of this batch gave up: leave at once
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
     const int q = lane >> 4, rl = lane & 15;
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
@@ -255,10 +256,16 @@ k_lstm_split(SplitArgs a) {
             for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
             s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
-            const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
-            float hbar = L.y * s.z + (s.w + b.z);
-            hbar = tanh_ref_lean(hbar);
-            h = L.x * c + (1.0f - L.x) * hbar;
+            if (a.fast_gates) {
+                const float z = logistic_hw(s.x + b.x), r = logistic_hw(s.y + b.y);
+                const float hbar = tanh_hw(r * s.z + (s.w + b.z));
+                h = z * c + (1.0f - z) * hbar;
+            } else {
+                const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
+                float hbar = L.y * s.z + (s.w + b.z);
+                hbar = tanh_ref_lean(hbar);
+                h = L.x * c + (1.0f - L.x) * hbar;
+            }
             c = h;
         } else {
             v4f s = sbias[gj][q];
@@ -266,12 +273,19 @@ k_lstm_split(SplitArgs a) {
             for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
             s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
-            const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
-            const float tanh_g = (L.z + L.z) - 1.0f;
-            const float forget = L.y * c;
-            const float update = L.x * tanh_g;
-            c = forget + update;
-            h = L.w * tanh_ref_lean(c);
+            if (a.fast_gates) {
+                const float forget = logistic_hw(s.y) * c;
+                const float update = logistic_hw(s.x) * tanh_hw(s.z);
+                c = forget + update;
+                h = logistic_hw(s.w) * tanh_hw(c);
+            } else {
+                const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const float tanh_g = (L.z + L.z) - 1.0f;
+                const float forget = L.y * c;
+                const float update = L.x * tanh_g;
+                c = forget + update;
+                h = L.w * tanh_ref_lean(c);
+            }
         }
         if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
 #if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
@@ -569,7 +583,7 @@ k_rnn_split(RnnSplitArgs a) {
     if (Tb <= 0) return;
     const int ntl = (TbB > 0) ? 2 : 1;
     const int ut0 = m * N;
-    if (threadIdx.x == 0) lds_abort = 0;
+    if (threadIdx.x == 0) lds_abort = (__hip_atomic_load(a.abort_word, RLX_AGENT) != 0u) ? 1 : 0;      // an earlier layer of this batch gave up: leave at once
     const int q = lane >> 4, rl = lane & 15;
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     const bool gate_wave = wave < ntl * N;
@@ -946,9 +960,10 @@ unsigned long long *g_split_dbg = nullptr;
 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, const int *tbs, const int *tbt) {
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt) {
     SplitArgs a;
     a.acc_scale = split_pow2(scale_exp);
+    a.fast_gates = fast_gates;
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;

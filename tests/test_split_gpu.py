@@ -236,3 +236,49 @@ def test_differential_fuzz_is_deterministic(B):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "diff_fuzz.py"), "6", "7"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "diff fuzz:" in out.stdout
+
+
+def test_timeout_falls_back_to_the_stepwise_kernels(B):
+    """Co-residency guard: when a persistent layer kernel gives up waiting for peer workgroups -- another
+    tenant holds part of the GPU -- ffhip_batch_finish re-runs the batch on the launch-per-step kernels instead of returning
+    FFHIP_ETIMEOUT, and the next runs go there directly.  The time-out is simulated (FFHIP_DEBUG_FORCE_ABORT pre-sets the abort
+    word; the layer kernels then leave at once, as they do when an earlier layer of a batch timed out)."""
+    import ctypes as C
+    import os
+    eng = B.Engine(0)                       # its own engine: the fallback state is per engine
+    L = B.lib()
+    L.ffhip_debug_fallback_count.argtypes = [C.c_void_p]
+    L.ffhip_debug_fallback_count.restype = C.c_int
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=7)
+    dm = B.DeviceModel(eng, mdl)
+    sig = np.random.default_rng(5).standard_normal((20, 900)).astype(np.float32)
+    b = B.Batch(dm, 20, 900)
+    b.set_signals(sig)
+    b.run(); b.finish()
+    assert b.rnn_path() == 3 and L.ffhip_debug_fallback_count(eng.h) == 0
+    want = [(b.basecall(r), b.quality(r), b.transitions(r)) for r in range(20)]
+    os.environ["FFHIP_DEBUG_FORCE_ABORT"] = "1"
+    try:
+        b.run(); b.finish()                 # "times out", is re-run stepwise inside finish()
+    finally:
+        del os.environ["FFHIP_DEBUG_FORCE_ABORT"]
+    assert L.ffhip_debug_fallback_count(eng.h) == 1 and b.rnn_path() == 0
+    for r in range(20):
+        assert b.basecall(r) == want[r][0] and b.quality(r) == want[r][1]
+        assert np.abs(b.transitions(r) - want[r][2]).max() <= 1e-4
+    b.run(); b.finish()                     # still wary of the co-tenant: straight to the stepwise kernels, no second fallback
+    assert b.rnn_path() == 0 and L.ffhip_debug_fallback_count(eng.h) == 1
+    os.environ["FFHIP_NO_FALLBACK"] = "1"
+    os.environ["FFHIP_DEBUG_FORCE_ABORT"] = "1"
+    try:
+        eng2 = B.Engine(0)
+        dm2 = B.DeviceModel(eng2, mdl)
+        b2 = B.Batch(dm2, 20, 900)
+        b2.set_signals(sig)
+        b2.run()
+        with pytest.raises(B.FFHipError):   # the old behaviour stays available
+            b2.finish()
+        b2.close(); dm2.close(); eng2.close()
+    finally:
+        del os.environ["FFHIP_NO_FALLBACK"], os.environ["FFHIP_DEBUG_FORCE_ABORT"]
+    b.close(); dm.close(); eng.close()
