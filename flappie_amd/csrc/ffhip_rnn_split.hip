@@ -119,11 +119,16 @@ __device__ __forceinline__ void mm6(const v4u (&w)[N][NC][NS], int cc, const v4u
 }
 
 // KIND 0 = LSTM (gate rows i, f, g, o), 1 = GRUmod (gate rows z, r, candidate, -; layers.c:571-715)
-template <int KIND, int N>
-__global__ void __launch_bounds__(512, 1)
+// TS = read tiles per group.  2: one workgroup per CU, a group serves a PAIR of read tiles (weights read once for 32 reads).
+// 1: a group serves ONE read tile and TWO workgroups share a CU (<= 128 VGPRs, launch bound 4 waves per SIMD): two
+// independent recurrences per CU, so that one's hand-off wait, sweep latency and gate phase run under the other's matrix
+// work -- latency hiding by occupancy instead of by schedule; the two workgroups' gate phases also stop colliding on the same
+// two SIMDs in lock step (six gate tiles on four SIMDs).
+template <int KIND, int N, int TS>
+__global__ void __launch_bounds__(512, TS == 1 ? 4 : 1)
 k_lstm_split(SplitArgs a) {
-    __shared__ v4f px[2][4][2][N][64];      // projection partials, double-buffered: [step parity][K quarter][tile of the pair][unit tile][lane]
-    __shared__ v4f ph[4][2][N][64];         // gate pre-activations by K quarter: projection partial + recurrent partial
+    __shared__ v4f px[2][4][TS][N][64];     // projection partials, double-buffered: [step parity][K quarter][tile of the group][unit tile][lane]
+    __shared__ v4f ph[4][TS][N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial
     __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
     __shared__ unsigned short gsl[8][NS][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
     __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
@@ -135,15 +140,15 @@ k_lstm_split(SplitArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool xw = wave < 4;
     const int kw = wave & 3;
-    const int ngroup = (a.nrt + 1) >> 1;
+    const int ngroup = (a.nrt + TS - 1) / TS;
     int g, m;
     {
         const int b = blockIdx.x;
         if ((ngroup & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
         else { g = b / G; m = b % G; }
     }
-    const int rtA = a.rt0 + 2 * g;
-    const bool haveB = (2 * g + 1 < a.nrt);
+    const int rtA = a.rt0 + TS * g;
+    const bool haveB = TS == 2 && (2 * g + 1 < a.nrt);
     const int TbA = a.tbt ? a.tbt[rtA] : a.Tb;
     const int TbB = haveB ? (a.tbt ? a.tbt[rtA + 1] : a.Tb) : 0;
     const int Tb = TbA > TbB ? TbA : TbB;                 // steps of this pair of read tiles
@@ -330,11 +335,11 @@ k_lstm_split(SplitArgs a) {
         // registers right after the MFMAs that consumed x(step i+1): a whole step ahead of its use (it comes from HBM),
         // and never in the gate phase, where the issue of 18 KiB of loads per wave (the CU's path to L2 takes 64 B/clk)
         // would delay a gating x wave and with it the critical path.
-        v4u xb[2][N][NS];
+        v4u xb[TS][N][NS];
         auto load_x = [&](int i) {
             const int t = step_t(i);
 #pragma unroll
-            for (int ts = 0; ts < 2; ts++) {
+            for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
                 const v4u *p = (const v4u *)(tile_ptr(a.xin, t, ts) + lane_off);
 #pragma unroll
@@ -348,7 +353,7 @@ k_lstm_split(SplitArgs a) {
         };
         auto project = [&](int i) {           // xb holds x(step i): partial Wi x -> px[i & 1]
 #pragma unroll
-            for (int ts = 0; ts < 2; ts++) {
+            for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
                 v4f acc[N];
 #pragma unroll
@@ -365,7 +370,7 @@ k_lstm_split(SplitArgs a) {
         // sweep and the gate waves' stores.  Each member therefore TOUCHES 1/32 of the lines of x(step i+3) -- one dword
         // load of <= 18 lanes per step, issued behind its own prefetch -- so that the prefetches of step i+3 are L2 hits.
         constexpr int WARM = 3;
-        constexpr int LPM = Hc * NS * 8 * 2 / 32;            // 128-byte lines of a pair's x(step) per member
+        constexpr int LPM = (Hc * NS * 8 * TS + 31) / 32;    // 128-byte lines of the group's x(step) per member
         unsigned touched = 0, sink = 0;
         auto touch_x = [&](int i) {
             const int line = m * LPM + lane;
@@ -409,14 +414,14 @@ k_lstm_split(SplitArgs a) {
         // check riding along; (3) only if that check fails (a producer's store instruction became visible line by line)
         // the classic re-sweep loop and a recomputation.
         constexpr int NPROD = 8 * N;                      // unit tiles (= producing gate waves' tiles per read tile) in my K slice
-        constexpr int NCH = 2 * N;                        // (tile, chunk) pairs of my K slice
+        constexpr int NCH = TS * N;                       // (tile, chunk) pairs of my K slice
         raw_barrier();                                        // matches the x waves' prologue barrier
         for (int i = 0; i < Tb; i++) {
             TL(0);
-            v4f acc[2][N];
+            v4f acc[TS][N];
             auto init_acc = [&]() {
 #pragma unroll
-                for (int ts = 0; ts < 2; ts++)
+                for (int ts = 0; ts < TS; ts++)
 #pragma unroll
                     for (int j = 0; j < N; j++) {
                         const v4f p = px[i & 1][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
@@ -427,7 +432,7 @@ k_lstm_split(SplitArgs a) {
             if (i > 0) {
                 const int tp = step_t(i - 1);
                 const unsigned char *hp = tile_ptr(a.hout, tp, 0);          // the pair's two tiles are adjacent
-                __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(2 * tileB), 0x00020000);
+                __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)hp, 0, (int)(TS * tileB), 0x00020000);
                 bool timed_out = false;
                 {
                     const int ul = lane % NPROD, pts = lane / NPROD;
@@ -450,7 +455,7 @@ k_lstm_split(SplitArgs a) {
                 // Both tiles of the pair are always swept and multiplied (an absent second tile re-reads the first one and
                 // its products are dropped): a branch on ntl between the loads makes the outstanding-load count path
                 // dependent, and the compiler then waits vmcnt(0) before the first MFMA instead of counting.
-                const int offB = (ntl > 1) ? (int)tileB : 0;
+                const int offB = (TS > 1 && ntl > 1) ? (int)tileB : 0;
                 auto load_chunk = [&](int k) {          // k = ts*N + cc
                     const int ts = k / N, cc = k % N;
 #if FFHIP_SPLIT_ABLATE & 8              // 8 = no sweep: operands are whatever the registers hold
@@ -517,7 +522,7 @@ k_lstm_split(SplitArgs a) {
                 if (timed_out && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
             }
 #pragma unroll
-            for (int ts = 0; ts < 2; ts++) {
+            for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
 #pragma unroll
                 for (int j = 0; j < N; j++) ph[kw][ts][j][lane] = acc[ts][j];
@@ -951,10 +956,21 @@ constexpr int kSplitMaxN = 3;
 #else
 constexpr int kSplitMaxN = 4;
 #endif
+// tiles per group by [kind][H / 128 - 1] (measured on MI355X)
+// 256 reads x 4000 samples, MI355X, Msamples/s TS = 2 -> 1: LSTM H = 256 97.4 -> 106.6, GRUmod H = 256 39.4 -> 44.3; at N = 3 the
+// one-tile form needs 161 registers (33 spilled at 128: 77.6 -> 67.5), at N = 4 it is hopeless (102 spilled)
+constexpr int kSplitTS[2][4] = { { 1, 1, 2, 2 }, { 1, 1, 2, 2 } };
+int split_tiles_per_group(int kind, int H);
 bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 128 * (kind == 0 ? kSplitMaxN : 3); }      // GRUmod at N = 4 spills 169 registers; no GRUmod model is that wide
-// read tiles (of 16) one launch takes: one workgroup per CU, 32 per pair of tiles
+// read tiles (of 16) one launch takes: 32 workgroups per group; one workgroup per CU and a pair of tiles per group, or two
+// workgroups per CU and one tile per group -- 2 * (ncu / 32) tiles either way
 int split_max_tiles(int ncu) { return 2 * (ncu / 32); }
-size_t split_flag_words(int nrt) { return (size_t)((nrt + 1) / 2) * 32; }
+size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
+int split_tiles_per_group(int kind, int H) {
+    const char *force = getenv("FFHIP_SPLIT_TS");      // development: 1 or 2
+    if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
+    return kSplitTS[kind & 1][H / 128 - 1];
+}
 
 unsigned long long *g_split_dbg = nullptr;
 
@@ -968,8 +984,11 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
-    const int ngroup = (nrt + 1) / 2;
-#define SPLIT_LAUNCH(K, NN) hipLaunchKernelGGL((k_lstm_split<K, NN>), dim3(ngroup * 32), dim3(512), 0, s, a); return true
+    // tiles per group: 1 (two workgroups per CU, one read tile each) where that is faster, else 2 (kSplitTS)
+    const int ts = split_tiles_per_group(kind, H);
+    const int ngroup_l = (nrt + ts - 1) / ts;
+#define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
+                                 else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)
 #ifdef FFHIP_SPLIT_BF16X3
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
