@@ -76,6 +76,7 @@ struct SplitArgs {
     int Tb, B16, H, rt0, nrt, backward, mode;
     float acc_scale;          // 2^S: the exponent both products of this layer carry (ffhip_split.hpp); the bias is added in that space
     int fast_gates;           // FFHIP_RUN_FAST_GATES: hardware exp / reciprocal in the gate phase (ffhip_math.hpp logistic_hw)
+    int split_gate;           // LSTM, N = 3, pairs: gate tiles 4 and 5 are each worked by TWO x waves on different SIMDs (front / back)
     const int *tbs, *tbt;     // ragged batch (see PersistArgs)
     unsigned long long *dbg;
 };
@@ -134,6 +135,8 @@ k_lstm_split(SplitArgs a) {
     __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
     __shared__ int lds_abort;
     __shared__ int lds_fast;
+    __shared__ float cx[2][64];             // split gate tiles: cell state c(t) from the front wave to the back wave of tiles 4 and 5
+    __shared__ int cxflag[2];               // ... and the step it belongs to (+1)
     constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
@@ -162,9 +165,20 @@ k_lstm_split(SplitArgs a) {
     // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
     // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
     // the hardware on one SIMD run in ~2500 cycles, two tiles back to back in one wave in ~3300).
-    const int g6 = xw ? 4 + wave : kw;
-    const bool gate_wave = g6 < ntl * N;
+    // With six tiles (LSTM, H = 384, a pair) two SIMDs would carry two whole gate chains and two SIMDs one -- and the gate
+    // phase is bound by VALU issue (~270 instruction slots per tile), so it would last as long as the loaded SIMDs need.  Tiles
+    // 4 and 5 are therefore each worked by TWO x waves that sit on different SIMDs: the FRONT wave (x wave 0 / 1, the SIMDs of
+    // h waves 0 / 1) evaluates the input, forget and candidate gates and the cell state, hands c(t) over through LDS, and the
+    // BACK wave (x wave 2 / 3, the SIMDs of h waves 2 / 3) evaluates the output gate while it waits, then tanh(c), h(t), the
+    // split and the store: every SIMD carries ~1.5 tiles' worth.  Same operations on the same values: results are bit-identical.
+    constexpr bool SGK = (KIND == 0 && N == 3 && TS == 2);
+    const bool sg = SGK && ntl == 2 && a.split_gate != 0;
+    const bool sg_front = sg && xw && wave < 2, sg_back = sg && xw && wave >= 2;
+    const int g6 = xw ? (sg ? 4 + (wave & 1) : 4 + wave) : kw;
+    const bool gate_wave = !(sg && xw) && g6 < ntl * N;      // works a whole tile
+    const bool store_wave = gate_wave || sg_back;            // publishes a tile's h(t)
     const int my_gts = g6 / N, my_gj = g6 % N;
+    if (threadIdx.x < 2) cxflag[threadIdx.x] = 0;
     // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
     auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * NS + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
     auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
@@ -179,7 +193,7 @@ k_lstm_split(SplitArgs a) {
     // i.e. at least AHEAD-1 whole steps after that sentinel was written.  No host-side fill of the (reused) buffer.
     constexpr int AHEAD = 3;
     const v2u sentinel2 = { kSplitSentinel, kSplitSentinel };
-    if (gate_wave && q < NS)
+    if (store_wave && q < NS)
         for (int k = 0; k < AHEAD && k < Tb; k++) store_wt(out_tile(step_t(k), my_gts), out_off(my_gj), sentinel2);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my sentinels are in L2 ...
     __syncthreads();                          // ... and so are those of the other waves, before this member checks in
@@ -245,6 +259,40 @@ k_lstm_split(SplitArgs a) {
     // ---- gate math of one 16 x 16 tile (4 units x 4 gates x 16 reads; layers.c:1005-1025) and the store of its h(t), already
     // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
     const float inv_scale = 1.0f / a.acc_scale;
+    // h(t) of one tile -> the split layout (and the hand-off): Split h ONCE, in the lane that owns it, and transpose through a
+    // wave-private LDS patch: lane (unit q, read rl) writes its slices to [slice][read][unit]; quarter-wave q then reads the
+    // 8 bytes [slice q][read rl][units 0..3] -- the packed operand piece it stores.  (Four ds_bpermute + a 4-value split in
+    // every lane cost ~3x the VALU work.)
+    auto publish_h = [&](int i, int gts, int gj, float h) {
+        const int t = step_t(i);
+#if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
+        if (h == 123.0f) a.flags[0] = 1; else return;
+#endif
+        {
+            unsigned sl[NS];
+            split_slices(h * split_pow2(kSplitExpH), sl);        // |h| <= 1: in range without a clamp
+#pragma unroll
+            for (int k = 0; k < NS; k++) gsl[wave][k][rl][q] = (unsigned short)sl[k];
+        }
+        if (a.hout_f32) gf32[wave][rl][q] = h;
+        asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
+        const int ut = ut0 + gj;
+        const unsigned off = out_off(gj);
+        if (q < NS) {
+            const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
+            unsigned char *tp_out = out_tile(t, gts);
+            if (fast) {                                    // the group shares one L2: plain stores
+                *(v2u *)(tp_out + off) = sl;               // (the data first: it is what the consumers wait for)
+                if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
+            } else {
+                store_wt(tp_out, off, sl);
+                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
+            }
+        } else if (q == NS && a.hout_f32) {
+            const v4f hv = *(const v4f *)&gf32[wave][rl][0];
+            *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
+        }
+    };
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
         const int t = step_t(i);
         float h;
@@ -293,39 +341,44 @@ k_lstm_split(SplitArgs a) {
             }
         }
         if (t >= my_tb) { h = 0.0f; c = 0.0f; }          // beyond this read's end (ragged batch)
-#if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
-        if (h == 123.0f) a.flags[0] = 1; else return;
-#endif
-        // Split h ONCE, in the lane that owns it, and transpose through a wave-private LDS patch: lane (unit q, read rl) writes its
-        // three bf16 slices to [slice][read][unit]; quarter-wave q then reads the 8 bytes [slice q][read rl][units 0..3] -- the
-        // packed operand piece it stores.  (Four ds_bpermute + a 4-value split in every lane cost ~3x the VALU work.)
-        {
-            unsigned sl[NS];
-            split_slices(h * split_pow2(kSplitExpH), sl);        // |h| <= 1: in range without a clamp
+        publish_h(i, gts, gj, h);
+    };
+    // the two halves of a split gate tile (see `sg` above): the same arithmetic as gate_tile's LSTM branch, operation for operation
+    auto gate_front = [&](int i, int gts, int gj, float &c, int my_tb) {
+        v4f s = sbias[gj][q];
 #pragma unroll
-            for (int k = 0; k < NS; k++) gsl[wave][k][rl][q] = (unsigned short)sl[k];
+        for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+        s = s * inv_scale;
+        float forget, update;
+        if (a.fast_gates) {
+            forget = logistic_hw(s.y) * c;
+            update = logistic_hw(s.x) * tanh_hw(s.z);
+        } else {
+            const ffv2 L = logistic_ref2_lean((ffv2){ s.x, s.y });
+            forget = L.y * c;
+            update = L.x * tanh_ref_lean(s.z);          // = 2 logistic(2 z) - 1, the form gate_tile evaluates
         }
-        if (a.hout_f32) gf32[wave][rl][q] = h;
-        asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
-        const int ut = ut0 + gj;
-        const unsigned off = out_off(gj);
-        if (q < NS) {
-            const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
-            unsigned char *tp_out = out_tile(t, gts);
-            if (fast) {                                    // the group shares one L2: plain stores
-                *(v2u *)(tp_out + off) = sl;               // (the data first: it is what the consumers wait for)
-                if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
-            } else {
-                store_wt(tp_out, off, sl);
-                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
-            }
-        } else if (a.hout_f32) {
-            const v4f hv = *(const v4f *)&gf32[wave][rl][0];
-            *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
-        }
+        c = forget + update;
+        if (step_t(i) >= my_tb) c = 0.0f;
+        cx[wave & 1][lane] = c;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (LDS operations of a wave execute in order; the flag follows the data)
+        if (lane == 0) *(volatile int *)&cxflag[wave & 1] = i + 1;
+    };
+    auto gate_back = [&](int i, int gts, int gj, int my_tb) {
+        float so = sbias[gj][q].w;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) so = so + ph[w2][gts][gj][lane].w;
+        so = so * inv_scale;
+        const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
+        while (*(volatile int *)&cxflag[wave & 1] != i + 1) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const float c = cx[wave & 1][lane];
+        float h = o * (a.fast_gates ? tanh_hw(c) : tanh_ref_lean(c));
+        if (step_t(i) >= my_tb) h = 0.0f;
+        publish_h(i, gts, gj, h);
     };
     int my_tb = 0;
-    if (gate_wave) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
+    if (gate_wave || sg_front || sg_back) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
     float c = 0.0f;
 
     // The two roles run their own step loop (two barriers per step each), so that the register allocator sees each
@@ -400,7 +453,12 @@ k_lstm_split(SplitArgs a) {
             raw_barrier();
             TL(3);
             if (lds_abort) return;
-            if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            if (sg_front) {
+                __builtin_amdgcn_s_setprio(3);               // the back wave (and with it the closing barrier) waits for this c(t)
+                gate_front(i, my_gts, my_gj, c, my_tb);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
+            else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
             TL(4);
             raw_barrier();                                   // closes the gate phase
             TL(5);
@@ -980,6 +1038,7 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     SplitArgs a;
     a.acc_scale = split_pow2(scale_exp);
     a.fast_gates = fast_gates;
+    a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
