@@ -88,6 +88,8 @@ struct ConvDev {
     float *bias = nullptr;      // [Fout] or [Mpad] for the MFMA layer
     float4 *Wp = nullptr;       // A-fragment order     (last layer)
     int K16 = 0, Mpad = 0;
+    void *Wsplit = nullptr;     // last layer with 16 input features: fp16 slices in 16x16x32 A order for k_conv_split (ffhip_split.hpp)
+    int split_S = 0;            // exponent its accumulators carry: weight exponent + kSplitExpX
 };
 struct RnnDev {
     float4 *iWp = nullptr, *sWp = nullptr;
@@ -190,6 +192,27 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
             c.Wp = (float4 *)dev_upload(m, wp.data(), wp.size() * 4);
             c.bias = (float *)dev_upload(m, bias.data(), bias.size() * 4);
             if (!c.Wp || !c.bias) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+            if (kSplitF16 && Fin == 16 && l > 0 && m->act == ACT_SWISH) {
+                // the same weights for the split-operand kernel: [mt][chunk of two taps][slice][lane][8 halves], k = 16 tap + feature
+                const int Mt = Hp / 16, NC = (c.winlen + 1) / 2;
+                float mx = 0.0f;
+                for (int row = 0; row < c.Fout; row++)
+                    for (int k = 0; k < K; k++) mx = fmaxf(mx, fabsf(w(row, k)));
+                const int sw = split_weight_exp(mx);
+                c.split_S = sw + kSplitExpX;
+                std::vector<uint16_t> sp((size_t)Mt * NC * kSplitNS * 64 * 8);
+                for (int mt = 0; mt < Mt; mt++)
+                    for (int ch = 0; ch < NC; ch++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int e = 0; e < 8; e++) {
+                                uint16_t sl[kSplitNS];
+                                split_host_slices(w(mt * 16 + (lane & 15), ch * 32 + (lane >> 4) * 8 + e), sw, sl);
+                                const size_t base = (((size_t)mt * NC + ch) * kSplitNS) * 64 * 8 + (size_t)lane * 8 + e;
+                                for (int k2 = 0; k2 < kSplitNS; k2++) sp[base + (size_t)k2 * 64 * 8] = sl[k2];
+                            }
+                c.Wsplit = dev_upload(m, sp.data(), sp.size() * 2);
+                if (!c.Wsplit) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+            }
         }
         Fin = c.Fout;
     }
@@ -661,12 +684,18 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
     mark(b, 0);
     // ---- convolutions (layers.c:189-276, activations :24-49)
+    // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
+    const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT_CONV") && !(flags & FFHIP_RUN_F32_RNN);
     for (int l = 0; l < m->nconv; l++) {
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
             launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
-                              b->ragged ? b->rag_tin[l] : nullptr);
+                              b->ragged ? b->rag_tin[l] : nullptr, (conv_f16 && l == m->nconv - 2) ? kSplitExpX : -100000);
+        } else if (conv_f16) {
+            launch_conv_split(s, b->sbuf[l], b->act[0], c.Wsplit, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
+                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
+                              conv_split ? b->actS[0] : nullptr, kSplitExpX, c.split_S);
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0,

@@ -51,12 +51,18 @@ void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf ds
 // VALU convolution for the thin front layers; W dense taps [Fout][winlen][Fin]
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
                        const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0,     // ldp: entries per read of a per-read window table (0 = shared)
-                       const int *tin = nullptr);                                 // stride-1 layer of a ragged batch: per-read input lengths instead of a table
+                       const int *tin = nullptr,                                  // stride-1 layer of a ragged batch: per-read input lengths instead of a table
+                       int split_exp = -100000);                                  // > -1000 (16 output features): write fp16 slices of value * 2^split_exp for launch_conv_split
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
                       const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0,
                       void *out_split = nullptr, int split_exp = 0);      // != nullptr: write the split layout of ffhip_rnn_split.hip (values * 2^split_exp) INSTEAD of `out` (M % 128 == 0)
+
+// the same convolution on split operands (16 input features): `in` holds fp16 slices (launch_conv_small with split_exp = kSplitExpX),
+// Wp the split weight pack [M/16][ceil(winlen/2)][2][64] x 16 B scaled by 2^(acc_exp - kSplitExpX)
+void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp);
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,

@@ -22,6 +22,8 @@
 namespace ffhip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ v4f mfma4(v4f a, v4f b, v4f c) {
     // four k-steps of 16x16x4: k = 16*k16 + 4*kq + {0,1,2,3}; the k order inside the 16 is free as
@@ -52,7 +54,7 @@ template <int MAXF>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp,
-             const int *__restrict__ tin) {
+             const int *__restrict__ tin, float split_scale) {
     extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
     const int Fin = in.F, Fout = out.F, K = winlen * Fin;
     for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
@@ -87,21 +89,36 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
         }
     }
     float *o = out.p + (size_t)r * out.rs + (size_t)(kSamplePad + c) * Fout;
+    if (MAXF == 16 && split_scale != 0.0f) {
+        // the next layer is the split-operand convolution (k_conv_split): this sample's 16 features leave as kSplitNS 16-bit
+        // slices of value * split_scale (ffhip_split.hpp) in the SAME 64-byte row -- [slice][16 features] -- the zero rows of
+        // the padding are zeros in either reading
+        unsigned short *oh = (unsigned short *)o;
+#pragma unroll
+        for (int f = 0; f < 16; f++) {
+            unsigned sl[kSplitNS];
+            split_slices<true>(apply_act(acc[f], act) * split_scale, sl);
+#pragma unroll
+            for (int k = 0; k < kSplitNS && k < 2; k++) oh[k * 16 + f] = (unsigned short)sl[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int f = 0; f < MAXF; f++)
         if (f < Fout) o[f] = apply_act(acc[f], act);
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin) {
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin, int split_exp) {
     dim3 grid((Tout + 255) / 256, Bp), block(256);
+    const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
     if (out.F <= 4)
-        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f);
     else if (out.F <= 16)
-        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale);
     else
-        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin);
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -234,6 +251,125 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
     else
         hipLaunchKernelGGL(k_conv_mfma<false>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
                            x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp));
+}
+
+// ---- last convolution on split operands ---------------------------------------------------------------------------
+// The same implicit GEMM as k_conv_mfma for a 16-feature input (the r941 / r103 / rle models: 16 -> H, 19 taps), on the 16-bit
+// matrix pipes over two fp16 slices of both operands (ffhip_split.hpp: three products per fp32 multiply-add, accuracy of an
+// fp32 GEMM; 30 MFMAs of 16 cycles per 16 x 16 tile instead of 76 of 32).  K = tap * 16 + feature; a K chunk of 32 is two taps.
+//   input    sample-major rows of 64 bytes [slice][16 features] fp16, written by k_conv_small (value * 2^kSplitExpX)
+//            B operand of chunk c, lane (kq, read r): 16 bytes at row x0 + 2c + (kq >> 1), slice s, features 8 (kq & 1) ..
+//   weights  Wp[mt][c][slice][lane] 16 B: row 16 mt + (lane & 15), k = 32 c + 8 (lane >> 4) .., zero beyond K (the phantom
+//            20th tap); a lane whose tap is the phantom one reads a ZERO row instead of the sample behind the window (0 x NaN)
+// Accumulators live in the scaled space 2^S (S = weight exponent + kSplitExpX; bias pre-multiplied, result multiplied by 2^-S).
+__global__ void __launch_bounds__(256)
+k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
+             const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int NC, int winlen, int act, int ldp,
+             unsigned char *__restrict__ out_split, float split_scale, float acc_scale) {
+    constexpr int TM = 4, TN = 4, NSL = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
+    const int ntile = Tout * B16;
+    const int nNblk = (ntile + 2 * TN - 1) / (2 * TN);
+    const int L = xcd_remap(blockIdx.x, nMblk * nNblk);
+    const int mblk = L % nMblk, nblk = L / nMblk;
+    const int mt0 = (mblk * 2 + wm) * TM, nt0 = (nblk * 2 + wn) * TN;
+    const int kq = lane >> 4, rl = lane & 15;
+    v4f acc[TM][TN];
+    const v4u_t *ap[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(mt0 + i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * NC * NSL * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + kq * 4) * acc_scale;
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+    const unsigned char *zero_row = (const unsigned char *)in.p;            // the leading pad of read 0: zeros
+    for (int pass = 0; pass < 2; pass++) {
+        const unsigned char *bp[TN];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = min(nt0 + j, ntile - 1);
+            const int c = nt / B16, rt = nt % B16;
+            const size_t pi = (size_t)(rt * 16 + rl) * ldp + c;
+            int x0 = pass == 0 ? x0a[pi] : x0b[pi];
+            const bool have = (x0 != kNoWindow && x0 != kZeroCol);
+            any |= have;
+            if (!have) x0 = -kSamplePad;
+            bp[j] = (const unsigned char *)(in.p + (size_t)(rt * 16 + rl) * in.rs + (size_t)(kSamplePad + x0) * 16) + (kq >> 1) * 64 + (kq & 1) * 16;
+        }
+        if (pass == 1 && !__any(any)) break;
+        v4u_t A0[TM][NSL], B0[TN][NSL], A1[TM][NSL], B1[TN][NSL];
+        auto load = [&](v4u_t (&A)[TM][NSL], v4u_t (&B)[TN][NSL], int c) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int sl = 0; sl < NSL; sl++) A[i][sl] = ap[i][(size_t)(c * NSL + sl) * 64];
+            const bool phantom = (2 * c + (kq >> 1) >= winlen);
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const unsigned char *p = phantom ? zero_row : bp[j] + (size_t)c * 128;
+#pragma unroll
+                for (int sl = 0; sl < NSL; sl++) B[j][sl] = *(const v4u_t *)(p + sl * 32);
+            }
+        };
+        auto mma = [&](v4u_t (&A)[TM][NSL], v4u_t (&B)[TN][NSL]) {
+            constexpr int WS[3] = { 1, 0, 0 }, XS[3] = { 0, 1, 0 };
+#pragma unroll
+            for (int term = 0; term < 3; term++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][WS[term]]), __builtin_bit_cast(v8h_t, B[j][XS[term]]), acc[i][j], 0, 0, 0);
+        };
+        load(A0, B0, 0);
+        for (int c = 0; c < NC; c += 2) {
+            if (c + 1 < NC) load(A1, B1, c + 1);
+            mma(A0, B0);
+            if (c + 1 < NC) {
+                if (c + 2 < NC) load(A0, B0, c + 2);
+                mma(A1, B1);
+            }
+        }
+    }
+    const float inv_scale = 1.0f / acc_scale;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = mt0 + i;
+        if (mt >= Mt) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            v4f v = acc[i][j] * inv_scale;
+            v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
+            v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+            if (out_split) {
+                unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 32 * kSplitNS) +
+                                     (size_t)(((mt >> 1) * kSplitNS * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);
+                const float f[4] = { v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale };
+                unsigned sb[4][kSplitNS];
+#pragma unroll
+                for (int e = 0; e < 4; e++) split_slices<true>(f[e], sb[e]);
+#pragma unroll
+                for (int sl = 0; sl < kSplitNS; sl++)
+                    *(uint2 *)(dst + (size_t)sl * 1024) = make_uint2(sb[0][sl] | (sb[1][sl] << 16), sb[2][sl] | (sb[3][sl] << 16));
+            } else
+                *(v4f *)(out + ((size_t)nt * Mt + mt) * 256 + lane * 4) = v;
+        }
+    }
+}
+
+void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp) {
+    const int Mt = M / 16, NC = (winlen + 1) / 2;
+    const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
+    hipLaunchKernelGGL(k_conv_split, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
+                       (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
 }
 
 // ---- input projection: Xa[nt][mt] = Wp[mt] . act[nt] + b ----------------------------------

@@ -15,6 +15,7 @@ from flappie_amd import model as M  # noqa: E402
 
 hidden = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 counts = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["256", "1024"])]
+readers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["4"]      # --readers values to time (0 = the reader thread in the process)
 d = tempfile.mkdtemp(prefix="flappie_cli_")
 t0 = time.time()
 M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native"))
@@ -37,18 +38,19 @@ for i in range(nmax):
     total.append(n)
 print("%d fast5 files written in %.1f s" % (nmax, time.time() - t0), flush=True)
 env = dict(os.environ, FLAPPIE_MODEL_DIR=d)
-res = []
-for n in counts:
-    t0 = time.time()
-    env["FLAPPIE_CLI_TIMING"] = "1"
-    r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie"), "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
-                       capture_output=True, text=True)
-    dt = time.time() - t0
-    nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
-    print("flappie --limit %d: rc %d, %d records, %.2f s   %s" % (n, r.returncode, nrec, dt, "\n" + r.stderr.strip()[-600:]), flush=True)
-    res.append((n, dt))
-if len(res) >= 2:
-    (n0, t0_), (n1, t1_) = res[0], res[-1]
-    per_read = (t1_ - t0_) / (n1 - n0)
-    print("marginal cost %.3f ms per read (~%d samples) = %.2f Msamples/s; fixed cost %.1f s" % (per_read * 1e3, int(np.mean(total)),
-          np.mean(total) / per_read / 1e6, t0_ - n0 * per_read))
+for nr in readers:
+    res = []
+    for n in counts:
+        t0 = time.time()
+        env["FLAPPIE_CLI_TIMING"] = "1"
+        r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie"), "--readers", nr, "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
+                           capture_output=True, text=True)
+        dt = time.time() - t0
+        nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
+        print("flappie --readers %s --limit %d: rc %d, %d records, %.2f s   %s" % (nr, n, r.returncode, nrec, dt, "\n" + r.stderr.strip()[-600:]), flush=True)
+        res.append((n, dt))
+    if len(res) >= 2:
+        (n0, t0_), (n1, t1_) = res[0], res[-1]
+        per_read = (t1_ - t0_) / (n1 - n0)
+        print("readers %s: marginal cost %.3f ms per read (~%d samples) = %.2f Msamples/s; fixed cost %.1f s" % (nr, per_read * 1e3, int(np.mean(total)),
+              np.mean(total) / per_read / 1e6, t0_ - n0 * per_read), flush=True)

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -- python bench.py $S > /dev/null 2>&1
 # SQ counters in passes small enough for the hardware's counter slots
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/prof_${tag}_sq1 -- python bench.py $S > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d gpurun_out/prof_${tag}_sq2 -- python bench.py $S > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d gpurun_out/prof_${tag}_sq2 -- python bench.py $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d gpurun_out/prof_${tag}_sq3 -- python bench.py $S > /dev/null 2>&1
 python tools/profile_summary.py $tag $cfg gpurun_out $O
 cat $O/${tag}_bench.json

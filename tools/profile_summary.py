@@ -70,7 +70,7 @@ def main():
     print("\n".join(out[:14]))
 
     # SQ counters of the recurrent kernels
-    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
              "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"]
     vals, meta = {}, {}
     for leg, ns in (("sq1", names[0:3]), ("sq2", names[3:6]), ("sq3", names[6:9])):
@@ -91,7 +91,7 @@ def main():
         sq.append("\"%s\",%d,%.3f,%s,%.4f,%s" % (k, len(d[k]), sum(d[k]) / len(d[k]), ",".join("%.0f" % x for x in row), frac,
                                                   ",".join(str(m.get(c, "")) for c in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"))))
     open(os.path.join(outdir, "%s_sq_pmc.csv" % tag), "w").write(
-        "# three separate passes (counter slots): rocprofv3 --kernel-trace --pmc {SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES} -- %s\n"
+        "# three separate passes (counter slots): rocprofv3 --kernel-trace --pmc {SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES} -- %s\n"
         "# per-launch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)\n" % cmd + "\n".join(sq) + "\n")
     print("\n".join(sq))
 
