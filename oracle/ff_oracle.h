@@ -5,16 +5,21 @@
  *  tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *  The product (flappie_amd/, include/) never links, imports or calls it.
  *
- *  PINNING STATUS (see DESIGN.md "Oracle"):
- *    - signal preparation rows (N1) are pinned by the reference's own fixtures
- *      raw_signal/trimmed_signal/normalised_signal (tests/golden/) AND by the
- *      reference's util.c/flappie_common.c compiled unchanged into oracle/_ref;
- *    - exp/ELU, row_normalise, median, identity convolution are pinned by the
- *      known-answer values of the reference's CUnit tests;
- *    - the neural network + CRF + decode rows (A3 strided conv quirk, A5-A13) have
- *      NO golden vector in the reference and the reference's layers.c/
- *      flappie_matrix.c need an external BLAS (<cblas.h>, absent from this image)
- *      so they cannot be built here:  **parity unpinned** for those rows.
+ *  PINNING STATUS (tests/test_ref_pins.py, tests/test_oracle_cpu.py):
+ *    - scalar math (exp_ps / log_ps, logistic, tanh, elu, logsumexpf, logsumexp, qscoref / phredf): BIT FOR BIT against the
+ *      reference's own header-inline code compiled by oracle/ref_inline.c (oracle/_ref/libflappie_inlref.so), > 10^7 inputs
+ *      per function;
+ *    - the decode half (features_from_raw, transpost_crf_flipflop, decode_crf_flipflop, change_positions, exp +
+ *      trace_from_posterior, decode_crf_runlength, transpost_crf_runlength): BIT FOR BIT against the reference's decode.c +
+ *      util.c + nnfeatures.c compiled unchanged (oracle/_ref/libflappie_decref.so) with the declared glue of
+ *      oracle/ref_decode_glue.c for the ten allocation / normalisation symbols of the unbuildable flappie_matrix.c / layers.c;
+ *    - signal preparation (N1): the reference's own fixtures raw_signal / trimmed_signal / normalised_signal (tests/golden/)
+ *      AND the reference's util.c / flappie_common.c compiled unchanged (oracle/_ref/libflappie_sigref.so), bit for bit;
+ *    - ELU, row_normalise, median, identity convolution: the known-answer values of the reference's CUnit tests;
+ *    - strided convolution (A3), affine maps, LSTM / GRUmod cells, globalnorm_flipflop and the partition-function recursion
+ *      (A5-A9): NO golden vector in the reference, and layers.c / flappie_matrix.c need an external BLAS header (<cblas.h>,
+ *      absent from this image) so they cannot be built here:  **parity unpinned** for those rows (cross-checked against
+ *      PyTorch, autograd and brute-force enumeration: tests/test_oracle_vs_torch.py).
  *
  *  Every function cites the reference file:line it restates (paths relative to
  *  /root/reference/src).
