@@ -93,19 +93,34 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
         // the next layer is the split-operand convolution (k_conv_split): this sample's 16 features leave as kSplitNS 16-bit
         // slices of value * split_scale (ffhip_split.hpp) in the SAME 64-byte row -- [slice][16 features] -- the zero rows of
         // the padding are zeros in either reading
-        unsigned short *oh = (unsigned short *)o;
+        unsigned pk[2][8];                   // [slice][feature pair]: the row leaves as four 16-byte stores, not 32 two-byte ones
 #pragma unroll
-        for (int f = 0; f < 16; f++) {
-            unsigned sl[kSplitNS];
-            split_slices<true>(apply_act(acc[f], act) * split_scale, sl);
+        for (int f = 0; f < 16; f += 4) {
+            const ffv4 y = apply_act4((ffv4){ acc[f], acc[f + 1], acc[f + 2], acc[f + 3] }, act) * split_scale;
+            unsigned s0[kSplitNS], s1[kSplitNS], s2[kSplitNS], s3[kSplitNS];
+            split_slices<true>(y.x, s0); split_slices<true>(y.y, s1); split_slices<true>(y.z, s2); split_slices<true>(y.w, s3);
 #pragma unroll
-            for (int k = 0; k < kSplitNS && k < 2; k++) oh[k * 16 + f] = (unsigned short)sl[k];
+            for (int k = 0; k < 2; k++) {
+                pk[k][f >> 1] = s0[k % kSplitNS] | (s1[k % kSplitNS] << 16);
+                pk[k][(f >> 1) + 1] = s2[k % kSplitNS] | (s3[k % kSplitNS] << 16);
+            }
+        }
+        uint4 *o4 = (uint4 *)o;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            o4[2 * k] = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+            o4[2 * k + 1] = make_uint4(pk[k][4], pk[k][5], pk[k][6], pk[k][7]);
         }
         return;
     }
 #pragma unroll
-    for (int f = 0; f < MAXF; f++)
-        if (f < Fout) o[f] = apply_act(acc[f], act);
+    for (int f = 0; f < MAXF; f += 4) {
+        const ffv4 y = apply_act4((ffv4){ acc[f], acc[f + 1], acc[f + 2], acc[f + 3] }, act);
+        if (f < Fout) o[f] = y.x;
+        if (f + 1 < Fout) o[f + 1] = y.y;
+        if (f + 2 < Fout) o[f + 2] = y.z;
+        if (f + 3 < Fout) o[f + 3] = y.w;
+    }
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
@@ -220,8 +235,7 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
             const int nt = nt0 + j;
             if (nt >= ntile) continue;
             v4f v = acc[i][j];
-            v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
-            v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+            v = apply_act4(v, act);
             if (out_split) {
                 // split layout of the recurrent layer kernel (ffhip_rnn_split.hip, ffhip_split.hpp): kSplitNS 16-bit slices of
                 // value * 2^split_exp, [k/32][slice][(k%32)/8 * 16 + read][8]; this lane holds k = 16 mt + 4 kq + 0..3 of read rl
@@ -346,8 +360,7 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
             const int nt = nt0 + j;
             if (nt >= ntile) continue;
             v4f v = acc[i][j] * inv_scale;
-            v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
-            v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+            v = apply_act4(v, act);
             if (out_split) {
                 unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 32 * kSplitNS) +
                                      (size_t)(((mt >> 1) * kSplitNS * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);

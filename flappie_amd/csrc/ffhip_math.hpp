@@ -257,6 +257,14 @@ __device__ __forceinline__ float tanh_hw(float x) {
     return (y + y) - 1.0f;
 }
 
+// four activations at once through the lean logistic (bit-identical to swish_ref / tanh_ref, ~50 fewer instructions per four:
+// the epilogues of the convolution kernels evaluate 80 million of them per headline batch)
+__device__ __forceinline__ ffv4 apply_act4(ffv4 x, int act) {
+    if (act == 1) { const ffv4 L = logistic_ref4_lean(x); return x * L; }
+    if (act == 2) { const ffv4 L = logistic_ref4_lean(x + x); return (L + L) - 1.0f; }
+    return x;
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? swish_ref(x) : (act == 2 ? tanh_ref(x) : x);
 }
