@@ -32,7 +32,7 @@ HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size i
 # the others let the driver or a reader reproduce the figures DESIGN.md quotes for configs[3] / configs[4] and the
 # smaller r941_native file with the same JSON line (own roofline, own CPU leg).  kind: 0 LSTM5, 1 GRUmod5, 2 LSTM5 + run-length head.
 CONFIGS = {
-    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, ident="r941native",
+    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
     "h256": dict(kind=0, hidden=256, nread=256, nsample=4000, steps=200, warmup=5, ident="r941native",
@@ -46,7 +46,7 @@ CONFIGS = {
                  metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",
                  label="r103_native-shape LSTM5 H=512 (SURVEY.md section 0.3: there is no r10C_pcr model), batch=256 synthetic 100000-sample reads per GPU, "
                        "posterior decode + trace (BASELINE.json configs[4])"),
-    "rle":  dict(kind=2, hidden=384, nread=256, nsample=4000, steps=100, warmup=3, ident="rle_r941native",
+    "rle":  dict(kind=2, hidden=384, nread=256, nsample=4000, steps=100, warmup=3, inflight=2, ident="rle_r941native",
                  metric="Msamples/s run-length called (rle_r941_native, 4k-sample chunks)",
                  label="rle_r941_native-shape LSTM5 H=384 + run-length head (runnie), batch=256 synthetic 4000-sample reads per GPU"),
 }
@@ -134,8 +134,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="workload: c2 = the headline (default); h256, c4, c5, rle = the other shapes DESIGN.md quotes")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FFHIP_INFLIGHT", "1")),
-                    help="batches in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FFHIP_INFLIGHT", "0")) or None,
+                    help="batches in flight per GPU, each on its own HIP stream (default: the workload's measured best -- 2 where one workgroup "
+                         "per CU runs the layers and the other batch's convolution / decode kernels fit beside them: c2 +2.9 %%, rle +24 %%; 1 where two "
+                         "workgroups per CU already fill the CUs: there a second batch costs up to 10 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
@@ -181,7 +183,7 @@ def main():
     dm = B.DeviceModel(eng, mdl)
     rng = np.random.default_rng(20260928 + rank)
     sig = rng.standard_normal((NREAD, NSAMPLE)).astype(np.float32)
-    nfl = max(1, min(args.inflight, 2))
+    nfl = max(1, min(args.inflight if args.inflight else cfg.get("inflight", 1), 2))
     batches = [B.Batch(dm, NREAD, NSAMPLE) for _ in range(nfl)]
     for b in batches:
         b.set_signals(sig)               # inputs resident in HBM before the timed region
@@ -298,6 +300,10 @@ def main():
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
             "roofline": roof,
             "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in prof[-1].items()},
+            "kernel_ms_note": ("one batch in flight: the kernels of a step run back to back" if nfl == 1 else
+                               "two batches in flight: the convolution / head / decode kernels of one batch run BESIDE the other batch's layer launches, "
+                               "so their durations here overlap those and do not add up to ms_per_step; `--inflight 1` gives the serial breakdown "
+                               "(profiles/r02_c2_inflight1_bench.json)"),
             # decode side (posterior + Viterbi + assembly + trace): algorithmic bytes per block (SURVEY.md section 8d:
             # 4P read + nstate traceback + 8 path/qpath, plus 4P read + 4P write for the posterior) against HBM peak.
             # At 256 reads these kernels are latency-bound chains, not bandwidth-bound.

@@ -26,7 +26,7 @@ def main():
     tag, cfgname, scratch, outdir = sys.argv[1:5]
     import bench
     cfg = bench.CONFIGS[cfgname]
-    cmd = "python bench.py --config %s --steps 4 --warmup 1 --no-cpu-baseline --no-h2d-leg" % cfgname
+    cmd = "python bench.py --config %s --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline --no-h2d-leg" % cfgname
     trace = find(scratch, tag, "trace", "kernel_trace.csv")
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
