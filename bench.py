@@ -35,12 +35,12 @@ CONFIGS = {
     "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
-    "h256": dict(kind=0, hidden=256, nread=256, nsample=4000, steps=200, warmup=5, ident="r941native",
+    "h256": dict(kind=0, hidden=256, nread=512, nsample=4000, steps=150, warmup=5, ident="r941native",
                  metric="Msamples/s basecalled (r941_native 20200220-size model, 4k-sample chunks)",
-                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace"),
-    "c4":   dict(kind=1, hidden=256, nread=256, nsample=4000, steps=100, warmup=3, ident="r941_5mC",
+                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=512 synthetic 4000-sample reads per GPU (what one layer launch takes at H <= 256), posterior decode + trace"),
+    "c4":   dict(kind=1, hidden=256, nread=512, nsample=4000, steps=60, warmup=3, ident="r941_5mC",
                  metric="Msamples/s basecalled (r941_5mC, 4k-sample chunks)",
-                 label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=256 synthetic 4000-sample reads per GPU, "
+                 label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=512 synthetic 4000-sample reads per GPU (what one layer launch takes at H <= 256), "
                        "posterior decode + trace (BASELINE.json configs[3])"),
     "c5":   dict(kind=0, hidden=512, nread=256, nsample=100000, steps=5, warmup=1, ident="r103native",
                  metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",
@@ -295,7 +295,7 @@ def main():
             "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the %s architecture)" % cfg["ident"],
-            "config": {"workload": cfg["label"].replace("H=%d" % CONFIGS[args.config]["hidden"], "H=%d" % H), "name": args.config,
+            "config": {"workload": cfg["label"].replace("H=%d" % CONFIGS[args.config]["hidden"], "H=%d" % H).replace("batch=%d" % CONFIGS[args.config]["nread"], "batch=%d" % NREAD), "name": args.config,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
                        "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
             "roofline": roof,

@@ -749,19 +749,22 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         }
         if (use_split) {
             if (prof) hipEventRecord(b->lev[l][1], s);
-            const int maxt = split_max_tiles(b->eng->prop.multiProcessorCount);
+            // H <= 256: a launch of the dense form (pairs of tiles, two workgroups per CU) takes twice the tiles; it is used for FULL
+            // launches only -- a partly filled one has a group count that is no multiple of 8 XCDs and loses the one-L2 hand-off
+            const int maxt1 = split_max_tiles(b->eng->prop.multiProcessorCount), maxt2 = split_max_tiles(b->eng->prop.multiProcessorCount, Hp);
             void *outS = b->actS[cur ^ 1];
             // (the output doubles as the hand-off flag; the kernel arms it itself a few steps ahead of its stores -- no fill)
             // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
             float *out_f32 = (l == 4 || keep) ? out : nullptr;
-            for (int rt0 = 0; rt0 < B16; rt0 += maxt) {
-                const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
+            for (int rt0 = 0, nrt = 0; rt0 < B16; rt0 += nrt) {
+                const int maxt = (B16 - rt0 >= maxt2) ? maxt2 : maxt1;
+                nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
                 HIP_TRY(hipMemsetAsync(b->pflags, 0, split_flag_words(nrt) * sizeof(unsigned), s), FFHIP_EHIP);
                 // one workgroup per CU: two such launches are co-resident only if together they need no more CUs than there are
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt))
+                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;

@@ -90,12 +90,12 @@ int persist_blocks_per_cu(int kind, int H);
 // persistent LSTM layer on bf16 MFMAs over three-way split operands (ffhip_rnn_split.hip): fp32-exact products at 2.7x
 // the f32 MFMA rate.  Activations in the SPLIT layout A[t][rt][k/32][slice 0..2][lane][8 bf16] (6 bytes per value).
 bool split_supported(int kind, int H);
-int split_max_tiles(int ncu);                              // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU
+int split_max_tiles(int ncu, int H = 512);                // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU (two at H <= 256)
 size_t split_flag_words(int nrt);
 inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 * kSplitNS; }      // 16 reads x H x 2 B x slices
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs = nullptr, const int *tbt = nullptr);      // scale_exp: the exponent S both products carry
+                       int scale_exp, int fast_gates, const int *tbs = nullptr, const int *tbt = nullptr, int ncu = 256);      // scale_exp: the exponent S both products carry
 // recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
 bool rnn_split_supported(int kind, int H);
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,

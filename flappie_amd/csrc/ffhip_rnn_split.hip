@@ -126,7 +126,7 @@ __device__ __forceinline__ void mm6(const v4u (&w)[N][NC][NS], int cc, const v4u
 // work -- latency hiding by occupancy instead of by schedule; the two workgroups' gate phases also stop colliding on the same
 // two SIMDs in lock step (six gate tiles on four SIMDs).
 template <int KIND, int N, int TS>
-__global__ void __launch_bounds__(512, TS == 1 ? 4 : 1)
+__global__ void __launch_bounds__(512, (TS == 1 || N <= 2) ? 4 : 1)
 k_lstm_split(SplitArgs a) {
     __shared__ v4f px[2][4][TS][N][64];     // projection partials, double-buffered: [step parity][K quarter][tile of the group][unit tile][lane]
     __shared__ v4f ph[4][TS][N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial
@@ -1022,7 +1022,10 @@ int split_tiles_per_group(int kind, int H);
 bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 128 * (kind == 0 ? kSplitMaxN : 3); }      // GRUmod at N = 4 spills 169 registers; no GRUmod model is that wide
 // read tiles (of 16) one launch takes: 32 workgroups per group; one workgroup per CU and a pair of tiles per group, or two
 // workgroups per CU and one tile per group -- 2 * (ncu / 32) tiles either way
-int split_max_tiles(int ncu) { return 2 * (ncu / 32); }
+// At H <= 256 the pair form also fits two workgroups per CU (<= 128 VGPRs, 53 KiB LDS): a launch then takes 4 * (ncu / 32) tiles --
+// 512 reads on 256 CUs, four independent 16-read recurrences per CU.  The step of this kernel is a latency chain (hand-off through
+// L2, sweep, gate math), so the reads in flight per launch are what sets its throughput.
+int split_max_tiles(int ncu, int H) { return (H <= 256 && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32); }
 size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
 int split_tiles_per_group(int kind, int H) {
     const char *force = getenv("FFHIP_SPLIT_TS");      // development: 1 or 2
@@ -1034,7 +1037,7 @@ unsigned long long *g_split_dbg = nullptr;
 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt) {
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu) {
     SplitArgs a;
     a.acc_scale = split_pow2(scale_exp);
     a.fast_gates = fast_gates;
@@ -1044,7 +1047,8 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
     // tiles per group: 1 (two workgroups per CU, one read tile each) where that is faster, else 2 (kSplitTS)
-    const int ts = split_tiles_per_group(kind, H);
+    // ... and 2 with two workgroups per CU when the launch carries more tiles than the one-tile form can take (H <= 256)
+    const int ts = (H <= 256 && nrt > 2 * (ncu / 32)) ? 2 : split_tiles_per_group(kind, H);
     const int ngroup_l = (nrt + ts - 1) / ts;
 #define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
                                  else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)

@@ -127,6 +127,35 @@ def test_split_kernel_agrees_with_f32_kernel(B, engine, kind, hidden, nread, T):
     dm.close()
 
 
+@pytest.mark.parametrize("kind,nread", [(M.NET_LSTM5, 512), (M.NET_GRUMOD5, 400)])
+def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monkeypatch):
+    """H <= 256 and more than 256 reads: one launch carries up to 512 reads (pair form, two workgroups per CU) instead of two
+    launches of 256 -- same arithmetic, so every score must be IDENTICAL to what the one-tile launches give (FFHIP_NO_DENSE=1);
+    ragged lengths, the last pair of the 400-read batch has one member"""
+    mdl = M.synthetic_model(kind, 256, seed=5 + kind)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(nread)
+    T = 1000
+    lens = rng.integers(200, T + 1, size=nread)
+    lens[:3] = (T, 200, 237)
+    sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
+    res = []
+    for dense in (True, False):
+        if dense:
+            monkeypatch.delenv("FFHIP_NO_DENSE", raising=False)
+        else:
+            monkeypatch.setenv("FFHIP_NO_DENSE", "1")
+        b = B.Batch(dm, nread, T)
+        b.set_signals_ragged(sigs)
+        b.run(); b.finish()
+        res.append([(b.transitions(r), b.basecall(r), b.quality(r)) for r in range(nread)])
+        b.close()
+    for r in range(nread):
+        assert np.array_equal(res[0][r][0], res[1][r][0]), r
+        assert res[0][r][1:] == res[1][r][1:], r
+    dm.close()
+
+
 def test_split_layout_round_trip(B, engine):
     """fp32 -> slices -> fp32 through the operand format of the split layer kernels (ffhip_split.hpp).  Default build: two
     fp16 slices of x * 2^12 hold |x| <= 1 to 2^-22 relative (absolute floor 2^-37); the -DFFHIP_SPLIT_BF16X3 build's three
