@@ -1,31 +1,29 @@
-// ffhip_rnn_split.hip -- persistent LSTM layer on the bf16 matrix pipes with fp32-exact products.
+// ffhip_rnn_split.hip -- persistent LSTM / GRUmod layer on the 16-bit matrix pipes with fp32-grade products.
 //
 // Same layer as k_lstm_fused (ffhip_rnn_persist.hip; lstm_forward/lstm_backward + lstm_step, layers.c:877-1026)
-// but the two GEMMs of a step, Wi x(t) and sW h(t-1), run as bf16 MFMAs over a three-way split of BOTH operands:
+// but the two GEMMs of a step, Wi x(t) and sW h(t-1), run as 16-bit MFMAs over a split of BOTH operands (ffhip_split.hpp):
 //
-//     v = v0 + v1 + v2,   v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1)      (round to nearest even)
-//
-// The split is EXACT for every fp32 value (8 + 8 + 8 mantissa bits), each bf16 x bf16 product is exact in
-// fp32, and the six products kept -- w0x0, w0x1, w1x0, w1x1, w0x2, w2x0 -- cover every term down to 2^-24 of
-// the largest one: the three that are dropped (w1x2, w2x1, w2x2) are below the rounding of an fp32 product.
-// Measured on K = 768 dot products of this network's magnitudes: max error against fp64 9.4e-7 for the six-term
-// form, 3.4e-6 for a plain fp32 GEMM -- the accumulation rounding is the same fp32
-// rounding either way, the products are better than fp32's.  Six `v_mfma_f32_16x16x32_bf16` (16 cycles each,
-// 16 reads x 16 rows x 32 k) replace eight `v_mfma_f32_16x16x4_f32` (32 cycles each): 2.67x the rate.
+//   default       v * 2^e = h0 + h1 in fp16 (round to nearest even), products w0x0 + w0x1 + w1x0 -- three
+//                 `v_mfma_f32_16x16x32_f16` per fp32 multiply-add block, 4 B per value; the power-of-two scales (activations
+//                 2^12, weights per matrix, one exponent S per layer) keep both slices normal; error of a K = 768 dot product
+//                 against fp64 as an fp32 GEMM's (tests/test_split_numerics.py);
+//   -DFFHIP_SPLIT_BF16X3   round 1's form: three bf16 slices (exact), six products, 6 B per value -- kept as the comparison
+//                 build (profiles/r02_bf16x3_*).  The layout comments below say "NS slices" for both.
 //
 // Activations travel between layers ALREADY SPLIT, so that the split is computed once by the lane that produces
 // a value and not by each of its 32 consumers:
 //
-//   split layout   A[t][rt][c = k/32][s = 0..2][lane 0..63] 16 B      (H*6 bytes per read and block)
+//   split layout   A[t][rt][c = k/32][s = 0..NS-1][lane 0..63] 16 B   (H * 2 NS bytes per read and block)
 //                  lane l = (kq = l>>4, r = l&15) holds slice s of k = 32c + 8kq + 0..7 of read r: exactly the
-//                  B operand of v_mfma_f32_16x16x32_bf16, one 1 KiB coalesced load per (chunk, slice).
+//                  B operand of v_mfma_f32_16x16x32_f16 / _bf16, one 1 KiB coalesced load per (chunk, slice).
 //   weights        W[mat][ut][c][s][lane] 16 B: A operand, lane l = (row i = l&15 of unit tile ut, kq) holds slice s
 //                  of W[16ut + i][32c + 8kq + 0..7]; rows unit-major/gate-minor as everywhere else.
 //
-// Work decomposition (H = 128 N, N = 1..3; H = 384 is the headline shape):
+// Work decomposition (H = 128 N, N = 1..4; H = 384 is the headline shape; template parameter TS below for the variants):
 //   * one GROUP of 32 workgroups per PAIR of read tiles (32 reads); 256 CUs = 8 groups = 256 reads per launch, one
-//     workgroup of 8 waves per CU (the weights of a CU, 48 rows x 768 k x 6 B = 221 KiB, live in VGPRs: 108 per
-//     lane).  Member m owns N unit tiles (4N hidden units x 4 gates);
+//     workgroup of 8 waves per CU (the weights of a CU, 48 rows x 768 k x 2 NS B = 147 KiB (221 for bf16x3), live in
+//     VGPRs).  Member m owns N unit tiles (4N hidden units x 4 gates).  At N <= 2 two workgroups share a CU: one read
+//     tile per group (TS = 1) up to 256 reads per launch, the pair form again for full launches of 512 reads;
 //   * waves 0-3 ("x waves", low priority) hold the input weights of the member's rows, K split four ways, and compute
 //     the projection Wi x(t+1) one step AHEAD, under the hand-off latency of step t; x(t+2) is prefetched into
 //     registers right behind those MFMAs (it comes from HBM: a whole step of latency to hide);
@@ -44,9 +42,9 @@
 //     back to re-sweeping.  Plain stores when the 32 members verifiably share one XCD (= one L2), write-through
 //     otherwise; every spin is bounded (abort word -> FFHIP_ETIMEOUT).
 //
-// Measured (MI355X, 256 reads x 800 blocks, H = 384): 2.84 ms per layer = 170 TFLOP/s of fp32-equivalent work (the f32
-// MFMA kernel: 4.7 ms, 102 TFLOP/s).  Per step ~8500 cycles: hand-off poll ~1000, sweep + MFMAs ~4000 (the matrix
-// pipes carry 216 MFMAs = 3700 cycles per SIMD), gate phase ~2500, barriers ~300 -- DESIGN.md section 5.1.1.
+// Measured (MI355X, 256 reads x 800 blocks, H = 384): 2.29 ms per layer = 211 TFLOP/s of fp32-equivalent work (round 1's bf16x3
+// form 2.84 ms, the f32 MFMA kernel 4.7 ms).  Per step ~6900 cycles: hand-off wait ~1300, MFMAs 1728 per SIMD, gate math ~1150,
+// split / transpose / store ~500, barriers -- DESIGN.md section 5.1.1.
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
 #include "ffhip_split.hpp"
