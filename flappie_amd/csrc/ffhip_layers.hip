@@ -908,3 +908,88 @@ extern "C" int ffhip_op_posterior_flipflop(ffhip_engine *eng, ffhip_mat trans, f
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }
+
+// ---- development probe: packed-fp32 VALU instructions next to another kernel's MFMAs ----------------
+// Every op_sel / op_sel_hi form of v_pk_add_f32, v_pk_mul_f32 and v_pk_fma_f32 against the scalar instruction on the selected
+// halves, in a loop, on its own stream; mismatches are counted by (instruction, form, result half, quarter of the wave).
+namespace ffhip {
+typedef float pkf2 __attribute__((ext_vector_type(2)));
+#define PK_FORM(OPI, MNE, F, S0, S1, H0, H1)                                                                                                  \
+    {                                                                                                                                       \
+        pkf2 r;                                                                                                                             \
+        if (OPI == 2) asm volatile(MNE " %0, %1, %2, %3 op_sel:[" #S0 "," #S1 ",0] op_sel_hi:[" #H0 "," #H1 ",1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); \
+        else asm volatile(MNE " %0, %1, %2 op_sel:[" #S0 "," #S1 "] op_sel_hi:[" #H0 "," #H1 "]" : "=v"(r) : "v"(a), "v"(b));                 \
+        const float elo = ref(OPI, S0 ? a.y : a.x, S1 ? b.y : b.x, c.x), ehi = ref(OPI, H0 ? a.y : a.x, H1 ? b.y : b.x, c.y);                  \
+        if (__float_as_uint(r.x) != __float_as_uint(elo)) atomicAdd(&counts[(((OPI) * 16 + (F)) * 2 + 0) * 4 + quarter], 1u);                 \
+        if (__float_as_uint(r.y) != __float_as_uint(ehi)) atomicAdd(&counts[(((OPI) * 16 + (F)) * 2 + 1) * 4 + quarter], 1u);                 \
+    }
+#define PK_ALL(OPI, MNE)                                                                                                                     \
+    PK_FORM(OPI, MNE, 0, 0, 0, 0, 0) PK_FORM(OPI, MNE, 1, 0, 0, 0, 1) PK_FORM(OPI, MNE, 2, 0, 0, 1, 0) PK_FORM(OPI, MNE, 3, 0, 0, 1, 1)           \
+    PK_FORM(OPI, MNE, 4, 0, 1, 0, 0) PK_FORM(OPI, MNE, 5, 0, 1, 0, 1) PK_FORM(OPI, MNE, 6, 0, 1, 1, 0) PK_FORM(OPI, MNE, 7, 0, 1, 1, 1)           \
+    PK_FORM(OPI, MNE, 8, 1, 0, 0, 0) PK_FORM(OPI, MNE, 9, 1, 0, 0, 1) PK_FORM(OPI, MNE, 10, 1, 0, 1, 0) PK_FORM(OPI, MNE, 11, 1, 0, 1, 1)         \
+    PK_FORM(OPI, MNE, 12, 1, 1, 0, 0) PK_FORM(OPI, MNE, 13, 1, 1, 0, 1) PK_FORM(OPI, MNE, 14, 1, 1, 1, 0) PK_FORM(OPI, MNE, 15, 1, 1, 1, 1)
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_pk_probe(unsigned *counts, int iters) {
+    auto ref = [](int op, float x, float y, float z) {
+        float r;
+        if (op == 0) asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        else if (op == 1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        else asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+        return r;
+    };
+    const int lane = threadIdx.x & 63, quarter = lane >> 4;
+    float pad[NV];                    // register ballast: the probe's VGPR allocation decides which waves it can sit next to
+#pragma unroll
+    for (int k = 0; k < NV; k++) pad[k] = (float)(threadIdx.x * (k + 1));
+    for (int it = 0; it < iters; it++) {
+        const float t = (float)(it & 1023);
+        const pkf2 a = { 1.25f * lane + t, 1000.0f + 0.5f * lane - t }, b = { 3.0f + 0.125f * lane, -77.0f + t + 2.0f * lane }, c = { 0.5f * t, 9.0f - lane };
+        PK_ALL(0, "v_pk_add_f32")
+        PK_ALL(1, "v_pk_mul_f32")
+        PK_ALL(2, "v_pk_fma_f32")
+#define PK_MOV(F, S0, S1)                                                                                                                    \
+        {                                                                                                                                   \
+            pkf2 r;                                                                                                                         \
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[" #S0 "," #S1 "]" : "=v"(r) : "v"(a), "v"(b));                                      \
+            if (__float_as_uint(r.x) != __float_as_uint(S0 ? a.y : a.x)) atomicAdd(&counts[((3 * 16 + (F)) * 2 + 0) * 4 + quarter], 1u);      \
+            if (__float_as_uint(r.y) != __float_as_uint(S1 ? b.y : b.x)) atomicAdd(&counts[((3 * 16 + (F)) * 2 + 1) * 4 + quarter], 1u);      \
+        }
+        PK_MOV(0, 0, 0) PK_MOV(4, 0, 1) PK_MOV(8, 1, 0) PK_MOV(12, 1, 1)
+        // v_pk_fma_f32 with the LOW result taking the HIGH half of source 2 (counted under instruction 3, forms 1 and 2)
+#define PK_FMA2(F, S0, S1)                                                                                                                   \
+        {                                                                                                                                   \
+            pkf2 r;                                                                                                                         \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[" #S0 "," #S1 ",1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));       \
+            if (__float_as_uint(r.x) != __float_as_uint(ref(2, S0 ? a.y : a.x, S1 ? b.y : b.x, c.y))) atomicAdd(&counts[((3 * 16 + (F)) * 2 + 0) * 4 + quarter], 1u); \
+            if (__float_as_uint(r.y) != __float_as_uint(ref(2, a.y, b.y, c.x))) atomicAdd(&counts[((3 * 16 + (F)) * 2 + 1) * 4 + quarter], 1u); \
+        }
+        PK_FMA2(1, 0, 0) PK_FMA2(2, 1, 1)
+#pragma unroll
+        for (int k = 0; k < NV; k++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(pad[k]) : "v"(t));
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) s += pad[k];
+    if (s == 12345.678f) counts[0] = 0xFFFFFFFFu;       // keeps the ballast alive
+}
+}  // namespace ffhip
+
+extern "C" int ffhip_debug_pk_probe(ffhip_engine *eng, int iters, int nwg, int ballast, unsigned *counts) {
+    using namespace ffhip;
+    if (!eng || !counts || iters <= 0 || nwg <= 0) return FFHIP_EINVAL;
+    hipSetDevice(eng->device);
+    unsigned *d = nullptr;
+    hipStream_t s = nullptr;
+    if (hipMalloc(&d, 4 * 16 * 2 * 4 * 4) != hipSuccess) return FFHIP_ENOMEM;
+    hipMemset(d, 0, 4 * 16 * 2 * 4 * 4);
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (ballast >= 96) hipLaunchKernelGGL(k_pk_probe<96>, dim3(nwg), dim3(256), 0, s, d, iters);
+    else if (ballast >= 48) hipLaunchKernelGGL(k_pk_probe<48>, dim3(nwg), dim3(256), 0, s, d, iters);
+    else hipLaunchKernelGGL(k_pk_probe<1>, dim3(nwg), dim3(256), 0, s, d, iters);
+    hipStreamSynchronize(s);
+    hipMemcpy(counts, d, 4 * 16 * 2 * 4 * 4, hipMemcpyDeviceToHost);
+    hipStreamDestroy(s);
+    hipFree(d);
+    return FFHIP_OK;
+}

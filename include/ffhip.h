@@ -150,6 +150,11 @@ int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out,
  * patterns: 0 means bit-identical */
 int ffhip_debug_lean_math_check(ffhip_engine *eng, int exponent, int steps, unsigned long long *mismatches);
 
+/* debug tap: every op_sel / op_sel_hi form of the packed-fp32 VALU instructions checked against the scalar
+ * instructions in a loop on a stream of its own, so that it can run beside a batch's kernels; counts[4][16][2][4] mismatches by
+ * instruction (add, mul, fma, v_pk_mov_b32: forms 0, 4, 8, 12 only), form (op_sel[0], op_sel[1], op_sel_hi[0], op_sel_hi[1] as a 4-bit number), result half, wave quarter */
+int ffhip_debug_pk_probe(ffhip_engine *eng, int iters, int nwg, int ballast, unsigned *counts);
+
 /* ---- single-matrix decode entry points -------------------------------------------------------
  * Used by the reference-compatible wrappers in include/decode.h.  `trans` / `scores` / `post` are
  * host arrays in the reference's flappie_matrix image: `nblock` columns of `stride` floats, the

@@ -156,6 +156,69 @@ def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monk
     dm.close()
 
 
+@pytest.mark.parametrize("kind,hidden,nread", [(M.NET_LSTM5, 384, 256), (M.NET_LSTM5, 256, 512), (M.NET_GRUMOD5, 256, 256)])
+def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, nread):
+    """bench.py's default at c2 and the flappie binary keep two batches in flight (one stream each; the persistent layer launches of
+    the two are chained, every other kernel overlaps the other batch's layers).  Three rounds of run / run / finish / finish with
+    different signals per batch: every score identical to the same batch run alone"""
+    mdl = M.synthetic_model(kind, hidden, seed=3)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(hidden + nread)
+    T = 1500
+    sig = [rng.standard_normal((nread, T)).astype(np.float32) for _ in range(2)]
+    alone = []
+    for k in range(2):
+        b = B.Batch(dm, nread, T)
+        b.set_signals(sig[k])
+        b.run(); b.finish()
+        alone.append([(b.transitions(r), b.basecall(r), b.quality(r)) for r in range(0, nread, 7)])
+        b.close()
+    bs = [B.Batch(dm, nread, T) for _ in range(2)]
+    for rnd in range(3):
+        for k in range(2):
+            bs[k].set_signals(sig[(k + rnd) % 2])
+            bs[k].run()
+        for k in range(2):
+            bs[k].finish()
+            want = alone[(k + rnd) % 2]
+            for i, r in enumerate(range(0, nread, 7)):
+                assert np.array_equal(bs[k].transitions(r), want[i][0]), (rnd, k, r)
+                assert (bs[k].basecall(r), bs[k].quality(r)) == want[i][1:], (rnd, k, r)
+    for b in bs:
+        b.close()
+    dm.close()
+
+
+def test_packed_fp32_forms_beside_the_layer_kernel(B, engine):
+    """beside a wave that issues 16-bit MFMAs, v_pk_{add,mul,fma}_f32 ... op_sel:[0,1] returns a wrong low
+    half in lanes 48-63; tools/check_isa.py keeps that form out of the library.  The guard is only as good as its list, so: the
+    probe (every op_sel form against the scalar instructions) must be clean alone, and beside an H = 256 batch's layer kernels
+    every OTHER form must stay clean -- a new failing form has to show up here."""
+    import ctypes as C
+    lib = B.lib()
+    lib.ffhip_debug_pk_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint)]
+
+    def probe():
+        buf = (C.c_uint * (4 * 16 * 2 * 4))()
+        assert lib.ffhip_debug_pk_probe(engine.h, 4000, 2048, 1, buf) == 0
+        return np.frombuffer(buf, dtype=np.uint32).reshape(4, 16, 2, 4).copy()
+
+    assert probe().sum() == 0
+    mdl = M.synthetic_model(M.NET_LSTM5, 256, seed=3)
+    dm = B.DeviceModel(engine, mdl)
+    b = B.Batch(dm, 256, 20000)
+    b.set_signals(np.random.default_rng(9).standard_normal((256, 20000)).astype(np.float32))
+    b.run(1.0, B.RUN_NO_DECODE)
+    c = probe()
+    b.finish()
+    b.close(); dm.close()
+    known = np.zeros_like(c, dtype=bool)
+    known[0:3, 4:8, 0, :] = True                 # add / mul / fma, op_sel:[0,1] with any op_sel_hi, low half
+    assert c[~known].sum() == 0, np.argwhere((c > 0) & ~known)[:8]
+    print("packed-fp32 probe beside the H = 256 layer kernels: %d mismatches, all in op_sel:[0,1] low halves; by wave quarter %s"
+          % (int(c.sum()), c[known].reshape(-1, 4).sum(axis=0).tolist()))
+
+
 def test_split_layout_round_trip(B, engine):
     """fp32 -> slices -> fp32 through the operand format of the split layer kernels (ffhip_split.hpp).  Default build: two
     fp16 slices of x * 2^12 hold |x| <= 1 to 2^-22 relative (absolute floor 2^-37); the -DFFHIP_SPLIT_BF16X3 build's three
