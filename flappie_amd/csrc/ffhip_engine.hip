@@ -50,6 +50,7 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
         return nullptr;
     }
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
+    HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
     return e;
 }
@@ -57,6 +58,10 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
 extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     if (!e) return;
     for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
+    if (e->prep_stream) hipStreamDestroy(e->prep_stream);
+    if (e->prep_pin) hipHostFree(e->prep_pin);
+    for (int i = 0; i < 4; i++) if (e->prep_scratch[i]) hipFree(e->prep_scratch[i]);
+    for (auto &b : e->prep_pool) hipFree(b.first);
     if (e->persist_done) hipEventDestroy(e->persist_done);
     delete e;
 }
@@ -334,6 +339,7 @@ struct ffhip_batch {
     int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
     char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
     int32_t *trace = nullptr;
+    const float **d_gsrc = nullptr; int *d_glen = nullptr;              // ffhip_batch_set_prepared: source rows of the gather
     unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel XCC ids / abort word
     int persist_concurrent_ok = 0;      // two such batches fit on the chip at once
     float *scratch = nullptr;           // dense [Tb][H] for debug taps
@@ -632,10 +638,16 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
     if (int rc = apply_lengths(b, lens)) return rc;
     if (b->ragged) if (int rc = clear_signals(b)) return rc;
     SampleBuf &sb = b->sbuf[0];
-    for (int r = 0; r < b->nread; r++)
-        if (lens[r] > 0)
-            HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)r * sb.rs + kSamplePad), src[r], (size_t)lens[r] * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
-    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    // one gather launch for the whole batch (a device-to-device copy per read is a launch per read: 512 of them cost more than the copies)
+    if (!b->d_gsrc) {
+        b->d_gsrc = (const float **)dalloc(b, (size_t)b->nread * sizeof(float *), false);
+        b->d_glen = (int *)dalloc(b, (size_t)b->nread * 4, false);
+        if (!b->d_gsrc || !b->d_glen) return FFHIP_ENOMEM;
+    }
+    HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src.data(), (size_t)b->nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->d_glen, lens.data(), (size_t)b->nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, b->nread);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);             // src / lens go out of scope
     b->ran = b->finished = 0;
     return FFHIP_OK;
 }

@@ -25,6 +25,15 @@ struct ffhip_engine {
     // co-tenancy becomes a slowdown, not FFHIP_ETIMEOUT.
     int stepwise_batches = 0;
     int fallbacks = 0;          // how often that happened (ffhip_debug_fallback_count)
+    // Signal preparation (ffhip_prep.hip) runs on a stream of its own -- beside the batches, not queued behind one of them -- and
+    // keeps its buffers: a pinned staging area (one packed upload per chunk instead of one per read), the kernel's scratch, and a
+    // pool of output buffers handed to ffhip_prep objects (hipMalloc / hipFree per chunk would synchronise the device each time).
+    hipStream_t prep_stream = nullptr;
+    void *prep_pin = nullptr;
+    size_t prep_pin_cap = 0;
+    void *prep_scratch[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t prep_scratch_cap[4] = { 0, 0, 0, 0 };
+    std::vector<std::pair<void *, size_t>> prep_pool;       // free output buffers (pointer, bytes)
 };
 
 struct ffhip_prep;

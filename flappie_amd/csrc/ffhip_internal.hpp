@@ -89,6 +89,7 @@ int persist_blocks_per_cu(int kind, int H);
 
 // persistent LSTM layer on bf16 MFMAs over three-way split operands (ffhip_rnn_split.hip): fp32-exact products at 2.7x
 // the f32 MFMA rate.  Activations in the SPLIT layout A[t][rt][k/32][slice 0..2][lane][8 bf16] (6 bytes per value).
+void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow);
 bool split_supported(int kind, int H);
 int split_max_tiles(int ncu, int H = 512);                // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU (two at H <= 256)
 size_t split_flag_words(int nrt);

@@ -1984,4 +1984,15 @@ void launch_untile(hipStream_t s, const float *act, float *dense, int read, int 
     hipLaunchKernelGGL(k_untile, dim3((Tb * H + 255) / 256), dim3(256), 0, s, act, dense, read, Tb, B16, H);
 }
 
+// ---- rows of different lengths from anywhere on the device into the batch's signal buffer (ffhip_batch_set_prepared) ----
+__global__ void __launch_bounds__(256) k_gather_rows(const float *const *__restrict__ src, const int *__restrict__ lens, float *__restrict__ dst, size_t row_stride) {
+    const float *s = src[blockIdx.x];
+    const int n = lens[blockIdx.x];
+    float *d = dst + (size_t)blockIdx.x * row_stride;
+    for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow) {
+    hipLaunchKernelGGL(k_gather_rows, dim3(nrow), dim3(256), 0, s, src, lens, dst, row_stride);
+}
+
 }  // namespace ffhip

@@ -251,13 +251,60 @@ struct ffhip_prep {
     ffhip_engine *eng = nullptr;
     int nread = 0;
     float *d_out = nullptr;
+    size_t d_out_cap = 0;                // bytes, as taken from the engine's pool
     std::vector<size_t> off, start, end;
     std::vector<float> stats;
 };
 
+// ---- buffers kept by the engine (ffhip_host.hpp): no hipMalloc / hipFree -- i.e. no device-wide synchronisation -- per chunk ----
+static void *prep_scratch(ffhip_engine *e, int slot, size_t bytes) {
+    if (e->prep_scratch_cap[slot] >= bytes && e->prep_scratch[slot]) return e->prep_scratch[slot];
+    if (e->prep_scratch[slot]) hipFree(e->prep_scratch[slot]);
+    e->prep_scratch[slot] = nullptr; e->prep_scratch_cap[slot] = 0;
+    const size_t cap = bytes + bytes / 4 + 256;
+    if (hipMalloc(&e->prep_scratch[slot], cap) != hipSuccess) return nullptr;
+    e->prep_scratch_cap[slot] = cap;
+    return e->prep_scratch[slot];
+}
+static void *prep_pinned(ffhip_engine *e, size_t bytes) {
+    if (e->prep_pin_cap >= bytes && e->prep_pin) return e->prep_pin;
+    if (e->prep_pin) hipHostFree(e->prep_pin);
+    e->prep_pin = nullptr; e->prep_pin_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 256;
+    if (hipHostMalloc(&e->prep_pin, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    e->prep_pin_cap = cap;
+    return e->prep_pin;
+}
+static float *prep_pool_take(ffhip_engine *e, size_t bytes, size_t *cap_out) {
+    int best = -1;
+    for (int i = 0; i < (int)e->prep_pool.size(); i++)
+        if (e->prep_pool[i].second >= bytes && (best < 0 || e->prep_pool[i].second < e->prep_pool[best].second)) best = i;
+    if (best >= 0) {
+        void *q = e->prep_pool[best].first;
+        *cap_out = e->prep_pool[best].second;
+        e->prep_pool.erase(e->prep_pool.begin() + best);
+        return (float *)q;
+    }
+    void *q = nullptr;
+    const size_t cap = bytes + bytes / 4 + 256;
+    if (hipMalloc(&q, cap) != hipSuccess) return nullptr;
+    *cap_out = cap;
+    return (float *)q;
+}
+
 extern "C" void ffhip_prep_destroy(ffhip_prep *p) {
     if (!p) return;
-    if (p->d_out) hipFree(p->d_out);
+    if (p->d_out) {
+        // back to the engine's pool (at most four buffers wait there; the smallest goes when a fifth arrives)
+        auto &pool = p->eng->prep_pool;
+        pool.emplace_back((void *)p->d_out, p->d_out_cap);
+        if (pool.size() > 4) {
+            size_t k = 0;
+            for (size_t i = 1; i < pool.size(); i++) if (pool[i].second < pool[k].second) k = i;
+            hipFree(pool[k].first);
+            pool.erase(pool.begin() + k);
+        }
+    }
     delete p;
 }
 
@@ -271,7 +318,7 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     }
     if ((mode == FFHIP_PREP_DELTA || mode == FFHIP_PREP_SHIFT_SCALE) && !(delta != 0.0f)) { set_err(FFHIP_EINVAL, "delta scaling factor must be non-zero"); return nullptr; }
     hipSetDevice(eng->device);
-    hipStream_t s = eng->streams[0];
+    hipStream_t s = eng->prep_stream;      // beside the batches' streams: a chunk is prepared while the previous chunk's last batch runs
     ffhip_prep *p = new ffhip_prep();
     p->eng = eng;
     p->nread = nread;
@@ -288,14 +335,16 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
         p->off[r] = total; n_in[r] = rt.n; s_in[r] = rt.start; e_in[r] = rt.end;
         total += (rt.n + 3) & ~(size_t)3;
     }
-    TmpDev tmp;
-    float *d_raw = (float *)tmp.get(total * 4), *d_mad = (float *)tmp.get(total * 4);
-    size_t *d_sz = (size_t *)tmp.get((size_t)6 * nread * sizeof(size_t));
-    float *d_stats = (float *)tmp.get((size_t)2 * nread * 4);
+    float *d_raw = (float *)prep_scratch(eng, 0, total * 4), *d_mad = (float *)prep_scratch(eng, 1, total * 4);
+    size_t *d_sz = (size_t *)prep_scratch(eng, 2, (size_t)6 * nread * sizeof(size_t));
+    float *d_stats = (float *)prep_scratch(eng, 3, (size_t)2 * nread * 4);
+    float *pin = (float *)prep_pinned(eng, total * 4);
 #define PFAIL(code, msg) do { set_err(code, msg); ffhip_prep_destroy(p); return nullptr; } while (0)
-    if (!d_raw || !d_mad || !d_sz || !d_stats || hipMalloc((void **)&p->d_out, total * 4) != hipSuccess) PFAIL(FFHIP_ENOMEM, "device allocation failed");
-    for (int r = 0; r < nread; r++)
-        if (hipMemcpyAsync(d_raw + p->off[r], reads[r].raw, reads[r].n * 4, hipMemcpyHostToDevice, s) != hipSuccess) PFAIL(FFHIP_EHIP, "upload of raw signal failed");
+    if (!d_raw || !d_mad || !d_sz || !d_stats || !pin || !(p->d_out = prep_pool_take(eng, total * 4, &p->d_out_cap))) PFAIL(FFHIP_ENOMEM, "device allocation failed");
+    // one packed upload for the chunk: the reads are gathered in pinned memory first (a copy per read from pageable memory costs
+    // 10-20 us of launch and staging each -- 30 ms for 2048 reads, during which nothing else was submitted)
+    for (int r = 0; r < nread; r++) memcpy(pin + p->off[r], reads[r].raw, reads[r].n * 4);
+    if (hipMemcpyAsync(d_raw, pin, total * 4, hipMemcpyHostToDevice, s) != hipSuccess) PFAIL(FFHIP_EHIP, "upload of raw signal failed");
     size_t *d_off = d_sz, *d_n = d_sz + nread, *d_s = d_sz + 2 * (size_t)nread, *d_e = d_sz + 3 * (size_t)nread, *d_so = d_sz + 4 * (size_t)nread, *d_eo = d_sz + 5 * (size_t)nread;
     bool ok = hipMemcpyAsync(d_off, p->off.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_n, n_in.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;

@@ -65,7 +65,7 @@ static struct argp_option options[] = {
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default 256; 512 for models of at most 256 hidden units)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
-    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 4; 0 reads in this process)"},
+    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 8; 0 reads in this process)"},
     {0}
 };
 
@@ -96,7 +96,7 @@ static struct {
     int batch;
     int readers;
     int shard, nshard;
-} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 4, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
+} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 8, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
 
 static void print_models(FILE *fh) {
     for (int mdl = 0; mdl < (int)flappie_nmodel; mdl++)
@@ -237,11 +237,12 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
 
 /* A group of prepared reads in flight: submitted (upload + network + decode enqueued on the batch's stream), collected
  * later (flappie.c:264-316 after normalisation) -- so the host side of the next group overlaps the GPU side of this one. */
-typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_prep *prep; } pending_batch;
+struct chunk_ctx;
+typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_prep *prep; struct chunk_ctx *owner; } pending_batch;
 
 static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, int slot) {
     const int nmax = (n > args.batch) ? n : args.batch;
-    pending_batch pb = { NULL, 0, n, malloc(nmax * sizeof(int)), malloc(n * sizeof(item *)), prep };
+    pending_batch pb = { NULL, 0, n, malloc(nmax * sizeof(int)), malloc(n * sizeof(item *)), prep, NULL };
     memcpy(pb.its, its, n * sizeof(item *));
     for (int i = 0; i < nmax; i++) pb.idx[i] = (i < n) ? its[i]->prepared : -1;             /* -1: empty slot */
     size_t len = 0;                                          /* capacity = the longest read of the (sorted) group */
@@ -362,58 +363,58 @@ static void collect_batch(const struct ffhip_model *mdl, pending_batch *pb) {
     pb->b = NULL;
 }
 
+/* A chunk of reads on its way through the GPU: prepared in one device pass (flappie.c:248-262: trim/segment, then med-MAD or
+ * --delta), cut into batches of similar trimmed length, written in input order (flappie.c:371-384).  The batch pipeline does
+ * NOT drain between chunks: the first batch of chunk k+1 is submitted before the last batch of chunk k is collected, and chunk
+ * k is written while chunk k+1 runs -- the signal preparation of k+1 and the output of k overlap GPU work. */
+typedef struct chunk_ctx {
+    item *items;
+    int n, buf;                  /* buf: which of the reader's buffers holds the items (released when the chunk is written) */
+    ffhip_prep *prep;
+    raw_table *rts;
+    item **group;
+    int m2, submitted, collected, all_submitted, live;
+} chunk_ctx;
+
 static int by_length_desc(const void *x, const void *y) {
     const item *a = *(item *const *)x, *b = *(item *const *)y;
     const size_t la = a->res.rt.end - a->res.rt.start, lb = b->res.rt.end - b->res.rt.start;
     return (la < lb) - (la > lb);
 }
 
-/* flappie.c:248-262 for every read of the chunk in one device pass (trim/segment, then med-MAD or --delta),
- * then batches of equal trimmed length, output in input order (flappie.c:371-384) */
-static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, hid_t hdf5out) {
-    item **group = calloc(n > 0 ? n : 1, sizeof(item *));
-    char *done = calloc(n > 0 ? n : 1, 1);
-    raw_table *rts = calloc(n > 0 ? n : 1, sizeof(raw_table));
+static void chunk_begin(struct ffhip_engine *eng, chunk_ctx *c, item *items, int n, int buf) {
+    memset(c, 0, sizeof(*c));
+    c->items = items; c->n = n; c->buf = buf; c->live = 1;
+    c->group = calloc(n > 0 ? n : 1, sizeof(item *));
+    c->rts = calloc(n > 0 ? n : 1, sizeof(raw_table));
     int m = 0;
     for (int i = 0; i < n; i++) {
         items[i].prepared = -1;
-        if (NULL != items[i].res.rt.raw) { rts[m] = items[i].res.rt; items[i].prepared = m++; }
+        if (NULL != items[i].res.rt.raw) { c->rts[m] = items[i].res.rt; items[i].prepared = m++; }
     }
     double tp0 = now_s();
-    ffhip_prep *prep = (m > 0) ? ffhip_prep_create(eng, rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
-                                                   (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
+    c->prep = (m > 0) ? ffhip_prep_create(eng, c->rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
+                                          (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
     t_phase[1] += now_s() - tp0;
-    if (m > 0 && NULL == prep) warnx("%s", ffhip_last_error());
+    if (m > 0 && NULL == c->prep) warnx("%s", ffhip_last_error());
     for (int i = 0; i < n; i++) {
         if (items[i].prepared < 0) continue;
         size_t st = 0, en = 0;
-        if (NULL == prep || 0 != ffhip_prep_range(prep, items[i].prepared, &st, &en) || st >= en) { items[i].prepared = -1; continue; }
+        if (NULL == c->prep || 0 != ffhip_prep_range(c->prep, items[i].prepared, &st, &en) || st >= en) { items[i].prepared = -1; continue; }
         items[i].res.rt.start = st;
         items[i].res.rt.end = en;
     }
-    {   /* ragged batches: reads sorted by trimmed length, a batch takes up to --batch consecutive ones as long as the
-         * shortest is at least 3/4 of the longest (a read tile of 16 costs what its longest read costs) */
-        int m2 = 0;
-        for (int i = 0; i < n; i++) if (items[i].prepared >= 0) group[m2++] = &items[i];
-        qsort(group, m2, sizeof(item *), by_length_desc);
-        pending_batch prev = { NULL, 0, 0, NULL, NULL, NULL };
-        int have_prev = 0, slot = 0;
-        for (int i = 0; i < m2; ) {
-            const size_t longest = group[i]->res.rt.end - group[i]->res.rt.start;
-            int g = 1;
-            while (i + g < m2 && g < args.batch && 4 * (group[i + g]->res.rt.end - group[i + g]->res.rt.start) >= 3 * longest) g++;
-            pending_batch cur = submit_batch(eng, mdl, prep, group + i, g, slot);
-            if (have_prev) collect_batch(mdl, &prev);
-            prev = cur;
-            have_prev = 1;
-            slot ^= 1;
-            i += g;
-        }
-        if (have_prev) collect_batch(mdl, &prev);
-    }
+    /* ragged batches: reads sorted by trimmed length, a batch takes up to --batch consecutive ones as long as the
+     * shortest is at least 3/4 of the longest (a read tile of 16 costs what its longest read costs) */
+    for (int i = 0; i < n; i++) if (items[i].prepared >= 0) c->group[c->m2++] = &items[i];
+    qsort(c->group, c->m2, sizeof(item *), by_length_desc);
+}
+
+/* output of a finished chunk, in input order; releases what the chunk owns */
+static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
     const double to0 = now_s();
-    for (int i = 0; i < n; i++) {
-        item *it = &items[i];
+    for (int i = 0; i < c->n; i++) {
+        item *it = &c->items[i];
 #ifdef BUILD_RUNNIE
         if (NULL != it->rle_text) {
             fprintf(args.output, "# %s\n%s", it->res.rt.uuid ? it->res.rt.uuid : "", it->rle_text);      /* runnie.c:280 */
@@ -444,10 +445,68 @@ static void flush_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl,
         free(it->filename);
     }
     t_phase[5] += now_s() - to0;
-    ffhip_prep_destroy(prep);
-    free(rts);
-    free(group);
-    free(done);
+    ffhip_prep_destroy(c->prep);
+    free(c->rts);
+    free(c->group);
+    c->live = 0;
+}
+
+/* the pipeline's state: at most one batch submitted and not collected; chunks finish (are written) strictly in order */
+#define NCHUNKBUF 3
+static struct {
+    pending_batch prev;
+    int have_prev, slot;
+    chunk_ctx ctx[NCHUNKBUF];
+    long next_finish, nbegun;            /* chunk sequence numbers; chunk q lives in ctx[q % NCHUNKBUF] */
+    void (*released)(int buf, void *arg);
+    void *released_arg;
+} pipe_state;
+
+static void pipe_finish_ready(hid_t hdf5out) {
+    while (pipe_state.next_finish < pipe_state.nbegun) {
+        chunk_ctx *c = &pipe_state.ctx[pipe_state.next_finish % NCHUNKBUF];
+        if (!(c->all_submitted && c->collected == c->submitted)) break;
+        const int buf = c->buf;
+        chunk_finish(c, hdf5out);
+        pipe_state.next_finish++;
+        if (pipe_state.released) pipe_state.released(buf, pipe_state.released_arg);
+    }
+}
+
+static void pipe_collect_prev(const struct ffhip_model *mdl, hid_t hdf5out) {
+    if (!pipe_state.have_prev) return;
+    chunk_ctx *owner = pipe_state.prev.owner;
+    collect_batch(mdl, &pipe_state.prev);
+    pipe_state.have_prev = 0;
+    owner->collected++;
+    pipe_finish_ready(hdf5out);
+}
+
+static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out) {
+    chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
+    if (c->live) errx(EXIT_FAILURE, "internal error: chunk slot still in use");
+    chunk_begin(eng, c, items, n, buf);            /* the device pass runs beside the batch still in flight */
+    pipe_state.nbegun++;
+    for (int i = 0; i < c->m2; ) {
+        const size_t longest = c->group[i]->res.rt.end - c->group[i]->res.rt.start;
+        int g = 1;
+        while (i + g < c->m2 && g < args.batch && 4 * (c->group[i + g]->res.rt.end - c->group[i + g]->res.rt.start) >= 3 * longest) g++;
+        pending_batch cur = submit_batch(eng, mdl, c->prep, c->group + i, g, pipe_state.slot);
+        cur.owner = c;
+        c->submitted++;
+        pipe_collect_prev(mdl, hdf5out);           /* may complete and write the previous chunk */
+        pipe_state.prev = cur;
+        pipe_state.have_prev = 1;
+        pipe_state.slot ^= 1;
+        i += g;
+    }
+    c->all_submitted = 1;
+    pipe_finish_ready(hdf5out);                    /* a chunk without a single batch (every read failed) */
+}
+
+static void pipe_drain(const struct ffhip_model *mdl, hid_t hdf5out) {
+    pipe_collect_prev(mdl, hdf5out);
+    pipe_finish_ready(hdf5out);
 }
 
 /* ---- input side: the list of files (flappie.c:336-358), read one chunk ahead of the GPU by a reader thread ---- */
@@ -495,9 +554,9 @@ static void list_files(file_list *fl) {
 typedef struct {
     const file_list *fl;
     int chunk_cap;
-    item *items[2];
-    int nitem[2];
-    sem_t filled[2], empty[2];
+    item *items[NCHUNKBUF];              /* one more than the two chunks that can be unfinished at a time */
+    int nitem[NCHUNKBUF];
+    sem_t filled[NCHUNKBUF], empty[NCHUNKBUF];
 } reader_state;
 
 /* ---- reader PROCESSES.  Opening and reading a single-read fast5 costs ~0.1-0.15 ms of CPU in libhdf5 (~6800 files/s on one
@@ -612,10 +671,12 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
     *nitem = n;
 }
 
+static void release_buffer(int buf, void *arg) { sem_post(&((reader_state *)arg)->empty[buf]); }
+
 static void *reader_main(void *arg) {
     reader_state *rs = arg;
     size_t first = 0;
-    for (int k = 0; first < rs->fl->n; k ^= 1) {
+    for (int k = 0; first < rs->fl->n; k = (k + 1) % NCHUNKBUF) {
         sem_wait(&rs->empty[k]);
         /* the first chunk is one batch only, so that the GPU starts after --batch files instead of four times as many */
         read_chunk(rs->fl, first, first == 0 ? rs->chunk_cap / 4 : rs->chunk_cap, rs->items[k], &rs->nitem[k]);
@@ -644,7 +705,7 @@ int main(int argc, char *argv[]) {
     /* reads per batch: at H <= 256 one layer launch takes 512 reads (ffhip_rnn_split.hip, dense form), else 256 */
     if (0 == args.batch) args.batch = (ffhip_model_hidden(mdl) <= 256) ? 512 : 256;
     rs.chunk_cap = 4 * args.batch;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NCHUNKBUF; k++) {
         rs.items[k] = calloc(rs.chunk_cap, sizeof(item));
         sem_init(&rs.filled[k], 0, 0);
         sem_init(&rs.empty[k], 0, 1);
@@ -654,18 +715,21 @@ int main(int argc, char *argv[]) {
     if (threaded && 0 != pthread_create(&reader, NULL, reader_main, &rs)) errx(EXIT_FAILURE, "could not start the reader thread");
     size_t done = 0;
     double t_wait = 0.0;
-    for (int k = 0; done < fl.n; k ^= 1) {
+    if (threaded) { pipe_state.released = release_buffer; pipe_state.released_arg = &rs; }
+    for (int k = 0; done < fl.n; k = (k + 1) % NCHUNKBUF) {
         const double tw0 = now_s();
+        /* buffer k was released when the chunk three back was written: at most two chunks are unfinished at a time */
         if (threaded) sem_wait(&rs.filled[k]);
         else read_chunk(&fl, done, done == 0 ? rs.chunk_cap / 4 : rs.chunk_cap, rs.items[k], &rs.nitem[k]);
         t_wait += now_s() - tw0;
-        flush_chunk(eng, mdl, rs.items[k], rs.nitem[k], hdf5out);
-        done += rs.nitem[k];
-        if (threaded) sem_post(&rs.empty[k]);
+        const int nk = rs.nitem[k];              /* (the reader may refill the buffer as soon as the chunk is written) */
+        pipe_chunk(eng, mdl, rs.items[k], nk, k, hdf5out);
+        done += nk;
     }
+    pipe_drain(mdl, hdf5out);
     if (threaded) pthread_join(reader, NULL);
     stop_reader_procs();
-    for (int k = 0; k < 2; k++) free(rs.items[k]);
+    for (int k = 0; k < NCHUNKBUF; k++) free(rs.items[k]);
     free(fl.path);
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);

@@ -43,7 +43,8 @@ for nr in readers:
     for n in counts:
         t0 = time.time()
         env["FLAPPIE_CLI_TIMING"] = "1"
-        r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie"), "--readers", nr, "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
+        wrap = os.environ.get("FLAPPIE_WRAP", "").split() if n == counts[-1] else []      # e.g. "rocprofv3 --kernel-trace --output-format csv -d DIR --" on the largest run
+        r = subprocess.run(wrap + [os.path.join(ROOT, "flappie_amd", "flappie"), "--readers", nr, "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
                            capture_output=True, text=True)
         dt = time.time() - t0
         nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
