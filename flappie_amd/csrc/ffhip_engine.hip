@@ -324,6 +324,22 @@ struct ffhip_batch {
     // ragged batch (reads of different lengths, all <= T): per-read window tables, block counts and tile maxima
     bool ragged = false;
     std::vector<int> hT, hTb;           // samples / blocks of each read
+    // host images of the tables below: they stay alive here so that their uploads can be asynchronous on the batch's stream (a
+    // synchronous copy or a stream synchronisation in the set-up path waits for compute slots the other batch's layer launches hold)
+    // (pinned: an asynchronous copy from pageable memory is staged by the runtime and may block the caller)
+    struct Pinned {
+        void *p = nullptr; size_t cap = 0;
+        void *get(size_t bytes) {
+            if (cap >= bytes && p) return p;
+            if (p) hipHostFree(p);
+            p = nullptr; cap = 0;
+            if (hipHostMalloc(&p, bytes + bytes / 4 + 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+            cap = bytes + bytes / 4 + 64;
+            return p;
+        }
+        ~Pinned() { if (p) hipHostFree(p); }
+    };
+    Pinned h_tin[3], h_ta[3], h_tq[3], h_tbs, h_tbt, h_glen, h_gsrc;
     int *d_tbs = nullptr, *d_tbt = nullptr;
     int *rag_x0a[3] = { nullptr, nullptr, nullptr }, *rag_x0b[3] = { nullptr, nullptr, nullptr };
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
@@ -512,13 +528,15 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
         if (m->conv[l].stride == 1 && l < m->nconv - 1) {
             // stride 1: column c's window starts at c - padL for every length; the kernel only needs the lengths
             if (!b->rag_tin[l] && !(b->rag_tin[l] = (int *)dalloc(b, (size_t)b->Bp * 4, true))) return FFHIP_ENOMEM;
-            std::vector<int> tin(b->Bp, 0);
+            int *tin = (int *)b->h_tin[l].get((size_t)b->Bp * 4);
+            if (!tin) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+            memset(tin, 0, (size_t)b->Bp * 4);
             for (int r = 0; r < b->nread; r++) {
                 if (cur[r] != 0 && cur[r] < m->conv[l].winlen)
                     return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", r, cur[r], l, m->conv[l].winlen);
                 tin[r] = cur[r];
             }
-            HIP_TRY(hipMemcpy(b->rag_tin[l], tin.data(), tin.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->rag_tin[l], tin, (size_t)b->Bp * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
             continue;                                                  // output length = input length
         }
         const size_t n = (size_t)b->Bp * Tmax;
@@ -527,7 +545,9 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
             b->rag_x0b[l] = (int *)dalloc(b, n * 4, false);
             if (!b->rag_x0a[l] || !b->rag_x0b[l]) return FFHIP_ENOMEM;
         }
-        std::vector<int> ta(n, kZeroCol), tq(n, kZeroCol);
+        int *ta = (int *)b->h_ta[l].get(n * 4), *tq = (int *)b->h_tq[l].get(n * 4);
+        if (!ta || !tq) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+        std::fill(ta, ta + n, kZeroCol); std::fill(tq, tq + n, kZeroCol);
         std::map<int, std::pair<std::vector<int>, std::vector<int>>> cache;
         for (int r = 0; r < b->nread; r++) {
             if (cur[r] == 0) continue;                                 // empty slot: its row stays all kZeroCol
@@ -539,13 +559,12 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
                 it = cache.emplace(cur[r], std::make_pair(std::move(a), std::move(bq))).first;
             }
             const std::vector<int> &a = it->second.first, &bq = it->second.second;
-            memcpy(ta.data() + (size_t)r * Tmax, a.data(), a.size() * 4);
-            memcpy(tq.data() + (size_t)r * Tmax, bq.data(), bq.size() * 4);
+            memcpy(ta + (size_t)r * Tmax, a.data(), a.size() * 4);
+            memcpy(tq + (size_t)r * Tmax, bq.data(), bq.size() * 4);
             cur[r] = (int)a.size();
         }
-        HIP_TRY(hipMemcpyAsync(b->rag_x0a[l], ta.data(), n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
-        HIP_TRY(hipMemcpyAsync(b->rag_x0b[l], tq.data(), n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
-        HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);        // ta/tq go out of scope
+        HIP_TRY(hipMemcpyAsync(b->rag_x0a[l], ta, n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->rag_x0b[l], tq, n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     }
     b->hTb = cur;
     if (!b->d_tbs) {
@@ -553,10 +572,12 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
         b->d_tbt = (int *)dalloc(b, (size_t)b->B16 * 4, true);
         if (!b->d_tbs || !b->d_tbt) return FFHIP_ENOMEM;
     }
-    std::vector<int> tbs(b->Bp, 0), tbt(b->B16, 0);
+    int *tbs = (int *)b->h_tbs.get((size_t)b->Bp * 4), *tbt = (int *)b->h_tbt.get((size_t)b->B16 * 4);
+    if (!tbs || !tbt) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+    memset(tbs, 0, (size_t)b->Bp * 4); memset(tbt, 0, (size_t)b->B16 * 4);
     for (int r = 0; r < b->nread; r++) { tbs[r] = cur[r]; tbt[r / 16] = std::max(tbt[r / 16], cur[r]); }
-    HIP_TRY(hipMemcpy(b->d_tbs, tbs.data(), tbs.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
-    HIP_TRY(hipMemcpy(b->d_tbt, tbt.data(), tbt.size() * 4, hipMemcpyHostToDevice), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->d_tbs, tbs, (size_t)b->Bp * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->d_tbt, tbt, (size_t)b->B16 * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     b->ragged = true;
     return FFHIP_OK;
 }
@@ -626,8 +647,10 @@ extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
 extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads) {
     if (!b || !prep || !reads) return set_err(FFHIP_EINVAL, "bad prepared-read arguments");
     hipSetDevice(b->eng->device);
-    std::vector<int> lens(b->nread);
-    std::vector<const float *> src(b->nread);
+    std::vector<int> lens(b->nread, 0);
+    int *plen = (int *)b->h_glen.get((size_t)b->nread * 4);
+    const float **src = (const float **)b->h_gsrc.get((size_t)b->nread * sizeof(float *));
+    if (!plen || !src) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
     for (int r = 0; r < b->nread; r++) {
         size_t len = 0;
         if (reads[r] < 0) { src[r] = nullptr; lens[r] = 0; continue; }            // empty slot
@@ -644,10 +667,10 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
         b->d_glen = (int *)dalloc(b, (size_t)b->nread * 4, false);
         if (!b->d_gsrc || !b->d_glen) return FFHIP_ENOMEM;
     }
-    HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src.data(), (size_t)b->nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
-    HIP_TRY(hipMemcpyAsync(b->d_glen, lens.data(), (size_t)b->nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
-    launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, b->nread);
-    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);             // src / lens go out of scope
+    memcpy(plen, lens.data(), (size_t)b->nread * 4);
+    HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src, (size_t)b->nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->d_glen, plen, (size_t)b->nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, b->nread);      // (no wait here: the host images are members)
     b->ran = b->finished = 0;
     return FFHIP_OK;
 }

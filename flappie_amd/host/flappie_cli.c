@@ -202,8 +202,9 @@ static struct argp argp = { options, parse_arg, args_doc, doc };
 static pthread_mutex_t hdf5_lock = PTHREAD_MUTEX_INITIALIZER;
 
 /* FLAPPIE_CLI_TIMING=1: wall-clock split of the driver's phases on stderr at exit */
-static double t_phase[6];
-static const char *phase_name[6] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output" };
+static double t_phase[8];
+static const char *phase_name[8] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output",
+                                     "  of which set_prepared", "  of which batch_run" };
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 typedef struct {
@@ -256,7 +257,12 @@ static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_m
     (void)nslot;
     t_phase[2] += now_s() - t0; t0 = now_s();
     const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
-    if (NULL == pb.b || 0 != ffhip_batch_set_prepared(pb.b, prep, pb.idx) || 0 != ffhip_batch_run(pb.b, args.temperature, flags)) {
+    int rc_sub = (NULL == pb.b) ? -1 : ffhip_batch_set_prepared(pb.b, prep, pb.idx);
+    t_phase[6] += now_s() - t0;
+    const double t1 = now_s();
+    if (0 == rc_sub) rc_sub = ffhip_batch_run(pb.b, args.temperature, flags);
+    t_phase[7] += now_s() - t1;
+    if (0 != rc_sub) {
         warnx("%s", ffhip_last_error());
         if (pb.b && !pb.cached) ffhip_batch_destroy(pb.b);
         pb.b = NULL;
@@ -735,7 +741,7 @@ int main(int argc, char *argv[]) {
     if (stdout != args.output) fclose(args.output);
     for (int k = 0; k < 2; k++) if (batch_cache[k].b) ffhip_batch_destroy(batch_cache[k].b);
     if (getenv("FLAPPIE_CLI_TIMING")) {
-        for (int k = 0; k < 6; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
+        for (int k = 0; k < 8; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
         fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
                 "files listed -> done", now_s() - t_listed);
     }

@@ -48,7 +48,7 @@ for nr in readers:
                            capture_output=True, text=True)
         dt = time.time() - t0
         nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
-        print("flappie --readers %s --limit %d: rc %d, %d records, %.2f s   %s" % (nr, n, r.returncode, nrec, dt, "\n" + r.stderr.strip()[-600:]), flush=True)
+        print("flappie --readers %s --limit %d: rc %d, %d records, %.2f s   %s" % (nr, n, r.returncode, nrec, dt, "\n" + r.stderr.strip()[-800:]), flush=True)
         res.append((n, dt))
     if len(res) >= 2:
         (n0, t0_), (n1, t1_) = res[0], res[-1]
