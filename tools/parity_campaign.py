@@ -22,6 +22,14 @@ t0 = time.time()
 models = ((M.NET_LSTM5, 96, 1), (M.NET_LSTM5, 64, 2), (M.NET_GRUMOD5, 64, 3), (M.NET_LSTM5, 128, 4))
 if len(sys.argv) > 2 and sys.argv[2] == "split":        # only shapes the split-bf16 layer kernel takes (H = 128, 256)
     models = ((M.NET_LSTM5, 128, 4), (M.NET_LSTM5, 128, 5), (M.NET_LSTM5, 256, 6))
+# "inflight" as the third argument: every measured batch runs BESIDE another batch's layer kernels (H = 256, long reads) --
+# the mode bench.py and the flappie binary use; DESIGN.md section 5.4 is why this is worth a campaign of its own
+companion = None
+if len(sys.argv) > 3 and sys.argv[3] == "inflight":
+    cmdl = M.synthetic_model(M.NET_LSTM5, 256, seed=77)
+    cdm = B.DeviceModel(eng, cmdl)
+    companion = B.Batch(cdm, 256, 12000)
+    companion.set_signals(np.random.default_rng(5).standard_normal((256, 12000)).astype(np.float32))
 for kind, H, seed in models:
     mdl = M.synthetic_model(kind, H, seed=seed)
     om = ffo.OracleModel(mdl)
@@ -31,7 +39,9 @@ for kind, H, seed in models:
     sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
     b = B.Batch(dm, nread, int(lens.max()))
     b.set_signals_ragged(sigs)
+    if companion is not None: companion.run(1.0, B.RUN_NO_DECODE)
     b.run(); b.finish()
+    if companion is not None: companion.finish()
     for r, x in enumerate(sigs):
         ref = om.basecall(x)
         tot["reads"] += 1
