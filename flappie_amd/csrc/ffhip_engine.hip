@@ -355,6 +355,8 @@ struct ffhip_batch {
     int *path = nullptr; float *qpath = nullptr; float *score = nullptr;
     char *bases = nullptr, *quals = nullptr; int *lens = nullptr;
     int32_t *trace = nullptr;
+    unsigned split_epoch = 0;           // launch counter of the split layer kernel (its check-in words are never cleared)
+    int counted = 0;                    // this batch is in the engine's in_flight count (between run and finish)
     const float **d_gsrc = nullptr; int *d_glen = nullptr;              // ffhip_batch_set_prepared: source rows of the gather
     unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel XCC ids / abort word
     int persist_concurrent_ok = 0;      // two such batches fit on the chip at once
@@ -416,6 +418,7 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (!b) return;
     hipSetDevice(b->eng->device);
     hipStreamSynchronize(b->stream);
+    if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     for (void *p : b->owned) hipFree(p);
     if (b->h_bases) hipHostFree(b->h_bases);
     if (b->h_quals) hipHostFree(b->h_quals);
@@ -721,6 +724,10 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // ---- convolutions (layers.c:189-276, activations :24-49)
     // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
     const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT_CONV") && !(flags & FFHIP_RUN_F32_RNN);
+    // another batch is between run and finish: its layer launches hold 384 of every SIMD's 512 registers, so this batch's last
+    // convolution takes the shape that fits in what is left (FFHIP_LEAN_CONV=0 / 1 forces one)
+    const char *lean_env = getenv("FFHIP_LEAN_CONV");
+    const int lean_conv = lean_env ? (lean_env[0] == '1') : (b->eng->in_flight - (b->counted ? 1 : 0) > 0);
     for (int l = 0; l < m->nconv; l++) {
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
@@ -730,7 +737,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         } else if (conv_f16) {
             launch_conv_split(s, b->sbuf[l], b->act[0], c.Wsplit, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
-                              conv_split ? b->actS[0] : nullptr, kSplitExpX, c.split_S);
+                              conv_split ? b->actS[0] : nullptr, kSplitExpX, c.split_S, lean_conv);
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0,
@@ -783,7 +790,6 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             continue;
         }
         if (use_split) {
-            if (prof) hipEventRecord(b->lev[l][1], s);
             // H <= 256: a launch of the dense form (pairs of tiles, two workgroups per CU) takes twice the tiles; it is used for FULL
             // launches only -- a partly filled one has a group count that is no multiple of 8 XCDs and loses the one-L2 hand-off
             const int maxt1 = split_max_tiles(b->eng->prop.multiProcessorCount), maxt2 = split_max_tiles(b->eng->prop.multiProcessorCount, Hp);
@@ -794,12 +800,14 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
             for (int rt0 = 0, nrt = 0; rt0 < B16; rt0 += nrt) {
                 const int maxt = (B16 - rt0 >= maxt2) ? maxt2 : maxt1;
                 nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
-                HIP_TRY(hipMemsetAsync(b->pflags, 0, split_flag_words(nrt) * sizeof(unsigned), s), FFHIP_EHIP);
+                // (the check-in words carry the launch's epoch: no fill between launches)
+                b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
                 // one workgroup per CU: two such launches are co-resident only if together they need no more CUs than there are
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (prof && rt0 == 0) hipEventRecord(b->lev[l][1], s);      // behind the wait: the layer's time is its kernels', not the other batch's
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount))
+                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -911,6 +919,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     mark(b, 6);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     b->ran = 1; b->finished = 0;
+    if (!b->counted) { b->counted = 1; b->eng->in_flight++; }
     return FFHIP_OK;
 }
 
@@ -927,6 +936,7 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     }
     HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     if (*b->h_abort != 0) {
         if ((b->last_flags & FFHIP_RUN_STEPWISE_RNN) || getenv("FFHIP_NO_FALLBACK"))
@@ -1072,7 +1082,8 @@ extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP],
         float a = 0.f, c = 0.f;
         hipEventElapsedTime(&a, b->lev[l][0], b->lev[l][1]);
         hipEventElapsedTime(&c, b->lev[l][1], b->lev[l][2]);
-        ms_inproj += a; ms_rnn += c;
+        if (b->launches[1] > 0) ms_inproj += a;      // a fused layer has no projection launch: that interval is the wait for the other batch's layer launches
+        ms_rnn += c;
     }
     ms[0] = t01; ms[1] = ms_inproj; ms[2] = ms_rnn; ms[3] = t34; ms[4] = t45; ms[5] = t56;
     for (int i = 0; i < FFHIP_NGROUP; i++) launches[i] = b->launches[i];

@@ -25,6 +25,8 @@ struct ffhip_engine {
     // co-tenancy becomes a slowdown, not FFHIP_ETIMEOUT.
     int stepwise_batches = 0;
     int fallbacks = 0;          // how often that happened (ffhip_debug_fallback_count)
+    int in_flight = 0;          // batches between ffhip_batch_run and ffhip_batch_finish: kernels of a batch submitted beside another
+                                // take the shapes that fit next to a resident layer launch (k_conv_split<2, 2>)
     // Signal preparation (ffhip_prep.hip) runs on a stream of its own -- beside the batches, not queued behind one of them -- and
     // keeps its buffers: a pinned staging area (one packed upload per chunk instead of one per read), the kernel's scratch, and a
     // pool of output buffers handed to ffhip_prep objects (hipMalloc / hipFree per chunk would synchronise the device each time).

@@ -62,7 +62,7 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
 // the same convolution on split operands (16 input features): `in` holds fp16 slices (launch_conv_small with split_exp = kSplitExpX),
 // Wp the split weight pack [M/16][ceil(winlen/2)][2][64] x 16 B scaled by 2^(acc_exp - kSplitExpX)
 void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
-                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp);
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean = 0);      // lean: the <= 128-VGPR shape
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
@@ -96,7 +96,7 @@ size_t split_flag_words(int nrt);
 inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 * kSplitNS; }      // 16 reads x H x 2 B x slices
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs = nullptr, const int *tbt = nullptr, int ncu = 256);      // scale_exp: the exponent S both products carry
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch);      // scale_exp: the exponent S both products carry
 // recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
 bool rnn_split_supported(int kind, int H);
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,

@@ -276,11 +276,16 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
 //   weights  Wp[mt][c][slice][lane] 16 B: row 16 mt + (lane & 15), k = 32 c + 8 (lane >> 4) .., zero beyond K (the phantom
 //            20th tap); a lane whose tap is the phantom one reads a ZERO row instead of the sample behind the window (0 x NaN)
 // Accumulators live in the scaled space 2^S (S = weight exponent + kSplitExpX; bias pre-multiplied, result multiplied by 2^-S).
-__global__ void __launch_bounds__(256)
+// Two shapes.  <4, 4>: 4 x 4 tiles per wave, 216 VGPRs -- the fast one when the kernel has the chip to itself.  <2, 2>: 2 x 2 tiles,
+// <= 128 VGPRs (launch bound 2 waves per SIMD) -- the one that FITS BESIDE another batch's layer launch (two waves of 192 VGPRs per
+// SIMD leave 128): with two batches in flight the big shape only ran in the gaps between the other batch's launches and its
+// remainder (~0.35 ms) stood between that batch's last layer and this batch's first.
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM * TN <= 4 ? 2 : 1)
 k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int NC, int winlen, int act, int ldp,
              unsigned char *__restrict__ out_split, float split_scale, float acc_scale) {
-    constexpr int TM = 4, TN = 4, NSL = 2;
+    constexpr int NSL = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
@@ -378,10 +383,16 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
 }
 
 void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
-                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp) {
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean) {
     const int Mt = M / 16, NC = (winlen + 1) / 2;
+    if (lean) {
+        const int nMblk = (Mt + 3) / 4, nNblk = (Tout * B16 + 3) / 4;
+        hipLaunchKernelGGL((k_conv_split<2, 2>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
+                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
+        return;
+    }
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
-    hipLaunchKernelGGL(k_conv_split, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
+    hipLaunchKernelGGL((k_conv_split<4, 4>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
                        (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
 }
 

@@ -69,7 +69,8 @@ struct SplitArgs {
     const unsigned char *xin; // layer input, split layout
     unsigned char *hout;      // layer output, split layout, pre-filled with the sentinel
     float *hout_f32;          // optional fp32 tile-interleaved copy of the output (for the CRF head), or nullptr
-    unsigned *flags;          // [ngroup][32] XCC ids (zeroed before launch)
+    unsigned *flags;          // [ngroup][32] check-in words (zeroed once, when the batch is created)
+    unsigned epoch;           // this launch's number (> 0, < 2^27), see the start barrier
     unsigned *abort_word;
     int Tb, B16, H, rt0, nrt, backward, mode;
     float acc_scale;          // 2^S: the exponent both products of this layer carry (ffhip_split.hpp); the bias is added in that space
@@ -199,16 +200,18 @@ k_lstm_split(SplitArgs a) {
         // start barrier of the group (also tells whether all 32 members share one XCD, i.e. one L2)
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc = (xcc & 0xfu) + 1u;
+        // a check-in word is (launch epoch << 5) | (XCC id + 1): what earlier launches left behind carries an older epoch and
+        // counts as "not here yet", so the words need no clearing between launches (one fill kernel less per layer)
+        xcc = (a.epoch << 5) | ((xcc & 0xfu) + 1u);
         unsigned *ids = a.flags + (size_t)g * G;
         if (lane == 0) __hip_atomic_store(ids + m, xcc, RLX_AGENT);
         unsigned v = xcc;
         for (unsigned spin = 0; spin < 2000000u; spin++) {
             v = (lane < G) ? __hip_atomic_load(ids + lane, RLX_AGENT) : xcc;
-            if (__all(v != 0u)) break;
+            if (__all((v >> 5) == a.epoch)) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (!__all(v != 0u) && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }      // a member never arrived
+        if (!__all((v >> 5) == a.epoch) && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }      // a member never arrived
         const int fast_l = (a.mode == 0 && __all(v == xcc)) ? 1 : 0;
         if (lane == 0) lds_fast = fast_l;
     }
@@ -1035,8 +1038,9 @@ unsigned long long *g_split_dbg = nullptr;
 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu) {
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch) {
     SplitArgs a;
+    a.epoch = epoch;
     a.acc_scale = split_pow2(scale_exp);
     a.fast_gates = fast_gates;
     a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
