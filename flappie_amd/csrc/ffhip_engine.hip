@@ -674,6 +674,7 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
     HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src, (size_t)b->nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipMemcpyAsync(b->d_glen, plen, (size_t)b->nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, b->nread);      // (no wait here: the host images are members)
+    prep_mark_used(prep, b->stream);                // ffhip_prep_destroy waits for this gather, not for the batch
     b->ran = b->finished = 0;
     return FFHIP_OK;
 }

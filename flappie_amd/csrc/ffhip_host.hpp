@@ -98,5 +98,6 @@ static inline bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
 
 // device address and length of a prepared read's kept samples (ffhip_prep.hip); nullptr if rejected
 const float *prep_device_signal(const struct ::ffhip_prep *p, int read, size_t *len);
+void prep_mark_used(const struct ::ffhip_prep *p, hipStream_t s);      // an asynchronous reader of the prepared signals was enqueued on s
 
 }  // namespace ffhip

@@ -252,6 +252,7 @@ struct ffhip_prep {
     int nread = 0;
     float *d_out = nullptr;
     size_t d_out_cap = 0;                // bytes, as taken from the engine's pool
+    mutable hipEvent_t used = nullptr;   // recorded behind the last asynchronous read of d_out (ffhip_batch_set_prepared's gather)
     std::vector<size_t> off, start, end;
     std::vector<float> stats;
 };
@@ -292,8 +293,17 @@ static float *prep_pool_take(ffhip_engine *e, size_t bytes, size_t *cap_out) {
     return (float *)q;
 }
 
+// ffhip_batch_set_prepared reads d_out asynchronously on the batch's stream: the buffer may go back to the pool (and be written
+// by the next chunk's preparation) only when that read is done
+void ffhip::prep_mark_used(const ffhip_prep *p, hipStream_t s) {
+    if (!p) return;
+    if (!p->used && hipEventCreateWithFlags(&p->used, hipEventDisableTiming) != hipSuccess) { p->used = nullptr; hipStreamSynchronize(s); return; }
+    hipEventRecord(p->used, s);
+}
+
 extern "C" void ffhip_prep_destroy(ffhip_prep *p) {
     if (!p) return;
+    if (p->used) { hipEventSynchronize(p->used); hipEventDestroy(p->used); }
     if (p->d_out) {
         // back to the engine's pool (at most four buffers wait there; the smallest goes when a fifth arrives)
         auto &pool = p->eng->prep_pool;

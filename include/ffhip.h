@@ -244,11 +244,12 @@ typedef struct ffhip_prep ffhip_prep;
 #define FFHIP_PREP_SHIFT_SCALE 4   /* shift_scale_array (util.c:214-223), ffhip_array_transform only */
 ffhip_prep *ffhip_prep_create(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
                               size_t varseg_chunk, float varseg_thresh, int mode, float delta);
-void ffhip_prep_destroy(ffhip_prep *p);
+void ffhip_prep_destroy(ffhip_prep *p);      /* waits for the copies ffhip_batch_set_prepared enqueued from it, not for the batches */
 /* start >= end: the read was rejected (trim_and_segment_raw would have returned a NULL table) */
 int ffhip_prep_range(const ffhip_prep *p, int read, size_t *start, size_t *end);
 int ffhip_prep_stats(const ffhip_prep *p, int read, float *median, float *mad);      /* MEDMAD mode */
 int ffhip_prep_get_signal(const ffhip_prep *p, int read, float *out /* end-start floats */);
+/* device-to-device and asynchronous on the batch's stream (one gather launch; the call does not wait for the GPU) */
 int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep (-1 = empty slot); lengths <= capacity */);
 /* quantilef (util.c:100-139): p[] in, quantiles out */
 int ffhip_quantiles(ffhip_engine *eng, const float *x, size_t n, float *p, size_t np);
