@@ -333,7 +333,7 @@ class Batch:
         return out
 
     def rnn_path(self) -> int:
-        """0 launch per step, 1 persistent recurrence + projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel, 4 split-bf16 projection GEMM + recurrence-only split layer kernel"""
+        """0 launch per step, 1 persistent recurrence + projection GEMM, 2 fused f32 layer kernel, 3 split-operand (fp16 x 2) layer kernel, 4 split-operand projection GEMM + recurrence-only split layer kernel"""
         L = lib()
         L.ffhip_batch_rnn_path.argtypes = [C.c_void_p]
         L.ffhip_batch_rnn_path.restype = C.c_int

@@ -345,7 +345,7 @@ struct ffhip_batch {
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
     SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
     float *act[2] = { nullptr, nullptr };
-    void *actS[2] = { nullptr, nullptr };      // the same two buffers in the split-bf16 layout (ffhip_rnn_split.hip), allocated on first use
+    void *actS[2] = { nullptr, nullptr };      // the same two buffers in the split-operand layout (ffhip_rnn_split.hip), allocated on first use
     float *keep[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     float *xa = nullptr, *cstate = nullptr;
     float *trans = nullptr, *post = nullptr, *fwd = nullptr;
@@ -368,7 +368,7 @@ struct ffhip_batch {
     float last_temperature = 1.0f;
     int ran = 0, finished = 0;
     int final_act = 0;                  // which act[] holds the last recurrent layer's output
-    int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-bf16 layer kernel, 4 split-bf16 projection GEMM + recurrence-only layer kernel
+    int rnn_path = 0;                   // what the last run used: 0 launch per step, 1 persistent recurrence behind a projection GEMM, 2 fused f32 layer kernel, 3 split-operand layer kernel, 4 split-operand projection GEMM + recurrence-only layer kernel
     hipEvent_t ev[FFHIP_NGROUP + 1];
     int have_ev = 0;
     int launches[FFHIP_NGROUP];
@@ -704,7 +704,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         return FFHIP_OK;
     };
 
-    // split-bf16 layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM, H = 128/256/384)
+    // split-operand layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM H = 128..512, GRUmod H = 128..384)
     const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
     const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
     const bool want_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE");      // (use_fused also asks whether the f32 layer kernel takes the shape)

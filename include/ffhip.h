@@ -70,7 +70,7 @@ typedef struct {
 #define FFHIP_RUN_NO_DECODE      4u   /* stop after calculate_transitions (networks.c:108-111)                */
 #define FFHIP_RUN_STEPWISE_RNN   8u   /* force the launch-per-step recurrent kernels (debug / cross-check)    */
 #define FFHIP_RUN_UNFUSED_RNN   32u   /* separate input-projection GEMM + recurrent kernel (cross-check)      */
-#define FFHIP_RUN_F32_RNN       64u   /* f32-input MFMA recurrent kernel instead of the split-bf16 one (cross-check) */
+#define FFHIP_RUN_F32_RNN       64u   /* f32-input MFMA recurrent kernel instead of the split-operand (two fp16 slices) one (cross-check) */
 #define FFHIP_RUN_KEEP_ACTS     16u   /* keep every layer's activations for ffhip_batch_get_activation        */
 #define FFHIP_RUN_FAST_GATES   128u   /* split layer kernels: gate activations through the hardware exp / reciprocal (1 ulp) instead of the
                                        * instruction-for-instruction replay of the reference's exp_ps; opt-in, not bit-compatible */
@@ -138,11 +138,11 @@ int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out /*[nblock+1][ns
  * (0..4) as dense [nblock][hidden] */
 int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out);
 /* which recurrent implementation the last ffhip_batch_run used: 0 = one launch per step, 1 = persistent recurrence behind a
- * projection GEMM, 2 = fused f32-MFMA layer kernel, 3 = split-bf16 layer kernel (hidden 128/256/384), 4 = split-bf16 projection GEMM +
- * recurrence-only split-bf16 layer kernel (LSTM, hidden 512; hidden 256 under FFHIP_RUN_UNFUSED_RNN) */
+ * projection GEMM, 2 = fused f32-MFMA layer kernel, 3 = split-operand layer kernel (two fp16 slices per operand; hidden 128/256/384/512), 4 = split-operand projection GEMM +
+ * recurrence-only split-operand layer kernel (LSTM, hidden 256/512 under FFHIP_RUN_UNFUSED_RNN) */
 int ffhip_batch_rnn_path(const ffhip_batch *b);
-/* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split-bf16 activation layout of
- * the recurrent layer kernel and back; out == in bit for bit (three bf16 slices hold any fp32 exactly) */
+/* debug tap: `ntile` tiles of 16 reads x `hidden` values (hidden % 128 == 0) through the split activation layout of
+ * the recurrent layer kernel and back; two fp16 slices of value * 2^12 hold 22 bits: |out - in| <= 2^-22 for |in| <= 1 (the bf16x3 build: bit for bit) */
 int ffhip_debug_split_round_trip(ffhip_engine *eng, const float *in, float *out, size_t ntile, int hidden);
 /* debug tap: the gate math of the persistent layer kernels (reciprocal by Newton steps instead of the division expansion,
  * floor instead of truncate/compare/subtract) against the reference-order arithmetic, on every fp32 mantissa at binary
