@@ -378,6 +378,35 @@ def test_reader_processes_and_multi_gpu_script(cli_inputs, tmp_path):
         assert all(x == by_name[x[0]] for x in got)
 
 
+@needs_hdf5
+@pytest.mark.gpu
+def test_batch_pipeline_across_chunks(cli_inputs, tmp_path):
+    """the binary works in chunks of 4 x --batch reads and keeps its batch pipeline going across them (the first batch of a chunk
+    is submitted before the last batch of the previous chunk is collected, a chunk is written while the next one runs): 150 reads
+    through 6 chunks of tiny batches, through one chunk, and on the main thread only, give the same bytes in the same order --
+    and --trace carries the same tables"""
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    big = tmp_path / "reads"
+    big.mkdir()
+    rng = np.random.default_rng(17)
+    for i in range(150):
+        write_fast5(big / ("read_%03d.fast5" % i), "uuid-%04d" % i, synth_raw(rng, int(rng.integers(1200, 3000))))
+    outs = {}
+    for tag, extra, e2 in (("chunks", ["--batch", "8", "--readers", "3"], {}), ("one", ["--batch", "256", "--readers", "2"], {}),
+                           ("main", ["--batch", "8"], {"FLAPPIE_NO_READER_THREAD": "1"})):
+        r = subprocess.run([FLAPPIE, "--no-uuid", "--trace", str(tmp_path / (tag + ".hdf5"))] + extra + [str(big)], env=dict(env, **e2),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = r.stdout
+    assert len(_parse_fastq(outs["chunks"])) == 150
+    assert outs["chunks"] == outs["one"] == outs["main"]
+    for name in ("read_000.fast5", "read_077.fast5", "read_149.fast5"):
+        sa, ta = dump_trace(tmp_path / "chunks.hdf5", name)
+        sb, tb = dump_trace(tmp_path / "one.hdf5", name)
+        assert np.array_equal(sa, sb) and np.array_equal(ta, tb) and ta.size > 0
+
+
 RELINKED = os.path.join(ROOT, "oracle", "_ref", "relink", "flappie_relinked")
 
 
