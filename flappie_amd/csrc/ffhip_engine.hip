@@ -379,7 +379,13 @@ struct ffhip_batch {
 static void *dalloc(ffhip_batch *b, size_t bytes, bool zero) {
     void *d = nullptr;
     if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) { set_err(FFHIP_ENOMEM, "hipMalloc of %zu bytes failed", bytes); return nullptr; }
-    if (zero && hipMemset(d, 0, bytes) != hipSuccess) { hipFree(d); set_err(FFHIP_EHIP, "hipMemset failed"); return nullptr; }
+    // zero on the BATCH's stream: everything that touches the buffer afterwards is enqueued there.  (A hipMemset on the null stream
+    // is not ordered against the batch's non-blocking stream and may complete after the call returns: an asynchronous upload into
+    // a freshly allocated table could be overtaken by its own zero-fill -- seen as a wrong first ragged batch of a batch object.)
+    if (zero) {
+        const hipError_t e = b->stream ? hipMemsetAsync(d, 0, bytes, b->stream) : hipMemset(d, 0, bytes);
+        if (e != hipSuccess || (!b->stream && hipDeviceSynchronize() != hipSuccess)) { hipFree(d); set_err(FFHIP_EHIP, "hipMemset failed"); return nullptr; }
+    }
     b->owned.push_back(d);
     return d;
 }

@@ -219,6 +219,35 @@ def test_packed_fp32_forms_beside_the_layer_kernel(B, engine):
           % (int(c.sum()), c[known].reshape(-1, 4).sum(axis=0).tolist()))
 
 
+def test_first_ragged_batch_of_a_new_batch_object_beside_another(B, engine):
+    """regression: the tables of a ragged batch go up asynchronously on the batch's stream, and a batch object allocates (and
+    zero-fills) some of them on first ragged use -- a zero-fill on the NULL stream could overtake the upload and wipe the per-read
+    block counts (seen by tools/stress.py as a wrong first ragged batch of the second batch object on most boxes).  Eight fresh
+    pairs of batch objects, H = 512 and GRUmod H = 256: a probe read in the ragged batch must come out as in a uniform one"""
+    rng = np.random.default_rng(3)
+    probe = rng.standard_normal(2777).astype(np.float32)
+    for kind, hidden, nread in ((M.NET_LSTM5, 512, 256), (M.NET_GRUMOD5, 256, 512)):
+        mdl = M.synthetic_model(kind, hidden, seed=1)
+        dm = B.DeviceModel(engine, mdl)
+        ref = None
+        for rep in range(4):
+            b0, b1 = B.Batch(dm, nread, 4000), B.Batch(dm, nread, 4000)
+            uni = [probe if i == 7 else rng.standard_normal(4000).astype(np.float32) for i in range(nread)]
+            lens = np.sort(rng.integers(1500, 4000, nread))[::-1].copy()
+            slot = int(rng.integers(0, nread))
+            lens[slot] = probe.size
+            rag = [probe if i == slot else rng.standard_normal(int(n)).astype(np.float32) for i, n in enumerate(lens)]
+            b0.set_signals_ragged(uni); b0.run()
+            b1.set_signals_ragged(rag); b1.run()              # first (ragged) use of b1, beside b0
+            b0.finish(); b1.finish()
+            got0 = (b0.basecall(7), b0.quality(7), b0.transitions(7).tobytes())
+            got1 = (b1.basecall(slot), b1.quality(slot), b1.transitions(slot).tobytes())
+            ref = ref or got0
+            assert got0 == ref and got1 == ref, (kind, hidden, rep)
+            b0.close(); b1.close()
+        dm.close()
+
+
 def test_split_layout_round_trip(B, engine):
     """fp32 -> slices -> fp32 through the operand format of the split layer kernels (ffhip_split.hpp).  Default build: two
     fp16 slices of x * 2^12 hold |x| <= 1 to 2^-22 relative (absolute floor 2^-37); the -DFFHIP_SPLIT_BF16X3 build's three
