@@ -248,6 +248,17 @@ def test_first_ragged_batch_of_a_new_batch_object_beside_another(B, engine):
         dm.close()
 
 
+@pytest.mark.parametrize("kind,hidden,nread", [(0, 384, 256), (1, 256, 512)])
+def test_short_soak_two_batches_in_flight(B, kind, hidden, nread):
+    """a minute's worth of tools/stress.py in a few seconds: 30 uniform / sorted-ragged / unsorted-ragged batches through two batch
+    objects in flight, a probe read in a random slot of each; its bases, qualities, scores and path must never change"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "30", str(kind), str(hidden), "2", str(nread)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "stress ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
 def test_split_layout_round_trip(B, engine):
     """fp32 -> slices -> fp32 through the operand format of the split layer kernels (ffhip_split.hpp).  Default build: two
     fp16 slices of x * 2^12 hold |x| <= 1 to 2^-22 relative (absolute floor 2^-37); the -DFFHIP_SPLIT_BF16X3 build's three
