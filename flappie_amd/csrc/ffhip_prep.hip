@@ -252,6 +252,7 @@ struct ffhip_prep {
     int nread = 0;
     float *d_out = nullptr;
     size_t d_out_cap = 0;                // bytes, as taken from the engine's pool
+    mutable bool used_recorded = false;
     mutable hipEvent_t used = nullptr;   // recorded behind the last asynchronous read of d_out (ffhip_batch_set_prepared's gather)
     std::vector<size_t> off, start, end;
     std::vector<float> stats;
@@ -298,7 +299,10 @@ static float *prep_pool_take(ffhip_engine *e, size_t bytes, size_t *cap_out) {
 void ffhip::prep_mark_used(const ffhip_prep *p, hipStream_t s) {
     if (!p) return;
     if (!p->used && hipEventCreateWithFlags(&p->used, hipEventDisableTiming) != hipSuccess) { p->used = nullptr; hipStreamSynchronize(s); return; }
+    // readers on different streams: the new record must imply the earlier ones (an event remembers its last record only)
+    if (p->used_recorded) hipStreamWaitEvent(s, p->used, 0);
     hipEventRecord(p->used, s);
+    p->used_recorded = true;
 }
 
 extern "C" void ffhip_prep_destroy(ffhip_prep *p) {
