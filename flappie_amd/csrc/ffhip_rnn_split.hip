@@ -32,7 +32,9 @@
 //   * after one LDS-only barrier six waves (the h waves and x waves 0, 1) do the gate math of one 16 x 16 tile each
 //     (4 gates of one unit of one read per lane, cell state in a register; ffhip_math.hpp *_lean forms, bit-identical
 //     to the reference-order arithmetic), split h(t) and store it; a second barrier closes the gate phase, so that no
-//     MFMA stream starts next to a gate wave on its SIMD (a dependent VALU chain beside one runs ~3x slower);
+//     MFMA stream starts next to a gate wave on its SIMD (round 1's reason -- a VALU chain beside a dense f32-MFMA stream runs ~3x
+//     slower -- does not hold for the 16-bit MFMAs: 0.92-0.95, tools/dev/mfma_valu_probe2.cpp; the barrier still pays: without it the
+//     layer takes 2.40 instead of 2.29 ms);
 //   * hand-off: the payload is the flag.  A producer lane writes the sentinel 0xFFFFFFFF (two bf16 NaNs -- never a
 //     pair of slices of a finite value) to ITS slots of step t+3 when it publishes step t (and of steps 0..2 before
 //     the group's start barrier): no host-side fill of the reused buffer.  A consumer wave first polls ONE dword per
