@@ -142,3 +142,125 @@ void write_summary(hid_t hdf5file, const char *readname, const struct _raw_basec
     }
     H5Gclose(grp);
 }
+
+/* ---- write_summary in two steps: filters off the HDF5 lock (include/fast5_interface.h) -------------------------------- */
+#include <zlib.h>
+
+typedef struct { hsize_t dims[2], chunk[2]; int rank; size_t esize, nchunk; void **buf; size_t *len; void *plain; } packed_dset;
+struct summary_pack { int level, have_trace; packed_dset sig, tr; };
+
+/* one chunk through HDF5's shuffle (H5Zshuffle.c: byte j of every element together) and deflate (compress2) filters */
+static void *filter_chunk(const unsigned char *raw, size_t nelem, size_t esize, int level, size_t *out_len) {
+    const size_t nbytes = nelem * esize;
+    unsigned char *sh = (unsigned char *)raw, *tmp = NULL;
+    if (esize > 1) {
+        tmp = malloc(nbytes);
+        if (NULL == tmp) return NULL;
+        for (size_t j = 0; j < esize; j++)
+            for (size_t i = 0; i < nelem; i++) tmp[j * nelem + i] = raw[i * esize + j];
+        sh = tmp;
+    }
+    uLongf dl = compressBound(nbytes);
+    void *out = malloc(dl);
+    if (NULL == out || Z_OK != compress2(out, &dl, sh, nbytes, level)) { free(out); free(tmp); return NULL; }
+    free(tmp);
+    *out_len = dl;
+    return out;
+}
+
+/* `data`: the dataset row-major in its FILE type (esize bytes per element); chunks tile dimension 0 only */
+static int pack_dset(packed_dset *d, const void *data, int rank, const hsize_t *dims, hsize_t chunk0, size_t esize, int level) {
+    memset(d, 0, sizeof(*d));
+    d->rank = rank; d->esize = esize;
+    d->dims[0] = dims[0]; d->dims[1] = rank > 1 ? dims[1] : 1;
+    d->chunk[0] = chunk0 < dims[0] ? chunk0 : dims[0]; d->chunk[1] = d->dims[1];
+    const size_t rowb = (size_t)d->dims[1] * esize, total = (size_t)dims[0] * rowb;
+    if (level <= 0 || 0 == dims[0]) {
+        d->plain = malloc(total ? total : 1);
+        if (NULL == d->plain) return -1;
+        memcpy(d->plain, data, total);
+        return 0;
+    }
+    d->nchunk = (size_t)((dims[0] + d->chunk[0] - 1) / d->chunk[0]);
+    d->buf = calloc(d->nchunk, sizeof(void *));
+    d->len = calloc(d->nchunk, sizeof(size_t));
+    const size_t cb = (size_t)d->chunk[0] * rowb;
+    unsigned char *full = malloc(cb);                      /* an edge chunk is stored whole, padded with the fill value (0) */
+    if (NULL == d->buf || NULL == d->len || NULL == full) { free(full); return -1; }
+    for (size_t k = 0; k < d->nchunk; k++) {
+        const size_t r0 = k * (size_t)d->chunk[0], nr = (r0 + d->chunk[0] <= dims[0]) ? (size_t)d->chunk[0] : (size_t)(dims[0] - r0);
+        const unsigned char *src = (const unsigned char *)data + r0 * rowb;
+        if (nr < d->chunk[0]) { memset(full, 0, cb); memcpy(full, src, nr * rowb); src = full; }
+        d->buf[k] = filter_chunk(src, (size_t)d->chunk[0] * (size_t)d->dims[1], esize, level, &d->len[k]);
+        if (NULL == d->buf[k]) { free(full); return -1; }
+    }
+    free(full);
+    return 0;
+}
+
+static void free_dset(packed_dset *d) {
+    for (size_t k = 0; k < d->nchunk; k++) free(d->buf ? d->buf[k] : NULL);
+    free(d->buf); free(d->len); free(d->plain);
+}
+
+summary_pack *summary_pack_create(const struct _raw_basecall_info res, hsize_t chunk_size, int compression_level) {
+    summary_pack *p = calloc(1, sizeof(*p));
+    if (NULL == p || NULL == res.rt.raw || res.rt.end <= res.rt.start || 0 == chunk_size) { free(p); return NULL; }
+    p->level = compression_level;
+    hsize_t n = res.rt.end - res.rt.start;
+    int rc = pack_dset(&p->sig, res.rt.raw + res.rt.start, 1, &n, chunk_size, sizeof(float), compression_level);
+    if (0 == rc && NULL != res.trace) {
+        /* the trace leaves as u8 [nblock + 1][nstate]: what H5Dwrite's int32 -> u8 conversion gives (it saturates) */
+        const size_t nc = res.trace->nc, nr = res.trace->nr;
+        unsigned char *u8 = malloc((nc * nr > 0) ? nc * nr : 1);
+        if (NULL == u8) rc = -1;
+        else {
+            for (size_t c = 0; c < nc; c++)
+                for (size_t r = 0; r < nr; r++) {
+                    const int32_t v = res.trace->data.f[c * res.trace->stride + r];
+                    u8[c * nr + r] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+                }
+            hsize_t dims[2] = { nc, nr };
+            rc = pack_dset(&p->tr, u8, 2, dims, chunk_size, 1, compression_level);
+            p->have_trace = (0 == rc);
+            free(u8);
+        }
+    }
+    if (0 != rc) { summary_pack_free(p); return NULL; }
+    return p;
+}
+
+static void write_dset(hid_t grp, const char *name, hid_t ftype, hid_t mtype, const packed_dset *d, int level) {
+    hsize_t ch[2] = { d->chunk[0], d->chunk[1] };
+    hid_t space = H5Screate_simple(d->rank, d->dims, d->dims);
+    hid_t props = (0 == d->dims[0]) ? H5P_DEFAULT : compression(d->rank, ch, level);
+    hid_t dset = H5Dcreate(grp, name, ftype, space, H5P_DEFAULT, props, H5P_DEFAULT);
+    if (dset >= 0) {
+        if (NULL != d->plain) H5Dwrite(dset, mtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, d->plain);
+        else
+            for (size_t k = 0; k < d->nchunk; k++) {
+                const hsize_t off[2] = { (hsize_t)k * d->chunk[0], 0 };
+                if (H5Dwrite_chunk(dset, H5P_DEFAULT, 0, off, d->len[k], d->buf[k]) < 0) { warnx("Failed to write chunk %zu of \"%s\" %s:%d.", k, name, __FILE__, __LINE__); break; }
+            }
+        H5Dclose(dset);
+    }
+    if (props != H5P_DEFAULT) H5Pclose(props);
+    H5Sclose(space);
+}
+
+void summary_pack_write(hid_t hdf5file, const char *readname, const summary_pack *p) {
+    if (hdf5file < 0 || NULL == readname || NULL == p) return;
+    hid_t grp = H5Gcreate(hdf5file, readname, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (grp < 0) { warnx("Failed to create group \"%s\" %s:%d.", readname, __FILE__, __LINE__); return; }
+    write_dset(grp, "signal", H5T_IEEE_F32LE, H5T_NATIVE_FLOAT, &p->sig, p->level);
+    if (p->have_trace) write_dset(grp, "trace", H5T_STD_U8LE, H5T_NATIVE_UCHAR, &p->tr, p->level);
+    H5Gclose(grp);
+}
+
+void summary_pack_free(summary_pack *p) {
+    if (NULL == p) return;
+    free_dset(&p->sig);
+    free_dset(&p->tr);
+    free(p);
+}
+

@@ -416,9 +416,42 @@ static void chunk_begin(struct ffhip_engine *eng, chunk_ctx *c, item *items, int
     qsort(c->group, c->m2, sizeof(item *), by_length_desc);
 }
 
+/* --trace: the filters of the summary file (shuffle + deflate, 10-15 ms per 100 000-sample read) are the one expensive step of
+ * the output side and libhdf5 runs them under its caller's lock; here they run in worker threads, per read, outside libhdf5
+ * (summary_pack_create), and the writer below only hands finished chunks over */
+typedef struct { chunk_ctx *c; summary_pack **packs; int k, nthread; } pack_job;
+static void *pack_worker(void *arg) {
+    pack_job *j = arg;
+    for (int i = j->k; i < j->c->n; i += j->nthread) {
+        item *it = &j->c->items[i];
+        if (NULL != it->res.basecall) j->packs[i] = summary_pack_create(it->res, args.compression_chunk_size, args.compression_level);
+    }
+    return NULL;
+}
+static summary_pack **pack_chunk(chunk_ctx *c) {
+    summary_pack **packs = calloc(c->n > 0 ? c->n : 1, sizeof(*packs));
+    if (NULL == packs) return NULL;
+    const char *e = getenv("FLAPPIE_TRACE_THREADS");
+    int nthread = e ? atoi(e) : 16;
+    if (nthread < 1) nthread = 1;
+    if (nthread > 64) nthread = 64;
+    if (nthread > c->n) nthread = c->n > 0 ? c->n : 1;
+    pthread_t th[64];
+    pack_job jobs[64];
+    char started[64];
+    for (int k = 0; k < nthread; k++) {                       /* the last share runs here; so does any share whose thread did not start */
+        jobs[k] = (pack_job){ c, packs, k, nthread };
+        started[k] = (k + 1 < nthread) && 0 == pthread_create(&th[k], NULL, pack_worker, &jobs[k]);
+        if (!started[k]) pack_worker(&jobs[k]);
+    }
+    for (int k = 0; k < nthread; k++) if (started[k]) pthread_join(th[k], NULL);
+    return packs;
+}
+
 /* output of a finished chunk, in input order; releases what the chunk owns */
 static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
     const double to0 = now_s();
+    summary_pack **packs = (hdf5out >= 0) ? pack_chunk(c) : NULL;
     for (int i = 0; i < c->n; i++) {
         item *it = &c->items[i];
 #ifdef BUILD_RUNNIE
@@ -442,16 +475,18 @@ static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
             fprintf_format(args.outformat, args.output, uuid, base, args.uuid, args.prefix, it->res);
             if (hdf5out >= 0) {
                 pthread_mutex_lock(&hdf5_lock);
-                write_summary(hdf5out, args.uuid ? uuid : base, it->res, args.compression_chunk_size, args.compression_level);
+                if (packs && packs[i]) summary_pack_write(hdf5out, args.uuid ? uuid : base, packs[i]);
+                else write_summary(hdf5out, args.uuid ? uuid : base, it->res, args.compression_chunk_size, args.compression_level);
                 pthread_mutex_unlock(&hdf5_lock);
+                if (packs) { summary_pack_free(packs[i]); packs[i] = NULL; }
             }
             free(fn);
         }
         free_raw_basecall_info(&it->res);
         free(it->filename);
     }
+    if (packs) { for (int i = 0; i < c->n; i++) summary_pack_free(packs[i]); free(packs); }
     t_phase[5] += now_s() - to0;
-    ffhip_prep_destroy(c->prep);
     free(c->rts);
     free(c->group);
     c->live = 0;
@@ -468,15 +503,65 @@ static struct {
     void *released_arg;
 } pipe_state;
 
+/* A WRITER THREAD takes the finished chunks, strictly in order: formatting, --trace compression and the HDF5 writes of chunk k run
+ * while the main thread keeps submitting the batches of chunk k + 1 (with --trace on 100 000-sample reads the output side costs as
+ * much time as the GPU side; done on the main thread it stood between two submissions).  chunk sequence numbers in
+ * [writer.head, writer.tail) are ready to be written; FLAPPIE_NO_WRITER_THREAD=1 writes on the main thread. */
+static struct { pthread_t th; pthread_mutex_t mu; pthread_cond_t cv; long head, tail; int started, stop; hid_t hdf5out; } writer =
+    { 0, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, -1 };
+
+static void writer_do(long q) {
+    chunk_ctx *c = &pipe_state.ctx[q % NCHUNKBUF];
+    const int buf = c->buf;
+    chunk_finish(c, writer.hdf5out);                  /* sets c->live = 0 */
+    if (pipe_state.released) pipe_state.released(buf, pipe_state.released_arg);
+}
+
+static void *writer_main(void *arg) {
+    (void)arg;
+    pthread_mutex_lock(&writer.mu);
+    for (;;) {
+        while (writer.head == writer.tail && !writer.stop) pthread_cond_wait(&writer.cv, &writer.mu);
+        if (writer.head == writer.tail) break;
+        const long q = writer.head;
+        pthread_mutex_unlock(&writer.mu);
+        writer_do(q);
+        pthread_mutex_lock(&writer.mu);
+        writer.head++;
+        pthread_cond_broadcast(&writer.cv);
+    }
+    pthread_mutex_unlock(&writer.mu);
+    return NULL;
+}
+
 static void pipe_finish_ready(hid_t hdf5out) {
     while (pipe_state.next_finish < pipe_state.nbegun) {
         chunk_ctx *c = &pipe_state.ctx[pipe_state.next_finish % NCHUNKBUF];
         if (!(c->all_submitted && c->collected == c->submitted)) break;
-        const int buf = c->buf;
-        chunk_finish(c, hdf5out);
+        ffhip_prep_destroy(c->prep);                  /* (the engine's buffer pool belongs to this thread) */
+        c->prep = NULL;
+        writer.hdf5out = hdf5out;
+        if (!writer.started && !getenv("FLAPPIE_NO_WRITER_THREAD")) writer.started = (0 == pthread_create(&writer.th, NULL, writer_main, NULL)) ? 1 : -1;
+        if (writer.started == 1) {
+            pthread_mutex_lock(&writer.mu);
+            writer.tail = pipe_state.next_finish + 1;
+            pthread_cond_broadcast(&writer.cv);
+            pthread_mutex_unlock(&writer.mu);
+        } else {
+            writer_do(pipe_state.next_finish);
+        }
         pipe_state.next_finish++;
-        if (pipe_state.released) pipe_state.released(buf, pipe_state.released_arg);
     }
+}
+
+/* all chunks handed over so far are written (end of the run) */
+static void writer_finish(void) {
+    if (writer.started != 1) return;
+    pthread_mutex_lock(&writer.mu);
+    writer.stop = 1;
+    pthread_cond_broadcast(&writer.cv);
+    pthread_mutex_unlock(&writer.mu);
+    pthread_join(writer.th, NULL);
 }
 
 static void pipe_collect_prev(const struct ffhip_model *mdl, hid_t hdf5out) {
@@ -490,6 +575,11 @@ static void pipe_collect_prev(const struct ffhip_model *mdl, hid_t hdf5out) {
 
 static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out) {
     chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
+    if (writer.started == 1) {                        /* the slot's previous chunk may still be with the writer */
+        pthread_mutex_lock(&writer.mu);
+        while (c->live) pthread_cond_wait(&writer.cv, &writer.mu);
+        pthread_mutex_unlock(&writer.mu);
+    }
     if (c->live) errx(EXIT_FAILURE, "internal error: chunk slot still in use");
     chunk_begin(eng, c, items, n, buf);            /* the device pass runs beside the batch still in flight */
     pipe_state.nbegun++;
@@ -513,6 +603,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
 static void pipe_drain(const struct ffhip_model *mdl, hid_t hdf5out) {
     pipe_collect_prev(mdl, hdf5out);
     pipe_finish_ready(hdf5out);
+    writer_finish();
 }
 
 /* ---- input side: the list of files (flappie.c:336-358), read one chunk ahead of the GPU by a reader thread ---- */
@@ -659,8 +750,13 @@ static void stop_reader_procs(void) {
 }
 
 static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *items, int *nitem) {
+    /* a chunk is up to chunk_cap reads (four batches of the usual 4-8 k-sample reads) -- or, with long reads, what holds about as
+     * many SAMPLES but at least one batch: records leave when their chunk is done, and a 1024-read chunk of 100 000-sample reads
+     * would be four seconds of GPU work with nothing written (and nothing for the writer thread to overlap) */
+    const size_t sample_budget = (size_t)chunk_cap * 8192;
+    size_t nsamp = 0;
     int n = 0;
-    for (size_t f = first; f < fl->n && n < chunk_cap; f++, n++) {
+    for (size_t f = first; f < fl->n && n < chunk_cap && !(n >= args.batch && nsamp >= sample_budget); f++, n++) {
         item *it = &items[n];
         memset(it, 0, sizeof(*it));
         it->filename = fl->path[f];                                   /* ownership moves to the item */
@@ -673,6 +769,7 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
             pthread_mutex_unlock(&hdf5_lock);
         }
         t_phase[0] += now_s() - tr0;
+        if (NULL != it->res.rt.raw) nsamp += it->res.rt.n;
     }
     *nitem = n;
 }

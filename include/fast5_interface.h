@@ -22,6 +22,15 @@ hid_t open_or_create_hdf5(const char *filename);
 void write_summary(hid_t hdf5file, const char *readname, const struct _raw_basecall_info res, hsize_t chunk_size,
                    int compression_level);
 
+/* The same group in two steps, for writers that want the compression off the HDF5 lock: summary_pack_create does the
+ * filters' work (shuffle + deflate per chunk, the u8 conversion of the trace) WITHOUT calling libhdf5 -- any number of threads may
+ * run it --, summary_pack_write creates the datasets with the properties write_summary uses and hands the finished chunks over
+ * (H5Dwrite_chunk).  A file written this way reads back exactly like one written by write_summary. */
+typedef struct summary_pack summary_pack;
+summary_pack *summary_pack_create(const struct _raw_basecall_info res, hsize_t chunk_size, int compression_level);
+void summary_pack_write(hid_t hdf5file, const char *readname, const summary_pack *pack);
+void summary_pack_free(summary_pack *pack);
+
 #ifdef __cplusplus
 }
 #endif

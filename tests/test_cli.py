@@ -159,6 +159,49 @@ def test_write_summary_round_trip(tmp_path, f5lib, level):
 
 
 @needs_hdf5
+@pytest.mark.parametrize("level,chunk", [(0, 50), (1, 50), (6, 200), (1, 5000)])
+def test_summary_pack_reads_back_like_write_summary(tmp_path, f5lib, level, chunk):
+    """the two-step writer (filters in summary_pack_create, outside libhdf5 -- what the binary's worker threads run -- and
+    H5Dwrite_chunk in summary_pack_write) against write_summary: same groups, same signal, same trace after reading the files
+    back; chunk sizes that do not divide the data, a chunk larger than the data, out-of-range trace values (the int32 -> u8
+    conversion saturates)"""
+    host = C.CDLL(HOSTLIB)
+    host.make_flappie_imatrix.restype = C.POINTER(CIMat)
+    host.make_flappie_imatrix.argtypes = [C.c_size_t, C.c_size_t]
+    f5lib.summary_pack_create.restype = C.c_void_p
+    f5lib.summary_pack_create.argtypes = [BasecallInfo, C.c_uint64, C.c_int]
+    f5lib.summary_pack_write.argtypes = [C.c_int64, C.c_char_p, C.c_void_p]
+    f5lib.summary_pack_free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(level * 100 + chunk)
+    sig = rng.standard_normal(3000).astype(np.float32)
+    nblock, nstate = 533, 10
+    tr = host.make_flappie_imatrix(nstate, nblock + 1)
+    vals = rng.integers(0, 256, (nblock + 1, nstate)).astype(np.int32)
+    vals[3, 2], vals[7, 1] = 300, -5
+    np.ctypeslib.as_array(tr.contents.f, shape=(nblock + 1, tr.contents.stride))[:, :nstate] = vals
+    res = BasecallInfo(score=0.0, basecall=b"A", quality=b"!", basecall_length=1, nblock=nblock, trace=tr)
+    res.rt = RawTable(uuid=b"r", n=3000, start=120, end=2950, raw=_f(sig))
+    pa, pb = tmp_path / "a.hdf5", tmp_path / "b.hdf5"
+    h = f5lib.open_or_create_hdf5(str(pa).encode())
+    f5lib.write_summary(h, b"read", res, chunk, level)
+    assert f5lib.H5Fclose(h) >= 0
+    pack = f5lib.summary_pack_create(res, chunk, level)
+    assert pack
+    h = f5lib.open_or_create_hdf5(str(pb).encode())
+    f5lib.summary_pack_write(h, b"read", pack)
+    f5lib.summary_pack_free(pack)
+    assert f5lib.H5Fclose(h) >= 0
+    sa, ta = dump_trace(pa, "read")
+    sb, tb = dump_trace(pb, "read")
+    np.testing.assert_array_equal(sa, sig[120:2950])
+    np.testing.assert_array_equal(sb, sa)
+    np.testing.assert_array_equal(tb, ta)
+    np.testing.assert_array_equal(tb, np.clip(vals, 0, 255))
+    if level > 0:
+        assert os.path.getsize(pb) <= 1.02 * os.path.getsize(pa) + 4096      # the same filters: the same size within the headers
+
+
+@needs_hdf5
 def test_cli_options_without_gpu(tmp_path):
     run = lambda *a: subprocess.run([FLAPPIE] + list(a), capture_output=True, text=True, timeout=60)  # noqa: E731
     r = run("--help")
