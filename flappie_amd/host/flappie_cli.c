@@ -65,7 +65,7 @@ static struct argp_option options[] = {
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default 256; 512 for models of at most 256 hidden units)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
-    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 8; 0 reads in this process)"},
+    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 12; 0 reads in this process)"},
     {0}
 };
 
@@ -96,7 +96,7 @@ static struct {
     int batch;
     int readers;
     int shard, nshard;
-} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 8, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
+} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 12, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
 
 static void print_models(FILE *fh) {
     for (int mdl = 0; mdl < (int)flappie_nmodel; mdl++)
