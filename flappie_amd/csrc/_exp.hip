@@ -120,13 +120,6 @@ __device__ __forceinline__ void mm6(const v4u (&w)[N][NC][NS], int cc, const v4u
         for (int j = 0; j < N; j++) acc[j] = mm(w[j][cc][WS[term]], x[XS[term]], acc[j]);
 }
 
-// the sentinel pair, materialised where it is stored (hoisted out of the step loop it costs two registers for the whole layer)
-__device__ __forceinline__ v2u fresh_sentinel() {
-    v2u v;
-    asm volatile("v_mov_b32 %0, -1\n\tv_mov_b32 %1, -1" : "=v"(v.x), "=v"(v.y));
-    return v;
-}
-
 // s_waitcnt vmcnt(n) with n known after unrolling (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
     switch (n) {
@@ -212,11 +205,6 @@ k_lstm_split(SplitArgs a) {
         __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b64(v, wr, off, 0, 16 /*sc1*/);
     };
-    auto store_plain = [&](unsigned char *tile, unsigned off, v2u v) {   // the group shares one L2.  (Scalar base + 32-bit lane offset as
-        // above: a flat store keeps a 64-bit address per lane alive across the gate phase, which the 128-register forms cannot afford)
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, (int)tileB, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b64(v, wr, off, 0, 0);
-    };
     // The output doubles as the hand-off flag, and the kernel arms it itself: every producer lane writes the sentinel
     // to ITS slots of steps 0..AHEAD-1 here -- before the group's start barrier below -- and to step i+AHEAD when it
     // publishes step i.  Stores of one lane to one address stay in order, so its sentinel can never overtake or
@@ -291,8 +279,7 @@ k_lstm_split(SplitArgs a) {
 
     // ---- gate math of one 16 x 16 tile (4 units x 4 gates x 16 reads; layers.c:1005-1025) and the store of its h(t), already
     // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
-    // (a scalar, and told so: a VALU quotient would be kept -- splatted for the packed multiplies -- in two vector registers per use)
-    const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / a.acc_scale)));
+    const float inv_scale = 1.0f / a.acc_scale;
     // h(t) of one tile -> the split layout (and the hand-off): Split h ONCE, in the lane that owns it, and transpose through a
     // wave-private LDS patch: lane (unit q, read rl) writes its slices to [slice][read][unit]; quarter-wave q then reads the
     // 8 bytes [slice q][read rl][units 0..3] -- the packed operand piece it stores.  (Four ds_bpermute + a 4-value split in
@@ -302,37 +289,29 @@ k_lstm_split(SplitArgs a) {
 #if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
         if (h == 123.0f) a.flags[0] = 1; else return;
 #endif
-        // The lane-dependent addresses of this block are recomputed every step from an OPAQUE copy of the lane number: hoisted out
-        // of the step loop (where the compiler puts anything loop-invariant) they are six registers held for the whole layer, and
-        // the 128-register forms of this kernel spill them; a dozen integer instructions per step cost nothing beside that.
-        unsigned lv = (unsigned)lane;
-        asm volatile("" : "+v"(lv));
-        const unsigned q_ = lv >> 4, rl_ = lv & 15u;
-        unsigned short (*gs)[16][4] = gsl[wave];
         {
             unsigned sl[NS];
             split_slices(h * split_pow2(kSplitExpH), sl);        // |h| <= 1: in range without a clamp
 #pragma unroll
-            for (int k = 0; k < NS; k++) gs[k][rl_][q_] = (unsigned short)sl[k];
+            for (int k = 0; k < NS; k++) gsl[wave][k][rl][q] = (unsigned short)sl[k];
         }
-        if (a.hout_f32) gf32[wave][rl_][q_] = h;
+        if (a.hout_f32) gf32[wave][rl][q] = h;
         asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
         const int ut = ut0 + gj;
-        if (q_ < (unsigned)NS) {
-            const unsigned off = (unsigned)((((ut >> 3) * NS) * 64 + ((ut & 7) >> 1) * 16) * 16 + (ut & 1) * 8) + q_ * 1024u + rl_ * 16u;      // = out_off(gj)
-            const v2u sl = *(const v2u *)&gs[q_][rl_][0];
+        const unsigned off = out_off(gj);
+        if (q < NS) {
+            const v2u sl = *(const v2u *)&gsl[wave][q][rl][0];
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
-                store_plain(tp_out, off, sl);              // (the data first: it is what the consumers wait for)
-                if (i + AHEAD < Tb) store_plain(out_tile(step_t(i + AHEAD), gts), off, fresh_sentinel());
+                *(v2u *)(tp_out + off) = sl;               // (the data first: it is what the consumers wait for)
+                if (i + AHEAD < Tb) *(v2u *)(out_tile(step_t(i + AHEAD), gts) + off) = sentinel2;
             } else {
                 store_wt(tp_out, off, sl);
-                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, fresh_sentinel());
+                if (i + AHEAD < Tb) store_wt(out_tile(step_t(i + AHEAD), gts), off, sentinel2);
             }
-        } else if (q_ == (unsigned)NS && a.hout_f32) {
-            const v4f hv = *(const v4f *)&gf32[wave][rl_][0];
-            __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64)), 0, Ut * 256, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, rl_ * 16u, ut * 256, 0);
+        } else if (q == NS && a.hout_f32) {
+            const v4f hv = *(const v4f *)&gf32[wave][rl][0];
+            *(v4f *)(a.hout_f32 + ((size_t)t * a.B16 + (rtA + gts)) * (size_t)(Ut * 64) + (size_t)ut * 64 + rl * 4) = hv;
         }
     };
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
@@ -486,6 +465,7 @@ k_lstm_split(SplitArgs a) {
                 project(i + 1);
 #endif
 #if !(FFHIP_SPLIT_ABLATE & 16)     // 16 = no prefetch of x (stale operands)
+                __builtin_amdgcn_sched_barrier(0);
                 if (i + 2 < Tb) load_x(i + 2);
 #endif
             }
@@ -495,21 +475,18 @@ k_lstm_split(SplitArgs a) {
             raw_barrier();
             TL(3);
             if (lds_abort) return;
-            if constexpr (TS == 2) {                         // (one tile per group: its N <= 4 gate tiles all belong to h waves -- and said at
-                                                             // compile time, so that no gate temporaries are live beside the prefetch)
-                if (sg_front) {
-                    __builtin_amdgcn_s_setprio(3);           // the back wave (and with it the closing barrier) waits for this c(t)
-                    gate_front(i, my_gts, my_gj, c, my_tb);
-                    __builtin_amdgcn_s_setprio(0);
-                } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
-                else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
-            }
+            if (sg_front) {
+                __builtin_amdgcn_s_setprio(3);               // the back wave (and with it the closing barrier) waits for this c(t)
+                gate_front(i, my_gts, my_gj, c, my_tb);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
+            else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
             TL(4);
             raw_barrier();                                   // closes the gate phase
             TL(5);
         }
         if (sink == 0x9e3779b9u && a.Tb < 0) a.flags[0] = sink;      // never true: the touches must not be optimised away
-    } else {
+    } else if (a.Tb == -12345) {
         // ---- h waves: recurrent half of step i on top of the projection partial of my K quarter, then one gate tile.
         // Hand-off of h(step i-1): (1) a LIGHT poll -- one dword per producing gate wave of my K slice (16N lanes, one
         // load) until none is the sentinel; a full sweep is 24N KiB per wave and 64 B/clk per CU, far too heavy to
@@ -608,7 +585,6 @@ k_lstm_split(SplitArgs a) {
                 // for vmcnt(0) before the first one), and it may move nothing across these statements.
                 auto recur_lds = [&]() -> bool {
                     bool ok = true;
-#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass rejects the LDS-DMA builtin, and then silently drops the kernel's stub)
                     if constexpr (HL) {
 #pragma unroll
                         for (int k = 0; k < N; k++) {
@@ -639,7 +615,6 @@ k_lstm_split(SplitArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-#endif
 #if FFHIP_SPLIT_ABLATE & 2
                     return true;
 #endif
@@ -1106,7 +1081,7 @@ constexpr int kSplitMaxN = 4;
 // tiles per group by [kind][H / 128 - 1] (measured on MI355X)
 // 256 reads x 4000 samples, MI355X, Msamples/s TS = 2 -> 1: LSTM H = 256 97.4 -> 106.6, GRUmod H = 256 39.4 -> 44.3; at N = 3 the
 // one-tile form needs 161 registers (33 spilled at 128: 77.6 -> 67.5), at N = 4 it is hopeless (102 spilled)
-constexpr int kSplitTS[2][4] = { { 1, 1, 1, 2 }, { 1, 1, 2, 2 } };
+constexpr int kSplitTS[2][4] = { { 1, 1, 2, 2 }, { 1, 1, 2, 2 } };
 int split_tiles_per_group(int kind, int H);
 bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 128 == 0 && H >= 128 && H <= 128 * (kind == 0 ? kSplitMaxN : 3); }      // GRUmod at N = 4 spills 169 registers; no GRUmod model is that wide
 // read tiles (of 16) one launch takes: 32 workgroups per group; one workgroup per CU and a pair of tiles per group, or two

@@ -1,11 +1,16 @@
 /*  fast5_tool -- test utility: write single-read fast5 files and dump trace files, with the HDF5 C API.
  *    fast5_tool write  out.fast5 READ_ID digitisation offset range sampling_rate samples.i16
+ *    fast5_tool synth  DIR COUNT MINLEN MAXLEN SEED [FIRST [STEP]]   COUNT files DIR/read_%06d.fast5 with indices FIRST, FIRST+STEP, ...:
+ *                      seeded noise around 500 +- 60 counts behind a 300-sample quiet stretch (what the trimming step removes),
+ *                      lengths uniform in [MINLEN, MAXLEN); prints "files N samples S".  The signal of a file depends on SEED and
+ *                      its index only, so several processes can fill one directory (bench.py's host-fed leg, tools/cli_throughput.py)
  *    fast5_tool dump   trace.hdf5 GROUP          (prints "signal N" + values, "trace R C" + values)
  *  Layout written: /Raw/Reads/Read_1/Signal (int16) with attribute read_id (fixed string) and
  *  /UniqueGlobalKey/channel_id {digitisation, offset, range, sampling_rate} (doubles), i.e. what
  *  read_raw (fast5_interface.c:231-318) consumes.
  */
 #include <hdf5.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,7 +22,48 @@ static void dattr(hid_t g, const char *name, double v) {
     H5Aclose(a); H5Sclose(s);
 }
 
+static int write_read(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n);
+
+static unsigned long long rng_next(unsigned long long *s) {      /* splitmix64 */
+    unsigned long long z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static double rng_unit(unsigned long long *s) { return ((double)(rng_next(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
 int main(int argc, char **argv) {
+    if (argc >= 7 && 0 == strcmp(argv[1], "synth")) {
+        const long count = atol(argv[3]), minlen = atol(argv[4]), maxlen = atol(argv[5]);
+        const unsigned long long seed = strtoull(argv[6], NULL, 10);
+        const long first = argc > 7 ? atol(argv[7]) : 0, step = argc > 8 ? atol(argv[8]) : 1;
+        if (count < 0 || minlen < 1 || maxlen <= minlen || step < 1) return 1;
+        short *raw = malloc((size_t)maxlen * sizeof(short));
+        unsigned long long total = 0;
+        for (long k = 0; k < count; k++) {
+            const long idx = first + k * step;
+            unsigned long long st = seed * 0x100000001B3ull + (unsigned long long)idx;
+            const long n = minlen + (long)(rng_unit(&st) * (double)(maxlen - minlen));
+            for (long i = 0; i < n; i += 2) {                      /* Box-Muller, two values per draw */
+                const double u = rng_unit(&st), v = rng_unit(&st);
+                const double r = sqrt(-2.0 * log(u)), a = 6.283185307179586 * v;
+                const double g[2] = { r * cos(a), r * sin(a) };
+                for (int e = 0; e < 2 && i + e < n; e++) {
+                    double x = (i + e < 300) ? 520.0 + 4.0 * g[e] : 500.0 + 60.0 * g[e];
+                    x = x < 0.0 ? 0.0 : (x > 8191.0 ? 8191.0 : x);
+                    raw[i + e] = (short)(x + 0.5);
+                }
+            }
+            char path[4096], id[64];
+            snprintf(path, sizeof(path), "%s/read_%06ld.fast5", argv[2], idx);
+            snprintf(id, sizeof(id), "uuid-%06ld", idx);
+            if (write_read(path, id, 8192.0, 10.0, 1400.0, 4000.0, raw, (hsize_t)n)) return 2;
+            total += (unsigned long long)n;
+        }
+        free(raw);
+        printf("files %ld samples %llu\n", count, total);
+        return 0;
+    }
     if (argc >= 9 && 0 == strcmp(argv[1], "write")) {
         FILE *fh = fopen(argv[8], "rb");
         if (!fh) return 2;
@@ -26,26 +72,9 @@ int main(int argc, char **argv) {
         short *raw = malloc(bytes);
         if (fread(raw, 2, n, fh) != n) return 2;
         fclose(fh);
-        hid_t f = H5Fcreate(argv[2], H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-        hid_t g1 = H5Gcreate(f, "/Raw", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        hid_t g2 = H5Gcreate(f, "/Raw/Reads", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        hid_t g3 = H5Gcreate(f, "/Raw/Reads/Read_1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, strlen(argv[3]) + 1);
-        hid_t ss = H5Screate(H5S_SCALAR);
-        hid_t a = H5Acreate(g3, "read_id", st, ss, H5P_DEFAULT, H5P_DEFAULT);
-        H5Awrite(a, st, argv[3]);
-        H5Aclose(a); H5Sclose(ss); H5Tclose(st);
-        hid_t sp = H5Screate_simple(1, &n, NULL);
-        hid_t d = H5Dcreate(g3, "Signal", H5T_STD_I16LE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        H5Dwrite(d, H5T_NATIVE_SHORT, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw);
-        H5Dclose(d); H5Sclose(sp);
-        hid_t u1 = H5Gcreate(f, "/UniqueGlobalKey", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        hid_t u2 = H5Gcreate(f, "/UniqueGlobalKey/channel_id", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-        dattr(u2, "digitisation", atof(argv[4])); dattr(u2, "offset", atof(argv[5]));
-        dattr(u2, "range", atof(argv[6])); dattr(u2, "sampling_rate", atof(argv[7]));
-        H5Gclose(u2); H5Gclose(u1); H5Gclose(g3); H5Gclose(g2); H5Gclose(g1); H5Fclose(f);
+        const int rc = write_read(argv[2], argv[3], atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7]), raw, n);
         free(raw);
-        return 0;
+        return rc;
     }
     if (argc >= 4 && 0 == strcmp(argv[1], "dump")) {
         hid_t f = H5Fopen(argv[2], H5F_ACC_RDONLY, H5P_DEFAULT);
@@ -73,4 +102,27 @@ int main(int argc, char **argv) {
     }
     fprintf(stderr, "usage: fast5_tool write|dump ...\n");
     return 1;
+}
+
+static int write_read(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n) {
+    hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    if (f < 0) return 2;
+    hid_t g1 = H5Gcreate(f, "/Raw", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t g2 = H5Gcreate(f, "/Raw/Reads", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t g3 = H5Gcreate(f, "/Raw/Reads/Read_1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, strlen(read_id) + 1);
+    hid_t ss = H5Screate(H5S_SCALAR);
+    hid_t a = H5Acreate(g3, "read_id", st, ss, H5P_DEFAULT, H5P_DEFAULT);
+    H5Awrite(a, st, read_id);
+    H5Aclose(a); H5Sclose(ss); H5Tclose(st);
+    hid_t sp = H5Screate_simple(1, &n, NULL);
+    hid_t d = H5Dcreate(g3, "Signal", H5T_STD_I16LE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    H5Dwrite(d, H5T_NATIVE_SHORT, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw);
+    H5Dclose(d); H5Sclose(sp);
+    hid_t u1 = H5Gcreate(f, "/UniqueGlobalKey", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t u2 = H5Gcreate(f, "/UniqueGlobalKey/channel_id", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    dattr(u2, "digitisation", digitisation); dattr(u2, "offset", offset);
+    dattr(u2, "range", range); dattr(u2, "sampling_rate", rate);
+    H5Gclose(u2); H5Gclose(u1); H5Gclose(g3); H5Gclose(g2); H5Gclose(g1); H5Fclose(f);
+    return 0;
 }

@@ -206,6 +206,9 @@ static double t_phase[8];
 static const char *phase_name[8] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output",
                                      "  of which set_prepared", "  of which batch_run" };
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+/* what the run basecalled: reads, samples of their trimmed ranges (the metric of SURVEY.md section 8d), samples read from the files */
+static unsigned long long n_called_reads, n_called_samples, n_raw_samples;
+static int reader_failures;              /* reader children that ended abnormally: the exit status says so */
 
 typedef struct {
     char *filename;                     /* owned */
@@ -337,6 +340,9 @@ static void collect_batch(const struct ffhip_model *mdl, pending_batch *pb) {
     for (int i = 0; i < n; i++) {
         struct _raw_basecall_info *r = &its[i]->res;
         const size_t nblock = ffhip_batch_read_nblock(b, i);
+        n_called_reads++;
+        n_called_samples += r->rt.end - r->rt.start;
+        n_raw_samples += r->rt.n;
         size_t blen = 0;
         const char *bases = ffhip_batch_basecall(b, i, &blen);
         r->basecall = strdup(bases);
@@ -489,7 +495,7 @@ static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
     t_phase[5] += now_s() - to0;
     free(c->rts);
     free(c->group);
-    c->live = 0;
+    __atomic_store_n(&c->live, 0, __ATOMIC_RELEASE);
 }
 
 /* the pipeline's state: at most one batch submitted and not collected; chunks finish (are written) strictly in order */
@@ -577,7 +583,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
     if (writer.started == 1) {                        /* the slot's previous chunk may still be with the writer */
         pthread_mutex_lock(&writer.mu);
-        while (c->live) pthread_cond_wait(&writer.cv, &writer.mu);
+        while (__atomic_load_n(&c->live, __ATOMIC_ACQUIRE)) pthread_cond_wait(&writer.cv, &writer.mu);
         pthread_mutex_unlock(&writer.mu);
     }
     if (c->live) errx(EXIT_FAILURE, "internal error: chunk slot still in use");
@@ -597,7 +603,21 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         i += g;
     }
     c->all_submitted = 1;
-    pipe_finish_ready(hdf5out);                    /* a chunk without a single batch (every read failed) */
+    /* A chunk without a single batch (every read failed) collects nothing on its own account: the batch still in flight belongs
+     * to an OLDER chunk, whose reader buffer is only released when it is written -- two such chunks in a row and the reader
+     * thread would wait for that buffer while this thread waits for the reader.  Collect it now. */
+    if (0 == c->m2) pipe_collect_prev(mdl, hdf5out);
+    pipe_finish_ready(hdf5out);
+}
+
+/* Without the reader thread (FLAPPIE_NO_READER_THREAD=1) this thread fills the reader buffers itself: buffer k may only be
+ * overwritten once the chunk that last used it has been WRITTEN -- by the writer thread, possibly still at work. */
+static void pipe_wait_slot_written(void) {
+    chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
+    if (writer.started != 1) return;               /* no writer thread: chunks are written by this thread, in pipe_finish_ready */
+    pthread_mutex_lock(&writer.mu);
+    while (__atomic_load_n(&c->live, __ATOMIC_ACQUIRE)) pthread_cond_wait(&writer.cv, &writer.mu);
+    pthread_mutex_unlock(&writer.mu);
 }
 
 static void pipe_drain(const struct ffhip_model *mdl, hid_t hdf5out) {
@@ -663,7 +683,7 @@ typedef struct {
  * reads files k, k + R, k + 2R ... in order (read_raw, fast5_interface.c:231-318, with the pA scaling of flappie.c:248) and
  * streams {nsample, uuid, samples} records down its own pipe; the parent's reader thread takes file f from pipe f % R, so
  * the input order is kept.  Children run ahead by what a pipe holds (1 MiB: ~50 reads each). */
-typedef struct { pid_t pid; int fd; } reader_proc;
+typedef struct { pid_t pid; int fd; int dead; } reader_proc;
 static reader_proc *rprocs = NULL;
 static int nrproc = 0;
 
@@ -688,7 +708,12 @@ static int read_all(int fd, void *buf, size_t n) {
 }
 
 static void reader_child(const file_list *fl, int k, int R, int fd) {
+    signal(SIGPIPE, SIG_IGN);            /* a parent that went away is a failed write, not a signal (the PARENT keeps the default: `flappie ... | head` ends) */
+    long kill_k = -1, kill_f = -1;       /* tests: FLAPPIE_DEBUG_KILL_READER=k:f -- child k dies (SIGKILL) when it reaches file index f */
+    const char *kill_env = getenv("FLAPPIE_DEBUG_KILL_READER");
+    if (kill_env && 2 != sscanf(kill_env, "%ld:%ld", &kill_k, &kill_f)) kill_k = -1;
     for (size_t f = (size_t)k; f < fl->n; f += (size_t)R) {
+        if (kill_k == k && (long)f >= kill_f) raise(SIGKILL);
         raw_table rt = read_raw(fl->path[f], true);
         uint64_t hdr[2] = { (NULL != rt.raw) ? (uint64_t)rt.n : 0, (NULL != rt.uuid && NULL != rt.raw) ? (uint64_t)strlen(rt.uuid) : 0 };
         if (0 != write_all(fd, hdr, sizeof(hdr)) || (hdr[1] && 0 != write_all(fd, rt.uuid, hdr[1])) ||
@@ -724,16 +749,35 @@ static void start_reader_procs(const file_list *fl, int R) {
     }
 }
 
-static raw_table read_from_proc(size_t f) {
+/* A reader child that dies (libhdf5 crashing on a corrupt file, an OOM kill) takes its stripe with it: the file it died on is
+ * reported unreadable, every LATER file of the stripe is read in this process instead (as with --readers 0), and the exit status
+ * of the run says that a reader failed.  A stream cut in the middle of a record is out of sync and handled the same way. */
+static raw_table reader_lost(size_t f, const char *path) {
     raw_table rt = { NULL, 0, 0, 0, NULL };
+    reader_proc *rp = &rprocs[f % (size_t)nrproc];
+    if (!rp->dead) {
+        rp->dead = 1;
+        reader_failures++;
+        warnx("reader process %zu ended early at %s; the rest of its files are read in-process", f % (size_t)nrproc, path);
+        return rt;                                                         /* this file: whatever killed the child stays unread */
+    }
+    pthread_mutex_lock(&hdf5_lock);
+    rt = read_raw(path, true);
+    pthread_mutex_unlock(&hdf5_lock);
+    return rt;
+}
+
+static raw_table read_from_proc(size_t f, const char *path) {
+    raw_table rt = { NULL, 0, 0, 0, NULL };
+    if (rprocs[f % (size_t)nrproc].dead) return reader_lost(f, path);
     const int fd = rprocs[f % (size_t)nrproc].fd;
     uint64_t hdr[2];
-    if (0 != read_all(fd, hdr, sizeof(hdr))) { warnx("reader process %zu ended early", f % (size_t)nrproc); return rt; }
+    if (0 != read_all(fd, hdr, sizeof(hdr))) return reader_lost(f, path);
     char *uuid = hdr[1] ? calloc(hdr[1] + 1, 1) : NULL;
-    if (hdr[1] && (NULL == uuid || 0 != read_all(fd, uuid, hdr[1]))) { free(uuid); return rt; }
+    if (hdr[1] && (NULL == uuid || 0 != read_all(fd, uuid, hdr[1]))) { free(uuid); return reader_lost(f, path); }
     if (0 == hdr[0]) { free(uuid); return rt; }                        /* the child could not read the file (it said why) */
     float *raw = malloc(hdr[0] * sizeof(float));
-    if (NULL == raw || 0 != read_all(fd, raw, hdr[0] * sizeof(float))) { free(raw); free(uuid); return rt; }
+    if (NULL == raw || 0 != read_all(fd, raw, hdr[0] * sizeof(float))) { free(raw); free(uuid); return reader_lost(f, path); }
     rt = (raw_table){ uuid, hdr[0], 0, hdr[0], raw };
     return rt;
 }
@@ -742,7 +786,11 @@ static void stop_reader_procs(void) {
     for (int k = 0; k < nrproc; k++) {
         close(rprocs[k].fd);
         int st = 0;
-        (void)waitpid(rprocs[k].pid, &st, 0);
+        if (waitpid(rprocs[k].pid, &st, 0) == rprocs[k].pid && !rprocs[k].dead) {
+            /* exit status 1 = its pipe closed under it (this process stopped reading early: --limit, an error) -- not a failure of the child */
+            if (WIFSIGNALED(st)) { warnx("reader process %d was killed by signal %d", k, WTERMSIG(st)); reader_failures++; }
+            else if (WIFEXITED(st) && WEXITSTATUS(st) > 1) { warnx("reader process %d exited with status %d", k, WEXITSTATUS(st)); reader_failures++; }
+        }
     }
     free(rprocs);
     rprocs = NULL;
@@ -762,7 +810,7 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
         it->filename = fl->path[f];                                   /* ownership moves to the item */
         const double tr0 = now_s();
         if (nrproc > 0) {
-            it->res.rt = read_from_proc(f);
+            it->res.rt = read_from_proc(f, it->filename);
         } else {
             pthread_mutex_lock(&hdf5_lock);
             it->res.rt = read_raw(it->filename, true);                /* flappie.c:248 */
@@ -796,7 +844,6 @@ int main(int argc, char *argv[]) {
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
     const double t_listed = now_s();
-    signal(SIGPIPE, SIG_IGN);
     start_reader_procs(&fl, getenv("FLAPPIE_NO_READER_THREAD") ? 0 : args.readers);      /* before the HIP runtime and libhdf5 are touched here */
     const struct ffhip_model *mdl = flappie_hip_model(args.model);
     if (NULL == mdl) { stop_reader_procs(); errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model)); }
@@ -823,7 +870,7 @@ int main(int argc, char *argv[]) {
         const double tw0 = now_s();
         /* buffer k was released when the chunk three back was written: at most two chunks are unfinished at a time */
         if (threaded) sem_wait(&rs.filled[k]);
-        else read_chunk(&fl, done, done == 0 ? rs.chunk_cap / 4 : rs.chunk_cap, rs.items[k], &rs.nitem[k]);
+        else { pipe_wait_slot_written(); read_chunk(&fl, done, done == 0 ? rs.chunk_cap / 4 : rs.chunk_cap, rs.items[k], &rs.nitem[k]); }
         t_wait += now_s() - tw0;
         const int nk = rs.nitem[k];              /* (the reader may refill the buffer as soon as the chunk is written) */
         pipe_chunk(eng, mdl, rs.items[k], nk, k, hdf5out);
@@ -841,7 +888,9 @@ int main(int argc, char *argv[]) {
         for (int k = 0; k < 8; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
         fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
                 "files listed -> done", now_s() - t_listed);
+        fprintf(stderr, "basecalled: %llu reads, %llu samples (trimmed ranges), %llu raw samples\n", n_called_reads, n_called_samples, n_raw_samples);
     }
     flappie_hip_shutdown();
+    if (reader_failures) { warnx("%d reader process(es) failed; see the warnings above", reader_failures); return EXIT_FAILURE; }
     return EXIT_SUCCESS;
 }

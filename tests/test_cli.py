@@ -450,6 +450,52 @@ def test_batch_pipeline_across_chunks(cli_inputs, tmp_path):
         assert np.array_equal(sa, sb) and np.array_equal(ta, tb) and ta.size > 0
 
 
+@needs_hdf5
+@pytest.mark.gpu
+def test_pipeline_with_bad_chunks_a_dead_reader_and_a_closed_stdout(cli_inputs, tmp_path):
+    """ADVICE r2, executed.  (a) More than two whole chunks of unreadable files in the middle of the input (--batch 8: a chunk is 32
+    files) used to leave the batch in flight uncollected and its reader buffer unreleased: the run hung.  (b) A reader child that
+    dies costs the file it died on; the rest of its stripe is read in-process and the exit status is non-zero.  (c) The binary
+    dies of SIGPIPE like the reference when its stdout closes (`flappie ... | head`)."""
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    big = tmp_path / "reads"
+    big.mkdir()
+    rng = np.random.default_rng(23)
+    good = []
+    for i in range(130):
+        fn = "read_%03d.fast5" % i
+        if 20 <= i < 110:                                           # 90 bad files: chunks of 8, 32, 32, ... -> at least two all-bad chunks
+            (big / fn).write_bytes(b"not an hdf5 file")
+        else:
+            write_fast5(big / fn, "uuid-%04d" % i, synth_raw(rng, int(rng.integers(1200, 2600))))
+            good.append(fn)
+    outs = {}
+    for tag, extra, e2 in (("procs", ["--readers", "3"], {}), ("thread", ["--readers", "0"], {}), ("main", ["--readers", "0"], {"FLAPPIE_NO_READER_THREAD": "1"})):
+        r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid"] + extra + [str(big)], env=dict(env, **e2), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stderr.count("No basecall returned") == 90
+        outs[tag] = r.stdout
+    assert sorted(x[0] for x in _parse_fastq(outs["procs"])) == good
+    assert outs["procs"] == outs["thread"] == outs["main"]
+    # (b) reader 1 of 3 is killed when it reaches file 40 (of the sorted list): one read lost, everything else identical, status non-zero
+    files = [str(big / fn) for fn in good]
+    whole = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "3"] + files, env=env, capture_output=True, text=True, timeout=300)
+    assert whole.returncode == 0, whole.stderr
+    r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "3"] + files, env=dict(env, FLAPPIE_DEBUG_KILL_READER="1:20"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "ended early" in r.stderr and "reader process(es) failed" in r.stderr
+    recs, ref = _parse_fastq(r.stdout), _parse_fastq(whole.stdout)
+    lost = [x[0] for x in ref if x[0] not in {y[0] for y in recs}]
+    assert len(lost) == 1 and good.index(lost[0]) % 3 == 1 and good.index(lost[0]) >= 20
+    assert recs == [x for x in ref if x[0] != lost[0]]
+    # (c) stdout closes after the first record: the process ends by SIGPIPE instead of basecalling everything into a closed pipe
+    p = subprocess.Popen([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "2"] + files * 8, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p.stdout.readline()
+    p.stdout.close()
+    assert p.wait(timeout=120) == -13
+
+
 RELINKED = os.path.join(ROOT, "oracle", "_ref", "relink", "flappie_relinked")
 
 
