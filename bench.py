@@ -32,7 +32,7 @@ HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size i
 # the others let the driver or a reader reproduce the figures DESIGN.md quotes for configs[3] / configs[4] and the
 # smaller r941_native file with the same JSON line (own roofline, own CPU leg).  kind: 0 LSTM5, 1 GRUmod5, 2 LSTM5 + run-length head.
 CONFIGS = {
-    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, ident="r941native",
+    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=1, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
     "h256": dict(kind=0, hidden=256, nread=512, nsample=4000, steps=150, warmup=5, ident="r941native",
@@ -53,14 +53,50 @@ CONFIGS = {
 SURVEY_OPENBLAS_PER_CORE = {(0, 384): 0.010, (0, 256): 0.035, (0, 512): 0.0046, (1, 256): 0.0185}   # Msamples/s/core, SURVEY.md section 6 [probe]
 
 
+def find_openblas():
+    """An LP64 OpenBLAS on this host, if any: the one scipy ships (`scipy_cblas_*` symbols), a distribution's libopenblas, conda's.
+    (numpy's own `libscipy_openblas64_` is the ILP64 build: other symbol names, 64-bit integers -- not taken.)"""
+    import glob
+    import sysconfig
+    roots = {sysconfig.get_paths().get("purelib", ""), sysconfig.get_paths().get("platlib", "")} | {p for p in sys.path if p.endswith("-packages")}
+    cands = []
+    for r in sorted(x for x in roots if x):
+        cands += sorted(glob.glob(os.path.join(r, "scipy.libs", "libscipy_openblas-*.so"))) + sorted(glob.glob(os.path.join(r, "scipy_openblas32", "lib", "*.so")))
+    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib/x86_64-linux-gnu/openblas-*/libopenblas.so*", "/usr/lib64/libopenblas.so*",
+                "/opt/conda/lib/libopenblas.so*"):
+        cands += sorted(glob.glob(pat))
+    return cands
+
+
+def _oracle_with_blas(mode):
+    """the oracle library in dot mode `mode`; mode 3 (OpenBLAS) falls back to 2 (own vectorised kernels) when no library loads"""
+    import ctypes as C
+    from oracle import ffo
+    L = ffo.lib()
+    used = None
+    if mode == 3:
+        L.fo_blas_open.restype = C.c_int
+        L.fo_blas_open.argtypes = [C.c_char_p]
+        L.fo_blas_config.restype = C.c_char_p
+        for path in find_openblas():
+            if L.fo_blas_open(path.encode()) == 0:
+                used = (os.path.basename(path), L.fo_blas_config().decode(errors="replace").strip())
+                break
+        if used is None:
+            mode = 2
+    L.fo_set_dot_mode(mode)
+    return mode, used
+
+
 def _cpu_worker(job):
     """One host core: the oracle's whole path over its own reads until the time budget is spent."""
     kind, hidden, ident, nsample, seed, budget_s, max_reads, mode = job
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"          # README.md:76-79: one thread per process
     from flappie_amd import model as M
     from oracle import ffo
     mdl = M.synthetic_model(kind, hidden, seed=1, ident=ident)
     om = ffo.OracleModel(mdl)
-    ffo.lib().fo_set_dot_mode(mode)
+    _oracle_with_blas(mode)
     sig = np.random.default_rng(seed).standard_normal((max_reads, nsample)).astype(np.float32)
     call = om.runlength_call if kind == M.NET_LSTM5_RLE else (lambda x: om.basecall(x, want_trans=False))
     t0 = time.time()
@@ -86,8 +122,10 @@ def cpu_baseline(cfg, budget_s=12.0):
     ncore = max(1, min(ncore, 64))
     nsample = min(cfg["nsample"], 20000)        # long-read configs: a 20 000-sample prefix per read keeps the sample bounded
     max_reads = max(2, int(400000 // nsample))
-    jobs = [(cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 777 + k, budget_s, max_reads, 2) for k in range(ncore)]
-    one = _cpu_worker((cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 776, 3.0, 2, 2))      # one core alone, nothing competing for memory bandwidth
+    mode, blas = _oracle_with_blas(3)                 # 3 = the GEMV / GEMM calls go to a real OpenBLAS when this host has one
+    jobs = [(cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 777 + k, budget_s, max_reads, mode) for k in range(ncore)]
+    one = _cpu_worker((cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 776, 3.0, 2, mode))      # one core alone, nothing competing for memory bandwidth
+    own = _cpu_worker((cfg["kind"], cfg["hidden"], cfg["ident"], nsample, 776, 3.0, 2, 2)) if mode == 3 else one      # the same on the port's own kernels
     t0 = time.time()
     if ncore == 1:
         res = [_cpu_worker(jobs[0])]
@@ -97,14 +135,20 @@ def cpu_baseline(cfg, budget_s=12.0):
     wall = time.time() - t0
     nread = sum(r[0] for r in res)
     dt = max(r[1] for r in res)
-    return dict(value=round(nread * nsample / dt / 1e6, 6), unit="Msamples/s", cores=ncore, kind="port",
-                sample="%d synthetic reads of %d samples over %d single-threaded processes (whole path, oracle algorithm on the vectorised "
-                       "kernels of oracle/cpu_ref.c), slowest worker %.1f s, %.1f s wall" % (nread, nsample, ncore, dt, wall),
+    return dict(value=round(nread * nsample / dt / 1e6, 6), unit="Msamples/s", cores=ncore, kind="port+openblas" if blas else "port",
+                sample="%d synthetic reads of %d samples over %d single-threaded processes (whole path: oracle algorithm, %s), slowest worker %.1f s, %.1f s wall"
+                       % (nread, nsample, ncore, ("GEMV / GEMM through %s [%s], one thread each; element-wise loops oracle/cpu_ref.c" % blas) if blas else
+                          "vectorised kernels of oracle/cpu_ref.c", dt, wall),
                 per_core=round(nread * nsample / dt / 1e6 / ncore, 6),
                 one_core_alone=round(one[0] * nsample / one[1] / 1e6, 6),
+                one_core_alone_own_kernels=round(own[0] * nsample / own[1] / 1e6, 6),
+                blas_library=blas[0] if blas else None,
                 reference_openblas_per_core_survey=SURVEY_OPENBLAS_PER_CORE.get((cfg["kind"] % 2, cfg["hidden"])),
-                note="kind=port: the reference's OpenBLAS build cannot be made in this image; reference_openblas_per_core_survey is the "
-                     "survey container's probe of it (SURVEY.md section 6, other host), for scale")
+                note=("kind=port+openblas: the reference's layers.c / flappie_matrix.c cannot be built in this image (no <cblas.h>); this is the oracle's restatement of "
+                      "them calling the SAME cblas_sgemv / cblas_sgemm shapes (layers.c:1009, :250, flappie_matrix.c:384) in an OpenBLAS found on this host, dlopen()ed. "
+                      if blas else "kind=port: no LP64 OpenBLAS found on this host; the port's own vectorised kernels. ") +
+                     "per_core = all cores loaded (every step re-streams the recurrent matrix: the cores compete for memory bandwidth); one_core_alone = one process on an idle host; "
+                     "reference_openblas_per_core_survey = the survey container's probe of the real reference (SURVEY.md section 6, other host)")
 
 
 def measured_traffic(name, cfg, rnn_path):
@@ -127,6 +171,140 @@ def measured_traffic(name, cfg, rnn_path):
     return best
 
 
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): become the launcher the driver would have
+    been -- one rank per GPU under torch.distributed.run on 127.0.0.1 -- instead of asserting.  Returns only on exec failure."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+class _StubBatch:
+    """FFHIP_BENCH_STUB=1 (CPU tests of the launch / timing / reduction plumbing): stands where a batch of the HIP engine stands."""
+    nblock = 800
+
+    def __init__(self, *a):
+        pass
+
+    def set_signals(self, sig):
+        pass
+
+    def run(self, temperature, flags):
+        time.sleep(0.002)
+
+    def finish(self):
+        pass
+
+    def profile(self):
+        z = {"ms": 1.0, "launches": 5}
+        return {"conv": dict(z), "inproj": {"ms": 0.0, "launches": 0}, "recurrent": dict(z), "head_crf": dict(z), "posterior": dict(z), "viterbi_assembly": dict(z)}
+
+    def rnn_path(self):
+        return 3
+
+    def close(self):
+        pass
+
+
+class _StubEngine:
+    def __init__(self, *a):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def set_profiling(self, on):
+        pass
+
+    def close(self):
+        pass
+
+
+def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
+    """The path that feeds a GPU in production, per rank, beside `value` (never as it): the `flappie` BINARY over this rank's shard of a
+    directory of single-read fast5 files -- reader child processes -> GPU signal preparation -> ragged batches -> FASTQ (README.md:81-83
+    runs one flappie per core with GNU parallel; here one per GPU, `--shard rank/world`, no inter-process traffic; flappie.c:334-385).
+    Readers per process = what the host's cores allow per GPU.  The rate is MARGINAL (a long run minus a short run over the same
+    shard), so the fixed start-up (model text parse, HIP start, first allocations) is not in it; whole-job = all ranks' samples / the
+    slowest rank's time.  Returns a dict for rank 0, None elsewhere; {"skipped": why} when the binary or libhdf5 is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    from flappie_amd import model as M
+    exe, tool = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
+    if cfg["kind"] != M.NET_LSTM5 or not (os.path.exists(exe) and os.path.exists(tool)):
+        return {"skipped": "needs the flappie binary + fast5_tool (libhdf5 at build time) and an LSTM5 flip-flop model"} if rank == 0 else None
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or 1
+    readers = max(1, min(12, ncore // max(1, world) - 2))
+    nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_HOSTFED_FILES", "12288"))      # per rank
+    n_short = max(512, nfiles // 6)
+    obj = [None]
+    if rank == 0:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        obj[0] = tempfile.mkdtemp(prefix="ffhip_hostfed_", dir=base)
+        os.mkdir(os.path.join(obj[0], "reads"))
+    if dist is not None:
+        dist.broadcast_object_list(obj, src=0)
+    d = obj[0]
+    out = None
+    try:
+        t0 = time.time()
+        # every rank fills its own stripe of the shared directory (file index = rank + k * world: exactly the files `--shard rank/world` takes)
+        gen = subprocess.run([tool, "synth", os.path.join(d, "reads"), str(nfiles), "3500", "5500", "20260928", str(rank), str(world)], capture_output=True, text=True)
+        if rank == 0:
+            M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(cfg["kind"], cfg["hidden"], seed=1, ident=cfg["ident"]))
+        t_gen = time.time() - t0
+        if dist is not None:
+            dist.barrier()
+        env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1")
+        res = []
+        for n in (n_short, nfiles):
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--readers", str(readers), "--shard", "%d/%d" % (rank, world), "--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % rank),
+                                os.path.join(d, "reads")], env=env, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            called = [ln for ln in r.stderr.splitlines() if ln.startswith("basecalled:")]
+            reads, samples, raw = (int(x) for x in (called[-1].replace(",", " ").split()[1], called[-1].split()[3], called[-1].split()[7])) if called else (0, 0, 0)
+            res.append((r.returncode, dt, reads, samples, raw))
+        ok = gen.returncode == 0 and all(x[0] == 0 for x in res) and res[1][2] == nfiles and res[0][2] == n_short
+        d_t, d_samples, d_raw = res[1][1] - res[0][1], res[1][3] - res[0][3], res[1][4] - res[0][4]
+        mine = {"rank": rank, "ok": bool(ok), "marginal_s": d_t, "samples": d_samples, "raw_samples": d_raw, "long_run_s": res[1][1], "short_run_s": res[0][1],
+                "Msamples_per_s": (d_raw / d_t / 1e6) if d_t > 0 else None}
+        allr = [None] * world
+        if dist is not None:
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        if rank == 0:
+            tmax = max(x["marginal_s"] for x in allr)
+            good = all(x["ok"] for x in allr) and tmax > 0
+            out = {"value": round(sum(x["raw_samples"] for x in allr) / tmax / 1e6, 4) if good else None, "unit": "Msamples/s",
+                   "per_rank": [round(x["Msamples_per_s"], 3) if x["Msamples_per_s"] else None for x in allr],
+                   "max_marginal_s": round(tmax, 4), "files_per_rank": nfiles, "readers_per_rank": readers, "host_cores": ncore,
+                   "fixed_cost_s": round(res[0][1] - n_short * (d_t / max(1, nfiles - n_short)), 3),
+                   "note": "flappie binary per rank: --shard rank/%d over one directory of %d generated single-read fast5 files (3500-5500 raw samples), "
+                           "--readers %d (host cores %d / ranks %d), FASTQ out; raw samples of files [%d, %d) of each shard / the slowest rank's time between a "
+                           "%d-file and a %d-file run; generation %.1f s (not timed)" % (world, world * nfiles, readers, ncore, world, n_short, nfiles, n_short, nfiles, t_gen)}
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,9 +318,12 @@ def main():
                          "workgroups per CU already fill the CUs: there a second batch costs up to 10 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true")
+    ap.add_argument("--no-host-fed-leg", action="store_true", help="skip the per-rank run of the flappie binary over generated fast5 files")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
     ap.add_argument("--nread", type=int, default=int(os.environ.get("FFHIP_BENCH_NREAD", "0")) or None, help="override the config's reads per batch")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("FFHIP_BENCH_NO_SELF_LAUNCH"):
+        self_launch(args.gpus, sys.argv[1:])          # does not return
     cfg = dict(CONFIGS[args.config])
     if args.hidden:
         cfg["hidden"] = args.hidden
@@ -166,21 +347,31 @@ def main():
     # FFHIP_BENCH_FORCE_DIST=1: take the RCCL code path (init, barrier, MAX all-reduce) with a single rank too --
     # lets a 1-GPU box exercise exactly what the N > 1 launches run
     dist_on = world > 1 or bool(os.environ.get("FFHIP_BENCH_FORCE_DIST"))
+    stub = bool(os.environ.get("FFHIP_BENCH_STUB"))          # CPU tests: gloo, no engine (tests/test_bench_launch.py)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE %d != --gpus %d (start it as `python bench.py --gpus N`, or under torch.distributed.run with N ranks)" % (world, args.gpus))
 
-    from flappie_amd import binding as B
     from flappie_amd import model as M
-
-    eng = B.Engine(local_rank)
     mdl = M.synthetic_model(cfg["kind"], H, seed=1, ident=cfg["ident"])
-    dm = B.DeviceModel(eng, mdl)
+    if stub:
+        eng, dm = _StubEngine(), None
+
+        class B:          # noqa: N801 -- stands for the binding module below
+            Batch = _StubBatch
+    else:
+        from flappie_amd import binding as B
+        eng = B.Engine(local_rank)
+        dm = B.DeviceModel(eng, mdl)
     rng = np.random.default_rng(20260928 + rank)
     sig = rng.standard_normal((NREAD, NSAMPLE)).astype(np.float32)
     nfl = max(1, min(args.inflight if args.inflight else cfg.get("inflight", 1), 2))
@@ -192,7 +383,7 @@ def main():
         if dist_on:
             dist.barrier()
         eng.synchronize()
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and not stub:
             torch.cuda.synchronize()
 
     def run_steps(n, upload=False):
@@ -217,12 +408,13 @@ def main():
     dt = time.perf_counter() - t0
     prof = [b.profile() for b in batches]
     eng.set_profiling(False)
+    nblock_, rnn_path_ = batches[0].nblock, batches[-1].rnn_path()      # (the batches are closed before the line is put together)
 
     # second leg, reported beside `value`, never as it: the same steps with the batch's signal handed over as a HOST buffer
     # every step (SURVEY.md section 8d counts "from first H2D")
     dt_h2d, steps_h2d = None, 0
     if not args.no_h2d_leg:
-        steps_h2d = max(1, min(steps, 50))
+        steps_h2d = steps                # the same K steps as `value`
         barrier()
         t1 = time.perf_counter()
         run_steps(steps_h2d, upload=True)
@@ -230,13 +422,31 @@ def main():
         dt_h2d = time.perf_counter() - t1
 
     if dist_on:       # MAX over ranks of the timed region (flappie_amd/shard.py::max_over_ranks, inlined so that it also runs at world 1)
-        tmax = torch.tensor([dt, dt_h2d or 0.0], dtype=torch.float64, device="cuda")
+        dt_rank = dt
+        tmax = torch.tensor([dt, dt_h2d or 0.0], dtype=torch.float64, device="cpu" if stub else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0].item())
         dt_h2d = float(tmax[1].item()) if dt_h2d is not None else None
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(steps * NREAD * NSAMPLE / dt_rank / 1e6, 4))
+    else:
+        per_rank = [round(steps * NREAD * NSAMPLE / dt / 1e6, 4)]
+
+    # the engine is closed before the host-fed leg: that leg is a `flappie` process per rank on the same GPU
+    for b in batches:
+        b.close()
+    if dm is not None:
+        dm.close()
+    eng.close()
+    hostfed = None
+    if not args.no_host_fed_leg and not stub:
+        try:
+            hostfed = host_fed_leg(cfg, rank, local_rank, world, dist if dist_on else None)
+        except Exception as e:      # a reported leg, not the benchmark: its failure must not lose the line
+            hostfed = {"skipped": "host-fed leg failed: %r" % (e,)} if rank == 0 else None
 
     if rank == 0:
-        nblock = batches[0].nblock
+        nblock = nblock_
         value = world * steps * NREAD * NSAMPLE / dt / 1e6
         # dominant kernel: one recurrent layer.  Algorithmic work per read per block:
         # 2*H*G*H FLOP for the recurrence (G = 4 gates for LSTM, 3 for GRUmod), and the same again for the input
@@ -244,7 +454,7 @@ def main():
         G = 3 if cfg["kind"] == M.NET_GRUMOD5 else 4
         rec = prof[-1]["recurrent"]
         fused = prof[-1]["inproj"]["launches"] == 0
-        rnn_path = batches[-1].rnn_path()
+        rnn_path = rnn_path_
         flop_layer = (2.0 if fused else 1.0) * 2.0 * H * G * H * NREAD * nblock
         launches_per_layer = rec["launches"] / 5.0
         ms_layer = rec["ms"] / 5.0
@@ -310,6 +520,10 @@ def main():
             "decode_hbm": {"achieved": round(float(NREAD) * nblock * bytes_per_block / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else None,
                            "peak": 8000.0, "unit": "GB/s", "bytes_per_block": bytes_per_block, "ms": round(dec_ms, 4)},
         }
+        out["per_rank_Msamples_per_s"] = per_rank
+        out["max_over_ranks_s"] = round(dt, 6)
+        if hostfed is not None:
+            out["host_fed"] = hostfed
         if dt_h2d is not None:
             out["h2d_inclusive"] = {"value": round(world * steps_h2d * NREAD * NSAMPLE / dt_h2d / 1e6, 4), "unit": "Msamples/s",
                                     "ms_per_step": round(dt_h2d / steps_h2d * 1e3, 4), "steps": steps_h2d,
@@ -318,10 +532,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    for b in batches:
-        b.close()
-    dm.close()
-    eng.close()
     if dist_on:
         dist.destroy_process_group()
 

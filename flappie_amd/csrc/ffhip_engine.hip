@@ -809,8 +809,9 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
                 // (the check-in words carry the launch's epoch: no fill between launches)
                 b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
-                // one workgroup per CU: two such launches are co-resident only if together they need no more CUs than there are
-                const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
+                // two such launches (this batch's and another's in flight) run beside each other only if ALL their workgroups fit on the chip together
+                const int ncu_ = b->eng->prop.multiProcessorCount;
+                const bool chain = 2 * split_launch_workgroups(m->cell, Hp, nrt, ncu_) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt, ncu_);
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (prof && rt0 == 0) hipEventRecord(b->lev[l][1], s);      // behind the wait: the layer's time is its kernels', not the other batch's
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,

@@ -127,6 +127,19 @@ __device__ __forceinline__ v2u fresh_sentinel() {
     return v;
 }
 
+// Running maximum (as unsigned) over the dwords of one chunk's operands: it is 0xFFFFFFFF at the end iff one of them was the
+// sentinel.  Four v_max3_u32 per chunk and ONE register, evaluated where it stands (a chain of compares whose only use is the
+// final test gets sunk there by the compiler -- and keeps every operand register alive until then).
+__device__ __forceinline__ unsigned sentinel_max(unsigned seen, const v4u (&r)[kSplitNS]) {
+#pragma unroll
+    for (int s = 0; s < kSplitNS; s++) {
+        seen = max(max(seen, r[s].x), r[s].y);
+        seen = max(max(seen, r[s].z), r[s].w);
+    }
+    asm volatile("" : "+v"(seen));
+    return seen;
+}
+
 // s_waitcnt vmcnt(n) with n known after unrolling (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
     switch (n) {
@@ -137,6 +150,12 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -147,11 +166,18 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 // independent recurrences per CU, so that one's hand-off wait, sweep latency and gate phase run under the other's matrix
 // work -- latency hiding by occupancy instead of by schedule; the two workgroups' gate phases also stop colliding on the same
 // two SIMDs in lock step (six gate tiles on four SIMDs).
-template <int KIND, int N, int TS>
-__global__ void __launch_bounds__(512, (TS == 1 || N <= 2) ? 4 : 1)
+// DN ("dense", TS = 2 only): the PAIR form in 128 registers and 77 KiB of LDS, so that TWO such workgroups -- of one launch or of the
+// launches of two batches in flight -- share a CU: four independent 16-read recurrences per CU.  The sweep of h(t-1) lands in
+// LDS (as in the one-tile form at N = 3) one tile after the other through ONE set of accumulators, the recurrent partials are
+// written over the landing zone they came from, the projection partials are single-buffered behind a per-(K quarter, tile)
+// "consumed" flag, and the x waves load x(t+1) just in time (it is L2-warm) instead of a step ahead across the gate phase.
+template <int KIND, int N, int TS, bool DN = false>
+__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
 k_lstm_split(SplitArgs a) {
-    __shared__ v4f px[2][4][TS][N][64];     // projection partials, double-buffered: [step parity][K quarter][tile of the group][unit tile][lane]
-    __shared__ v4f ph[4][TS][N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial
+    static_assert(!DN || TS == 2, "the dense form is a pair form");
+    __shared__ v4f px[DN ? 1 : 2][4][TS][N][64];     // projection partials, double-buffered (DN: single): [step parity][K quarter][tile of the group][unit tile][lane]
+    __shared__ v4f ph_[DN ? 1 : 4][DN ? 1 : TS][DN ? 1 : N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial (DN: in the landing zone)
+    __shared__ int pxc[4][2];               // DN: step (+1) whose projection partial of (K quarter, tile) the h wave has consumed
     __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
     __shared__ unsigned short gsl[8][NS][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
     __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
@@ -161,8 +187,13 @@ k_lstm_split(SplitArgs a) {
     __shared__ int cxflag[2];               // ... and the step it belongs to (+1)
     // HL: the sweep of h(t-1) LANDS IN LDS (buffer_load ... lds: no destination registers) and feeds the MFMAs through ds_read_b128.
     // The one-tile kernel at N = 3 then fits 128 registers: TWO workgroups -- two independent recurrences -- share a CU.
-    constexpr bool HL = (TS == 1 && N == 3);
-    __shared__ v4u hland[HL ? 4 : 1][HL ? N : 1][NS][64];      // per h wave: its K slice of h(t-1), [chunk][slice][lane]
+    constexpr bool HL = (TS == 1 && N == 3) || DN;
+    __shared__ v4u hland[HL ? 4 : 1][HL ? TS : 1][HL ? N : 1][NS][64];      // per h wave: its K slice of h(t-1), [tile][chunk][slice][lane]
+    // partials of K quarter w for gate tile (ts, j): 64 x 16 B
+    auto ph_at = [&](int w, int ts, int j) -> v4f * {
+        if constexpr (DN) return (v4f *)&hland[w][ts][0][0][0] + j * 64;      // over the (consumed) first chunks of that tile's landing zone
+        else return &ph_[w][ts][j][0];
+    };
     constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
@@ -205,6 +236,7 @@ k_lstm_split(SplitArgs a) {
     const bool store_wave = gate_wave || sg_back;            // publishes a tile's h(t)
     const int my_gts = g6 / N, my_gj = g6 % N;
     if (threadIdx.x < 2) cxflag[threadIdx.x] = 0;
+    if (threadIdx.x < 8) pxc[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
     auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * NS + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
     auto out_tile = [&](int t, int gts) { return a.hout + ((size_t)t * a.B16 + (rtA + gts)) * tileB; };
@@ -339,7 +371,7 @@ k_lstm_split(SplitArgs a) {
         const int t = step_t(i);
         float h;
 #if FFHIP_SPLIT_ABLATE & 4              // 4 = no gate math (one LDS read stands in for it)
-        h = ph[0][gts][gj][lane].x * 1e-3f;
+        h = ph_at(0, gts, gj)[lane].x * 1e-3f;
         if (false)
 #endif
         if (KIND == 1) {
@@ -348,7 +380,7 @@ k_lstm_split(SplitArgs a) {
             // `c` carries this lane's own h(t-1).
             v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-            for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
             s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
             if (a.fast_gates) {
@@ -365,7 +397,7 @@ k_lstm_split(SplitArgs a) {
         } else {
             v4f s = sbias[gj][q];
 #pragma unroll
-            for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+            for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
             s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
             if (a.fast_gates) {
@@ -389,7 +421,7 @@ k_lstm_split(SplitArgs a) {
     auto gate_front = [&](int i, int gts, int gj, float &c, int my_tb) {
         v4f s = sbias[gj][q];
 #pragma unroll
-        for (int w2 = 0; w2 < 4; w2++) s = s + ph[w2][gts][gj][lane];
+        for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
         s = s * inv_scale;
         float forget, update;
         if (a.fast_gates) {
@@ -409,7 +441,7 @@ k_lstm_split(SplitArgs a) {
     auto gate_back = [&](int i, int gts, int gj, int my_tb) {
         float so = sbias[gj][q].w;
 #pragma unroll
-        for (int w2 = 0; w2 < 4; w2++) so = so + ph[w2][gts][gj][lane].w;
+        for (int w2 = 0; w2 < 4; w2++) so = so + ph_at(w2, gts, gj)[lane].w;
         so = so * inv_scale;
         const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
         while (*(volatile int *)&cxflag[wave & 1] != i + 1) __builtin_amdgcn_s_sleep(1);
@@ -425,7 +457,65 @@ k_lstm_split(SplitArgs a) {
 
     // The two roles run their own step loop (two barriers per step each), so that the register allocator sees each
     // role's live ranges alone.
-    if (xw) {
+    if (xw && DN) {
+        // ---- x waves, dense form: per step and tile -- load x(step i+1) of my K quarter (24 registers; an L2 hit: the group touched
+        // these lines three steps ago), project, wait until h wave kw has taken the previous partial of that tile (it always has), write
+        // the new one.  Nothing is in flight across the gate phase, where x waves 0-3 work gate tiles 4 and 5.
+        if constexpr (DN) {
+        v4u xb[N][NS];
+        auto load_x_tile = [&](int i, int ts) {
+            __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.xin, step_t(i), ts), 0, (int)tileB, 0x00020000);
+#pragma unroll
+            for (int cc = 0; cc < N; cc++) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) xb[cc][s] = __builtin_amdgcn_raw_buffer_load_b128(rx, lane_off, ((chunk[cc] * NS + s) * 64) * 16, 0);
+                if (cc + 1 < N) __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        auto project_tile = [&](int ts, int want) {          // xb -> px[0][kw][ts]; want = the step (+1) whose partial must have been consumed (0: none)
+            v4f acc[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[cc], acc);
+            if (want > 0)
+                for (unsigned spin = 0; *(volatile int *)&pxc[kw][ts] != want && 0 == *(volatile int *)&lds_abort && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int j = 0; j < N; j++) px[0][kw][ts][j][lane] = acc[j];
+        };
+        constexpr int WARM = 3;
+        constexpr int LPM = (Hc * NS * 8 * TS + 31) / 32;    // 128-byte lines of the group's x(step) per member
+        unsigned touched = 0, sink = 0;
+        auto touch_x = [&](int i) {                          // L2 warming, spread over the group (see the classic loop below)
+            const int line = m * LPM + lane;
+            unsigned t = 0;
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
+                t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
+            touched = t;
+        };
+        for (int ts = 0; ts < ntl; ts++) { load_x_tile(0, ts); project_tile(ts, 0); }
+        touch_x(1);
+        sink ^= touched;
+        touch_x(2);
+        raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
+        for (int i = 0; i < Tb; i++) {
+            if (i + 1 < Tb)
+                for (int ts = 0; ts < ntl; ts++) { load_x_tile(i + 1, ts); project_tile(ts, i + 1); }
+            sink ^= touched;
+            touch_x(i + WARM);
+            raw_barrier();
+            if (lds_abort) return;
+            if (sg_front) {
+                __builtin_amdgcn_s_setprio(3);
+                gate_front(i, my_gts, my_gj, c, my_tb);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
+            else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            raw_barrier();                                   // closes the gate phase
+        }
+        if (sink == 0x9e3779b9u && a.Tb < 0) a.flags[0] = sink;
+        }
+    } else if (xw) {
         // ---- x waves: projection of step i+1 under the hand-off latency of step i.  x(step i+2) is prefetched into
         // registers right after the MFMAs that consumed x(step i+1): a whole step ahead of its use (it comes from HBM),
         // and never in the gate phase, where the issue of 18 KiB of loads per wave (the CU's path to L2 takes 64 B/clk)
@@ -456,7 +546,7 @@ k_lstm_split(SplitArgs a) {
 #pragma unroll
                 for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[ts][cc], acc);
 #pragma unroll
-                for (int j = 0; j < N; j++) px[i & 1][kw][ts][j][lane] = acc[j];
+                for (int j = 0; j < N; j++) px[DN ? 0 : (i & 1)][kw][ts][j][lane] = acc[j];
             }
         };
         // L2 warming, spread over the group.  x is the previous layer's output, far larger than L2: the first of the 32 members
@@ -527,11 +617,11 @@ k_lstm_split(SplitArgs a) {
                 for (int ts = 0; ts < TS; ts++)
 #pragma unroll
                     for (int j = 0; j < N; j++) {
-                        const v4f p = px[i & 1][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+                        const v4f p = px[DN ? 0 : (i & 1)][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
                         acc[ts][j] = KIND == 1 ? (v4f){ p.x, p.y, 0.0f, p.z } : p;      // GRUmod: the projection's candidate row moves to the free row
                     }
             };
-            init_acc();
+            if constexpr (!DN) init_acc();
             if (i > 0) {
                 const int tp = step_t(i - 1);
                 const unsigned char *hp = tile_ptr(a.hout, tp, 0);          // the pair's two tiles are adjacent
@@ -607,18 +697,18 @@ k_lstm_split(SplitArgs a) {
                 // written out: the compiler does not see that an LDS read depends on a buffer_load ... lds (left to itself it waits
                 // for vmcnt(0) before the first one), and it may move nothing across these statements.
                 auto recur_lds = [&]() -> bool {
-                    bool ok = true;
+                    unsigned seen = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass rejects the LDS-DMA builtin, and then silently drops the kernel's stub)
-                    if constexpr (HL) {
+                    if constexpr (HL && !DN) {
 #pragma unroll
                         for (int k = 0; k < N; k++) {
 #pragma unroll
                             for (int s = 0; s < NS; s++)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)&hland[kw][k][s][0], 16,
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)&hland[kw][0][k][s][0], 16,
                                                                          lane_off, ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
                             if (k + 1 < N) __builtin_amdgcn_s_sleep(1);
                         }
-                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][lane];
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
                         v4u r[2][NS];
                         auto fetch = [&](int k) {           // chunk k has landed -> issue its two LDS reads
                             wait_vmcnt_upto(NS * (N - 1 - k));
@@ -630,11 +720,7 @@ k_lstm_split(SplitArgs a) {
                         for (int k = 0; k < N; k++) {
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[k & 1][0]), "+v"(r[k & 1][1]) :: "memory");
                             if (k + 1 < N) fetch(k + 1);
-#pragma unroll
-                            for (int s = 0; s < NS; s++) {
-                                const v4u rr = r[k & 1][s];
-                                ok = ok && rr.x != kSplitSentinel && rr.y != kSplitSentinel && rr.z != kSplitSentinel && rr.w != kSplitSentinel;
-                            }
+                            seen = sentinel_max(seen, r[k & 1]);
                             mm6<N>(wf, k, r[k & 1], acc[0]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -643,9 +729,64 @@ k_lstm_split(SplitArgs a) {
 #if FFHIP_SPLIT_ABLATE & 2
                     return true;
 #endif
-                    return __all(ok) != 0;
+                    return __all(seen != kSplitSentinel) != 0;
                 };
-                auto recur_any = [&]() -> bool { if constexpr (HL) return recur_lds(); else return recur(); };
+                // Dense form: both tiles' 2N KiB each land in this wave's zone; ONE set of accumulators takes tile A, then tile B (each
+                // starting from the projection partial of that tile), and each tile's partials go over the first N KiB of its own,
+                // consumed, landing zone.  false: a sentinel was among the operands -- everything is done again from the (still
+                // unreleased) projection partials.
+                auto recur_dn = [&]() -> bool {
+                    unsigned seen = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if constexpr (DN) {
+#pragma unroll
+                        for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+                            for (int k = 0; k < N; k++) {
+#pragma unroll
+                                for (int s = 0; s < NS; s++)
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)&hland[kw][ts][k][s][0], 16,
+                                                                             lane_off, ts * offB + ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
+                                if (ts * N + k + 1 < 2 * N) __builtin_amdgcn_s_sleep(1);
+                            }
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
+                        v4u r[2][NS];
+                        auto fetch = [&](int c) {           // (tile, chunk) c = ts * N + k has landed -> issue its two LDS reads
+                            wait_vmcnt_upto(NS * (2 * N - 1 - c));
+                            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                                         : "=&v"(r[c & 1][0]), "=&v"(r[c & 1][1]) : "v"(la + (unsigned)(c * NS * 1024)) : "memory");
+                        };
+                        fetch(0);
+#pragma unroll
+                        for (int ts = 0; ts < 2; ts++) {
+                            v4f accd[N];
+#pragma unroll
+                            for (int j = 0; j < N; j++) {
+                                const v4f p = px[0][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+                                accd[j] = KIND == 1 ? (v4f){ p.x, p.y, 0.0f, p.z } : p;
+                            }
+#pragma unroll
+                            for (int k = 0; k < N; k++) {
+                                const int c = ts * N + k;
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[c & 1][0]), "+v"(r[c & 1][1]) :: "memory");
+                                if (c + 1 < 2 * N) fetch(c + 1);
+                                seen = sentinel_max(seen, r[c & 1]);
+                                mm6<N>(wf, k, r[c & 1], accd);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (ts < ntl) {
+#pragma unroll
+                                for (int j = 0; j < N; j++) ph_at(kw, ts, j)[lane] = accd[j];
+                            }
+                        }
+                    }
+#endif
+#if FFHIP_SPLIT_ABLATE & 2
+                    return true;
+#endif
+                    return __all(seen != kSplitSentinel) != 0;
+                };
+                auto recur_any = [&]() -> bool { if constexpr (DN) return recur_dn(); else if constexpr (HL) return recur_lds(); else return recur(); };
                 if (!timed_out) {
                     // gfx9 counts loads and stores on ONE counter and they complete out of order with respect to each other:
                     // while this wave's gate-phase stores of step i-1 may be pending the compiler can only wait vmcnt(0).
@@ -661,18 +802,33 @@ k_lstm_split(SplitArgs a) {
                                 if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                             }
                             __builtin_amdgcn_s_sleep(1);
-                            init_acc();
+                            if constexpr (!DN) init_acc();
                             if (recur_any()) break;
                         }
                     }
                 }
                 if (timed_out && lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
             }
+            if constexpr (DN) {
+                if (i == 0) {                                    // h(-1) = 0: the gate pre-activations are the projection alone
+                    init_acc();
 #pragma unroll
-            for (int ts = 0; ts < TS; ts++) {
-                if (ts >= ntl) continue;
+                    for (int ts = 0; ts < TS; ts++) {
+                        if (ts >= ntl) continue;
 #pragma unroll
-                for (int j = 0; j < N; j++) ph[kw][ts][j][lane] = acc[ts][j];
+                        for (int j = 0; j < N; j++) ph_at(kw, ts, j)[lane] = acc[ts][j];
+                    }
+                }
+                // the projection partials of this step are consumed: the x wave of my K quarter may write the next ones
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;
+            } else {
+#pragma unroll
+                for (int ts = 0; ts < TS; ts++) {
+                    if (ts >= ntl) continue;
+#pragma unroll
+                    for (int j = 0; j < N; j++) ph_at(kw, ts, j)[lane] = acc[ts][j];
+                }
             }
             TL(2);
             raw_barrier();
@@ -1114,7 +1270,32 @@ bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 1
 // At H <= 256 the pair form also fits two workgroups per CU (<= 128 VGPRs, 53 KiB LDS): a launch then takes 4 * (ncu / 32) tiles --
 // 512 reads on 256 CUs, four independent 16-read recurrences per CU.  The step of this kernel is a latency chain (hand-off through
 // L2, sweep, gate math), so the reads in flight per launch are what sets its throughput.
-int split_max_tiles(int ncu, int H) { return (H <= 256 && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32); }
+// H = 384 (LSTM): the dense pair form k_lstm_split<0, 3, 2, true> -- 128 registers, 77 KiB of LDS, two workgroups per CU: a launch takes
+// 512 reads, and the launches of two 256-read batches in flight run BESIDE each other instead of one after the other
+// (FFHIP_SPLIT_DENSE=0: the one-tile form)
+static bool split_dense3(int kind, int H) {
+    const char *e = getenv("FFHIP_SPLIT_DENSE");
+    return kind == 0 && H == 384 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS");
+}
+int split_max_tiles(int ncu, int H) { return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32); }
+// tiles per group of a launch of nrt read tiles
+static int split_launch_ts(int kind, int H, int nrt, int ncu) {
+    // the dense forms (two workgroups per CU, a pair of tiles each) take launches with more tiles than the one-tile form can:
+    // FULL launches of 4 * (ncu / 32) tiles in practice (the engine's layer loop cuts a batch that way)
+    if ((H <= 256 || split_dense3(kind, H)) && nrt > 2 * (ncu / 32)) return 2;
+    if (split_dense3(kind, H) && getenv("FFHIP_SPLIT_DENSE_ALWAYS")) return 2;
+    return split_tiles_per_group(kind, H);
+}
+static bool split_launch_dense3(int kind, int H, int nrt, int ncu) {
+    return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || getenv("FFHIP_SPLIT_DENSE_ALWAYS"));      // (development: the dense form for every launch)
+}
+// workgroups of such a launch, and how many workgroups of its kernel share a CU: two launches (of two batches in flight) are
+// co-resident -- every workgroup of both must be, they wait for their peers -- iff together they fit
+int split_launch_workgroups(int kind, int H, int nrt, int ncu) { const int ts = split_launch_ts(kind, H, nrt, ncu); return (nrt + ts - 1) / ts * 32; }
+int split_workgroups_per_cu(int kind, int H, int nrt, int ncu) {
+    const int ts = split_launch_ts(kind, H, nrt, ncu);
+    return (ts == 1 || H <= 256 || split_launch_dense3(kind, H, nrt, ncu)) ? 2 : 1;
+}
 size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
 int split_tiles_per_group(int kind, int H) {
     const char *force = getenv("FFHIP_SPLIT_TS");      // development: 1 or 2
@@ -1138,8 +1319,11 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
     // tiles per group: 1 (two workgroups per CU, one read tile each) where that is faster, else 2 (kSplitTS)
     // ... and 2 with two workgroups per CU when the launch carries more tiles than the one-tile form can take (H <= 256)
-    const int ts = (H <= 256 && nrt > 2 * (ncu / 32)) ? 2 : split_tiles_per_group(kind, H);
+    const int ts = split_launch_ts(kind, H, nrt, ncu);
     const int ngroup_l = (nrt + ts - 1) / ts;
+#ifndef FFHIP_SPLIT_BF16X3
+    if (split_launch_dense3(kind, H, nrt, ncu)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
+#endif
 #define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
                                  else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)
 #ifdef FFHIP_SPLIT_BF16X3

@@ -294,13 +294,57 @@ int fo_get_dot_mode(void) { return g_dot_mode; }
 void fo_fast_gemv_t(float *y, const float *W, size_t ldW, size_t nout, size_t len, const float *x);
 void fo_fast_gemm_tn(float *Y, size_t ldY, const float *W, size_t ldW, size_t nout, size_t len,
                      const float *X, size_t ldX, size_t ncol);
+
+/* Dot mode 3: the same two shapes through a real OpenBLAS, where the host has one (bench.py's cpu_baseline: "Flappie's own OpenBLAS
+ * CPU path" -- the reference calls cblas_sgemv(ColMajor, Trans, ...) at layers.c:1009 / :697 / :224 / :268 and cblas_sgemm(ColMajor,
+ * Trans, NoTrans, ...) at flappie_matrix.c:384 / layers.c:250 with exactly these arguments).  The image has no <cblas.h>; the library
+ * is dlopen()ed and called through the prototypes below (the CBLAS ABI, LP64 build: scipy's `scipy_cblas_*`, or plain `cblas_*`). */
+#include <dlfcn.h>
+#include <stdio.h>
+typedef void (*sgemv_fn)(int order, int trans, int m, int n, float alpha, const float *a, int lda, const float *x, int incx, float beta, float *y, int incy);
+typedef void (*sgemm_fn)(int order, int ta, int tb, int m, int n, int k, float alpha, const float *a, int lda, const float *b, int ldb, float beta, float *c, int ldc);
+static sgemv_fn g_sgemv = NULL;
+static sgemm_fn g_sgemm = NULL;
+static char g_blas_config[256];
+/* 0 = ready (mode 3 usable); the library's threads are set to one, as the reference's README asks (OPENBLAS_NUM_THREADS=1) */
+int fo_blas_open(const char *path) {
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    static const char *pre[2] = { "scipy_", "" };
+    for (int k = 0; k < 2; k++) {
+        char name[64];
+        snprintf(name, sizeof name, "%scblas_sgemv", pre[k]);
+        sgemv_fn gv = (sgemv_fn)dlsym(h, name);
+        snprintf(name, sizeof name, "%scblas_sgemm", pre[k]);
+        sgemm_fn gm = (sgemm_fn)dlsym(h, name);
+        if (!gv || !gm) continue;
+        snprintf(name, sizeof name, "%sopenblas_set_num_threads", pre[k]);
+        void (*setn)(int) = (void (*)(int))dlsym(h, name);
+        if (setn) setn(1);
+        snprintf(name, sizeof name, "%sopenblas_get_config", pre[k]);
+        char *(*cfg)(void) = (char *(*)(void))dlsym(h, name);
+        snprintf(g_blas_config, sizeof g_blas_config, "%s", cfg ? cfg() : "unknown BLAS");
+        g_sgemv = gv; g_sgemm = gm;
+        return 0;
+    }
+    return -2;
+}
+const char *fo_blas_config(void) { return g_sgemv ? g_blas_config : ""; }
+static void dot_gemv_t(float *y, const float *W, size_t ldW, size_t nout, size_t len, const float *x) {
+    if (g_dot_mode == 3 && g_sgemv) g_sgemv(102 /*ColMajor*/, 112 /*Trans*/, (int)len, (int)nout, 1.0f, W, (int)ldW, x, 1, 1.0f, y, 1);
+    else fo_fast_gemv_t(y, W, ldW, nout, len, x);
+}
+static void dot_gemm_tn(float *Y, size_t ldY, const float *W, size_t ldW, size_t nout, size_t len, const float *X, size_t ldX, size_t ncol) {
+    if (g_dot_mode == 3 && g_sgemm) g_sgemm(102, 112, 111 /*NoTrans*/, (int)nout, (int)ncol, (int)len, 1.0f, W, (int)ldW, X, (int)ldX, 1.0f, Y, (int)ldY);
+    else fo_fast_gemm_tn(Y, ldY, W, ldW, nout, len, X, ldX, ncol);
+}
 void fo_fast_lstm_gates(const float *xF, float *state, float *hout, size_t size);
 void fo_fast_grumod_gates(float *xF, const float *x, const float *hprev, float *hout, size_t size);
 
 /* y[f] += sum_{i<len} W[woff + i + f*ldW] * x[i]     (the reference's sgemv(T) shape) */
 static void window_accumulate(float *y, const fo_mat *W, size_t woff, size_t len, const float *x) {
-    if (g_dot_mode == 2) {
-        fo_fast_gemv_t(y, W->f + woff, W->stride, W->nc, len, x);
+    if (g_dot_mode >= 2) {
+        dot_gemv_t(y, W->f + woff, W->stride, W->nc, len, x);
         return;
     }
     if (g_dot_mode == 1) {
@@ -359,8 +403,8 @@ fo_mat *fo_convolution(const fo_mat *X, const fo_mat *W, const fo_mat *b, size_t
     for (long w = 0; w < winlen; w += s) {                    /* body */
         const long ncol = (T - shiftX - w) / nstepX;          /* ifloor, :248 */
         const long col0 = ncolsL + w / s;
-        if (g_dot_mode == 2 && ncol > 0) {                    /* the reference's one sgemm per family, :250 */
-            fo_fast_gemm_tn(C->f + ldC * col0, (size_t)(ldC * nstepC), W->f, W->stride, W->nc, W->nr,
+        if (g_dot_mode >= 2 && ncol > 0) {                    /* the reference's one sgemm per family, :250 */
+            dot_gemm_tn(C->f + ldC * col0, (size_t)(ldC * nstepC), W->f, W->stride, W->nc, W->nr,
                             X->f + ldX * (shiftX + w), (size_t)(ldX * nstepX), (size_t)ncol);
             continue;
         }
@@ -392,8 +436,8 @@ fo_mat *fo_affine_map(const fo_mat *X, const fo_mat *W, const fo_mat *b) {
     fo_mat *C = fo_make_mat(W->nc, X->nc);
     if (!C) return NULL;
     for (size_t c = 0; c < X->nc; c++) memcpy(C->f + c * C->stride, b->f, C->stride * sizeof(float));
-    if (g_dot_mode == 2) {
-        fo_fast_gemm_tn(C->f, C->stride, W->f, W->stride, W->nc, W->nr, X->f, X->stride, X->nc);
+    if (g_dot_mode >= 2) {
+        dot_gemm_tn(C->f, C->stride, W->f, W->stride, W->nc, W->nr, X->f, X->stride, X->nc);
         return C;
     }
     for (size_t c = 0; c < X->nc; c++) window_accumulate(C->f + c * C->stride, W, 0, W->nr, X->f + c * X->stride);
@@ -407,7 +451,7 @@ static void lstm_step(const float *xaff, const float *hprev, const fo_mat *sW,
     const size_t size = sW->nr;
     memcpy(xF, xaff, 4 * size * sizeof(float));
     window_accumulate(xF, sW, 0, size, hprev);
-    if (g_dot_mode == 2) { fo_fast_lstm_gates(xF, state, hout, size); return; }
+    if (g_dot_mode >= 2) { fo_fast_lstm_gates(xF, state, hout, size); return; }
     for (size_t i = 0; i < size; i++) {
         const float forget = fo_logisticf(xF[size + i]) * state[i];
         const float update = fo_logisticf(xF[i]) * fo_tanhf(xF[2 * size + i]);
@@ -445,7 +489,7 @@ static void grumod_step(const float *x, const float *hprev, const fo_mat *sW, fl
     memcpy(xF, x, 3 * size * sizeof(float));
     memset(xF + 2 * size, 0, size * sizeof(float));
     window_accumulate(xF, sW, 0, size, hprev);
-    if (g_dot_mode == 2) { fo_fast_grumod_gates(xF, x, hprev, hout, size); return; }
+    if (g_dot_mode >= 2) { fo_fast_grumod_gates(xF, x, hprev, hout, size); return; }
     for (size_t i = 0; i < 2 * size; i++) xF[i] = fo_logisticf(xF[i]);
     const float *z = xF, *r = xF + size;
     float *hbar = xF + 2 * size;

@@ -256,7 +256,7 @@ def _oracle_calls(mdl, raws, viterbi=False, temperature=1.0, trim=(200, 10)):
 
 
 def _parse_fastq(text):
-    lines = text.strip().split("\n")
+    lines = text[:-1].split("\n") if text.endswith("\n") else text.split("\n")      # (a read may have an EMPTY sequence and quality line: no strip())
     recs = []
     for k in range(0, len(lines), 4):
         assert lines[k][0] == "@" and lines[k + 2] == "+"

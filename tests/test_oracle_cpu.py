@@ -357,3 +357,24 @@ def test_dot_modes_stay_within_rounding_of_the_oracle():
             assert np.abs(alt["trans"] - ref["trans"]).max() <= 5e-5, (kind, hidden, mode)
             assert alt["basecall"] == ref["basecall"]
         assert np.array_equal(om.basecall(sig)["trans"], ref["trans"])      # mode restored
+
+
+def test_openblas_dot_mode_matches_the_oracle():
+    """Dot mode 3 -- the GEMV / GEMM calls of the reference (layers.c:1009, :250, flappie_matrix.c:384) made in a real OpenBLAS found on
+    this host through dlopen (bench.py's cpu_baseline, kind "port+openblas") -- is the same network: transition scores within a few
+    1e-5 of the reference-order oracle, identical calls.  Skipped where no LP64 OpenBLAS exists."""
+    import bench
+    mode, blas = bench._oracle_with_blas(3)
+    ffo.lib().fo_set_dot_mode(0)
+    if blas is None:
+        pytest.skip("no LP64 OpenBLAS on this host")
+    assert mode == 3 and "OpenBLAS" in blas[1]
+    for kind, hidden, T in ((M.NET_LSTM5, 96, 1505), (M.NET_GRUMOD5, 64, 1200)):
+        mdl = M.synthetic_model(kind, hidden, seed=3)
+        om = ffo.OracleModel(mdl)
+        sig = np.random.default_rng(hidden).standard_normal(T).astype(np.float32)
+        ref = om.basecall(sig)
+        with ffo.dot_mode(3):
+            alt = om.basecall(sig)
+        assert np.abs(alt["trans"] - ref["trans"]).max() <= 5e-5, (kind, hidden)
+        assert alt["basecall"] == ref["basecall"]

@@ -5,7 +5,7 @@ import re, subprocess, sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "--" else ""
 extra = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
-noslp = [] if "rnn_split" in src else ["-fno-slp-vectorize"]
+noslp = [] if ("rnn_split" in src or "_exp" in src) else ["-fno-slp-vectorize"]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", "flappie_amd/csrc", "-c", src,
        "-o", "/tmp/reguse.o", "-Rpass-analysis=kernel-resource-usage"] + noslp + extra
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
