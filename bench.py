@@ -32,7 +32,7 @@ HIDDEN = 384                      # r941_native (flipflop5_202003) hidden size i
 # the others let the driver or a reader reproduce the figures DESIGN.md quotes for configs[3] / configs[4] and the
 # smaller r941_native file with the same JSON line (own roofline, own CPU leg).  kind: 0 LSTM5, 1 GRUmod5, 2 LSTM5 + run-length head.
 CONFIGS = {
-    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=1, ident="r941native",
+    "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, pair=1, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
     "h256": dict(kind=0, hidden=256, nread=512, nsample=4000, steps=150, warmup=5, ident="r941native",
@@ -46,7 +46,7 @@ CONFIGS = {
                  metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",
                  label="r103_native-shape LSTM5 H=512 (SURVEY.md section 0.3: there is no r10C_pcr model), batch=256 synthetic 100000-sample reads per GPU, "
                        "posterior decode + trace (BASELINE.json configs[4])"),
-    "rle":  dict(kind=2, hidden=384, nread=256, nsample=4000, steps=100, warmup=3, inflight=2, ident="rle_r941native",
+    "rle":  dict(kind=2, hidden=384, nread=256, nsample=4000, steps=100, warmup=3, inflight=2, pair=1, ident="rle_r941native",
                  metric="Msamples/s run-length called (rle_r941_native, 4k-sample chunks)",
                  label="rle_r941_native-shape LSTM5 H=384 + run-length head (runnie), batch=256 synthetic 4000-sample reads per GPU"),
 }
@@ -317,6 +317,7 @@ def main():
                          "per CU runs the layers and the other batch's convolution / decode kernels fit beside them: c2 +2.9 %%, rle +24 %%; 1 where two "
                          "workgroups per CU already fill the CUs: there a second batch costs up to 10 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair", action="store_true", help="c2 / rle: submit the batches one by one (ffhip_batch_run) instead of in pairs (ffhip_batch_run_pair)")
     ap.add_argument("--no-h2d-leg", action="store_true")
     ap.add_argument("--no-host-fed-leg", action="store_true", help="skip the per-rank run of the flappie binary over generated fast5 files")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
@@ -375,7 +376,10 @@ def main():
     rng = np.random.default_rng(20260928 + rank)
     sig = rng.standard_normal((NREAD, NSAMPLE)).astype(np.float32)
     nfl = max(1, min(args.inflight if args.inflight else cfg.get("inflight", 1), 2))
-    batches = [B.Batch(dm, NREAD, NSAMPLE) for _ in range(nfl)]
+    # pair: two batches go to the GPU together, their recurrent layers as ONE launch per layer (ffhip_batch_run_pair: at H = 384 a 256-read
+    # batch is half of what the layer kernel's dense form carries); `nfl` then counts PAIRS in flight.  A step is still one batch.
+    pair = bool(cfg.get("pair")) and not args.no_pair and not stub and nfl >= 1
+    batches = [B.Batch(dm, NREAD, NSAMPLE) for _ in range(nfl * (2 if pair else 1))]
     for b in batches:
         b.set_signals(sig)               # inputs resident in HBM before the timed region
 
@@ -388,6 +392,26 @@ def main():
 
     def run_steps(n, upload=False):
         pending = []
+        if pair:
+            for i in range(0, n, 2):
+                k = (i // 2) % nfl
+                b0, b1 = batches[2 * k], batches[2 * k + 1]
+                if len(pending) == nfl:
+                    for b in pending.pop(0):
+                        b.finish()
+                if upload:
+                    b0.set_signals(sig)
+                    b1.set_signals(sig)
+                if i + 1 < n:
+                    b0.run_pair(b1, 1.0, 0)
+                    pending.append((b0, b1))
+                else:                      # an odd step count: the last batch runs alone
+                    b0.run(1.0, 0)
+                    pending.append((b0,))
+            for bs in pending:
+                for b in bs:
+                    b.finish()
+            return
         for i in range(n):
             b = batches[i % nfl]
             if len(pending) == nfl:
@@ -409,6 +433,7 @@ def main():
     prof = [b.profile() for b in batches]
     eng.set_profiling(False)
     nblock_, rnn_path_ = batches[0].nblock, batches[-1].rnn_path()      # (the batches are closed before the line is put together)
+    paired_ = (not stub) and pair and batches[0].paired()
 
     # second leg, reported beside `value`, never as it: the same steps with the batch's signal handed over as a HOST buffer
     # every step (SURVEY.md section 8d counts "from first H2D")
@@ -455,7 +480,8 @@ def main():
         rec = prof[-1]["recurrent"]
         fused = prof[-1]["inproj"]["launches"] == 0
         rnn_path = rnn_path_
-        flop_layer = (2.0 if fused else 1.0) * 2.0 * H * G * H * NREAD * nblock
+        # a paired launch (ffhip_batch_run_pair) carries the layer of TWO batches: its duration is recorded with both, its work is 2 x
+        flop_layer = (2.0 if fused else 1.0) * 2.0 * H * G * H * NREAD * nblock * (2 if paired_ else 1)
         launches_per_layer = rec["launches"] / 5.0
         ms_layer = rec["ms"] / 5.0
         achieved = flop_layer / (ms_layer * 1e-3) / 1e12
@@ -466,8 +492,8 @@ def main():
             # tests/test_split_numerics.py).  `achieved` counts the ALGORITHMIC fp32 FLOPs; the ceiling of this
             # formulation is the dense fp16/bf16 MFMA peak / 3.
             if rnn_path == 3:
-                kname = "k_lstm_split<%d,%d> (%s input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps)" % (
-                    1 if G == 3 else 0, H // 128, cell, nblock)
+                kname = "k_lstm_split%s<%d,%d> (%s input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps%s)" % (
+                    "_pair" if paired_ else "", 1 if G == 3 else 0, H // 128, cell, nblock, "; ONE launch for the layer of two %d-read batches" % NREAD if paired_ else "")
             else:
                 kname = "k_rnn_split (%s recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps; its projection GEMM k_inproj_split is a separate launch)" % (cell, nblock)
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
@@ -507,7 +533,7 @@ def main():
             "data": "synthetic (seeded N(0,1) signal, seeded random-init weights of the %s architecture)" % cfg["ident"],
             "config": {"workload": cfg["label"].replace("H=%d" % CONFIGS[args.config]["hidden"], "H=%d" % H).replace("batch=%d" % CONFIGS[args.config]["nread"], "batch=%d" % NREAD), "name": args.config,
                        "reads_per_step": NREAD, "samples_per_read": NSAMPLE, "blocks_per_read": nblock,
-                       "batches_in_flight": nfl, "parallelism": "reads sharded by rank, no collective"},
+                       "batches_in_flight": nfl * (2 if pair else 1), "paired_layer_launches": bool(paired_), "parallelism": "reads sharded by rank, no collective"},
             "roofline": roof,
             "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in prof[-1].items()},
             "kernel_ms_note": ("one batch in flight: the kernels of a step run back to back" if nfl == 1 else

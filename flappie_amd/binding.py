@@ -91,6 +91,8 @@ def lib():
     L.ffhip_batch_set_reads.argtypes = [vp, C.POINTER(CRawTable)]
     L.ffhip_batch_set_signals.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     L.ffhip_batch_run.argtypes = [vp, C.c_float, C.c_uint]
+    L.ffhip_batch_run_pair.argtypes = [vp, vp, C.c_float, C.c_uint]
+    L.ffhip_batch_paired.argtypes = [vp]
     L.ffhip_batch_read_nblock.restype = C.c_size_t
     L.ffhip_batch_read_nblock.argtypes = [vp, C.c_int]
     L.ffhip_batch_set_signals_ragged.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
@@ -286,6 +288,13 @@ class Batch:
 
     def run(self, temperature: float = 1.0, flags: int = 0):
         _check(lib().ffhip_batch_run(self.h, temperature, flags))
+
+    def run_pair(self, other: "Batch", temperature: float = 1.0, flags: int = 0):
+        """this batch and `other` (same model, same shape) with the recurrent layers of both as one launch per layer"""
+        _check(lib().ffhip_batch_run_pair(self.h, other.h, temperature, flags))
+
+    def paired(self) -> bool:
+        return bool(lib().ffhip_batch_paired(self.h))
 
     def finish(self):
         _check(lib().ffhip_batch_finish(self.h))

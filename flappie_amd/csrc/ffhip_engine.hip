@@ -10,6 +10,9 @@
 #include <vector>
 #include <map>
 #include <string>
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #include "../../include/ffhip.h"
 #include "ffhip_internal.hpp"
@@ -55,8 +58,92 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     return e;
 }
 
+// ---- device buffer pool and copy accounting (ffhip_host.hpp) ------------------------------------------------------
+#undef hipMemcpyAsync
+#undef hipMemcpy
+#undef hipMemcpy2DAsync
+namespace ffhip {
+namespace {
+std::mutex g_pool_mu;
+std::unordered_map<void *, int> g_pool_class;                 // every buffer the pool handed out or holds -> its size class
+std::vector<void *> g_pool_free[48];
+std::atomic<unsigned long long> g_copy[5];
+std::atomic<int> g_matrix_policy{ -1 };
+int size_class(size_t bytes) { int c = 12; while (((size_t)1 << c) < bytes && c < 47) c++; return c; }
+void count_copy(size_t n, hipMemcpyKind kind) {
+    if (kind == hipMemcpyHostToDevice) { g_copy[0]++; g_copy[1] += n; }
+    else if (kind == hipMemcpyDeviceToHost) {
+        g_copy[2]++; g_copy[3] += n;
+        unsigned long long cur = g_copy[4].load();
+        while (n > cur && !g_copy[4].compare_exchange_weak(cur, n)) { }
+    }
+}
+}  // namespace
+void *pool_get(size_t bytes) {
+    const int c = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool_free[c].empty()) { void *p = g_pool_free[c].back(); g_pool_free[c].pop_back(); return p; }
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, (size_t)1 << c) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_class[d] = c;
+    return d;
+}
+void pool_put(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_class.find(p);
+    if (it == g_pool_class.end()) { hipFree(p); return; }      // not ours (never happens): free it the plain way
+    g_pool_free[it->second].push_back(p);
+}
+void pool_trim() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &v : g_pool_free) {
+        for (void *p : v) { g_pool_class.erase(p); hipFree(p); }
+        v.clear();
+    }
+}
+hipError_t counted_memcpy_async(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) { count_copy(n, kind); return ::hipMemcpyAsync(dst, src, n, kind, s); }
+hipError_t counted_memcpy(void *dst, const void *src, size_t n, hipMemcpyKind kind) { count_copy(n, kind); return ::hipMemcpy(dst, src, n, kind); }
+hipError_t counted_memcpy_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s) {
+    count_copy(width * height, kind);
+    return ::hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
+}
+int matrix_policy() {
+    int p = g_matrix_policy.load();
+    if (p < 0) { const char *e = getenv("FLAPPIE_HOST_MATRICES"); p = (e && e[0] && e[0] != '0') ? 0 : 1; g_matrix_policy.store(p); }
+    return p;
+}
+}  // namespace ffhip
+#define hipMemcpyAsync(...) ::ffhip::counted_memcpy_async(__VA_ARGS__)
+#define hipMemcpy(...) ::ffhip::counted_memcpy(__VA_ARGS__)
+#define hipMemcpy2DAsync(...) ::ffhip::counted_memcpy_2d_async(__VA_ARGS__)
+
+extern "C" void ffhip_set_matrix_policy(int device_images) { ffhip::g_matrix_policy.store(device_images ? 1 : 0); }
+extern "C" int ffhip_matrix_policy(void) { return ffhip::matrix_policy(); }
+extern "C" void ffhip_copy_counts(unsigned long long out[5], int reset) {
+    for (int i = 0; i < 5; i++) { if (out) out[i] = ffhip::g_copy[i].load(); if (reset) ffhip::g_copy[i].store(0); }
+}
+extern "C" void ffhip_dev_release(void *dev) { ffhip::pool_put(dev); }
+extern "C" int ffhip_dev_download(const void *dev, float *host, size_t nfloat) {
+    if (!dev || !host) return set_err(FFHIP_EINVAL, "null image");
+    HIP_TRY(hipMemcpy(host, dev, nfloat * sizeof(float), hipMemcpyDeviceToHost), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+extern "C" void *ffhip_dev_upload(const float *host, size_t nfloat) {
+    if (!host || !nfloat) return nullptr;
+    void *d = ffhip::pool_get(nfloat * sizeof(float));
+    if (d && hipMemcpy(d, host, nfloat * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ffhip::pool_put(d); return nullptr; }
+    return d;
+}
+
 extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    ffhip::pool_trim();
     for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
     if (e->prep_stream) hipStreamDestroy(e->prep_stream);
     if (e->prep_pin) hipHostFree(e->prep_pin);
@@ -373,6 +460,10 @@ struct ffhip_batch {
     int have_ev = 0;
     int launches[FFHIP_NGROUP];
     hipEvent_t lev[5][3];
+    hipEvent_t pair_ev = nullptr;       // ffhip_batch_run_pair: orders the two streams around the paired layer launches
+    int run_cur = 0;                    // which of act[] / actS[] holds the current activations between the phases of a run
+    unsigned run_flags = 0;
+    int paired_last = 0;                // the last run's layers were one launch with another batch's
     int profiled = 0;
 };
 
@@ -434,6 +525,7 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->have_ev) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
+        if (b->pair_ev) hipEventDestroy(b->pair_ev);
     }
     delete b;
 }
@@ -509,6 +601,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     for (int l = 0; l < 5; l++)
         for (int i = 0; i < 3; i++)
             if (hipEventCreate(&b->lev[l][i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
+    if (hipEventCreateWithFlags(&b->pair_ev, hipEventDisableTiming) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
     b->have_ev = 1;
 #undef BFAIL
     return b;
@@ -689,19 +782,28 @@ static void mark(ffhip_batch *b, int i) {
     if (b->eng->profiling) hipEventRecord(b->ev[i], b->stream);
 }
 
-extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags) {
+// One run of a batch is enqueued in three phases -- front (convolutions), the recurrent stack, back (head, CRF, decode) -- so that
+// ffhip_batch_run_pair can put the layer launches of TWO batches into one grid between their fronts and backs.
+enum { PH_FRONT = 1, PH_LAYERS = 2, PH_BACK = 4, PH_ALL = 7 };
+static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int phases) {
     if (!b) return set_err(FFHIP_EINVAL, "null batch");
     const ffhip_model *m = b->mdl;
     hipSetDevice(b->eng->device);
     hipStream_t s = b->stream;
     const int Tb = b->Tb, B16 = b->B16, Bp = b->Bp, Hp = m->Hp;
-    if (b->eng->stepwise_batches > 0 && !(flags & FFHIP_RUN_STEPWISE_RNN)) {      // a co-tenant was seen recently (ffhip_batch_finish)
-        flags |= FFHIP_RUN_STEPWISE_RNN;
-        b->eng->stepwise_batches--;
+    if (phases & PH_FRONT) {
+        if (b->eng->stepwise_batches > 0 && !(flags & FFHIP_RUN_STEPWISE_RNN)) {      // a co-tenant was seen recently (ffhip_batch_finish)
+            flags |= FFHIP_RUN_STEPWISE_RNN;
+            b->eng->stepwise_batches--;
+        }
+        b->run_flags = flags;
+        b->last_temperature = temperature;
+        memset(b->launches, 0, sizeof(b->launches));
+    } else {
+        flags = b->run_flags;
+        temperature = b->last_temperature;
     }
-    b->last_temperature = temperature;
     const bool keep = (flags & FFHIP_RUN_KEEP_ACTS) != 0;
-    memset(b->launches, 0, sizeof(b->launches));
     const int *tbs = b->ragged ? b->d_tbs : nullptr, *tbt = b->ragged ? b->d_tbt : nullptr;      // ragged batch: per-read / per-tile block counts
     auto keep_copy = [&](int slot, const float *src) -> int {
         if (!keep) return FFHIP_OK;
@@ -720,13 +822,19 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // on split operands (also what FFHIP_RUN_UNFUSED_RNN selects at H = 256)
     const bool use_split2 = !use_split && use_persist && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
                             rnn_split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
+    // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
+    const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
+    const bool prof = b->eng->profiling != 0;
+    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
+    const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
+    const int persist_mode = pm_env ? atoi(pm_env) : 0;
+    int cur = b->run_cur;
+  if (phases & PH_FRONT) {
     if (use_split || use_split2) {
         const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
         for (int i = 0; i < 2; i++)
             if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
     }
-    // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
-    const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
     mark(b, 0);
     // ---- convolutions (layers.c:189-276, activations :24-49)
     // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
@@ -757,16 +865,15 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     // ---- recurrent stack: B,F,B,F,B (networks.c:556-580 / :459-483)
     // profiling groups 1 (in-projection) and 2 (recurrent) interleave; their events bracket the
     // whole stack and the split is measured with per-layer events when profiling is on.
-    int cur = 0;
-    const bool prof = b->eng->profiling != 0;
+    cur = 0;
     HIP_TRY(hipMemsetAsync(b->pabort, (use_persist && getenv("FFHIP_DEBUG_FORCE_ABORT")) ? 1 : 0, sizeof(unsigned), s), FFHIP_EHIP);      // (debug: pretend a wait timed out)
-    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
-    const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
-    const int persist_mode = pm_env ? atoi(pm_env) : 0;
     if ((use_split || use_split2) && !conv_split) {
         launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH);
         b->launches[0]++;
     }
+    b->run_cur = cur;
+  }      // PH_FRONT
+  if (phases & PH_LAYERS) {
     for (int l = 0; l < 5; l++) {
         const RnnDev &r = m->rnn[l];
         const bool backward = (l % 2 == 0);
@@ -811,11 +918,13 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
                 b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
                 // two such launches (this batch's and another's in flight) run beside each other only if ALL their workgroups fit on the chip together
                 const int ncu_ = b->eng->prop.multiProcessorCount;
-                const bool chain = 2 * split_launch_workgroups(m->cell, Hp, nrt, ncu_) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt, ncu_);
+                // another batch is between run and finish: at H = 384 this batch's launches take the dense form, which fits beside that batch's
+                const int beside = (b->eng->in_flight - (b->counted ? 1 : 0) > 0) ? 1 : 0;
+                const bool chain = 2 * split_launch_workgroups(m->cell, Hp, nrt, ncu_, beside) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt, ncu_, beside);
                 if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
                 if (prof && rt0 == 0) hipEventRecord(b->lev[l][1], s);      // behind the wait: the layer's time is its kernels', not the other batch's
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch))
+                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch, beside))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
                 b->launches[2]++;
@@ -873,6 +982,9 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
         cur ^= 1;
         if (int rc = keep_copy(l + 1, b->act[cur])) return rc;
     }
+    b->run_cur = cur;
+  }      // PH_LAYERS
+  if (!(phases & PH_BACK)) return FFHIP_OK;
     b->profiled = prof;
     b->final_act = cur;
     b->rnn_path = use_split ? 3 : (use_split2 ? 4 : (use_persist ? (use_fused ? 2 : 1) : 0));
@@ -930,6 +1042,71 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
     if (!b->counted) { b->counted = 1; b->eng->in_flight++; }
     return FFHIP_OK;
 }
+
+extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags) {
+    if (b) b->paired_last = 0;
+    return batch_run_impl(b, temperature, flags, PH_ALL);
+}
+
+// Two batches of the same model and shape, their recurrent layers as ONE launch per layer (k_lstm_split_pair: the dense form of the
+// H = 384 layer kernel, two workgroups per CU -- 512 reads in flight as with one 512-read batch).  Everything else of a run is
+// enqueued per batch on its own stream as ffhip_batch_run does; shapes this does not apply to simply run one after the other.
+extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temperature, unsigned flags) {
+    if (!b0 || !b1 || b0 == b1) return set_err(FFHIP_EINVAL, "two distinct batches are needed");
+    const ffhip_model *m = b0->mdl;
+    ffhip_engine *eng = b0->eng;
+    const int ncu = eng->prop.multiProcessorCount;
+    const bool pairable = b1->mdl == m && b1->eng == eng && b0->Tb == b1->Tb && b0->B16 == b1->B16 && b0->B16 <= 2 * (ncu / 32) && (((b0->B16 + 1) / 2) & 7) == 0 &&
+                          !(flags & (FFHIP_RUN_KEEP_ACTS | FFHIP_RUN_STEPWISE_RNN | FFHIP_RUN_F32_RNN | FFHIP_RUN_UNFUSED_RNN)) && eng->stepwise_batches == 0 &&
+                          m->cell == 0 && m->Hp == 384 && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT") &&
+                          !getenv("FFHIP_NO_FUSE") && !getenv("FFHIP_NO_PAIR") && persist_supported(m->cell, m->Hp, ncu);
+    if (!pairable) {
+        if (int rc = ffhip_batch_run(b0, temperature, flags)) return rc;
+        return ffhip_batch_run(b1, temperature, flags);
+    }
+    hipSetDevice(eng->device);
+    if (int rc = batch_run_impl(b0, temperature, flags, PH_FRONT)) return rc;
+    if (int rc = batch_run_impl(b1, temperature, flags, PH_FRONT)) return rc;
+    hipStream_t s = b0->stream;
+    HIP_TRY(hipEventRecord(b1->pair_ev, b1->stream), FFHIP_EHIP);
+    HIP_TRY(hipStreamWaitEvent(s, b1->pair_ev, 0), FFHIP_EHIP);              // the second batch's convolutions are done before the first paired layer
+    const bool prof = eng->profiling != 0;
+    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
+    const char *pm_env = getenv("FFHIP_PERSIST_MODE");
+    const int persist_mode = pm_env ? atoi(pm_env) : 0;
+    ffhip_batch *bb[2] = { b0, b1 };
+    bool paired = true;
+    for (int l = 0; l < 5 && paired; l++) {
+        const RnnDev &r = m->rnn[l];
+        SplitLaunch p[2];
+        for (int k = 0; k < 2; k++) {
+            ffhip_batch *b = bb[k];
+            const int cur = b->run_cur;
+            b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
+            p[k] = SplitLaunch{ r.Wsplit, r.bias, b->actS[cur], b->actS[cur ^ 1], (l == 4) ? b->act[cur ^ 1] : nullptr, b->pflags, b->pabort,
+                                b->Tb, b->B16, 0, b->B16, (l % 2 == 0) ? 1 : 0, persist_mode, r.split_S, fast_gates,
+                                b->ragged ? b->d_tbs : nullptr, b->ragged ? b->d_tbt : nullptr, b->split_epoch };
+            if (prof) { hipEventRecord(b->lev[l][0], s); hipEventRecord(b->lev[l][1], s); }
+        }
+        if (eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, eng->persist_done, 0), FFHIP_EHIP);      // a paired launch fills the chip: after any other layer launch
+        if (!launch_lstm_split_pair(s, m->cell, m->Hp, ncu, p[0], p[1])) { paired = false; break; }
+        HIP_TRY(hipEventRecord(eng->persist_done, s), FFHIP_EHIP);
+        eng->persist_chained = 1;
+        for (int k = 0; k < 2; k++) {
+            if (prof) hipEventRecord(bb[k]->lev[l][2], s);
+            bb[k]->launches[2]++;
+            bb[k]->run_cur ^= 1;
+        }
+    }
+    if (!paired) return set_err(FFHIP_EINVAL, "paired layer launch refused a shape ffhip_batch_run_pair had accepted");
+    HIP_TRY(hipEventRecord(b0->pair_ev, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamWaitEvent(b1->stream, b0->pair_ev, 0), FFHIP_EHIP);     // the second batch's head and decode follow the paired layers
+    b0->paired_last = b1->paired_last = 1;
+    if (int rc = batch_run_impl(b0, temperature, flags, PH_BACK)) return rc;
+    return batch_run_impl(b1, temperature, flags, PH_BACK);
+}
+
+extern "C" int ffhip_batch_paired(const ffhip_batch *b) { return (b && b->paired_last) ? 1 : 0; }
 
 extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     if (!b) return set_err(FFHIP_EINVAL, "null batch");
@@ -1010,6 +1187,19 @@ static int get_scores(ffhip_batch *b, const float *src, int read, float *out) {
     return FFHIP_OK;
 }
 extern "C" int ffhip_batch_get_transitions(ffhip_batch *b, int read, float *out) { return b ? get_scores(b, b->trans, read, out) : FFHIP_EINVAL; }
+extern "C" int ffhip_batch_transitions_to(ffhip_batch *b, int read, ffhip_mat out) {
+    if (!results_ok(b, read) || !out.dev || !out.dev_state) return b ? set_err(FFHIP_EINVAL, "bad arguments") : FFHIP_EINVAL;
+    const ffhip_model *m = b->mdl;
+    const size_t nb = b->hTb[read];
+    if (out.nr != (size_t)m->P || out.nc != nb || out.stride != (size_t)m->Ps) return set_err(FFHIP_EINVAL, "transition matrix must be %d x %zu", m->P, nb);
+    hipSetDevice(b->eng->device);
+    if (!*out.dev && !(*out.dev = pool_get(nb * m->Ps * 4))) return set_err(FFHIP_ENOMEM, "device allocation failed");
+    // the batch holds read r's scores as [block][Ps]: the matrix image itself
+    HIP_TRY(hipMemcpyAsync(*out.dev, b->trans + (size_t)read * b->Tb * m->Ps, nb * m->Ps * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    *out.dev_state = 2;
+    return FFHIP_OK;
+}
 extern "C" int ffhip_batch_get_posterior(ffhip_batch *b, int read, float *out) {
     if (b && (b->last_flags & (FFHIP_RUN_VITERBI_ONLY | FFHIP_RUN_NO_DECODE))) return set_err(FFHIP_EINVAL, "posterior was not computed in this run");
     return b ? get_scores(b, b->post, read, out) : FFHIP_EINVAL;
@@ -1101,40 +1291,43 @@ extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP],
 
 // ------------------------------------------------------------------------------------ single-matrix decode
 
-extern "C" int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nblock, size_t nparam, size_t stride,
-                               int return_log, float *post_out) {
+extern "C" int ffhip_op_transpost(ffhip_engine *eng, ffhip_mat trans, int return_log, ffhip_mat post) {
     int nbase;
-    if (!eng || !trans || !post_out || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad transpost arguments");
+    const size_t nblock = trans.nc, nparam = trans.nr, stride = trans.stride;
+    if (!eng || !trans.data || !post.data || nblock == 0 || !flipflop_dims(nparam, stride, &nbase) || post.nr != nparam || post.nc != nblock || post.stride != stride)
+        return set_err(FFHIP_EINVAL, "bad transpost arguments");
     hipSetDevice(eng->device);
     hipStream_t s = eng->streams[0];
     TmpDev t;
     const size_t n = nblock * stride;
-    float *d_tr = (float *)t.get(n * 4), *d_po = (float *)t.get(n * 4), *d_fw = (float *)t.get(2 * (nblock + 1) * kMaxState * 4);
+    const bool lazy = mat_has_dev(trans);                  // the scores live on the device: so does the posterior
+    float *d_tr = mat_in(t, trans, s), *d_po = mat_out(t, post, lazy), *d_fw = (float *)t.get(2 * (nblock + 1) * kMaxState * 4);
     if (!d_tr || !d_po || !d_fw) return set_err(FFHIP_ENOMEM, "device allocation failed");
-    HIP_TRY(hipMemcpyAsync(d_tr, trans, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(d_po, 0, n * 4, s), FFHIP_EHIP);
     launch_transpost(s, d_tr, d_po, d_fw, 1, (int)nblock, nbase, (int)stride);
-    if (!return_log) launch_exp_inplace(s, d_po, n);
-    HIP_TRY(hipMemcpyAsync(post_out, d_po, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    if (!return_log) launch_exp_inplace(s, d_po, n);        // (the reference's exp touches pad lanes too: exp(0) = 1, as this one does)
+    HIP_TRY(mat_done(post, d_po, lazy, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
-    if (!return_log && stride != nparam)      // the reference's exp touches pad lanes too: exp(0) = 1
-        for (size_t c = 0; c < nblock; c++) for (size_t r = nparam; r < stride; r++) post_out[c * stride + r] = 1.0f;
     return FFHIP_OK;
 }
+extern "C" int ffhip_transpost(ffhip_engine *eng, const float *trans, size_t nblock, size_t nparam, size_t stride,
+                               int return_log, float *post_out) {
+    if (!trans || !post_out) return set_err(FFHIP_EINVAL, "bad transpost arguments");
+    const ffhip_mat tv = { (float *)trans, nparam, nblock, stride, nullptr, nullptr }, pv = { post_out, nparam, nblock, stride, nullptr, nullptr };
+    return ffhip_op_transpost(eng, tv, return_log, pv);
+}
 
-extern "C" int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblock, size_t nparam, size_t stride,
-                             int combine_stays, int *path, float *qpath, float *score) {
+extern "C" int ffhip_op_viterbi(ffhip_engine *eng, ffhip_mat scores, int combine_stays, int *path, float *qpath, float *score) {
     int nbase;
-    if (!eng || !scores || !path || !qpath || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad viterbi arguments");
+    const size_t nblock = scores.nc, nparam = scores.nr, stride = scores.stride;
+    if (!eng || !scores.data || !path || !qpath || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad viterbi arguments");
     hipSetDevice(eng->device);
     hipStream_t s = eng->streams[0];
     TmpDev t;
-    const size_t n = nblock * stride;
-    float *d_sc = (float *)t.get(n * 4), *d_q = (float *)t.get((nblock + 1) * 4), *d_s = (float *)t.get(4);
+    float *d_sc = mat_in(t, scores, s), *d_q = (float *)t.get((nblock + 1) * 4), *d_s = (float *)t.get(4);
     uint8_t *d_tb = (uint8_t *)t.get(nblock * kMaxState);
     int *d_p = (int *)t.get((nblock + 1) * 4);
     if (!d_sc || !d_q || !d_s || !d_tb || !d_p) return set_err(FFHIP_ENOMEM, "device allocation failed");
-    HIP_TRY(hipMemcpyAsync(d_sc, scores, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
     launch_viterbi(s, d_sc, d_tb, d_p, d_q, d_s, 1, (int)nblock, nbase, (int)stride);
     HIP_TRY(hipMemcpyAsync(path, d_p, (nblock + 1) * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
     HIP_TRY(hipMemcpyAsync(qpath, d_q, (nblock + 1) * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
@@ -1146,20 +1339,31 @@ extern "C" int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblo
         for (size_t b = 0; b <= nblock; b++) path[b] = (path[b] < nbase) ? path[b] : -1;
     return FFHIP_OK;
 }
+extern "C" int ffhip_viterbi(ffhip_engine *eng, const float *scores, size_t nblock, size_t nparam, size_t stride,
+                             int combine_stays, int *path, float *qpath, float *score) {
+    if (!scores) return set_err(FFHIP_EINVAL, "bad viterbi arguments");
+    const ffhip_mat v = { (float *)scores, nparam, nblock, stride, nullptr, nullptr };
+    return ffhip_op_viterbi(eng, v, combine_stays, path, qpath, score);
+}
 
-extern "C" int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t nparam, size_t stride, int32_t *out) {
+extern "C" int ffhip_op_trace(ffhip_engine *eng, ffhip_mat post, int32_t *out) {
     int nbase;
-    if (!eng || !post || !out || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad trace arguments");
+    const size_t nblock = post.nc, nparam = post.nr, stride = post.stride;
+    if (!eng || !post.data || !out || nblock == 0 || !flipflop_dims(nparam, stride, &nbase)) return set_err(FFHIP_EINVAL, "bad trace arguments");
     hipSetDevice(eng->device);
     hipStream_t s = eng->streams[0];
     TmpDev t;
-    const size_t n = nblock * stride, nt = (nblock + 1) * 2 * nbase;
-    float *d_po = (float *)t.get(n * 4);
+    const size_t nt = (nblock + 1) * 2 * nbase;
+    float *d_po = mat_in(t, post, s);
     int32_t *d_tr = (int32_t *)t.get(nt * 4);
     if (!d_po || !d_tr) return set_err(FFHIP_ENOMEM, "device allocation failed");
-    HIP_TRY(hipMemcpyAsync(d_po, post, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
     launch_trace(s, d_po, d_tr, 1, (int)nblock, nbase, (int)stride, 0);
     HIP_TRY(hipMemcpyAsync(out, d_tr, nt * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
+}
+extern "C" int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t nparam, size_t stride, int32_t *out) {
+    if (!post) return set_err(FFHIP_EINVAL, "bad trace arguments");
+    const ffhip_mat v = { (float *)post, nparam, nblock, stride, nullptr, nullptr };
+    return ffhip_op_trace(eng, v, out);
 }

@@ -72,14 +72,28 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // strided-convolution column plan (layers.c:216-271 restated in index space); returns Tout, <0 on failure
 int build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<int> &bq);
 
+// Process-wide pool of device buffers (power-of-two size classes from 4 KiB): the device images that flappie matrices own and
+// the scratch of the single-matrix calls.  hipMalloc / hipFree per call cost more than the kernels of a one-read call, and hipFree
+// synchronises the device.  A buffer goes back only when no enqueued work uses it (the single-matrix calls are synchronous).
+void *pool_get(size_t bytes);
+void pool_put(void *p);
+void pool_trim();                     // hipFree every unused buffer (engine destruction)
+
+// every host<->device copy of the library goes through these: ffhip_copy_counts (include/ffhip.h)
+hipError_t counted_memcpy_async(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s);
+hipError_t counted_memcpy(void *dst, const void *src, size_t n, hipMemcpyKind kind);
+hipError_t counted_memcpy_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s);
+#define hipMemcpyAsync(...) ::ffhip::counted_memcpy_async(__VA_ARGS__)
+#define hipMemcpy(...) ::ffhip::counted_memcpy(__VA_ARGS__)
+#define hipMemcpy2DAsync(...) ::ffhip::counted_memcpy_2d_async(__VA_ARGS__)
+
 // scratch device allocations of one single-matrix call
 struct TmpDev {
     std::vector<void *> p;
-    ~TmpDev() { for (void *q : p) hipFree(q); }
+    ~TmpDev() { for (void *q : p) pool_put(q); }
     void *get(size_t bytes) {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return nullptr;
-        p.push_back(d);
+        void *d = pool_get(bytes ? bytes : 4);
+        if (d) p.push_back(d);
         return d;
     }
     void *upload(const void *host, size_t bytes, hipStream_t s) {
@@ -88,6 +102,30 @@ struct TmpDev {
         return d;
     }
 };
+
+// ---- device images of flappie matrices (include/ffhip.h, "flappie matrices with a device image")
+int matrix_policy();
+static inline bool mat_has_dev(const ffhip_mat &m) { return m.dev && m.dev_state && *m.dev && *m.dev_state >= 1 && matrix_policy() != 0; }
+// the image an operator READS: the matrix's device image when it has one, an uploaded copy of the host image otherwise
+static inline float *mat_in(TmpDev &t, const ffhip_mat &m, hipStream_t s) {
+    if (mat_has_dev(m)) return (float *)*m.dev;
+    return (float *)t.upload(m.data, m.nc * m.stride * sizeof(float), s);
+}
+// the image an operator WRITES: `lazy` (the result stays on the device, the matrix owns the buffer) or scratch to be downloaded
+static inline float *mat_out(TmpDev &t, const ffhip_mat &m, bool lazy) {
+    const size_t bytes = m.nc * m.stride * sizeof(float);
+    if (lazy && m.dev && m.dev_state) {
+        if (!*m.dev) *m.dev = pool_get(bytes);
+        return (float *)*m.dev;
+    }
+    return (float *)t.get(bytes);
+}
+// after the kernels that wrote `d` were enqueued on s: mark the device image current (lazy) or download it
+static inline hipError_t mat_done(const ffhip_mat &m, float *d, bool lazy, hipStream_t s) {
+    if (lazy && m.dev && m.dev_state && d == (float *)*m.dev) { *m.dev_state = 2; return hipSuccess; }
+    if (m.dev && m.dev_state && *m.dev && d != (float *)*m.dev) { pool_put(*m.dev); *m.dev = nullptr; *m.dev_state = 0; }      // a reused output: its old device image is stale
+    return hipMemcpyAsync(m.data, d, m.nc * m.stride * sizeof(float), hipMemcpyDeviceToHost, s);
+}
 
 static inline bool flipflop_dims(size_t nparam, size_t stride, int *nbase) {
     const int nb = (int)roundf((-1.0f + sqrtf(1.0f + 2.0f * (float)nparam)) / 2.0f);

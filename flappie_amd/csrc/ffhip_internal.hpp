@@ -91,14 +91,19 @@ int persist_blocks_per_cu(int kind, int H);
 // the f32 MFMA rate.  Activations in the SPLIT layout A[t][rt][k/32][slice 0..2][lane][8 bf16] (6 bytes per value).
 void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow);
 bool split_supported(int kind, int H);
-int split_launch_workgroups(int kind, int H, int nrt, int ncu);      // workgroups of one launch of nrt read tiles ...
-int split_workgroups_per_cu(int kind, int H, int nrt, int ncu);      // ... and how many of them share a CU
+int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside);      // workgroups of one launch of nrt read tiles ...
+int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside);      // ... and how many of them share a CU
 int split_max_tiles(int ncu, int H = 512);                // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU (two at H <= 256)
 size_t split_flag_words(int nrt);
 inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 * kSplitNS; }      // 16 reads x H x 2 B x slices
+struct SplitLaunch {          // one batch's share of a paired layer launch
+    const void *Wp; const float *bias; const void *xin; void *hout; float *hout_f32; unsigned *flags, *abort_word;
+    int Tb, B16, rt0, nrt, backward, mode, scale_exp, fast_gates; const int *tbs, *tbt; unsigned epoch;
+};
+bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const SplitLaunch &p0, const SplitLaunch &p1);
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch);      // scale_exp: the exponent S both products carry
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside);      // scale_exp: the exponent S both products carry
 // recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
 bool rnn_split_supported(int kind, int H);
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,

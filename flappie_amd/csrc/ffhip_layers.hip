@@ -171,7 +171,7 @@ inline unsigned nblk(size_t n, int per = 256) { return (unsigned)((n + per - 1) 
 bool view_ok(const ffhip_mat &m) { return m.data && m.nr > 0 && m.nc > 0 && m.stride >= m.nr; }
 
 // image of a whole matrix, device side
-float *upload_img(TmpDev &t, const ffhip_mat &m, hipStream_t s) { return (float *)t.upload(m.data, m.nc * m.stride * sizeof(float), s); }
+float *upload_img(TmpDev &t, const ffhip_mat &m, hipStream_t s) { return mat_in(t, m, s); }      // the matrix's device image if it has one, else an upload
 
 // A-fragment weights of W^T for `W` an [K x M] flappie matrix (column m holds output row m)
 std::vector<float> pack_weight_T(const ffhip_mat &W, int Mt, int K16) {
@@ -202,37 +202,40 @@ std::vector<float> pack_recurrent(const ffhip_mat &sW, int H, int G, int Hp) {
 // ------------------------------------------------------------------------------------ element-wise ops
 extern "C" int ffhip_op_activation(ffhip_engine *eng, ffhip_mat C, int act, float p0, float p1) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(C);      // in place on the device image when there is one
     if (!view_ok(C) || act < FFHIP_ACT_NONE || act > FFHIP_ACT_SHIFT_SCALE) return set_err(FFHIP_EINVAL, "bad activation arguments");
     const size_t n = C.nc * C.stride;
     float *d = upload_img(tmp, C, s);
     if (!d) OP_NOMEM();
     hipLaunchKernelGGL(k_activation, dim3(nblk(n)), dim3(256), 0, s, d, n, act, p0, p1, C.nr, C.stride);
-    HIP_TRY(hipMemcpyAsync(C.data, d, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }
 
 extern "C" int ffhip_op_add_inplace(ffhip_engine *eng, ffhip_mat Y, ffhip_mat X) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(Y);
     if (!view_ok(Y) || !view_ok(X) || X.nr != Y.nr || X.nc != Y.nc || X.stride != Y.stride) return set_err(FFHIP_EINVAL, "residual: shapes differ");
     const size_t n = Y.nc * Y.stride;
     float *dy = upload_img(tmp, Y, s), *dx = upload_img(tmp, X, s);
     if (!dy || !dx) OP_NOMEM();
     hipLaunchKernelGGL(k_add_inplace, dim3(nblk(n)), dim3(256), 0, s, dy, dx, n);
-    HIP_TRY(hipMemcpyAsync(Y.data, dy, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(Y, dy, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }
 
 extern "C" int ffhip_op_row_normalise(ffhip_engine *eng, ffhip_mat C, int log_space) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(C);      // in place on the device image when there is one
     if (!view_ok(C) || C.stride % 4 != 0) return set_err(FFHIP_EINVAL, "bad row-normalise arguments");
     const size_t n = C.nc * C.stride;
     float *d = upload_img(tmp, C, s);
     if (!d) OP_NOMEM();
     if (log_space) hipLaunchKernelGGL(k_log_row_normalise, dim3(nblk(C.nc, 64)), dim3(64), 0, s, d, (int)C.nr, C.stride, (int)C.nc);
     else hipLaunchKernelGGL(k_row_normalise, dim3(nblk(C.nc, 64)), dim3(64), 0, s, d, (int)C.nr, (int)(C.stride / 4), (int)C.nc);
-    HIP_TRY(hipMemcpyAsync(C.data, d, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }
@@ -242,6 +245,7 @@ extern "C" int ffhip_op_row_normalise(ffhip_engine *eng, ffhip_mat C, int log_sp
 // kernel, wide ones the MFMA implicit-GEMM kernel, as in the batched pipeline.
 extern "C" int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, size_t conv_stride, ffhip_mat C) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(X);      // the inputs live on the device: so does the result
     if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C) || conv_stride < 1) return set_err(FFHIP_EINVAL, "bad convolution arguments");
     const int Fin = (int)X.nr, nf_pad = round_up(Fin, 4), Fout = (int)W.nc, T = (int)X.nc, cs = (int)conv_stride;
     const int wrows = round_up((int)W.nr, 4);
@@ -262,7 +266,7 @@ extern "C" int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W,
     float *d_x = upload_img(tmp, X, s);
     float *d_in = (float *)tmp.get(in_rows * Fin * 4);
     int *d_pa = (int *)tmp.upload(pa.data(), pa.size() * 4, s), *d_pb = (int *)tmp.upload(pb.data(), pb.size() * 4, s);
-    float *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    float *d_c = mat_out(tmp, C, lazy_);
     if (!d_x || !d_in || !d_pa || !d_pb || !d_c) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_in, 0, in_rows * Fin * 4, s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
@@ -298,7 +302,7 @@ extern "C" int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W,
         launch_conv_mfma(s, in, d_out, (const float4 *)d_w, d_b, d_pa, d_pb, 1, Tout, Mpad, K16, ACT_NONE);
         hipLaunchKernelGGL(k_tiles_to_img, dim3(nblk((size_t)Tout * Fout)), dim3(256), 0, s, d_out, Mpad, Fout, Tout, d_c, C.stride);
     }
-    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d_c, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     return FFHIP_OK;
@@ -308,6 +312,7 @@ extern "C" int ffhip_op_convolution(ffhip_engine *eng, ffhip_mat X, ffhip_mat W,
 // affine_map / affine_map2 (flappie_matrix.c:361-419): C = Wf^T Xf (+ Wb^T Xb) + b.  Xb/Wb may be empty.
 extern "C" int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ffhip_mat Xb, ffhip_mat Wb, ffhip_mat b, ffhip_mat C) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(Xf) && (Xb.data == nullptr || mat_has_dev(Xb));      // the inputs live on the device: so does the result
     const bool two = Xb.data != nullptr;
     if (!view_ok(Xf) || !view_ok(Wf) || !view_ok(b) || !view_ok(C) || (two && (!view_ok(Xb) || !view_ok(Wb))))
         return set_err(FFHIP_EINVAL, "bad affine arguments");
@@ -326,7 +331,7 @@ extern "C" int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ff
     float *d_xf = upload_img(tmp, Xf, s), *d_xb = two ? upload_img(tmp, Xb, s) : nullptr;
     float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
     float *d_in = (float *)tmp.get((size_t)ntile * K16 * 256 * 4), *d_xa = (float *)tmp.get((size_t)ntile * Mt * 256 * 4);
-    float *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    float *d_c = mat_out(tmp, C, lazy_);
     if (!d_xf || (two && !d_xb) || !d_w || !d_b || !d_in || !d_xa || !d_c) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)ntile * K16f * 64)), dim3(256), 0, s, d_xf, Xf.stride, (int)Xf.nr, nc, K16f, K16, 0, 0, ntile, d_in);
@@ -334,7 +339,7 @@ extern "C" int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ff
         hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)ntile * K16b * 64)), dim3(256), 0, s, d_xb, Xb.stride, (int)Xb.nr, nc, K16b, K16, 4 * K16f, 0, ntile, d_in);
     launch_inproj(s, d_in, d_xa, (const float4 *)d_w, d_b, ntile, Mpad, K16);
     hipLaunchKernelGGL(k_dfrag_to_img, dim3(nblk((size_t)ntile * Mt * 64)), dim3(256), 0, s, d_xa, Mt, M, nc, ntile, d_c, C.stride);
-    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d_c, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     return FFHIP_OK;
@@ -346,6 +351,7 @@ extern "C" int ffhip_op_affine(ffhip_engine *eng, ffhip_mat Xf, ffhip_mat Wf, ff
 // runs the layer when it supports the shape, the launch-per-step kernels otherwise.
 extern "C" int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffhip_mat sW, int backward, ffhip_mat out) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(Xa);      // the inputs live on the device: so does the result
     if (kind != FFHIP_NET_LSTM5 && kind != FFHIP_NET_GRUMOD5) return set_err(FFHIP_EINVAL, "unknown recurrent kind %d", kind);
     if (!view_ok(Xa) || !view_ok(sW) || !view_ok(out)) return set_err(FFHIP_EINVAL, "bad recurrent-layer arguments");
     const int G = (kind == FFHIP_NET_LSTM5) ? 4 : 3, H = (int)sW.nr, T = (int)Xa.nc;
@@ -356,7 +362,7 @@ extern "C" int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffh
     float *d_x = upload_img(tmp, Xa, s);
     float *d_w = (float *)tmp.upload(sp.data(), sp.size() * 4, s);
     float *d_xa = (float *)tmp.get((size_t)T * Ut * 256 * 4), *d_h = (float *)tmp.get((size_t)T * Hp * 16 * 4);
-    float *d_o = (float *)tmp.get(out.nc * out.stride * 4);
+    float *d_o = mat_out(tmp, out, lazy_);
     if (!d_x || !d_w || !d_xa || !d_h || !d_o) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_o, 0, out.nc * out.stride * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_gates_to_dfrag, dim3(nblk((size_t)T * Ut * 64)), dim3(256), 0, s, d_x, Xa.stride, H, G, Ut, T, d_xa);
@@ -385,7 +391,7 @@ extern "C" int ffhip_op_recurrent(ffhip_engine *eng, int kind, ffhip_mat Xa, ffh
         }
     }
     hipLaunchKernelGGL(k_tiles_to_img, dim3(nblk((size_t)T * H)), dim3(256), 0, s, d_h, Hp, H, T, d_o, out.stride);
-    HIP_TRY(hipMemcpyAsync(out.data, d_o, out.nc * out.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(out, d_o, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     if (h_abort) return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
@@ -467,6 +473,7 @@ extern "C" int ffhip_op_partition_function_scaled(ffhip_engine *eng, ffhip_mat S
 // globalnorm_flipflop (layers.c:1082-1106): C = tanh(W^T X + b) / (temperature/5) - logZ/nblock
 extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(X);      // the inputs live on the device: so does the result
     int nbase;
     if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C)) return set_err(FFHIP_EINVAL, "bad globalnorm arguments");
     if (W.nr != X.nr || b.nr != W.nc || C.nr != W.nc || C.nc != X.nc) return set_err(FFHIP_EINVAL, "globalnorm: shapes do not agree");
@@ -477,7 +484,7 @@ extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhi
     for (int p = 0; p < P; p++) bias[p] = b.data[p];
     float *d_x = upload_img(tmp, X, s);
     float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
-    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = mat_out(tmp, C, lazy_);
     if (!d_x || !d_w || !d_b || !d_in || !d_c) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
@@ -485,7 +492,7 @@ extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhi
     double *d_z = (double *)tmp.get(sizeof(double));
     if (!d_z) OP_NOMEM();
     launch_crf_norm(s, d_c, 1, T, nbase, (int)C.stride, d_z);
-    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d_c, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     return FFHIP_OK;
@@ -495,6 +502,7 @@ extern "C" int ffhip_op_globalnorm_flipflop(ffhip_engine *eng, ffhip_mat X, ffhi
 // globalnorm_runlengthV2 (layers.c:1325-1358)
 extern "C" int ffhip_op_globalnorm_runlength(ffhip_engine *eng, ffhip_mat X, ffhip_mat W, ffhip_mat b, float temperature, ffhip_mat C) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(X);      // the inputs live on the device: so does the result
     int nbase;
     if (!view_ok(X) || !view_ok(W) || !view_ok(b) || !view_ok(C)) return set_err(FFHIP_EINVAL, "bad globalnorm arguments");
     if (W.nr != X.nr || b.nr != W.nc || C.nr != W.nc || C.nc != X.nc) return set_err(FFHIP_EINVAL, "globalnorm: shapes do not agree");
@@ -505,14 +513,14 @@ extern "C" int ffhip_op_globalnorm_runlength(ffhip_engine *eng, ffhip_mat X, ffh
     for (int p = 0; p < P; p++) bias[p] = b.data[p];
     float *d_x = upload_img(tmp, X, s);
     float *d_w = (float *)tmp.upload(wp.data(), wp.size() * 4, s), *d_b = (float *)tmp.upload(bias.data(), bias.size() * 4, s);
-    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = (float *)tmp.get(C.nc * C.stride * 4);
+    float *d_in = (float *)tmp.get((size_t)T * K16 * 256 * 4), *d_c = mat_out(tmp, C, lazy_);
     double *d_z = (double *)tmp.get(sizeof(double));
     if (!d_x || !d_w || !d_b || !d_in || !d_c || !d_z) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_c, 0, C.nc * C.stride * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_img_to_tiles, dim3(nblk((size_t)T * K16 * 64)), dim3(256), 0, s, d_x, X.stride, H, T, K16, K16, 0, 1, T, d_in);
     launch_head(s, d_in, d_c, (const float4 *)d_w, d_b, T, 1, 1, P, (int)C.stride, K16, 1.0f, 1);
     launch_rle_head_finish(s, d_c, d_z, 1, T, nbase, (int)C.stride, temperature);
-    HIP_TRY(hipMemcpyAsync(C.data, d_c, C.nc * C.stride * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(C, d_c, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     return FFHIP_OK;
@@ -896,15 +904,16 @@ extern "C" int ffhip_op_constrained_flipflop(ffhip_engine *eng, ffhip_mat post, 
 // posterior_crf_flipflop (decode.c:275-372), log space: out is [nstate x nblk + 1] (column stride out.stride)
 extern "C" int ffhip_op_posterior_flipflop(ffhip_engine *eng, ffhip_mat trans, ffhip_mat out) {
     OP_ENTER(eng);
+    const bool lazy_ = mat_has_dev(trans);
     int nbase;
     if (!view_ok(trans) || !view_ok(out) || !flipflop_dims(trans.nr, trans.stride, &nbase) || out.nr != (size_t)(2 * nbase) || out.nc != trans.nc + 1)
         return set_err(FFHIP_EINVAL, "bad posterior_crf_flipflop arguments");
     const size_t n = out.nc * out.stride;
-    float *d = upload_img(tmp, trans, s), *d_o = (float *)tmp.get(n * 4);
+    float *d = upload_img(tmp, trans, s), *d_o = mat_out(tmp, out, lazy_);
     if (!d || !d_o) OP_NOMEM();
     HIP_TRY(hipMemsetAsync(d_o, 0, n * 4, s), FFHIP_EHIP);
     hipLaunchKernelGGL(k_posterior_flipflop, dim3(1), dim3(64), 0, s, d, trans.stride, nbase, (int)trans.nc, d_o, out.stride);
-    HIP_TRY(hipMemcpyAsync(out.data, d_o, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(mat_done(out, d_o, lazy_, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
     return FFHIP_OK;
 }

@@ -52,6 +52,9 @@
 #include "ffhip_split.hpp"
 #include <stdlib.h>
 
+#ifndef FFHIP_EXP
+#define FFHIP_EXP 0               // development builds only (tools/dev/build_variants.sh): timing experiments on the hand-off, bit by bit
+#endif
 #ifndef FFHIP_SPLIT_ABLATE
 #define FFHIP_SPLIT_ABLATE 0      // development builds only (tools/dev/ablate.py): leave parts of the step out to time the rest
 #endif
@@ -76,10 +79,15 @@ struct SplitArgs {
     unsigned *abort_word;
     int Tb, B16, H, rt0, nrt, backward, mode;
     float acc_scale;          // 2^S: the exponent both products of this layer carry (ffhip_split.hpp); the bias is added in that space
+    int scale_exp;            // S
     int fast_gates;           // FFHIP_RUN_FAST_GATES: hardware exp / reciprocal in the gate phase (ffhip_math.hpp logistic_hw)
     int split_gate;           // LSTM, N = 3, pairs: gate tiles 4 and 5 are each worked by TWO x waves on different SIMDs (front / back)
     const int *tbs, *tbt;     // ragged batch (see PersistArgs)
     unsigned long long *dbg;
+};
+
+struct SplitArgsOther {       // what the second batch of a paired launch brings of its own (k_lstm_split_pair)
+    const unsigned char *xin; unsigned char *hout; float *hout_f32; unsigned *flags, *abort_word; const int *tbs, *tbt; unsigned epoch; int nwg0;
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -171,9 +179,8 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 // LDS (as in the one-tile form at N = 3) one tile after the other through ONE set of accumulators, the recurrent partials are
 // written over the landing zone they came from, the projection partials are single-buffered behind a per-(K quarter, tile)
 // "consumed" flag, and the x waves load x(t+1) just in time (it is L2-warm) instead of a step ahead across the gate phase.
-template <int KIND, int N, int TS, bool DN = false>
-__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
-k_lstm_split(SplitArgs a) {
+template <int KIND, int N, int TS, bool DN>
+__device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int block_index) {
     static_assert(!DN || TS == 2, "the dense form is a pair form");
     __shared__ v4f px[DN ? 1 : 2][4][TS][N][64];     // projection partials, double-buffered (DN: single): [step parity][K quarter][tile of the group][unit tile][lane]
     __shared__ v4f ph_[DN ? 1 : 4][DN ? 1 : TS][DN ? 1 : N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial (DN: in the landing zone)
@@ -203,7 +210,7 @@ k_lstm_split(SplitArgs a) {
     const int ngroup = (a.nrt + TS - 1) / TS;
     int g, m;
     {
-        const int b = blockIdx.x;
+        const int b = block_index;
         if ((ngroup & 7) == 0) { const int xcd = b & 7, j = b >> 3; g = xcd + 8 * (j / G); m = j % G; }
         else { g = b / G; m = b % G; }
     }
@@ -323,8 +330,10 @@ k_lstm_split(SplitArgs a) {
 
     // ---- gate math of one 16 x 16 tile (4 units x 4 gates x 16 reads; layers.c:1005-1025) and the store of its h(t), already
     // split.  ph holds the gate pre-activations Wi x + sW h by K quarter.
-    // (a scalar, and told so: a VALU quotient would be kept -- splatted for the packed multiplies -- in two vector registers per use)
-    const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / a.acc_scale)));
+    // out of the accumulators' scaled space: x * 2^-S as v_ldexp_f32 with a SCALAR exponent (exact either way; a multiplication by
+    // the float 2^-S gets packed, and the packed form keeps the factor splatted in a vector register pair for the whole layer)
+    const int neg_exp = -a.scale_exp;
+    auto unscale4 = [&](v4f v) -> v4f { return (v4f){ __builtin_ldexpf(v.x, neg_exp), __builtin_ldexpf(v.y, neg_exp), __builtin_ldexpf(v.z, neg_exp), __builtin_ldexpf(v.w, neg_exp) }; };
     // h(t) of one tile -> the split layout (and the hand-off): Split h ONCE, in the lane that owns it, and transpose through a
     // wave-private LDS patch: lane (unit q, read rl) writes its slices to [slice][read][unit]; quarter-wave q then reads the
     // 8 bytes [slice q][read rl][units 0..3] -- the packed operand piece it stores.  (Four ds_bpermute + a 4-value split in
@@ -381,7 +390,7 @@ k_lstm_split(SplitArgs a) {
             v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
-            s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
+            s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
             if (a.fast_gates) {
                 const float z = logistic_hw(s.x + b.x), r = logistic_hw(s.y + b.y);
@@ -398,7 +407,7 @@ k_lstm_split(SplitArgs a) {
             v4f s = sbias[gj][q];
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
-            s = s * inv_scale;                               // out of the scaled space (a power of two: exact)
+            s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
             if (a.fast_gates) {
                 const float forget = logistic_hw(s.y) * c;
@@ -422,7 +431,7 @@ k_lstm_split(SplitArgs a) {
         v4f s = sbias[gj][q];
 #pragma unroll
         for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
-        s = s * inv_scale;
+        s = unscale4(s);
         float forget, update;
         if (a.fast_gates) {
             forget = logistic_hw(s.y) * c;
@@ -442,7 +451,7 @@ k_lstm_split(SplitArgs a) {
         float so = sbias[gj][q].w;
 #pragma unroll
         for (int w2 = 0; w2 < 4; w2++) so = so + ph_at(w2, gts, gj)[lane].w;
-        so = so * inv_scale;
+        so = __builtin_ldexpf(so, neg_exp);
         const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
         while (*(volatile int *)&cxflag[wave & 1] != i + 1) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
@@ -472,16 +481,27 @@ k_lstm_split(SplitArgs a) {
                 if (cc + 1 < N) __builtin_amdgcn_s_sleep(1);
             }
         };
-        auto project_tile = [&](int ts, int want) {          // xb -> px[0][kw][ts]; want = the step (+1) whose partial must have been consumed (0: none)
-            v4f acc[N];
+        // Both tiles' partials are computed BEFORE the wait for the h wave's "consumed" flags -- those are raised at the end of its
+        // recurrent pass, and a projection of the second tile started only then would stand between the h waves and the barrier.
+        auto project_step = [&](int i, int want) {           // x(step i) of both tiles -> px[0][kw][*]; want = the step (+1) whose partials must have been consumed (0: none)
+            v4f acc[TS][N];
 #pragma unroll
-            for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            for (int ts = 0; ts < TS; ts++) {
+                if (ts >= ntl) continue;
+                load_x_tile(i, ts);
 #pragma unroll
-            for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[cc], acc);
-            if (want > 0)
-                for (unsigned spin = 0; *(volatile int *)&pxc[kw][ts] != want && 0 == *(volatile int *)&lds_abort && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
+                for (int j = 0; j < N; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-            for (int j = 0; j < N; j++) px[0][kw][ts][j][lane] = acc[j];
+                for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[cc], acc[ts]);
+            }
+#pragma unroll
+            for (int ts = 0; ts < TS; ts++) {
+                if (ts >= ntl) continue;
+                if (want > 0)
+                    for (unsigned spin = 0; *(volatile int *)&pxc[kw][ts] != want && 0 == *(volatile int *)&lds_abort && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int j = 0; j < N; j++) px[0][kw][ts][j][lane] = acc[ts][j];
+            }
         };
         constexpr int WARM = 3;
         constexpr int LPM = (Hc * NS * 8 * TS + 31) / 32;    // 128-byte lines of the group's x(step) per member
@@ -493,14 +513,13 @@ k_lstm_split(SplitArgs a) {
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
-        for (int ts = 0; ts < ntl; ts++) { load_x_tile(0, ts); project_tile(ts, 0); }
+        project_step(0, 0);
         touch_x(1);
         sink ^= touched;
         touch_x(2);
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
-            if (i + 1 < Tb)
-                for (int ts = 0; ts < ntl; ts++) { load_x_tile(i + 1, ts); project_tile(ts, i + 1); }
+            if (i + 1 < Tb) project_step(i + 1, i + 1);
             sink ^= touched;
             touch_x(i + WARM);
             raw_barrier();
@@ -531,7 +550,7 @@ k_lstm_split(SplitArgs a) {
                 for (int cc = 0; cc < N; cc++) {
 #pragma unroll
                     for (int s = 0; s < NS; s++) xb[ts][cc][s] = p[(chunk[cc] * NS + s) * 64];
-                    __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
+                    if (!(FFHIP_EXP & 4)) __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
                                                        // occupying it with an 18 KiB burst per wave
                 }
             }
@@ -633,7 +652,7 @@ k_lstm_split(SplitArgs a) {
                     const bool act = pts < ntl;
                     const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * NS * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
 #if !(FFHIP_SPLIT_ABLATE & 2)          // 2 = no hand-off wait at all (timing of the compute pipeline alone)
-                    for (unsigned spin = 0;; spin++) {
+                    for (unsigned spin = 0; !((FFHIP_EXP & 1) && HL); spin++) {      // EXP 1: no light poll in the LDS-landing forms: the sweep itself is the poll
                         const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
                         if (__all(v != kSplitSentinel)) break;
                         if (spin > 6000000u || (spin & 511u) == 511u) {
@@ -702,11 +721,14 @@ k_lstm_split(SplitArgs a) {
                     if constexpr (HL && !DN) {
 #pragma unroll
                         for (int k = 0; k < N; k++) {
+#if FFHIP_SPLIT_ABLATE & 8              // 8 = no sweep: operands are whatever the landing zone holds
+                            if (i > 1) continue;
+#endif
 #pragma unroll
                             for (int s = 0; s < NS; s++)
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)&hland[kw][0][k][s][0], 16,
                                                                          lane_off, ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
-                            if (k + 1 < N) __builtin_amdgcn_s_sleep(1);
+                            if (k + 1 < N && !(FFHIP_EXP & 2)) __builtin_amdgcn_s_sleep(1);
                         }
                         const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
                         v4u r[2][NS];
@@ -801,7 +823,7 @@ k_lstm_split(SplitArgs a) {
                                 const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
                                 if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                             }
-                            __builtin_amdgcn_s_sleep(1);
+                            if (!(FFHIP_EXP & 8)) __builtin_amdgcn_s_sleep(1);
                             if constexpr (!DN) init_acc();
                             if (recur_any()) break;
                         }
@@ -844,8 +866,26 @@ k_lstm_split(SplitArgs a) {
     }
 #ifdef FFHIP_TIMELINE
     if (a.dbg && Tb >= 132)
-        for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)blockIdx.x * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
+        for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)block_index * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
 #endif
+}
+
+template <int KIND, int N, int TS, bool DN = false>
+__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
+k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN>(a, (int)blockIdx.x); }
+
+// The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
+// others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
+// For the dense form at H = 384: 2 x 256 reads = 16 groups = two workgroups on every CU, and ONE launch whose duration is the pair's.
+template <int KIND, int N, int TS, bool DN>
+__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
+k_lstm_split_pair(SplitArgs a, SplitArgsOther o) {
+    int bi = (int)blockIdx.x;
+    if (bi >= o.nwg0) {                                           // uniform: the second batch differs in its buffers only (same model, same shape)
+        bi -= o.nwg0;
+        a.xin = o.xin; a.hout = o.hout; a.hout_f32 = o.hout_f32; a.flags = o.flags; a.abort_word = o.abort_word; a.tbs = o.tbs; a.tbt = o.tbt; a.epoch = o.epoch;
+    }
+    lstm_split_body<KIND, N, TS, DN>(a, bi);
 }
 
 // ---- recurrence only, behind the projection GEMM: shapes whose two weight matrices do not fit a CU's registers ------
@@ -1279,22 +1319,23 @@ static bool split_dense3(int kind, int H) {
 }
 int split_max_tiles(int ncu, int H) { return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32); }
 // tiles per group of a launch of nrt read tiles
-static int split_launch_ts(int kind, int H, int nrt, int ncu) {
+// `beside`: another batch is between run and finish -- its layer launches are on the chip; the dense form runs BESIDE them
+static bool split_launch_dense3(int kind, int H, int nrt, int ncu, int beside) {
+    return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || beside || getenv("FFHIP_SPLIT_DENSE_ALWAYS"));      // (the variable: development)
+}
+static int split_launch_ts(int kind, int H, int nrt, int ncu, int beside) {
     // the dense forms (two workgroups per CU, a pair of tiles each) take launches with more tiles than the one-tile form can:
     // FULL launches of 4 * (ncu / 32) tiles in practice (the engine's layer loop cuts a batch that way)
-    if ((H <= 256 || split_dense3(kind, H)) && nrt > 2 * (ncu / 32)) return 2;
-    if (split_dense3(kind, H) && getenv("FFHIP_SPLIT_DENSE_ALWAYS")) return 2;
+    if (H <= 256 && nrt > 2 * (ncu / 32)) return 2;
+    if (split_launch_dense3(kind, H, nrt, ncu, beside)) return 2;
     return split_tiles_per_group(kind, H);
-}
-static bool split_launch_dense3(int kind, int H, int nrt, int ncu) {
-    return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || getenv("FFHIP_SPLIT_DENSE_ALWAYS"));      // (development: the dense form for every launch)
 }
 // workgroups of such a launch, and how many workgroups of its kernel share a CU: two launches (of two batches in flight) are
 // co-resident -- every workgroup of both must be, they wait for their peers -- iff together they fit
-int split_launch_workgroups(int kind, int H, int nrt, int ncu) { const int ts = split_launch_ts(kind, H, nrt, ncu); return (nrt + ts - 1) / ts * 32; }
-int split_workgroups_per_cu(int kind, int H, int nrt, int ncu) {
-    const int ts = split_launch_ts(kind, H, nrt, ncu);
-    return (ts == 1 || H <= 256 || split_launch_dense3(kind, H, nrt, ncu)) ? 2 : 1;
+int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside) { const int ts = split_launch_ts(kind, H, nrt, ncu, beside); return (nrt + ts - 1) / ts * 32; }
+int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside) {
+    const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
+    return (ts == 1 || H <= 256 || split_launch_dense3(kind, H, nrt, ncu, beside)) ? 2 : 1;
 }
 size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
 int split_tiles_per_group(int kind, int H) {
@@ -1305,12 +1346,44 @@ int split_tiles_per_group(int kind, int H) {
 
 unsigned long long *g_split_dbg = nullptr;
 
+// one launch for the layers of two batches (the dense form at H = 384 only); false: shapes this does not take -- launch them one by one
+bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const SplitLaunch &p0, const SplitLaunch &p1) {
+#ifdef FFHIP_SPLIT_BF16X3
+    return false;
+#else
+    if (!split_dense3(kind, H) || getenv("FFHIP_NO_PAIR") || p0.nrt > 2 * (ncu / 32) || p1.nrt > 2 * (ncu / 32) || p0.nrt < 1 || p1.nrt < 1) return false;
+    auto mk = [&](const SplitLaunch &p) {
+        SplitArgs a;
+        a.epoch = p.epoch; a.acc_scale = split_pow2(p.scale_exp); a.scale_exp = p.scale_exp; a.fast_gates = p.fast_gates;
+        a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
+        a.Wp = (const v4u *)p.Wp; a.bias = p.bias; a.xin = (const unsigned char *)p.xin; a.hout = (unsigned char *)p.hout; a.hout_f32 = p.hout_f32;
+        a.flags = p.flags; a.abort_word = p.abort_word;
+        a.Tb = p.Tb; a.B16 = p.B16; a.H = H; a.rt0 = p.rt0; a.nrt = p.nrt; a.backward = p.backward; a.mode = p.mode;
+        a.tbs = p.tbs; a.tbt = p.tbt; a.dbg = nullptr;
+        return a;
+    };
+    const int g0 = (p0.nrt + 1) / 2, g1 = (p1.nrt + 1) / 2;
+    if ((g0 & 7) != 0) return false;              // (the second batch's block indices must start at a multiple of the 8 XCDs)
+    // the two batches share everything but their buffers: same model (weights, exponents), same capacity and tile count
+    if (p0.Wp != p1.Wp || p0.bias != p1.bias || p0.Tb != p1.Tb || p0.B16 != p1.B16 || p0.rt0 != p1.rt0 || p0.nrt != p1.nrt || p0.backward != p1.backward ||
+        p0.mode != p1.mode || p0.scale_exp != p1.scale_exp || p0.fast_gates != p1.fast_gates || (p0.hout_f32 == nullptr) != (p1.hout_f32 == nullptr) ||
+        (p0.tbs == nullptr) != (p1.tbs == nullptr)) return false;
+    const SplitArgs a1 = mk(p1);
+    SplitArgsOther o;
+    o.xin = a1.xin; o.hout = a1.hout; o.hout_f32 = a1.hout_f32; o.flags = a1.flags; o.abort_word = a1.abort_word; o.tbs = a1.tbs; o.tbt = a1.tbt; o.epoch = a1.epoch;
+    o.nwg0 = g0 * 32;
+    hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
+    return true;
+#endif
+}
+
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch) {
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside) {
     SplitArgs a;
     a.epoch = epoch;
     a.acc_scale = split_pow2(scale_exp);
+    a.scale_exp = scale_exp;
     a.fast_gates = fast_gates;
     a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
@@ -1319,10 +1392,10 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
     // tiles per group: 1 (two workgroups per CU, one read tile each) where that is faster, else 2 (kSplitTS)
     // ... and 2 with two workgroups per CU when the launch carries more tiles than the one-tile form can take (H <= 256)
-    const int ts = split_launch_ts(kind, H, nrt, ncu);
+    const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
     const int ngroup_l = (nrt + ts - 1) / ts;
 #ifndef FFHIP_SPLIT_BF16X3
-    if (split_launch_dense3(kind, H, nrt, ncu)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
+    if (split_launch_dense3(kind, H, nrt, ncu, beside)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
 #endif
 #define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
                                  else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)

@@ -10,7 +10,7 @@
 #include "../../include/ffhip.h"
 
 static ffhip_mat mview(const_flappie_matrix m) {
-    ffhip_mat v = { m->data.f, m->nr, m->nc, m->stride };
+    ffhip_mat v = { m->data.f, m->nr, m->nc, m->stride, (void **)&((flappie_matrix)m)->dev, (int *)&((flappie_matrix)m)->dev_state };
     return v;
 }
 
@@ -54,7 +54,7 @@ float decode_crf_flipflop(const_flappie_matrix trans, bool combine_stays, int *p
     struct ffhip_engine *eng = flappie_hip_engine();
     if (NULL == eng) return NAN;
     float score = NAN;
-    if (0 != ffhip_viterbi(eng, trans->data.f, trans->nc, trans->nr, trans->stride, combine_stays, path, qpath, &score)) {
+    if (0 != ffhip_op_viterbi(eng, mview(trans), combine_stays, path, qpath, &score)) {
         warnx("%s", ffhip_last_error());
         return NAN;
     }
@@ -94,7 +94,7 @@ flappie_matrix transpost_crf_flipflop(const_flappie_matrix trans, bool return_lo
     if (NULL == eng) return NULL;
     flappie_matrix tpost = make_flappie_matrix(trans->nr, trans->nc);
     if (NULL == tpost) return NULL;
-    if (0 != ffhip_transpost(eng, trans->data.f, trans->nc, trans->nr, trans->stride, return_log, tpost->data.f)) {
+    if (0 != ffhip_op_transpost(eng, mview(trans), return_log, mview(tpost))) {      /* scores on the device: the posterior stays there too */
         warnx("%s", ffhip_last_error());
         return free_flappie_matrix(tpost);
     }
@@ -110,7 +110,7 @@ flappie_imatrix trace_from_posterior(flappie_matrix tpost) {
     flappie_imatrix trace = make_flappie_imatrix(nstate, tpost->nc + 1);
     int32_t *tmp = malloc((tpost->nc + 1) * nstate * sizeof(int32_t));
     if (NULL == trace || NULL == tmp ||
-        0 != ffhip_trace(eng, tpost->data.f, tpost->nc, tpost->nr, tpost->stride, tmp)) {
+        0 != ffhip_op_trace(eng, mview(tpost), tmp)) {
         free(tmp);
         return free_flappie_imatrix(trace);
     }
@@ -137,5 +137,6 @@ flappie_matrix transpost_crf_runlength(const_flappie_matrix param) {
     flappie_matrix post = make_flappie_matrix(param->nr, param->nc);
     if (NULL == post) return NULL;
     if (0 != ffhip_runlength_transpost(eng, mview(param), mview(post))) { warnx("%s: %s", __func__, ffhip_last_error()); return free_flappie_matrix(post); }
+    flappie_matrix_sync(post);          /* (runnie.c:294-307 reads this matrix's data.f directly: it is returned with a current host image) */
     return post;
 }

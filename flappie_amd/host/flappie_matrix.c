@@ -6,13 +6,70 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include "../../include/ffhip.h"
 #include "../../include/flappie_matrix.h"
 #include "../../include/flappie_structures.h"
+
+static void *forget_device_image(const void *mat);
+
+/* ---- device images (include/flappie_matrix.h) ---- */
+void flappie_matrix_sync(const_flappie_matrix mat) {
+    if (NULL == mat || 2 != mat->dev_state || NULL == mat->dev) return;
+    flappie_matrix m = (flappie_matrix)mat;               /* the mirror state is a cache: logically const */
+    if (0 == ffhip_dev_download(m->dev, m->data.f, m->nc * m->stride)) m->dev_state = 1;
+    else warnx("%s: %s", __func__, ffhip_last_error());
+}
+
+bool flappie_matrix_to_device(flappie_matrix mat) {
+    if (NULL == mat) return false;
+    if (mat->dev_state >= 1 && NULL != mat->dev) return true;
+    if (NULL != mat->dev) { ffhip_dev_release(mat->dev); mat->dev = NULL; }
+    mat->dev = ffhip_dev_upload(mat->data.f, mat->nc * mat->stride);
+    mat->dev_state = (NULL != mat->dev) ? 1 : 0;
+    return NULL != mat->dev;
+}
+
+void flappie_matrix_host_changed(flappie_matrix mat) {
+    if (NULL == mat) return;
+    (void)forget_device_image(mat);
+    if (NULL != mat->dev) ffhip_dev_release(mat->dev);
+    mat->dev = NULL;
+    mat->dev_state = 0;
+}
+
+/* The reference's own calculate_post releases the transition matrix with a plain free() (flappie.c:281): the struct goes, its data
+ * -- and here its device image -- would leak, one per read.  Matrices handed out with a device image by calculate_transitions are
+ * therefore remembered by ADDRESS: when malloc returns the address of a remembered struct for a new matrix, the old one was freed
+ * behind this library's back, and its device buffer goes back to the pool.  (The host image leaks as it does in the reference.) */
+#define NOWNER 64
+static struct { const void *mat; void *dev; } dev_owner[NOWNER];
+
+void flappie_matrix_remember_device_image(const_flappie_matrix mat) {
+    if (NULL == mat || NULL == mat->dev) return;
+    int slot = -1;
+    for (int i = 0; i < NOWNER; i++) {
+        if (dev_owner[i].mat == mat) { slot = i; break; }
+        if (slot < 0 && NULL == dev_owner[i].mat) slot = i;
+    }
+    if (slot < 0) return;                     /* table full: that matrix is not watched */
+    dev_owner[slot].mat = mat;
+    dev_owner[slot].dev = mat->dev;
+}
+
+static void *forget_device_image(const void *mat) {
+    for (int i = 0; i < NOWNER; i++)
+        if (dev_owner[i].mat == mat) { void *d = dev_owner[i].dev; dev_owner[i].mat = NULL; dev_owner[i].dev = NULL; return d; }
+    return NULL;
+}
 
 flappie_matrix make_flappie_matrix(size_t nr, size_t nc) {
     if (nr == 0 || nc == 0) return NULL;
     flappie_matrix mat = malloc(sizeof(*mat));
     if (NULL == mat) return NULL;
+    {
+        void *orphan = forget_device_image(mat);      /* this address was a remembered matrix: it was free()d, not free_flappie_matrix()ed */
+        if (NULL != orphan) ffhip_dev_release(orphan);
+    }
     mat->nr = nr;
     mat->nrq = (nr + 3) / 4;
     mat->nc = nc;
@@ -34,6 +91,8 @@ flappie_matrix make_flappie_matrix(size_t nr, size_t nc) {
 
 flappie_matrix free_flappie_matrix(flappie_matrix mat) {
     if (NULL != mat) {
+        (void)forget_device_image(mat);
+        if (NULL != mat->dev) ffhip_dev_release(mat->dev);          /* back to the engine's pool */
         free(mat->data.v);
         free(mat);
     }
@@ -52,12 +111,14 @@ flappie_matrix copy_flappie_matrix(const_flappie_matrix M) {
     if (NULL == M) return NULL;
     flappie_matrix C = make_flappie_matrix(M->nr, M->nc);
     if (NULL == C) return NULL;
+    flappie_matrix_sync(M);
     memcpy(C->data.f, M->data.f, sizeof(float) * C->stride * C->nc);
     return C;
 }
 
 void zero_flappie_matrix(flappie_matrix M) {
     if (NULL == M) return;
+    flappie_matrix_host_changed(M);
     memset(M->data.f, 0, M->stride * M->nc * sizeof(float));
 }
 
@@ -70,6 +131,7 @@ flappie_matrix mat_from_array(const float *x, size_t nr, size_t nc) {
 
 float *array_from_flappie_matrix(const_flappie_matrix mat) {
     if (NULL == mat) return NULL;
+    flappie_matrix_sync(mat);
     float *res = calloc(mat->nr * mat->nc, sizeof(float));
     if (NULL == res) return NULL;
     for (size_t c = 0; c < mat->nc; c++) memcpy(res + c * mat->nr, mat->data.f + c * mat->stride, mat->nr * sizeof(float));
@@ -79,6 +141,8 @@ float *array_from_flappie_matrix(const_flappie_matrix mat) {
 bool equality_flappie_matrix(const_flappie_matrix mat1, const_flappie_matrix mat2, const float tol) {
     if (NULL == mat1 || NULL == mat2) return NULL == mat1 && NULL == mat2;
     if (mat1->nc != mat2->nc || mat1->nr != mat2->nr) return false;
+    flappie_matrix_sync(mat1);
+    flappie_matrix_sync(mat2);
     for (size_t c = 0; c < mat1->nc; ++c)
         for (size_t r = 0; r < mat1->nr; ++r)
             if (fabsf(mat1->data.f[c * mat1->stride + r] - mat2->data.f[c * mat2->stride + r]) > tol) return false;
@@ -148,6 +212,7 @@ void zero_flappie_imatrix(flappie_imatrix M) {
  *      on the GPU. ---- */
 void fprint_flappie_matrix(FILE *fh, const char *header, const_flappie_matrix mat, size_t nr, size_t nc, bool include_padding) {
     if (NULL == fh || NULL == mat) return;
+    flappie_matrix_sync(mat);
     const size_t rlim = include_padding ? mat->stride : mat->nr;
     if (nr <= 0 || nr > rlim) nr = rlim;
     if (nc <= 0 || nc > mat->nc) nc = mat->nc;
@@ -168,6 +233,7 @@ void fprint_flappie_matrix(FILE *fh, const char *header, const_flappie_matrix ma
 bool validate_flappie_matrix(flappie_matrix mat, float lower, const float upper, const float maskval, const bool only_finite,
                              const char *file, const int line) {
     if (NULL == mat || NULL == mat->data.f || 0 == mat->nc || 0 == mat->nr || mat->stride < mat->nr || mat->nrq * 4 != mat->stride) return false;
+    flappie_matrix_sync(mat);
     const size_t nc = mat->nc, nr = mat->nr, ld = mat->stride;
     for (size_t c = 0; c < nc; ++c) {
         const float *col = mat->data.f + c * ld;
@@ -185,6 +251,7 @@ bool validate_flappie_matrix(flappie_matrix mat, float lower, const float upper,
 
 float max_flappie_matrix(const_flappie_matrix x) {
     if (NULL == x) return NAN;
+    flappie_matrix_sync(x);
     float amax = x->data.f[0];
     for (size_t col = 0; col < x->nc; col++)
         for (size_t r = 0; r < x->nr; r++)
@@ -195,6 +262,7 @@ float max_flappie_matrix(const_flappie_matrix x) {
 /* flappie_matrix.c:487-502 */
 float min_flappie_matrix(const_flappie_matrix x) {
     if (NULL == x) return NAN;
+    flappie_matrix_sync(x);
     float amin = x->data.f[0];
     for (size_t col = 0; col < x->nc; col++)
         for (size_t r = 0; r < x->nr; r++)
@@ -223,6 +291,8 @@ bool validate_ivector(int *vec, const size_t n, const int lower, const int upper
 /* flappie_matrix.c:647-720: signal-conditioning helpers of the delta-sample path, element selection only */
 void clip_matrix_inplace(flappie_matrix C, float thresh) {
     if (NULL == C) return;
+    flappie_matrix_sync(C);
+    flappie_matrix_host_changed(C);          /* host-side element selection: the host image is the current one afterwards */
     for (size_t c = 0; c < C->nc; c++)
         for (size_t r = 0; r < C->nr; r++) {
             const float obs = C->data.f[c * C->stride + r];
@@ -232,6 +302,8 @@ void clip_matrix_inplace(flappie_matrix C, float thresh) {
 
 void filter_matrix_inplace(flappie_matrix C, float fill_val, float thresh) {
     if (NULL == C) return;
+    flappie_matrix_sync(C);
+    flappie_matrix_host_changed(C);          /* host-side element selection: the host image is the current one afterwards */
     for (size_t c = 0; c < C->nc; c++)
         for (size_t r = 0; r < C->nr; r++)
             if (fabsf(C->data.f[c * C->stride + r]) > thresh) C->data.f[c * C->stride + r] = fill_val;
@@ -239,6 +311,8 @@ void filter_matrix_inplace(flappie_matrix C, float fill_val, float thresh) {
 
 void difference_matrix_inplace(flappie_matrix C, float val) {
     if (NULL == C) return;
+    flappie_matrix_sync(C);
+    flappie_matrix_host_changed(C);          /* host-side element selection: the host image is the current one afterwards */
     for (size_t c = 1; c < C->nc; c++)
         for (size_t r = 0; r < C->nr; r++)
             C->data.f[(c - 1) * C->stride + r] = C->data.f[c * C->stride + r] - C->data.f[(c - 1) * C->stride + r];

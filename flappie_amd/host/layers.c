@@ -12,8 +12,12 @@
 #include "../../include/networks.h"
 
 static ffhip_mat view(const_flappie_matrix m) {
-    ffhip_mat v = { NULL, 0, 0, 0 };
-    if (NULL != m) { v.data = m->data.f; v.nr = m->nr; v.nc = m->nc; v.stride = m->stride; }
+    ffhip_mat v = { NULL, 0, 0, 0, NULL, NULL };
+    if (NULL != m) {
+        v.data = m->data.f; v.nr = m->nr; v.nc = m->nc; v.stride = m->stride;
+        v.dev = (void **)&((flappie_matrix)m)->dev;             /* the device image the matrix owns (a cache: logically const) */
+        v.dev_state = (int *)&((flappie_matrix)m)->dev_state;
+    }
     return v;
 }
 
@@ -62,6 +66,7 @@ flappie_matrix window(const_flappie_matrix input, size_t w, size_t stride) {
     const size_t wh = (w + 1) / 2;
     flappie_matrix output = make_flappie_matrix(input->nr * w, (size_t)ceilf(input->nc / (float)stride));
     if (NULL == output) return NULL;
+    flappie_matrix_sync(input);                 /* a host-side copy loop: it reads the host image */
     for (size_t col = 0; col < output->nc; col++) {
         const size_t out_offset = col * output->stride;
         const int icol = (int)(col * stride);
@@ -151,6 +156,8 @@ flappie_matrix residual(const_flappie_matrix X, const_flappie_matrix fX, flappie
     if (C == X) { residual_inplace(fX, C); return C; }          /* output aliases the first input: X += fX (the sum is symmetric) */
     C = remake_flappie_matrix(C, X->nr, X->nc);
     if (NULL == C) return NULL;
+    flappie_matrix_sync(fX);
+    flappie_matrix_host_changed(C);
     memcpy(C->data.f, fX->data.f, fX->stride * fX->nc * sizeof(float));
     residual_inplace(X, C);
     return C;

@@ -13,6 +13,8 @@
 #include "../../include/ffhip.h"
 #include "mdl_loader.h"
 
+void flappie_matrix_remember_device_image(const_flappie_matrix mat);      /* flappie_matrix.c */
+
 /* registry slot -> what the reference includes (networks.c:10-14) and the tensor name stems
  * (networks.c:218-361) */
 typedef struct {
@@ -190,6 +192,15 @@ const struct ffhip_model *flappie_hip_model(enum model_type model) {
     return g.model[model];
 }
 
+/* FLAPPIE_REPORT_COPIES=1: the library's host<->device copies of the whole run on stderr at exit (tests/test_cli.py counts what a
+ * relinked flappie.c moves per read: the signal up; path, qualities' scores and trace down; never a matrix) */
+__attribute__((destructor)) static void report_copies(void) {
+    if (NULL == getenv("FLAPPIE_REPORT_COPIES")) return;
+    unsigned long long c[5];
+    ffhip_copy_counts(c, 0);
+    fprintf(stderr, "ffhip copies: h2d %llu calls %llu bytes, d2h %llu calls %llu bytes, largest d2h %llu bytes\n", c[0], c[1], c[2], c[3], c[4]);
+}
+
 void flappie_hip_shutdown(void) {
     for (int i = 0; i < NSLOT; i++) {
         if (g.model[i]) ffhip_model_free(g.model[i]);
@@ -212,7 +223,13 @@ static flappie_matrix transitions_for(const raw_table signal, float temperature,
         0 == ffhip_batch_finish(b)) {
         const size_t P = ffhip_model_nparam(mdl), nblock = ffhip_batch_nblock(b);
         trans = make_flappie_matrix(P, nblock);
-        if (trans) {
+        if (trans && 0 != ffhip_matrix_policy()) {
+            /* the scores stay in HBM: a device-to-device copy into the image the matrix owns (dev_state 2); transpost_crf_flipflop,
+             * decode_crf_flipflop, exp_activation_inplace and trace_from_posterior (flappie.c:266-300) then never move a matrix */
+            const ffhip_mat v = { trans->data.f, trans->nr, trans->nc, trans->stride, &trans->dev, &trans->dev_state };
+            if (0 != ffhip_batch_transitions_to(b, 0, v)) { warnx("%s", ffhip_last_error()); trans = free_flappie_matrix(trans); }
+            else flappie_matrix_remember_device_image(trans);      /* flappie.c:281 frees this matrix with a plain free() */
+        } else if (trans) {
             float *tmp = malloc(P * nblock * sizeof(float));
             if (tmp && 0 == ffhip_batch_get_transitions(b, 0, tmp)) {
                 for (size_t c = 0; c < nblock; c++) memcpy(trans->data.f + c * trans->stride, tmp + c * P, P * sizeof(float));

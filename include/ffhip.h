@@ -121,6 +121,13 @@ size_t ffhip_batch_read_nblock(const ffhip_batch *b, int read);
  * (flappie.c:284-292) + exp_activation_inplace / trace_from_posterior (flappie.c:299-300)
  * for the whole batch.  Asynchronous on the batch's stream; results stay in HBM. */
 int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags);
+/* The same for TWO batches of one model and one shape (reads per batch, capacity), with the recurrent layers of both as ONE launch
+ * per layer: at H = 384 a 256-read batch fills half of what the layer kernel's dense form carries (two workgroups per CU, 512
+ * reads), so a pair runs its five layers in about the time one batch needs alone.  Each batch is still finished and read on its
+ * own (ffhip_batch_finish).  Shapes or flags the paired launch does not take run one batch after the other, as two ffhip_batch_run calls. */
+int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temperature, unsigned flags);
+/* 1 if the last run's layer launches were shared with another batch (ffhip_batch_run_pair took the paired path) */
+int ffhip_batch_paired(const ffhip_batch *b);
 /* copy the small results (calls, qualities, lengths, scores) to pinned host memory and wait */
 int ffhip_batch_finish(ffhip_batch *b);
 
@@ -155,6 +162,34 @@ int ffhip_debug_lean_math_check(ffhip_engine *eng, int exponent, int steps, unsi
  * instruction (add, mul, fma, v_pk_mov_b32: forms 0, 4, 8, 12 only), form (op_sel[0], op_sel[1], op_sel_hi[0], op_sel_hi[1] as a 4-bit number), result half, wave quarter */
 int ffhip_debug_pk_probe(ffhip_engine *eng, int iters, int nwg, int ballast, unsigned *counts);
 
+/* ---- flappie matrices with a device image -------------------------------------------------------
+ * An ffhip_mat describes one flappie matrix (flappie_matrix.h:18-24: column-major, `nc` columns of `stride` = 4*ceil(nr/4) floats):
+ * its HOST image `data` and, through `dev` / `dev_state`, the device image the matrix owns (the two members include/flappie_matrix.h
+ * appends to `_Mat`; both may be NULL for a plain host array).  *dev_state: 0 = host only, 1 = host and device equal, 2 = the DEVICE
+ * image is the current one (the host image is stale until flappie_matrix_sync()).  The operators below read the device image when
+ * there is one (no upload), and leave their result on the device (state 2, no download) when the matrix they are given was produced
+ * there -- see INTEGRATION.md section 3 for the rules and FLAPPIE_HOST_MATRICES=1 for the reference's host-only behaviour. */
+typedef struct { float *data; size_t nr, nc, stride; void **dev; int *dev_state; } ffhip_mat;
+/* buffers of device images come from (and go back to) a process-wide pool: no hipMalloc / hipFree per matrix */
+void ffhip_dev_release(void *dev);
+/* device image -> host image (the whole [nc][stride] image); synchronous */
+int ffhip_dev_download(const void *dev, float *host, size_t nfloat);
+/* host image -> a new device image (pool buffer); NULL on failure */
+void *ffhip_dev_upload(const float *host, size_t nfloat);
+/* 0: never keep device images (every operator uploads its inputs and downloads its result: the reference's semantics, FLAPPIE_HOST_MATRICES=1);
+ * 1 (default): as described above */
+void ffhip_set_matrix_policy(int device_images);
+int ffhip_matrix_policy(void);
+/* calls and bytes of host<->device copies this library has made since the last reset: {h2d calls, h2d bytes, d2h calls, d2h bytes,
+ * largest single d2h in bytes} -- what tests/test_host_layer.py counts for the relinked flappie.c */
+void ffhip_copy_counts(unsigned long long out[5], int reset);
+/* the transition matrix of read `read` of a finished batch as a device image owned by `out` (device-to-device; out.dev / out.dev_state set) */
+int ffhip_batch_transitions_to(ffhip_batch *b, int read, ffhip_mat out);
+/* transpost_crf_flipflop / decode_crf_flipflop / trace_from_posterior on matrices with device images (decode.c:377-497, :119-204, :499-543) */
+int ffhip_op_transpost(ffhip_engine *eng, ffhip_mat trans, int return_log, ffhip_mat post);
+int ffhip_op_viterbi(ffhip_engine *eng, ffhip_mat scores, int combine_stays, int *path, float *qpath, float *score);
+int ffhip_op_trace(ffhip_engine *eng, ffhip_mat post, int32_t *out);
+
 /* ---- single-matrix decode entry points -------------------------------------------------------
  * Used by the reference-compatible wrappers in include/decode.h.  `trans` / `scores` / `post` are
  * host arrays in the reference's flappie_matrix image: `nblock` columns of `stride` floats, the
@@ -170,12 +205,9 @@ int ffhip_trace(ffhip_engine *eng, const float *post, size_t nblock, size_t npar
 
 /* ---- layer operators on single matrices ---------------------------------------------------------
  * The reference's per-layer interface (layers.h:15-100, flappie_matrix.h:67-73) on the GPU, used by the
- * wrappers in include/layers.h.  An ffhip_mat is a HOST image of a flappie matrix: column-major, `nc`
- * columns of `stride` = 4*ceil(nr/4) floats.  Outputs must be allocated by the caller with the shape the
+ * wrappers in include/layers.h, on ffhip_mat views (above).  Outputs must be allocated by the caller with the shape the
  * reference function would return; every call is synchronous.  Batch-of-one use of the same kernels the
  * batched pipeline runs. */
-typedef struct { float *data; size_t nr, nc, stride; } ffhip_mat;
-
 /* the flip-flop decoders of decode.h that flappie.c does not use (one wave per call, reference order):
  * argmax_decoder (decode.c:17-36): seq[nc] = row of the column maximum (-1 for the last row), *score = their sum in block order */
 int ffhip_op_argmax_decoder(ffhip_engine *eng, ffhip_mat logpost, int *seq, float *score);

@@ -31,7 +31,7 @@ typedef struct {
     } data;
     /* -- extension (zero in static .mdl initialisers) -- */
     void *dev;            /* HIP device buffer holding the same [nc][stride] image, or NULL */
-    int dev_state;        /* 0 = host only, 1 = host and device in sync, 2 = device newer   */
+    int dev_state;        /* 0 = host only, 1 = host and device in sync, 2 = DEVICE NEWER: data.f is stale until flappie_matrix_sync() */
 } _Mat;
 
 typedef struct {
@@ -57,6 +57,16 @@ void zero_flappie_matrix(flappie_matrix M);
 flappie_matrix mat_from_array(const float *x, size_t nr, size_t nc);
 float *array_from_flappie_matrix(const_flappie_matrix mat);
 bool equality_flappie_matrix(const_flappie_matrix mat1, const_flappie_matrix mat2, const float tol);
+
+/* ---- device images (this boundary's addition) ------------------------------------------------------
+ * The matrices of the hot path live in HBM: calculate_transitions() returns its scores as a device image (dev_state 2), and every
+ * function of decode.h / layers.h / this header that is given a matrix with a device image reads THAT (no upload) and leaves its
+ * result on the device (no download).  The library's own host-side readers (array_from_flappie_matrix, fprint_*, equality_*,
+ * min / max / validate_*, copy_*) synchronise first; code that reads `->data.f` itself calls flappie_matrix_sync() before it does.
+ * FLAPPIE_HOST_MATRICES=1 in the environment restores the reference's behaviour (host images always current, a copy each way per call). */
+void flappie_matrix_sync(const_flappie_matrix mat);          /* host image := device image, if that is the newer one (dev_state 2 -> 1) */
+bool flappie_matrix_to_device(flappie_matrix mat);           /* device image := host image (dev_state 1): operators on it now stay on the device */
+void flappie_matrix_host_changed(flappie_matrix mat);        /* the caller wrote data.f: the device image is dropped (dev_state 0) */
 
 /* flappie_matrix.h:56-61 */
 flappie_imatrix make_flappie_imatrix(size_t nr, size_t nc);

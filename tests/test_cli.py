@@ -511,9 +511,24 @@ def test_reference_main_relinked_against_the_engine(cli_inputs):
     d, mdl, reads, raws = cli_inputs
     env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d), LD_LIBRARY_PATH=os.path.join(ROOT, "flappie_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     files = [str(reads / fn) for fn in sorted(raws)]
-    r = subprocess.run([RELINKED, "--model", "r941_native"] + files, env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([RELINKED, "--model", "r941_native"] + files, env=dict(env, FLAPPIE_REPORT_COPIES="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     recs = _parse_fastq(r.stdout)
+    # the reference's main, one read per call: what crosses PCIe is the signal (up) and path / quality scores (down) -- never a matrix.
+    # Per read: the signal + the convolution plans up; the abort word, path, qpath and score down.
+    import re
+    m = re.search(r"ffhip copies: h2d (\d+) calls (\d+) bytes, d2h (\d+) calls (\d+) bytes, largest d2h (\d+) bytes", r.stderr)
+    assert m, r.stderr
+    h2d_calls, h2d_bytes, d2h_calls, d2h_bytes, d2h_largest = (int(x) for x in m.groups())
+    nread = len(files)
+    nblock_max = max(len(raw) for _, raw in raws.values()) // 5 + 1
+    # (flappie.c:299-300 computes the trace for every read, --trace or not: (nblock + 1) x 8 states of int32 is the largest thing that
+    # comes down -- a fifth of a 40 x nblock matrix; the normalised signal of medmad_normalise_array, a host array in the reference's
+    # API, comes down too)
+    nsample_max = max(len(raw) for _, raw in raws.values())
+    assert d2h_largest <= (nblock_max + 1) * 8 * 4 < nblock_max * 40 * 4
+    assert d2h_calls <= 16 * nread + 8 and d2h_bytes <= nread * ((nblock_max + 1) * (8 + 32) + 4 * nsample_max + 256)
+    assert h2d_bytes <= sum(len(raw) for _, raw in raws.values()) * 4 + nread * 8 * (nblock_max + 64) * 4 + (64 << 20)      # signals + per-read plan tables + the model, once
     ref = _oracle_calls(mdl, raws)
     assert [x[0] for x in recs] == [ref[fn]["uuid"] for fn in sorted(raws)]          # the reference's loop: argument order, uuid names
     for (name, hdr, bases, quals), fn in zip(recs, sorted(raws)):

@@ -15,6 +15,16 @@ from flappie_amd import model as M
 pytestmark = pytest.mark.gpu
 
 TOL_SCORE = 1e-4
+TOL_POST = 5e-5          # log posterior: measured worst 1.9e-5 (tests/test_decode_gpu.py); round 2 allowed 2e-4
+_trace_cells = [0, 0]    # [cells compared, cells off by one count] of the current test
+
+
+@pytest.fixture(autouse=True)
+def _report_trace_rate():
+    _trace_cells[0] = _trace_cells[1] = 0
+    yield
+    if _trace_cells[0]:
+        print("trace: %d of %d cells differ from the oracle by one count (%.4f %%)" % (_trace_cells[1], _trace_cells[0], 100.0 * _trace_cells[1] / _trace_cells[0]))
 
 
 @pytest.fixture(scope="module")
@@ -50,8 +60,13 @@ def compare_read(b, r, ref, viterbi=False):
     assert b.quality(r) == ref["quality"]
     assert abs(b.score(r) - ref["score"]) <= 2e-3 * max(1.0, abs(ref["score"]) * 1e-2)
     if not viterbi:
-        assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
-        assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
+        # the posterior kernel's own deviation (<= TOL_POST on identical scores) on top of what the scores' deviation explains (a
+        # perturbation d of the scores moves a log posterior by at most 2 d)
+        assert np.abs(b.posterior(r) - ref["post"]).max() <= TOL_POST + 2.0 * float(np.abs(tr - ref["trans"]).max())
+        dt = np.abs(b.trace(r) - ref["trace"])
+        assert dt.max() <= 1          # round(255 p) at a rounding boundary; the rate is printed with every test (-rP / -s)
+        _trace_cells[0] += dt.size
+        _trace_cells[1] += int((dt == 1).sum())
 
 
 CASES = [

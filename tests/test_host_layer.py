@@ -77,7 +77,21 @@ def host():
     L.change_positions.restype = C.c_size_t
     L.change_positions.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_int)]
     L.flappie_hip_shutdown.restype = None
+    L.flappie_matrix_sync.argtypes = [C.POINTER(CMat)]
+    L.flappie_matrix_to_device.restype = C.c_bool
+    L.flappie_matrix_to_device.argtypes = [C.POINTER(CMat)]
+    L.flappie_matrix_host_changed.argtypes = [C.POINTER(CMat)]
+    L.ffhip_copy_counts.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    L.ffhip_set_matrix_policy.argtypes = [C.c_int]
+    L.tanh_activation_inplace.argtypes = [C.POINTER(CMat)]
+    L.array_from_flappie_matrix.restype = C.POINTER(C.c_float)
+    L.array_from_flappie_matrix.argtypes = [C.POINTER(CMat)]
+    global _HOST
+    _HOST = L
     return L
+
+
+_HOST = None
 
 
 def _f(a):
@@ -85,7 +99,11 @@ def _f(a):
 
 
 def _dense(pm):
+    """the meaningful rows of a matrix's HOST image; a matrix whose current image is on the device (dev_state 2) is synchronised first,
+    as include/flappie_matrix.h asks of code that reads data.f itself"""
     m = pm.contents
+    if m.dev_state == 2:
+        _HOST.flappie_matrix_sync(pm)
     return np.ctypeslib.as_array(m.f, shape=(m.nc, m.stride))[:, : m.nr].copy()
 
 
@@ -219,6 +237,85 @@ def test_calculate_post_sequence_matches_oracle(host, model_dir):
         assert not host.calculate_transitions(empty, 1.0, 0)
         assert not host.calculate_transitions(RawTable(None, 10, 0, 10, _f(np.zeros(10, np.float32))), 1.0, 1)   # model file absent
     finally:
+        host.flappie_hip_shutdown()
+        del os.environ["FLAPPIE_MODEL_DIR"]
+
+
+def _copy_counts(host, reset=False):
+    c = (C.c_ulonglong * 5)()
+    host.ffhip_copy_counts(c, 1 if reset else 0)
+    return dict(h2d_calls=c[0], h2d_bytes=c[1], d2h_calls=c[2], d2h_bytes=c[3], d2h_largest=c[4])
+
+
+@pytest.mark.gpu
+def test_matrices_of_the_hot_path_stay_on_the_device(host, model_dir):
+    """north_star: "flappie_matrix is backed by HIP device buffers" (type flappie_matrix.h:18-24).  calculate_transitions returns its
+    scores as a device image; transpost_crf_flipflop, decode_crf_flipflop, exp_activation_inplace and trace_from_posterior
+    (flappie.c:266-300) consume and produce device images -- between the signal going up and path / trace coming down NO matrix
+    crosses PCIe (counted: the library's own copy accounting) -- and the results equal those of the host-image mode
+    (FLAPPIE_HOST_MATRICES=1 / ffhip_set_matrix_policy(0)), which moves every matrix both ways as round 2 did."""
+    d, mdls = model_dir
+    os.environ["FLAPPIE_MODEL_DIR"] = d
+    try:
+        T = 3000
+        raw = np.random.default_rng(11).standard_normal(T).astype(np.float32)
+        rt = RawTable(None, raw.size, 0, T, _f(raw))
+        got = {}
+        for policy in (1, 0):
+            host.ffhip_set_matrix_policy(policy)
+            trans = host.calculate_transitions(rt, 1.0, 0)
+            assert trans
+            nblock, nparam, stride = trans.contents.nc, trans.contents.nr, trans.contents.stride
+            matrix_bytes = nblock * stride * 4
+            assert (trans.contents.dev_state, bool(trans.contents.dev)) == ((2, True) if policy else (0, False))
+            _copy_counts(host, reset=True)
+            post = host.transpost_crf_flipflop(trans, True)
+            path = np.zeros(nblock + 2, dtype=np.int32)
+            qpath = np.zeros(nblock + 2, dtype=np.float32)
+            score = host.decode_crf_flipflop(post, False, path.ctypes.data_as(C.POINTER(C.c_int)), _f(qpath))
+            host.exp_activation_inplace(post)
+            tr = host.trace_from_posterior(post)
+            c = _copy_counts(host)
+            trace = np.ctypeslib.as_array(tr.contents.f, shape=(nblock + 1, tr.contents.stride))[:, : tr.contents.nr].copy()
+            if policy:
+                assert post.contents.dev_state == 2
+                # down: path, qpath, score, trace -- and nothing as large as a matrix; up: nothing at all
+                assert c["h2d_calls"] == 0 and c["d2h_calls"] == 4, c
+                assert c["d2h_largest"] == (nblock + 1) * tr.contents.nr * 4 < matrix_bytes and c["d2h_bytes"] < matrix_bytes, (c, matrix_bytes)
+            else:
+                assert post.contents.dev_state == 0 and not post.contents.dev
+                assert c["h2d_bytes"] >= 4 * matrix_bytes and c["d2h_bytes"] >= 2 * matrix_bytes       # round 2's traffic: every call moves its matrix up, two move one down
+            got[policy] = (_dense(trans), _dense(post), path.copy(), qpath.copy(), score, trace)
+            assert post.contents.dev_state == (1 if policy else 0)                                  # _dense synchronised it: host and device equal
+            host.free_flappie_imatrix(tr)
+            host.free_flappie_matrix(post)
+            host.free_flappie_matrix(trans)
+        for a, b in zip(got[1], got[0]):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+        # operators of layers.h / flappie_matrix.h follow the same rule: on a matrix that was put on the device they work in place there,
+        # the library's own readers (array_from_flappie_matrix) see the current values, and a host-side write is declared
+        host.ffhip_set_matrix_policy(1)
+        x = np.random.default_rng(5).standard_normal((7, 10)).astype(np.float32)          # 7 columns of 10 rows (stride 12)
+        m = host.mat_from_array(_f(x), 10, 7)
+        assert host.flappie_matrix_to_device(m) and m.contents.dev_state == 1
+        _copy_counts(host, reset=True)
+        host.tanh_activation_inplace(m)
+        assert m.contents.dev_state == 2 and _copy_counts(host)["d2h_calls"] == 0
+        assert np.array_equal(np.ctypeslib.as_array(m.contents.f, shape=(7, 12))[:, :10], x)          # the host image is the OLD one until synchronised
+        arr = host.array_from_flappie_matrix(m)                                                       # synchronises
+        now = np.ctypeslib.as_array(arr, shape=(7, 10)).copy()
+        C.CDLL(None).free(arr)
+        ref = host.mat_from_array(_f(x), 10, 7)
+        host.tanh_activation_inplace(ref)                                                             # host-image path: upload, kernel, download
+        assert ref.contents.dev_state == 0 and np.array_equal(now, _dense(ref)) and not np.array_equal(now, x)
+        np.ctypeslib.as_array(m.contents.f, shape=(7, 12))[:] = 0.25
+        host.flappie_matrix_host_changed(m)
+        host.tanh_activation_inplace(m)
+        assert m.contents.dev_state == 0 and np.allclose(_dense(m), np.tanh(0.25), atol=1e-6)
+        host.free_flappie_matrix(m)
+        host.free_flappie_matrix(ref)
+    finally:
+        host.ffhip_set_matrix_policy(1)
         host.flappie_hip_shutdown()
         del os.environ["FLAPPIE_MODEL_DIR"]
 

@@ -487,7 +487,8 @@ def test_globalnorm_and_partition_function(L, nbase, H, T):
     from flappie_amd import binding as B
 
     class FMat(C.Structure):
-        _fields_ = [("data", C.POINTER(C.c_float)), ("nr", C.c_size_t), ("nc", C.c_size_t), ("stride", C.c_size_t)]
+        _fields_ = [("data", C.POINTER(C.c_float)), ("nr", C.c_size_t), ("nc", C.c_size_t), ("stride", C.c_size_t),
+                    ("dev", C.c_void_p), ("dev_state", C.c_void_p)]          # (a plain host array: no device image)
     eng = B.Engine(0)
     fn = B.lib().ffhip_op_partition_function_scaled
     fn.argtypes = [C.c_void_p, FMat, C.c_float, C.POINTER(C.c_double)]

@@ -25,13 +25,14 @@ def engine(B):
 
 def check_read(b, r, ref, viterbi_only=False):
     assert b.read_nblock(r) == ref["nblock"]
-    assert np.abs(b.transitions(r) - ref["trans"]).max() <= 1e-4
+    dtrans = float(np.abs(b.transitions(r) - ref["trans"]).max())
+    assert dtrans <= 1e-4
     path, qpath = b.path(r)
     assert np.array_equal(path, ref["path"])
     assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
     assert abs(b.score(r) - ref["score"]) <= 1e-3 * max(1.0, abs(ref["score"]))
     if not viterbi_only:
-        assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
+        assert np.abs(b.posterior(r) - ref["post"]).max() <= 5e-5 + 2.0 * dtrans      # the posterior kernel's own 5e-5 on top of what the scores' deviation explains
         assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
 
 

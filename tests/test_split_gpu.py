@@ -27,11 +27,12 @@ def engine(B):
 
 def check_read(b, r, ref):
     assert b.read_nblock(r) == ref["nblock"]
-    assert np.abs(b.transitions(r) - ref["trans"]).max() <= 1e-4
+    dtrans = float(np.abs(b.transitions(r) - ref["trans"]).max())
+    assert dtrans <= 1e-4
     path, _ = b.path(r)
     assert np.array_equal(path, ref["path"])
     assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
-    assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
+    assert np.abs(b.posterior(r) - ref["post"]).max() <= 5e-5 + 2.0 * dtrans      # the posterior kernel's own 5e-5 on top of what the scores' deviation explains
     assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
 
 
@@ -187,6 +188,57 @@ def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, 
     for b in bs:
         b.close()
     dm.close()
+
+
+def test_paired_layer_launches_give_the_results_of_each_batch_alone(B, engine):
+    """ffhip_batch_run_pair: at H = 384 the recurrent layers of two 256-read batches are ONE launch per layer (k_lstm_split_pair, the
+    dense form: two workgroups per CU).  Uniform and ragged pairs over three rounds, two pairs in flight as bench.py keeps them: every
+    score, base and quality string identical to the same batch run alone through ffhip_batch_run; shapes the paired launch does not
+    take (another hidden size, fewer reads) go through the same call and run one after the other."""
+    rng = np.random.default_rng(384)
+    for hidden, nread, T, ragged in ((384, 256, 1200, False), (384, 256, 1500, True), (256, 64, 900, False), (384, 48, 900, False)):
+        mdl = M.synthetic_model(M.NET_LSTM5, hidden, seed=5)
+        dm = B.DeviceModel(engine, mdl)
+
+        def signals():
+            if not ragged:
+                return rng.standard_normal((nread, T)).astype(np.float32)
+            lens = rng.integers(T // 2, T + 1, nread)
+            lens[rng.random(nread) < 0.1] = 0
+            lens[0] = T
+            return [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
+
+        def load(b, sg):
+            b.set_signals_ragged(sg) if ragged else b.set_signals(sg)
+
+        def live(sg, r):
+            return len(sg[r]) > 0
+
+        sigs = [signals() for _ in range(4)]
+        probe = list(range(0, nread, 11))
+        alone = []
+        for sg in sigs:
+            b = B.Batch(dm, nread, T)
+            load(b, sg)
+            b.run(); b.finish()
+            assert not b.paired()
+            alone.append({r: (b.transitions(r), b.basecall(r), b.quality(r)) for r in probe if live(sg, r)})
+            b.close()
+        bs = [B.Batch(dm, nread, T) for _ in range(4)]
+        for rnd in range(3):
+            order = [(k + rnd) % 4 for k in range(4)]
+            for k in range(4):
+                load(bs[k], sigs[order[k]])
+            bs[0].run_pair(bs[1]); bs[2].run_pair(bs[3])          # two pairs in flight
+            for k in range(4):
+                bs[k].finish()
+                assert bs[k].paired() == (hidden == 384 and nread == 256), (hidden, nread)
+                for r, want in alone[order[k]].items():
+                    assert np.array_equal(bs[k].transitions(r), want[0]), (hidden, nread, ragged, rnd, k, r)
+                    assert (bs[k].basecall(r), bs[k].quality(r)) == want[1:], (hidden, nread, ragged, rnd, k, r)
+        for b in bs:
+            b.close()
+        dm.close()
 
 
 def test_packed_fp32_forms_beside_the_layer_kernel(B, engine):
