@@ -32,7 +32,9 @@ def check_read(b, r, ref):
     path, _ = b.path(r)
     assert np.array_equal(path, ref["path"])
     assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
-    assert np.abs(b.posterior(r) - ref["post"]).max() <= 5e-5 + 2.0 * dtrans      # the posterior kernel's own 5e-5 on top of what the scores' deviation explains
+    # end to end: the scores' own deviation (<= 1e-4) propagates through two log-sum-exp recursions -- measured up to 1.2e-4 at |dtrans| = 2.6e-5 --
+    # so this bound cannot be the posterior kernel's; THAT is held to 2e-5 + 2e-6 |x| on identical scores in tests/test_decode_gpu.py
+    assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
     assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
 
 
