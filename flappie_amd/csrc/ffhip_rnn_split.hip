@@ -349,19 +349,37 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         unsigned lv = (unsigned)lane;
         asm volatile("" : "+v"(lv));
         const unsigned q_ = lv >> 4, rl_ = lv & 15u;
+        unsigned sl_[NS];
+        split_slices(h * split_pow2(kSplitExpH), sl_);        // |h| <= 1: in range without a clamp
+#if defined(FFHIP_SPLIT_BF16X3) || !(FFHIP_EXP & 32)          // EXP 32: the transpose in registers instead (measured: 0.5-2 % slower, below)
         unsigned short (*gs)[16][4] = gsl[wave];
-        {
-            unsigned sl[NS];
-            split_slices(h * split_pow2(kSplitExpH), sl);        // |h| <= 1: in range without a clamp
 #pragma unroll
-            for (int k = 0; k < NS; k++) gs[k][rl_][q_] = (unsigned short)sl[k];
+        for (int k = 0; k < NS; k++) gs[k][rl_][q_] = (unsigned short)sl_[k];
+#else
+        // Built and measured, not the default (c2 98.2 against 98.7 Msamples/s, h256 154.1 against 157.7, same device, interleaved: the
+        // swaps cost more than the LDS round trip they replace).  The 4 x 4 transpose across the wave's quarters in registers (gfx950's row / half swaps):
+        // w = both slices of my unit; one v_permlane16_swap of two copies leaves [u0 u0 u2 u2] and [u1 u1 u3 u3] by rows of 16 lanes,
+        // a v_permlane32_swap of each with a copy of itself spreads them -- every lane then holds the packed slices of units 0..3 of its read.
+        v2u pieces;
+        {
+            const unsigned w = sl_[0] | (sl_[1] << 16);
+            const v2u r16 = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+            const v2u a02 = __builtin_amdgcn_permlane32_swap(r16.x, r16.x, false, false);       // { u0 everywhere, u2 everywhere }
+            const v2u a13 = __builtin_amdgcn_permlane32_swap(r16.y, r16.y, false, false);       // { u1 everywhere, u3 everywhere }
+            const unsigned sel = (q_ == 0u) ? 0x05040100u : 0x07060302u;                        // quarter 0 stores slice 0 (low halves), quarter 1 slice 1
+            pieces = (v2u){ __builtin_amdgcn_perm(a13.x, a02.x, sel), __builtin_amdgcn_perm(a13.y, a02.y, sel) };
         }
+#endif
         if (a.hout_f32) gf32[wave][rl_][q_] = h;
         asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
         const int ut = ut0 + gj;
         if (q_ < (unsigned)NS) {
             const unsigned off = (unsigned)((((ut >> 3) * NS) * 64 + ((ut & 7) >> 1) * 16) * 16 + (ut & 1) * 8) + q_ * 1024u + rl_ * 16u;      // = out_off(gj)
+#if defined(FFHIP_SPLIT_BF16X3) || !(FFHIP_EXP & 32)
             const v2u sl = *(const v2u *)&gs[q_][rl_][0];
+#else
+            const v2u sl = pieces;
+#endif
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
                 store_plain(tp_out, off, sl);              // (the data first: it is what the consumers wait for)
@@ -509,7 +527,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         auto touch_x = [&](int i) {                          // L2 warming, spread over the group (see the classic loop below)
             const int line = m * LPM + lane;
             unsigned t = 0;
-            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb && !(FFHIP_EXP & 16))      // EXP 16: no L2 warming (counter calibration)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
@@ -579,7 +597,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         auto touch_x = [&](int i) {
             const int line = m * LPM + lane;
             unsigned t = 0;                               // (not `touched` itself: keeping the old value would make this a use of the old load)
-            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb && !(FFHIP_EXP & 16))      // EXP 16: no L2 warming (counter calibration)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
@@ -855,8 +873,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(2);
             raw_barrier();
             TL(3);
-            if (lds_abort) return;
+            // (the abort word is read here and looked at BEHIND the gate math: a read-wait-branch in front of it is ~100 cycles on the
+            // chain of every step; results of an aborted launch are discarded anyway)
+            const int aborted = *(volatile int *)&lds_abort;
             if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            if (aborted) return;
             TL(4);
             // close the gate phase before ph is rewritten (and before the x waves' MFMAs start next to gate VALU work)
             __builtin_amdgcn_s_barrier();

@@ -298,6 +298,10 @@ int ffhip_medmad_normalise(ffhip_engine *eng, float *x, size_t n, float *median,
 #define FFHIP_NGROUP 6
 int ffhip_engine_set_profiling(ffhip_engine *eng, int on);
 int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launches[FFHIP_NGROUP]);
+/* how often a batch of this engine was re-run on the launch-per-step kernels because a persistent layer launch timed out waiting for
+ * its peer workgroups (another tenant on the GPU); each occurrence also warns on stderr once per process and sends the next 64 runs
+ * to those kernels directly */
+int ffhip_debug_fallback_count(const ffhip_engine *eng);
 
 #ifdef __cplusplus
 }
