@@ -151,7 +151,7 @@ def cpu_baseline(cfg, budget_s=12.0):
                      "reference_openblas_per_core_survey = the survey container's probe of the real reference (SURVEY.md section 6, other host)")
 
 
-def measured_traffic(name, cfg, rnn_path):
+def measured_traffic(name, cfg, rnn_path, paired=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*traffic*.json:
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE, separate passes).  Counters cannot
     be read inside this process, so the value is the profile's, keyed by shape and kernel; null when no profile of this
@@ -166,7 +166,8 @@ def measured_traffic(name, cfg, rnn_path):
             continue
         for e in (t if isinstance(t, list) else [t]):
             if (e.get("hidden") == cfg["hidden"] and e.get("nread") == cfg["nread"] and e.get("nsample") == cfg["nsample"]
-                    and e.get("kind", 0) == cfg["kind"] and e.get("rnn_path", 2 if e.get("fused") else 1) == rnn_path):
+                    and e.get("kind", 0) == cfg["kind"] and e.get("rnn_path", 2 if e.get("fused") else 1) == rnn_path
+                    and e.get("reads_per_launch", cfg["nread"]) == cfg["nread"] * (2 if paired else 1)):
                 best = e.get("recurrent_layer_hbm_bytes_per_launch")
     return best
 
@@ -246,8 +247,8 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
     except AttributeError:
         ncore = os.cpu_count() or 1
     readers = max(1, min(12, ncore // max(1, world) - 2))
-    nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_HOSTFED_FILES", "12288"))      # per rank
-    n_short = max(512, nfiles // 6)
+    nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_HOSTFED_FILES", "32768"))      # per rank (the short run is a quarter of it: a steady-state marginal rate needs ~1 s of work)
+    n_short = max(512, nfiles // 4)
     obj = [None]
     if rank == 0:
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -510,7 +511,7 @@ def main():
             dtype = "f32"
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.config, cfg, rnn_path),
+                "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.config, cfg, rnn_path, paired_),
                 "peak_note": peak_note,
                 # the same algorithmic rate against the ceiling of round 1's formulation (six bf16 products per fp32 product,
                 # 2500 / 6 = 416.7 TFLOP/s), which VERDICT r1 priced the kernel with (0.39 then; its target: >= 0.50)

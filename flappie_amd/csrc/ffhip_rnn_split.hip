@@ -537,17 +537,24 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         touch_x(2);
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
+#if FFHIP_EXP & 64                     // EXP 64 / 128: the x waves stay out of the memory pipe while the h waves poll and sweep (~1500 / ~3000 cycles)
+            __builtin_amdgcn_s_sleep(24);
+#endif
+#if FFHIP_EXP & 128
+            __builtin_amdgcn_s_sleep(48);
+#endif
             if (i + 1 < Tb) project_step(i + 1, i + 1);
             sink ^= touched;
             touch_x(i + WARM);
             raw_barrier();
-            if (lds_abort) return;
+            const int aborted = *(volatile int *)&lds_abort;      // (looked at behind the gate math: see the h waves' loop)
             if (sg_front) {
                 __builtin_amdgcn_s_setprio(3);
                 gate_front(i, my_gts, my_gj, c, my_tb);
                 __builtin_amdgcn_s_setprio(0);
             } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
             else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            if (aborted) return;
             raw_barrier();                                   // closes the gate phase
         }
         if (sink == 0x9e3779b9u && a.Tb < 0) a.flags[0] = sink;
@@ -621,7 +628,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(2);
             raw_barrier();
             TL(3);
-            if (lds_abort) return;
+            const int aborted = *(volatile int *)&lds_abort;      // (looked at behind the gate math: see the h waves' loop)
             if constexpr (TS == 2) {                         // (one tile per group: its N <= 4 gate tiles all belong to h waves -- and said at
                                                              // compile time, so that no gate temporaries are live beside the prefetch)
                 if (sg_front) {
@@ -631,6 +638,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
                 else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
             }
+            if (aborted) return;
             TL(4);
             raw_barrier();                                   // closes the gate phase
             TL(5);

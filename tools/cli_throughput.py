@@ -21,21 +21,13 @@ t0 = time.time()
 M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native"))
 print("model file written in %.1f s" % (time.time() - t0), flush=True)
 tool = os.path.join(ROOT, "flappie_amd", "fast5_tool")
-rng = np.random.default_rng(1)
 nmax = max(counts)
 reads = os.path.join(d, "reads")
 os.mkdir(reads)
 t0 = time.time()
-total = []
-for i in range(nmax):
-    n = int(rng.integers(3500, 5500))
-    x = rng.normal(500, 60, n)
-    x[:300] = rng.normal(520, 4, 300)
-    raw = np.clip(np.rint(x), 0, 8191).astype("<i2")
-    tmp = os.path.join(d, "r.i16")
-    raw.tofile(tmp)
-    subprocess.run([tool, "write", os.path.join(reads, "read_%05d.fast5" % i), "uuid-%05d" % i, "8192", "10", "1400", "4000", tmp], check=True)
-    total.append(n)
+# seeded noise around 500 +- 60 counts behind a 300-sample quiet stretch, 3500-5500 samples per file, written in one process (fast5_tool synth)
+out = subprocess.run([tool, "synth", reads, str(nmax), "3500", "5500", "1"], check=True, capture_output=True, text=True).stdout.split()
+total = [int(out[3]) / max(1, nmax)] * nmax
 print("%d fast5 files written in %.1f s" % (nmax, time.time() - t0), flush=True)
 env = dict(os.environ, FLAPPIE_MODEL_DIR=d)
 for nr in readers:

@@ -11,8 +11,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
 O=gpurun_out/profiles; mkdir -p $O
-S="--config $cfg --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline --no-h2d-leg $*"      # one batch in flight: clean per-kernel times
-python bench.py --config $cfg "$@" > $O/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || tail -5 gpurun_out/${tag}_bench.err
+S="--config $cfg --steps ${PROFILE_STEPS:-4} --warmup 2 --inflight 1 --no-cpu-baseline --no-h2d-leg --no-host-fed-leg $*"      # one batch in flight: clean per-kernel times
+python bench.py --config $cfg --no-host-fed-leg "$@" > $O/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || tail -5 gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_trace -- python bench.py $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -- python bench.py $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -- python bench.py $S > /dev/null 2>&1

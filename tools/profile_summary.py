@@ -15,7 +15,7 @@ RECURRENT = ("k_lstm_split", "k_rnn_split", "k_lstm_fused", "k_rnn_persist")
 
 def find(scratch, tag, leg, suffix):
     hits = sorted(glob.glob(os.path.join(scratch, "prof_%s_%s" % (tag, leg), "**", "*" + suffix), recursive=True))
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getsize) if hits else None          # (a traced command may have children: the bench process's file is the big one)
 
 
 def short(name):
@@ -26,7 +26,7 @@ def main():
     tag, cfgname, scratch, outdir = sys.argv[1:5]
     import bench
     cfg = bench.CONFIGS[cfgname]
-    cmd = "python bench.py --config %s --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline --no-h2d-leg" % cfgname
+    cmd = "python bench.py --config %s --steps %s --warmup 2 --inflight 1 --no-cpu-baseline --no-h2d-leg --no-host-fed-leg" % (cfgname, os.environ.get("PROFILE_STEPS", "4"))
     trace = find(scratch, tag, "trace", "kernel_trace.csv")
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
@@ -62,7 +62,7 @@ def main():
         fa = sum(f[k]) / len(f[k])
         wa = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
         out.append("\"%s\",%d,%.1f,%.1f,%.2f,%.2f" % (k, len(f[k]), fa, wa, 2 * fa * 1024 / 1e6, wa * 1024 / 1e6))
-        res[k] = (2 * fa * 1024, wa * 1024)
+        res[k] = (2 * fa * 1024, wa * 1024, fa * 1024)
     open(os.path.join(outdir, "%s_hbm_traffic_pmc.csv" % tag), "w").write(
         "# separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE -- %s\n"
         "# FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)\n" % cmd
@@ -103,10 +103,19 @@ def main():
         G = 3 if cfg["kind"] == 1 else 4
         # algorithmic bytes per launch: split layer kernel reads x and writes h at 4 B per value (two fp16 slices); f32 fused 4 + 4;
         # recurrence-only kernels read the projected gates (G*H floats) and write h
-        alg = Tb * nread * H * {3: 8, 2: 8, 1: 4 * G + 4, 4: 4 * G + 4}[rnn_path]
+        paired = 2 if "_pair" in dom else 1                 # k_lstm_split_pair: one launch carries the layer of two batches
+        alg = Tb * nread * H * {3: 8, 2: 8, 1: 4 * G + 4, 4: 4 * G + 4}[rnn_path] * paired
+        # Round 3 calibrated FETCH_SIZE on the split layer kernel's own known byte count (profiles/r03_fetch_calibration.txt: the layer input is
+        # read exactly once; TCC_EA0_RDREQ counts one request per 64-byte sector of it): for these kernels the RAW value is the byte count, the
+        # doubling of MI355X_MICROARCH.md's streaming-read rule does not apply.  Both are recorded.
+        calibrated = rnn_path in (3, 4)
+        rd = res[dom][2] if calibrated else res[dom][0]
         entry = {"config": cfgname, "kind": cfg["kind"], "hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path in (2, 3), "kernel": dom,
-                 "recurrent_layer_hbm_bytes_per_launch": int(res[dom][0] + res[dom][1]),
-                 "read_bytes_corrected": int(res[dom][0]), "write_bytes": int(res[dom][1]),
+                 "reads_per_launch": nread * paired,
+                 "recurrent_layer_hbm_bytes_per_launch": int(rd + res[dom][1]),
+                 "read_bytes": int(rd), "write_bytes": int(res[dom][1]),
+                 "read_bytes_if_fetch_size_doubled": int(res[dom][0]), "hbm_bytes_if_fetch_size_doubled": int(res[dom][0] + res[dom][1]),
+                 "fetch_size_rule": "raw (64-byte requests: calibrated on this kernel, profiles/r03_fetch_calibration.txt)" if calibrated else "doubled (MI355X_MICROARCH.md, wide coalesced reads)",
                  "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % tag}
         json.dump([entry], open(os.path.join(outdir, "%s_traffic.json" % tag), "w"), indent=1)
         print(json.dumps(entry, indent=1))
