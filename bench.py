@@ -35,12 +35,12 @@ CONFIGS = {
     "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, pair=1, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
-    "h256": dict(kind=0, hidden=256, nread=512, nsample=4000, steps=150, warmup=5, ident="r941native",
+    "h256": dict(kind=0, hidden=256, nread=768, nsample=4000, steps=100, warmup=5, ident="r941native",
                  metric="Msamples/s basecalled (r941_native 20200220-size model, 4k-sample chunks)",
-                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=512 synthetic 4000-sample reads per GPU (what one layer launch takes at H <= 256), posterior decode + trace"),
-    "c4":   dict(kind=1, hidden=256, nread=512, nsample=4000, steps=60, warmup=3, ident="r941_5mC",
+                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=768 synthetic 4000-sample reads per GPU (what one layer launch takes at H = 256: three workgroups per CU), posterior decode + trace"),
+    "c4":   dict(kind=1, hidden=256, nread=768, nsample=4000, steps=40, warmup=3, ident="r941_5mC",
                  metric="Msamples/s basecalled (r941_5mC, 4k-sample chunks)",
-                 label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=512 synthetic 4000-sample reads per GPU (what one layer launch takes at H <= 256), "
+                 label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=768 synthetic 4000-sample reads per GPU (what one layer launch takes at H = 256: three workgroups per CU), "
                        "posterior decode + trace (BASELINE.json configs[3])"),
     "c5":   dict(kind=0, hidden=512, nread=256, nsample=100000, steps=5, warmup=1, ident="r103native",
                  metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",

@@ -912,8 +912,8 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
             float *out_f32 = (l == 4 || keep) ? out : nullptr;
             for (int rt0 = 0, nrt = 0; rt0 < B16; rt0 += nrt) {
-                const int maxt = (B16 - rt0 >= maxt2) ? maxt2 : maxt1;
-                nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
+                nrt = split_next_launch_tiles(Hp, B16 - rt0, b->eng->prop.multiProcessorCount);
+                (void)maxt1; (void)maxt2;
                 // (the check-in words carry the launch's epoch: no fill between launches)
                 b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
                 // two such launches (this batch's and another's in flight) run beside each other only if ALL their workgroups fit on the chip together

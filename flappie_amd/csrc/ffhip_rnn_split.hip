@@ -900,14 +900,14 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 }
 
 template <int KIND, int N, int TS, bool DN = false>
-__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
+__global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
 k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN>(a, (int)blockIdx.x); }
 
 // The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
 // others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
 // For the dense form at H = 384: 2 x 256 reads = 16 groups = two workgroups on every CU, and ONE launch whose duration is the pair's.
 template <int KIND, int N, int TS, bool DN>
-__global__ void __launch_bounds__(512, (TS == 1 || N <= 2 || DN) ? 4 : 1)
+__global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
 k_lstm_split_pair(SplitArgs a, SplitArgsOther o) {
     int bi = (int)blockIdx.x;
     if (bi >= o.nwg0) {                                           // uniform: the second batch differs in its buffers only (same model, same shape)
@@ -1346,9 +1346,27 @@ static bool split_dense3(int kind, int H) {
     const char *e = getenv("FFHIP_SPLIT_DENSE");
     return kind == 0 && H == 384 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS");
 }
-int split_max_tiles(int ncu, int H) { return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32); }
+// H = 256 (LSTM and GRUmod): the dense pair form needs 79 registers and 53 KiB there -- THREE workgroups per CU, six 16-read recurrences,
+// 768 reads per launch (FFHIP_DENSE256=0: at most the two-workgroup form of round 2, 512 reads)
+static bool split_dense256(int H) {
+    const char *e = getenv("FFHIP_DENSE256");
+    return H == 256 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS") && !getenv("FFHIP_NO_DENSE");
+}
+int split_max_tiles(int ncu, int H) {
+    if (split_dense256(H)) return 6 * (ncu / 32);
+    return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32);
+}
+// tiles the next launch of a batch takes when `remaining` are left: the dense forms are for FULL launches only (a partly filled
+// one has a group count that is no multiple of the 8 XCDs and loses the one-L2 hand-off)
+int split_next_launch_tiles(int H, int remaining, int ncu) {
+    const int unit = ncu / 32;
+    if (split_dense256(H) && remaining >= 6 * unit) return 6 * unit;
+    if ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") && remaining >= 4 * unit) return 4 * unit;
+    return remaining < 2 * unit ? remaining : 2 * unit;
+}
 // tiles per group of a launch of nrt read tiles
 // `beside`: another batch is between run and finish -- its layer launches are on the chip; the dense form runs BESIDE them
+static bool split_launch_dense256(int H, int nrt, int ncu) { return split_dense256(H) && nrt > 4 * (ncu / 32); }
 static bool split_launch_dense3(int kind, int H, int nrt, int ncu, int beside) {
     return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || beside || getenv("FFHIP_SPLIT_DENSE_ALWAYS"));      // (the variable: development)
 }
@@ -1364,6 +1382,7 @@ static int split_launch_ts(int kind, int H, int nrt, int ncu, int beside) {
 int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside) { const int ts = split_launch_ts(kind, H, nrt, ncu, beside); return (nrt + ts - 1) / ts * 32; }
 int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside) {
     const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
+    if (split_launch_dense256(H, nrt, ncu)) return 3;
     return (ts == 1 || H <= 256 || split_launch_dense3(kind, H, nrt, ncu, beside)) ? 2 : 1;
 }
 size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
@@ -1425,6 +1444,11 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     const int ngroup_l = (nrt + ts - 1) / ts;
 #ifndef FFHIP_SPLIT_BF16X3
     if (split_launch_dense3(kind, H, nrt, ncu, beside)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
+    if (split_launch_dense256(H, nrt, ncu)) {
+        if (kind == 0) hipLaunchKernelGGL((k_lstm_split<0, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_lstm_split<1, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
+        return true;
+    }
 #endif
 #define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
                                  else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)
