@@ -891,11 +891,11 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                 const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
                 HIP_TRY(hipMemsetAsync(b->pflags, 0, split_flag_words(nrt) * sizeof(unsigned), s), FFHIP_EHIP);
                 const bool chain = 2 * ((B16 + 1) / 2) * 32 > b->eng->prop.multiProcessorCount;
-                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (b->eng->persist_chained && (chain || !b->eng->persist_last_half)) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);      // beside another launch only if BOTH are half-chip ones
                 if (!launch_rnn_split(s, r.Wsplit, b->xa, b->actS[cur ^ 1], out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
                                       backward, persist_mode, r.split_S, tbs, tbt))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
-                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
+                { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; b->eng->persist_last_half = chain ? 0 : 1; }
                 b->launches[2]++;
             }
             if (prof) hipEventRecord(b->lev[l][2], s);
@@ -921,12 +921,12 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                 // another batch is between run and finish: at H = 384 this batch's launches take the dense form, which fits beside that batch's
                 const int beside = (b->eng->in_flight - (b->counted ? 1 : 0) > 0) ? 1 : 0;
                 const bool chain = 2 * split_launch_workgroups(m->cell, Hp, nrt, ncu_, beside) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt, ncu_, beside);
-                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (b->eng->persist_chained && (chain || !b->eng->persist_last_half)) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);      // beside another launch only if BOTH are half-chip ones
                 if (prof && rt0 == 0) hipEventRecord(b->lev[l][1], s);      // behind the wait: the layer's time is its kernels', not the other batch's
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
                                        backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch, beside))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
-                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
+                { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; b->eng->persist_last_half = chain ? 0 : 1; }
                 b->launches[2]++;
             }
             if (prof) hipEventRecord(b->lev[l][2], s);
@@ -959,12 +959,12 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                 const int nrt = (B16 - rt0 < maxt) ? B16 - rt0 : maxt;
                 HIP_TRY(hipMemsetAsync(b->pflags, 0, persist_flag_words(Hp, nrt) * sizeof(unsigned), s), FFHIP_EHIP);
                 const bool chain = !b->persist_concurrent_ok;
-                if (chain && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+                if (b->eng->persist_chained && (chain || !b->eng->persist_last_half)) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);      // beside another launch only if BOTH are half-chip ones
                 const bool okl = fuse
                     ? launch_lstm_fused(s, m->cell, r.sWp, r.iWp, r.bias, in, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode, tbs, tbt)
                     : launch_rnn_persist(s, m->cell, r.sWp, b->xa, out, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt, backward, persist_mode, tbs, tbt);
                 if (!okl) return set_err(FFHIP_EINVAL, "persistent recurrent kernel: unsupported shape");
-                if (chain) { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; }
+                { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; b->eng->persist_last_half = chain ? 0 : 1; }
                 b->launches[2]++;
             }
         } else
@@ -1092,6 +1092,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
         if (!launch_lstm_split_pair(s, m->cell, m->Hp, ncu, p[0], p[1])) { paired = false; break; }
         HIP_TRY(hipEventRecord(eng->persist_done, s), FFHIP_EHIP);
         eng->persist_chained = 1;
+        eng->persist_last_half = 0;
         for (int k = 0; k < 2; k++) {
             if (prof) hipEventRecord(bb[k]->lev[l][2], s);
             bb[k]->launches[2]++;
