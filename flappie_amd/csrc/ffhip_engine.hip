@@ -573,7 +573,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->crf_logz = (double *)dalloc(b, (size_t)nread * sizeof(double), true))) BFAIL();
     if (!(b->crf_e = (double *)dalloc(b, (size_t)nread * Tb * crf_exp_stride(m->P) * sizeof(double), false))) BFAIL();
     if (!(b->post = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
-    if (!(b->fwd = (float *)dalloc(b, (size_t)2 * nread * (Tb + 1) * kMaxState * 4, false))) BFAIL();      // forward + backward vectors
+    if (!(b->fwd = (float *)dalloc(b, (size_t)2 * nread * (Tb + 1) * kFwdRowBytes, false))) BFAIL();      // forward + backward vectors
     if (!(b->tb = (uint8_t *)dalloc(b, (size_t)nread * Tb * kMaxState, false))) BFAIL();
     if (!(b->path = (int *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
     if (!(b->qpath = (float *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
@@ -990,6 +990,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     b->rnn_path = use_split ? 3 : (use_split2 ? 4 : (use_persist ? (use_fused ? 2 : 1) : 0));
     mark(b, 3);
     const bool rle = (m->kind == FFHIP_NET_LSTM5_RLE);
+    bool post_done = false;                       // the posterior came out of the partition function's launch
     if (rle) {
         // ---- globalnorm_runlengthV2 (layers.c:1325-1358)
         launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, 1.0f, 1);
@@ -1001,17 +1002,28 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
         const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
-        if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz, 1, tbs);
-        else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz, 1, tbs);
-        b->launches[3] += 3;
+        // 8-state models, a block's scores spanning at most kFbRange: ONE pair of fp64 linear-space chains per read gives logZ, the
+        // normalised scores and (when asked for) the posterior (k_crf_fb8, ffhip_decode.hip)
+        post_done = R > 0 && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) && 10.0f / temperature <= kFbRange && !getenv("FFHIP_DECODE_R2");
+        if (post_done) {
+            const bool want_post = !(flags & FFHIP_RUN_NO_DECODE) && !(flags & FFHIP_RUN_VITERBI_ONLY);
+            launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
+            mark(b, 4);       // the profile's "posterior" slot times the chain launch: partition function + normalisation + posterior together
+            launch_crf_fb(s, m->nbase, b->crf_e, b->trans, b->post, (double *)b->fwd, b->nread, Tb, b->crf_logz, tbs, want_post ? 3 : 1, nullptr);
+            b->launches[3] += 2;
+        } else {
+            if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz, 1, tbs);
+            else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz, 1, tbs);
+            b->launches[3] += 3;
+        }
     }
-    mark(b, 4);
+    if (!post_done) mark(b, 4);
     b->last_flags = flags;
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
         const float *scores = b->trans;
         if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
             if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);       // decode.c:1037-1159
-            else launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);
+            else if (!post_done) launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);
             scores = b->post;
             b->launches[4]++;
         }
@@ -1302,10 +1314,12 @@ extern "C" int ffhip_op_transpost(ffhip_engine *eng, ffhip_mat trans, int return
     TmpDev t;
     const size_t n = nblock * stride;
     const bool lazy = mat_has_dev(trans);                  // the scores live on the device: so does the posterior
-    float *d_tr = mat_in(t, trans, s), *d_po = mat_out(t, post, lazy), *d_fw = (float *)t.get(2 * (nblock + 1) * kMaxState * 4);
+    float *d_tr = mat_in(t, trans, s), *d_po = mat_out(t, post, lazy), *d_fw = (float *)t.get(2 * (nblock + 1) * kFwdRowBytes);
+    double *d_e = ((nbase == 4 && stride == 40) || (nbase == 5 && stride == 60)) ? (double *)t.get(nblock * crf_exp_stride((int)nparam) * sizeof(double)) : nullptr;
+    int *d_wide = d_e ? (int *)t.get(sizeof(int)) : nullptr;
     if (!d_tr || !d_po || !d_fw) return set_err(FFHIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemsetAsync(d_po, 0, n * 4, s), FFHIP_EHIP);
-    launch_transpost(s, d_tr, d_po, d_fw, 1, (int)nblock, nbase, (int)stride);
+    launch_transpost(s, d_tr, d_po, d_fw, 1, (int)nblock, nbase, (int)stride, nullptr, d_e, d_wide);
     if (!return_log) launch_exp_inplace(s, d_po, n);        // (the reference's exp touches pad lanes too: exp(0) = 1, as this one does)
     HIP_TRY(mat_done(post, d_po, lazy, s), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);

@@ -716,7 +716,7 @@ __device__ __forceinline__ int ff10_src_lane(int s) { return s < 5 ? 8 * s : 40 
 constexpr int kExpBlocks = 64;
 __global__ void __launch_bounds__(256)
 k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t nblk /*nread*TbS*/, int P, int Ps, int Pd, int TbS,
-          const int *__restrict__ tbs) {
+          const int *__restrict__ tbs, int *__restrict__ wide, float limit) {
     __shared__ float sc[kExpBlocks * 64];
     __shared__ float mx[kExpBlocks];
     const size_t b0 = (size_t)blockIdx.x * kExpBlocks;
@@ -725,16 +725,22 @@ k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t nblk /
     __syncthreads();
     if (threadIdx.x < nb) {
         const float *S = sc + threadIdx.x * Ps;
-        float m = S[0];
-        for (int q = 1; q < P; q++) m = fmaxf(m, S[q]);
+        float m = S[0], lo = S[0];
+        bool finite = true;
+        for (int q = 1; q < P; q++) { m = fmaxf(m, S[q]); lo = fminf(lo, S[q]); }
+        for (int q = 0; q < P; q++) finite = finite && (fabsf(S[q]) < INFINITY);
         mx[threadIdx.x] = m;
+        // a block whose scores span more than `limit` (or are not finite): its read is not for the scaled linear-space recursions of
+        // ffhip_decode.hip (their scaling lags a pair of blocks behind the values)
+        const size_t blk = b0 + threadIdx.x;
+        if (wide && !(finite && m - lo <= limit) && !(tbs && (int)(blk % TbS) >= tbs[blk / TbS])) atomicOr(&wide[blk / TbS], 1);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb * Pd; i += 256) {
         const int k = i / Pd, p = i % Pd;
-        if (p > P) continue;
         const size_t blk = b0 + k;
         if (tbs && (int)(blk % TbS) >= tbs[blk / TbS]) continue;
+        if (p > P) { E[blk * Pd + p] = 0.0; continue; }          // the row's padding reads as "no such transition" (ffhip_decode.hip)
         E[blk * Pd + p] = (p == P) ? (double)mx[k] : exp((double)sc[k * Ps + p] - (double)mx[k]);
     }
 }
@@ -975,11 +981,17 @@ k_crf_chain10(const double *__restrict__ E, int TbS, int Pd, int R, double *__re
     if (lane == 0) logz_out[blockIdx.x] = logZ;
 }
 
+void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit) {
+    const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
+    const size_t nblk = (size_t)nread * Tb;
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, wide, limit);
+}
+
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
                             double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
     const size_t nblk = (size_t)nread * Tb;
-    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs);
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, (int *)nullptr, 0.0f);
     const int Rr = R < 1 ? 1 : R;
     if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
         hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
@@ -1082,8 +1094,9 @@ k_transpost(const float *__restrict__ trans, float *__restrict__ post, float *__
 // arithmetic per value as a single-wave walk; the dependent chain is halved.
 __global__ void __launch_bounds__(256)
 k_transpost8(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int TbS,
-             const int *__restrict__ tbs) {
+             const int *__restrict__ tbs, const int *__restrict__ only) {
     constexpr int P = 40, Ps = 40, ns = 8;
+    if (only && !only[blockIdx.x]) return;               // the reads k_crf_fb8 has left (score range too wide for its linear form)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
     float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
@@ -1387,8 +1400,9 @@ k_transpost_lds(const float *__restrict__ trans, float *__restrict__ post, float
 // association); k_transpost_lds keeps the reference's order of the sums (FFHIP_EXACT_ORDER, other nstate).
 __global__ void __launch_bounds__(256)
 k_transpost10(const float *__restrict__ trans, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int TbS,
-              int Ps, const int *__restrict__ tbs) {
+              int Ps, const int *__restrict__ tbs, const int *__restrict__ only) {
     constexpr int P = 60, ns = 10, nbase = 5, off = 50;
+    if (only && !only[blockIdx.x]) return;               // the reads k_crf_fb<10> has left (score range too wide for its linear form)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *T = trans + (size_t)blockIdx.x * TbS * Ps;
     float *Pp = post + (size_t)blockIdx.x * TbS * Ps;
@@ -1515,12 +1529,22 @@ k_transpost10(const float *__restrict__ trans, float *__restrict__ post, float *
     }
 }
 
-void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs) {
+void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs,
+                      double *E, int *wide) {
     const int P = 2 * nbase * (nbase + 1);
-    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
-        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs);
+    if (((nbase == 4 && Ps == 40) || (nbase == 5 && Ps == 60)) && E && wide && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_DECODE_R2")) {
+        // linear-space fp64 recursions on exp(score - block max) (ffhip_decode.hip); reads whose scores span too much keep the log-space kernel
+        hipMemsetAsync(wide, 0, (size_t)nread * sizeof(int), s);
+        launch_crf_exp(s, trans, E, nread, Tb, nbase, Ps, tbs, wide, kFbRange);
+        launch_crf_fb(s, nbase, E, (float *)trans, post, (double *)fwd, nread, Tb, nullptr, tbs, 2, wide);
+        if (nbase == 4)
+            hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs, (const int *)wide);
+        else
+            hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs, (const int *)wide);
+    } else if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
+        hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs, (const int *)nullptr);
     else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_CRF_GENERIC"))
-        hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs);
+        hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs, (const int *)nullptr);
     else if (!getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps, tbs);
     else
@@ -1888,8 +1912,12 @@ k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
                     int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    if (nbase == 4 && Ps == 40)
+    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2"))
+        launch_viterbi8x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
+    else if (nbase == 4 && Ps == 40)
         hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+    else if (nbase == 5 && Ps == 60 && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_DECODE_R2"))
+        launch_viterbi10x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
     else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER"))
         hipLaunchKernelGGL(k_viterbi10, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, Ps, tbs);
     else
