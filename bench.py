@@ -543,7 +543,9 @@ def main():
                                "(profiles/r02_c2_inflight1_bench.json)"),
             # decode side (posterior + Viterbi + assembly + trace): algorithmic bytes per block (SURVEY.md section 8d:
             # 4P read + nstate traceback + 8 path/qpath, plus 4P read + 4P write for the posterior) against HBM peak.
-            # At 256 reads these kernels are latency-bound chains, not bandwidth-bound.
+            # At 256 reads these kernels are latency-bound chains, not bandwidth-bound.  For the 8- and 10-state models the
+            # "posterior" time is the launch of k_crf_fb + k_post_fb: the partition function's chain, the normalisation and
+            # the posterior together (they share the chains), so this rate is a lower bound of the decode side's own.
             "decode_hbm": {"achieved": round(float(NREAD) * nblock * bytes_per_block / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else None,
                            "peak": 8000.0, "unit": "GB/s", "bytes_per_block": bytes_per_block, "ms": round(dec_ms, 4)},
         }

@@ -536,10 +536,12 @@ void launch_gru_step(hipStream_t s, const float4 *sWp, const float *xa_t, const 
 
 // ---- CRF head: trans[r][blk][p] = tanh(W^T h + b) / (temperature/5) --------------------------
 // layers.c:1084-1087 (+ shift_scale_matrix_inplace flappie_matrix.c:625-633: a true division).
+// TM = row tiles of 16 outputs a wave carries: 3 for the 40 scores of the 4-base models, 4 for 60 (5 bases) and the run-length head
+template <int TM>
 __global__ void __launch_bounds__(256)
 k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__restrict__ Wp,
        const float *__restrict__ bias, int Tb, int B16, int nread, int P, int Ps, int Mt, int K16, float scale, int raw) {
-    constexpr int TM = 4, TN = 4;
+    constexpr int TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntile = Tb * B16;
     const int nt0 = (blockIdx.x * 4 + wave) * TN;
@@ -586,8 +588,12 @@ void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw) {
     const int Mt = (P + 15) / 16;
     const int ntile = Tb * B16;
-    hipLaunchKernelGGL(k_head, dim3((ntile + 15) / 16), dim3(256), 0, s, in, trans, (const v4f *)Wp, bias, Tb, B16,
-                       nread, P, Ps, Mt, K16, scale, raw);
+    if (Mt <= 3)
+        hipLaunchKernelGGL(k_head<3>, dim3((ntile + 15) / 16), dim3(256), 0, s, in, trans, (const v4f *)Wp, bias, Tb, B16,
+                           nread, P, Ps, Mt, K16, scale, raw);
+    else
+        hipLaunchKernelGGL(k_head<4>, dim3((ntile + 15) / 16), dim3(256), 0, s, in, trans, (const v4f *)Wp, bias, Tb, B16,
+                           nread, P, Ps, Mt, K16, scale, raw);
 }
 
 // ---- CRF partition function + global normalisation -------------------------------------------

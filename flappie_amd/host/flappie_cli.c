@@ -219,7 +219,8 @@ typedef struct {
 
 /* Batch objects own gigabytes of workspace; creating one per group costs more than running it.  Full-size groups
  * (--batch reads) share one cached object whose capacity grows when a longer read turns up. */
-static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache[2];       /* two: one batch runs while the next is set up */
+#define NINFLIGHT 3                    /* batches submitted and not collected, at most: two stay on the GPU while the third is set up */
+static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache[NINFLIGHT];
 
 /* *nslot = reads the returned batch was created for: args.batch for the cached objects (groups of at least a quarter of
  * that are padded with empty slots), the group's own size for small groups */
@@ -498,11 +499,13 @@ static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
     __atomic_store_n(&c->live, 0, __ATOMIC_RELEASE);
 }
 
-/* the pipeline's state: at most one batch submitted and not collected; chunks finish (are written) strictly in order */
-#define NCHUNKBUF 3
+/* the pipeline's state: up to NINFLIGHT - 1 batches submitted and not collected (oldest first) while the next is submitted -- the GPU
+ * runs two batches' layer launches beside each other, so two must still be there while this thread prepares
+ * and submits a third; chunks finish (are written) strictly in order */
+#define NCHUNKBUF 4
 static struct {
-    pending_batch prev;
-    int have_prev, slot;
+    pending_batch fifo[NINFLIGHT - 1];
+    int nfifo, slot;
     chunk_ctx ctx[NCHUNKBUF];
     long next_finish, nbegun;            /* chunk sequence numbers; chunk q lives in ctx[q % NCHUNKBUF] */
     void (*released)(int buf, void *arg);
@@ -570,13 +573,19 @@ static void writer_finish(void) {
     pthread_join(writer.th, NULL);
 }
 
-static void pipe_collect_prev(const struct ffhip_model *mdl, hid_t hdf5out) {
-    if (!pipe_state.have_prev) return;
-    chunk_ctx *owner = pipe_state.prev.owner;
-    collect_batch(mdl, &pipe_state.prev);
-    pipe_state.have_prev = 0;
+/* collect the oldest batch in flight */
+static void pipe_collect_oldest(const struct ffhip_model *mdl, hid_t hdf5out) {
+    if (0 == pipe_state.nfifo) return;
+    pending_batch old = pipe_state.fifo[0];
+    for (int k = 1; k < pipe_state.nfifo; k++) pipe_state.fifo[k - 1] = pipe_state.fifo[k];
+    pipe_state.nfifo--;
+    chunk_ctx *owner = old.owner;
+    collect_batch(mdl, &old);
     owner->collected++;
     pipe_finish_ready(hdf5out);
+}
+static void pipe_collect_all(const struct ffhip_model *mdl, hid_t hdf5out) {
+    while (pipe_state.nfifo) pipe_collect_oldest(mdl, hdf5out);
 }
 
 static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out) {
@@ -596,17 +605,18 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         pending_batch cur = submit_batch(eng, mdl, c->prep, c->group + i, g, pipe_state.slot);
         cur.owner = c;
         c->submitted++;
-        pipe_collect_prev(mdl, hdf5out);           /* may complete and write the previous chunk */
-        pipe_state.prev = cur;
-        pipe_state.have_prev = 1;
-        pipe_state.slot ^= 1;
+        static int depth = 0;                         /* FLAPPIE_INFLIGHT=2: one batch runs while the next is set up (rounds 1-2) */
+        if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 2) ? 1 : NINFLIGHT - 1; }
+        while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);           /* may complete and write an earlier chunk */
+        pipe_state.fifo[pipe_state.nfifo++] = cur;
+        pipe_state.slot = (pipe_state.slot + 1) % NINFLIGHT;
         i += g;
     }
     c->all_submitted = 1;
     /* A chunk without a single batch (every read failed) collects nothing on its own account: the batch still in flight belongs
      * to an OLDER chunk, whose reader buffer is only released when it is written -- two such chunks in a row and the reader
      * thread would wait for that buffer while this thread waits for the reader.  Collect it now. */
-    if (0 == c->m2) pipe_collect_prev(mdl, hdf5out);
+    if (0 == c->m2) pipe_collect_all(mdl, hdf5out);
     pipe_finish_ready(hdf5out);
 }
 
@@ -621,7 +631,7 @@ static void pipe_wait_slot_written(void) {
 }
 
 static void pipe_drain(const struct ffhip_model *mdl, hid_t hdf5out) {
-    pipe_collect_prev(mdl, hdf5out);
+    pipe_collect_all(mdl, hdf5out);
     pipe_finish_ready(hdf5out);
     writer_finish();
 }
@@ -671,7 +681,7 @@ static void list_files(file_list *fl) {
 typedef struct {
     const file_list *fl;
     int chunk_cap;
-    item *items[NCHUNKBUF];              /* one more than the two chunks that can be unfinished at a time */
+    item *items[NCHUNKBUF];              /* one more than the chunks that can be unfinished at a time (one per batch in flight) */
     int nitem[NCHUNKBUF];
     sem_t filled[NCHUNKBUF], empty[NCHUNKBUF];
 } reader_state;
@@ -884,7 +894,7 @@ int main(int argc, char *argv[]) {
     free(fl.path);
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);
-    for (int k = 0; k < 2; k++) if (batch_cache[k].b) ffhip_batch_destroy(batch_cache[k].b);
+    for (int k = 0; k < NINFLIGHT; k++) if (batch_cache[k].b) ffhip_batch_destroy(batch_cache[k].b);
     if (getenv("FLAPPIE_CLI_TIMING")) {
         for (int k = 0; k < 8; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
         fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
