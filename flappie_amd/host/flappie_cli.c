@@ -219,7 +219,7 @@ typedef struct {
 
 /* Batch objects own gigabytes of workspace; creating one per group costs more than running it.  Full-size groups
  * (--batch reads) share one cached object whose capacity grows when a longer read turns up. */
-#define NINFLIGHT 3                    /* batches submitted and not collected, at most: two stay on the GPU while the third is set up */
+#define NINFLIGHT 3                    /* batches submitted and not collected, at most (FLAPPIE_INFLIGHT=3; default 2) */
 static struct { ffhip_batch *b; int nread; size_t cap; } batch_cache[NINFLIGHT];
 
 /* *nslot = reads the returned batch was created for: args.batch for the cached objects (groups of at least a quarter of
@@ -499,9 +499,8 @@ static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
     __atomic_store_n(&c->live, 0, __ATOMIC_RELEASE);
 }
 
-/* the pipeline's state: up to NINFLIGHT - 1 batches submitted and not collected (oldest first) while the next is submitted -- the GPU
- * runs two batches' layer launches beside each other, so two must still be there while this thread prepares
- * and submits a third; chunks finish (are written) strictly in order */
+/* the pipeline's state: up to NINFLIGHT - 1 batches submitted and not collected (oldest first) while the next is submitted (by default
+ * one: a batch runs while the next is set up); chunks finish (are written) strictly in order */
 #define NCHUNKBUF 4
 static struct {
     pending_batch fifo[NINFLIGHT - 1];
@@ -605,8 +604,11 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         pending_batch cur = submit_batch(eng, mdl, c->prep, c->group + i, g, pipe_state.slot);
         cur.owner = c;
         c->submitted++;
-        static int depth = 0;                         /* FLAPPIE_INFLIGHT=2: one batch runs while the next is set up (rounds 1-2) */
-        if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 2) ? 1 : NINFLIGHT - 1; }
+        /* default: one batch runs while the next is set up.  FLAPPIE_INFLIGHT=3 keeps two on the GPU while the third is set up: no
+         * measurable gain on 4000-sample reads (80-92 against 84-87 Msamples/s, run-to-run noise), and a third batch object costs
+         * long reads another 10+ GB of workspace and ~1 s of start-up */
+        static int depth = 0;
+        if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
         while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);           /* may complete and write an earlier chunk */
         pipe_state.fifo[pipe_state.nfifo++] = cur;
         pipe_state.slot = (pipe_state.slot + 1) % NINFLIGHT;
