@@ -566,7 +566,9 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     b->hT.assign(nread, b->T);
     b->hTb.assign(nread, b->Tb);
     const size_t Tb = b->Tb, Bp = b->Bp, Hp = m->Hp, Ps = m->Ps, ns = m->nstate;
-    for (int i = 0; i < 2; i++) if (!(b->act[i] = (float *)dalloc(b, Tb * Bp * Hp * 4, false))) BFAIL();
+    // b->act[0 / 1] (fp32 activations, Tb * Bp * Hp * 4 bytes each: 10.5 GB for 256 reads of 100 000 samples at H = 512) are allocated by the
+    // first run that needs them: the default path writes the last convolution and the layers in the split layout and only the last layer's fp32
+    // copy (act[1], what the head reads)
     // b->xa (gate pre-activations, 4x the size of an activation buffer) exists only on the unfused path: allocated on first use
     if (!(b->cstate = (float *)dalloc(b, Bp * Hp * 4, true))) BFAIL();
     if (!(b->trans = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
@@ -829,6 +831,11 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     int cur = b->run_cur;
+    {
+        const bool need0 = !conv_split;           // the convolution's fp32 output (every path but split layers behind a split-writing convolution)
+        for (int i = need0 ? 0 : 1; i < 2; i++)
+            if (!b->act[i] && !(b->act[i] = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4, false))) return FFHIP_ENOMEM;
+    }
   if (phases & PH_FRONT) {
     if (use_split || use_split2) {
         const size_t bytes = split_bytes((size_t)Tb * B16, Hp);
