@@ -483,7 +483,7 @@ def test_globalnorm_and_partition_function(L, nbase, H, T):
     got = L.crf_manystay_partition_function(mk(L, s))
     assert abs(got - want) <= 1e-9 * max(1.0, abs(want))
     assert L.nbase_from_flipflop_nparam(P) == nbase
-    # the pipeline's scaled linear-space recursion gives the same fp64 number (ffhip_kernels.hip k_crf_chain)
+    # the pipeline's scaled linear-space recursion gives the same fp64 number (ffhip_decode.hip: the forward chain of k_crf_fb; bounds beyond kFbRange / 2: k_crf_chain)
     from flappie_amd import binding as B
 
     class FMat(C.Structure):
