@@ -543,10 +543,13 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #if FFHIP_EXP & 128
             __builtin_amdgcn_s_sleep(48);
 #endif
+            TL(0);
             if (i + 1 < Tb) project_step(i + 1, i + 1);
             sink ^= touched;
             touch_x(i + WARM);
+            TL(2);
             raw_barrier();
+            TL(3);
             const int aborted = *(volatile int *)&lds_abort;      // (looked at behind the gate math: see the h waves' loop)
             if (sg_front) {
                 __builtin_amdgcn_s_setprio(3);
@@ -555,7 +558,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
             else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
             if (aborted) return;
+            TL(4);
             raw_barrier();                                   // closes the gate phase
+            TL(5);
         }
         if (sink == 0x9e3779b9u && a.Tb < 0) a.flags[0] = sink;
         }

@@ -28,7 +28,7 @@ int main(int argc, char **argv) {
         hipMemset(flags, 0, 4096 * 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        launch_lstm_split(0, 0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode);   // mode & 2: x waves skip their MFMAs (timing experiment)
+        launch_lstm_split(0, 0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode, 0, 0, nullptr, nullptr, 256, (unsigned)(rep + 1), 0);   // B16 = 32 at H = 384: the dense form, two workgroups per CU
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep < 2 || rep >= nrep - 2) printf("rep %d: layer %.3f ms = %.3f us/step = %.0f cycles/step\n", rep, ms, ms * 1e3 / Tb, ms * 1e3 / Tb * 2400);
@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
     std::vector<unsigned long long> h(ndbg);
     hipMemcpy(h.data(), dbg, ndbg * 8, hipMemcpyDeviceToHost);
     auto T = [&](int b, int w, int st, int k) { return h[(((size_t)b * 8 + w) * 32 + st) * 16 + k]; };
-    for (int b : { 0, 8 }) {
+    for (int b : { 0, 8, 256 }) {
         if (b >= nwg) continue;
         const unsigned long long base = T(b, 0, 0, 0);
         for (int st = 0; st < 3; st++)
