@@ -270,15 +270,21 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
         env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1")
         res = []
         for n in (n_short, nfiles):
-            if dist is not None:
-                dist.barrier()
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "--readers", str(readers), "--shard", "%d/%d" % (rank, world), "--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % rank),
-                                os.path.join(d, "reads")], env=env, capture_output=True, text=True)
-            dt = time.perf_counter() - t0
-            called = [ln for ln in r.stderr.splitlines() if ln.startswith("basecalled:")]
-            reads, samples, raw = (int(x) for x in (called[-1].replace(",", " ").split()[1], called[-1].split()[3], called[-1].split()[7])) if called else (0, 0, 0)
-            res.append((r.returncode, dt, reads, samples, raw))
+            best = None
+            for _rep in range(2):               # the faster of two runs each: a single run's wall varies by +-5 % (process and HIP start-up)
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "--readers", str(readers), "--shard", "%d/%d" % (rank, world), "--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % rank),
+                                    os.path.join(d, "reads")], env=env, capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                called = [ln for ln in r.stderr.splitlines() if ln.startswith("basecalled:")]
+                reads, samples, raw = (int(x) for x in (called[-1].replace(",", " ").split()[1], called[-1].split()[3], called[-1].split()[7])) if called else (0, 0, 0)
+                if best is None or r.returncode != 0 or (best[0] == 0 and dt < best[1]):
+                    best = (r.returncode, dt, reads, samples, raw)
+                if r.returncode != 0:
+                    break
+            res.append(best)
         ok = gen.returncode == 0 and all(x[0] == 0 for x in res) and res[1][2] == nfiles and res[0][2] == n_short
         d_t, d_samples, d_raw = res[1][1] - res[0][1], res[1][3] - res[0][3], res[1][4] - res[0][4]
         mine = {"rank": rank, "ok": bool(ok), "marginal_s": d_t, "samples": d_samples, "raw_samples": d_raw, "long_run_s": res[1][1], "short_run_s": res[0][1],
@@ -297,7 +303,7 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
                    "fixed_cost_s": round(res[0][1] - n_short * (d_t / max(1, nfiles - n_short)), 3),
                    "note": "flappie binary per rank: --shard rank/%d over one directory of %d generated single-read fast5 files (3500-5500 raw samples), "
                            "--readers %d (host cores %d / ranks %d), FASTQ out; raw samples of files [%d, %d) of each shard / the slowest rank's time between a "
-                           "%d-file and a %d-file run; generation %.1f s (not timed)" % (world, world * nfiles, readers, ncore, world, n_short, nfiles, n_short, nfiles, t_gen)}
+                           "%d-file and a %d-file run (the faster of two runs each); generation %.1f s (not timed)" % (world, world * nfiles, readers, ncore, world, n_short, nfiles, n_short, nfiles, t_gen)}
     finally:
         if dist is not None:
             dist.barrier()

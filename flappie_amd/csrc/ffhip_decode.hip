@@ -242,11 +242,11 @@ k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__re
     const bool want_post = (flags & 2) != 0;
     if (wave == 0) {
         if (want_post && lane < NS) F[lane] = 1.0;
-        fb_chain<NS, true>(Er, Tb, ebuf[0], stage[0], F, want_post && !(flags & 16), &s_logz);
+        fb_chain<NS, true>(Er, Tb, ebuf[0], stage[0], F, want_post, &s_logz);
         if (lane == 0 && logz_out) logz_out[blockIdx.x] = s_logz;
-    } else if (want_post && !(flags & 8)) {
+    } else if (want_post) {
         if (lane < NS) Bw[(size_t)Tb * NS + lane] = 1.0;
-        fb_chain<NS, false>(Er, Tb, ebuf[1], stage[1], Bw, !(flags & 16), nullptr);
+        fb_chain<NS, false>(Er, Tb, ebuf[1], stage[1], Bw, true, nullptr);
     }
 }
 
@@ -326,16 +326,15 @@ k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__r
 // flags: 1 = subtract (float)(logZ / Tb) from the scores, 2 = posterior wanted; logz: device doubles per read (required with flags & 1)
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
                    int flags, const int *wide) {
-    if (const char *e = getenv("FFHIP_FB_EXP")) flags |= atoi(e) & ~3;       // timing experiments: 4 no assembly, 8 no backward chain, 16 no vector stores
     const int NS = 2 * nbase;
     double *bwd = fwd + (size_t)nread * (Tb + 1) * NS;
     const dim3 grid((Tb + kPostBlocks - 1) / kPostBlocks, nread);
     if (nbase == 4) {
         hipLaunchKernelGGL(k_crf_fb<8>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide);
-        if ((flags & 3) && !(flags & 4)) hipLaunchKernelGGL(k_post_fb<8>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
+        if (flags & 3) hipLaunchKernelGGL(k_post_fb<8>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
     } else {
         hipLaunchKernelGGL(k_crf_fb<10>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide);
-        if ((flags & 3) && !(flags & 4)) hipLaunchKernelGGL(k_post_fb<10>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
+        if (flags & 3) hipLaunchKernelGGL(k_post_fb<10>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
     }
 }
 

@@ -55,6 +55,7 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
+    HIP_TRY(hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming), (delete e, nullptr));
     return e;
 }
 
@@ -150,6 +151,7 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     for (int i = 0; i < 4; i++) if (e->prep_scratch[i]) hipFree(e->prep_scratch[i]);
     for (auto &b : e->prep_pool) hipFree(b.first);
     if (e->persist_done) hipEventDestroy(e->persist_done);
+    if (e->batch_done) hipEventDestroy(e->batch_done);
     delete e;
 }
 
@@ -464,6 +466,7 @@ struct ffhip_batch {
     int run_cur = 0;                    // which of act[] / actS[] holds the current activations between the phases of a run
     unsigned run_flags = 0;
     int paired_last = 0;                // the last run's layers were one launch with another batch's
+    int pair_front = 0;                 // set by ffhip_batch_run_pair around the front phase: the layers to come are a paired (chip-filling) launch
     int profiled = 0;
 };
 
@@ -849,7 +852,20 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // another batch is between run and finish: its layer launches hold 384 of every SIMD's 512 registers, so this batch's last
     // convolution takes the shape that fits in what is left (FFHIP_LEAN_CONV=0 / 1 forces one)
     const char *lean_env = getenv("FFHIP_LEAN_CONV");
-    const int lean_conv = lean_env ? (lean_env[0] == '1') : (b->eng->in_flight - (b->counted ? 1 : 0) > 0);
+    // ... unless this batch's own layer launches fill the chip (a paired launch; a full launch of the dense forms; H = 512): the layer
+    // launches of whatever else is in flight do too, the convolution only ever shares the chip with other batches' convolutions and
+    // decodes, and the fat shape is the faster one there (in pairs at H = 384: 0.98 -> 0.6 ms per batch)
+    bool full_chip = b->pair_front != 0 || use_split2;
+    if (use_split && !full_chip) {
+        const int ncu_ = b->eng->prop.multiProcessorCount, beside_ = (b->eng->in_flight - (b->counted ? 1 : 0) > 0) ? 1 : 0;
+        const int nrt_ = split_next_launch_tiles(Hp, B16, ncu_);
+        full_chip = 2 * split_launch_workgroups(m->cell, Hp, nrt_, ncu_, beside_) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt_, ncu_, beside_);
+    }
+    const int lean_conv = lean_env ? (lean_env[0] == '1') : (!full_chip && b->eng->in_flight - (b->counted ? 1 : 0) > 0);
+    // Whole batches one after the other when this batch's layer launches fill the chip and it is not half of a pair: its convolutions
+    // would otherwise run beside the other batch's layer launches, whose workgroups then wait for slots (h256 with two 768-read batches
+    // in flight: 160 against 179 Msamples/s one at a time; c4: 65.5 against 75).  The host side still overlaps: this only orders the GPU.
+    if (full_chip && !b->pair_front && b->eng->batch_done_rec && !getenv("FFHIP_NO_BATCH_ORDER")) HIP_TRY(hipStreamWaitEvent(s, b->eng->batch_done, 0), FFHIP_EHIP);
     for (int l = 0; l < m->nconv; l++) {
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
@@ -1056,6 +1072,8 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         mark(b, 5);
     }
     mark(b, 6);
+    HIP_TRY(hipEventRecord(b->eng->batch_done, s), FFHIP_EHIP);
+    b->eng->batch_done_rec = 1;
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     b->ran = 1; b->finished = 0;
     if (!b->counted) { b->counted = 1; b->eng->in_flight++; }
@@ -1084,8 +1102,10 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
         return ffhip_batch_run(b1, temperature, flags);
     }
     hipSetDevice(eng->device);
-    if (int rc = batch_run_impl(b0, temperature, flags, PH_FRONT)) return rc;
-    if (int rc = batch_run_impl(b1, temperature, flags, PH_FRONT)) return rc;
+    b0->pair_front = b1->pair_front = 1;
+    const int rc0 = batch_run_impl(b0, temperature, flags, PH_FRONT), rc1 = rc0 ? rc0 : batch_run_impl(b1, temperature, flags, PH_FRONT);
+    b0->pair_front = b1->pair_front = 0;
+    if (rc1) return rc1;
     hipStream_t s = b0->stream;
     HIP_TRY(hipEventRecord(b1->pair_ev, b1->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamWaitEvent(s, b1->pair_ev, 0), FFHIP_EHIP);              // the second batch's convolutions are done before the first paired layer

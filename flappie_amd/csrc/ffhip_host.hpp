@@ -19,6 +19,8 @@ struct ffhip_engine {
     // launches are chained through this event.
     hipEvent_t persist_done = nullptr;
     int persist_chained = 0;
+    hipEvent_t batch_done = nullptr;     // end of the last submitted batch (any stream): see batch_run_impl, "whole batches one after the other"
+    int batch_done_rec = 0;
     int persist_last_half = 0;  // the engine's last persistent launch left room for a twin of its size: only then may the next half-chip launch run beside it
     // A persistent layer kernel whose workgroups are not all resident (another tenant on the GPU, e.g. a second flappie
     // process) gives up through its bounded waits (abort word).  ffhip_batch_finish then re-runs the batch on the

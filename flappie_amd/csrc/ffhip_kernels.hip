@@ -281,7 +281,7 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
 // SIMD leave 128): with two batches in flight the big shape only ran in the gaps between the other batch's launches and its
 // remainder (~0.35 ms) stood between that batch's last layer and this batch's first.
 template <int TM, int TN>
-__global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : ((TM * TN <= 8) ? 3 : 2))      // (waves per SIMD; <4, 4> at 1 took 216 + 64 registers and ran ONE wave per SIMD)
+__global__ void __launch_bounds__(256, 2)      // (two waves per SIMD for both shapes; <4, 4> without a bound took 216 + 64 registers and ran ONE wave per SIMD.  Measured and dropped: <4, 2> and <2, 4> at three waves per SIMD, 0.39 and 0.52 ms against 0.30)
 k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int NC, int winlen, int act, int ldp,
              unsigned char *__restrict__ out_split, float split_scale, float acc_scale) {
@@ -386,25 +386,6 @@ void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, 
                        int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean) {
     const int Mt = M / 16, NC = (winlen + 1) / 2;
     if (lean) {
-        const int nMblk = (Mt + 3) / 4, nNblk = (Tout * B16 + 3) / 4;
-        hipLaunchKernelGGL((k_conv_split<2, 2>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
-                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
-        return;
-    }
-    static const int shape = getenv("FFHIP_CONV_SHAPE") ? atoi(getenv("FFHIP_CONV_SHAPE")) : 44;
-    if (shape == 42) {
-        const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 3) / 4;
-        hipLaunchKernelGGL((k_conv_split<4, 2>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
-                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
-        return;
-    }
-    if (shape == 24) {
-        const int nMblk = (Mt + 3) / 4, nNblk = (Tout * B16 + 7) / 8;
-        hipLaunchKernelGGL((k_conv_split<2, 4>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
-                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
-        return;
-    }
-    if (shape == 22) {
         const int nMblk = (Mt + 3) / 4, nNblk = (Tout * B16 + 3) / 4;
         hipLaunchKernelGGL((k_conv_split<2, 2>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
                            (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
