@@ -509,8 +509,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 load_x_tile(i, ts);
 #pragma unroll
                 for (int j = 0; j < N; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#if !(FFHIP_SPLIT_ABLATE & 1)          // 1 = x waves issue no MFMAs
 #pragma unroll
                 for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[cc], acc[ts]);
+#endif
             }
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
@@ -792,8 +794,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     unsigned seen = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
                     if constexpr (DN) {
+#if !(FFHIP_SPLIT_ABLATE & 8)          // 8 = no sweep: operands are whatever the landing zone holds
 #pragma unroll
-                        for (int ts = 0; ts < 2; ts++)
+                        for (int ts = 0; ts < ((FFHIP_SPLIT_ABLATE & 128) ? 1 : 2); ts++)      // 128 = only the first tile is swept (the CU's L2 port carries half)
 #pragma unroll
                             for (int k = 0; k < N; k++) {
 #pragma unroll
@@ -802,6 +805,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                                                              lane_off, ts * offB + ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
                                 if (ts * N + k + 1 < 2 * N) __builtin_amdgcn_s_sleep(1);
                             }
+#endif
                         const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
                         v4u r[2][NS];
                         auto fetch = [&](int c) {           // (tile, chunk) c = ts * N + k has landed -> issue its two LDS reads
