@@ -160,7 +160,8 @@ def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monk
     dm.close()
 
 
-@pytest.mark.parametrize("kind,hidden,nread", [(M.NET_LSTM5, 384, 256), (M.NET_LSTM5, 256, 512), (M.NET_GRUMOD5, 256, 256)])
+# (384 x 512 and 256 x 768: every layer launch fills the chip -- such batches run one after the other on the GPU, ffhip_engine.hip "whole batches")
+@pytest.mark.parametrize("kind,hidden,nread", [(M.NET_LSTM5, 384, 256), (M.NET_LSTM5, 256, 512), (M.NET_GRUMOD5, 256, 256), (M.NET_LSTM5, 384, 512), (M.NET_LSTM5, 256, 768)])
 def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, nread):
     """bench.py's default at c2 and the flappie binary keep two batches in flight (one stream each; the persistent layer launches of
     the two are chained, every other kernel overlaps the other batch's layers).  Three rounds of run / run / finish / finish with
