@@ -88,6 +88,10 @@ template <int NS> __device__ __forceinline__ int ff_entry(int to, int from) { re
 template <int NS> __device__ __forceinline__ bool ff_has(int to, int from) { return to < NS / 2 || from == to || from == to - NS / 2; }
 __device__ __forceinline__ int ff8_entry(int to, int from) { return ff_entry<8>(to, from); }
 __device__ __forceinline__ bool ff8_has(int to, int from) { return ff_has<8>(to, from); }
+// TOPO 1: the run-length model's 8 states (4 move + 4 stay) in the same square: move state b1 is entered from every state of another base (entry 8 b1 + from of
+// a block's 32 transition scores), stay state 4 + b from the move and the stay state of its own base (entry 8 b + from)
+template <int TOPO> __device__ __forceinline__ int vit_entry(int to, int from) { return TOPO == 0 ? ff8_entry(to, from) : (to < 4 ? 8 * to + from : 8 * (to - 4) + from); }
+template <int TOPO> __device__ __forceinline__ bool vit_has(int to, int from) { return TOPO == 0 ? ff8_has(to, from) : (to < 4 ? (from & 3) != to : (from & 3) == to - 4); }
 
 // ---- partition function + normalisation + posterior ---------------------------------------------------------------------------
 // NS = 8: the square is the whole block.  NS = 10 (the 5-base models): the square carries states 0..7 and a second vector x the states
@@ -97,31 +101,36 @@ __device__ __forceinline__ bool ff8_has(int to, int from) { return ff_has<8>(to,
 //     x'    = reduce(f1 * x + f2 * a)        in the lanes whose out-position is 3 or 4: f1 extra -> extra (stay), f2 main source -> extra
 // and x' lands at positions 3, 4 of the form main' lands in.  Two independent reductions per step; everything else as for NS = 8.
 constexpr int kFbChunk = 32;             // blocks of E staged in LDS per chunk and direction
-template <int NS> struct FbDims {
-    static constexpr int P = NS * (NS / 2 + 1);
+template <int NS, int TOPO = 0> struct FbDims {
+    static constexpr int P = TOPO == 1 ? 32 : NS * (NS / 2 + 1);
     static constexpr int Pd = (P + 1 + 7) & ~7;               // crf_exp_stride(P): P entries, the block maximum at [P], zeros behind it
     static constexpr int kStage = kFbChunk * Pd / 64;         // doubles per lane and chunk
     static constexpr int pad = P + 1;                         // an entry that reads as zero
 };
 
 // coefficient index of "in-state -> out-state" for one direction: forwards out = to, in = from; backwards out = from, in = to
-template <int NS, bool FWD> __device__ __forceinline__ int fb_coef(int out, int in) {
+template <int NS, bool FWD, int TOPO = 0> __device__ __forceinline__ int fb_coef(int out, int in) {
     const int to = FWD ? out : in, from = FWD ? in : out;
-    return (to < NS && from < NS && ff_has<NS>(to, from)) ? ff_entry<NS>(to, from) : FbDims<NS>::pad;
+    if constexpr (TOPO == 1) return (to < NS && from < NS && vit_has<1>(to, from)) ? vit_entry<1>(to, from) : FbDims<NS, 1>::pad;
+    else return (to < NS && from < NS && ff_has<NS>(to, from)) ? ff_entry<NS>(to, from) : FbDims<NS>::pad;
 }
 
 // One direction of the recursion, one wave.  q counts the blocks in the order they are processed (forwards: block q, backwards:
 // block Tb - 1 - q); even q are lo steps, odd q hi steps.  `vec` receives the vector after every block: forwards vec[(q + 1) * NS],
 // backwards vec[(Tb - 1 - q) * NS]; the caller has written the all-ones start vector.
-template <int NS, bool FWD>
-__device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const int Tb, double *__restrict__ ebuf, double (*__restrict__ stage)[NS],
+// TOPO 1 (run-length model: its posterior is NOT normalised per block, decode.c:1037-1159): rows of 10 doubles -- the vector and, in [8], the offset C with
+// log(true value) = log(stored) + C (ln2 times the powers of two taken out so far + the block maxima so far), tracked in both directions.
+template <int NS, bool FWD, int TOPO = 0>
+__device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const int Tb, double *__restrict__ ebuf, double (*__restrict__ stage)[TOPO == 1 ? 10 : NS],
                                          double *__restrict__ vec, const bool store, double *__restrict__ logz) {
-    constexpr int Pd = FbDims<NS>::Pd, P = FbDims<NS>::P, kStage = FbDims<NS>::kStage;
+    constexpr int Pd = FbDims<NS, TOPO>::Pd, P = FbDims<NS, TOPO>::P, kStage = FbDims<NS, TOPO>::kStage;
+    constexpr bool ABS = TOPO == 1;
+    constexpr int RS = ABS ? 10 : NS;                           // doubles per stored row
     constexpr bool X = NS > 8;                                 // states 8, 9 ride in the second vector
     const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7;
     // lo step: out-position g, in-position j (reduce over lane bits 0..2); hi step: out-position j, in-position g (bits 3..5).
     // Entries that do not exist read the row's padding, which k_crf_exp fills with zeros: no select, no predicated load on the chain.
-    const int e1_lo = fb_coef<NS, FWD>(g, j), e1_hi = fb_coef<NS, FWD>(j, g);
+    const int e1_lo = fb_coef<NS, FWD, TOPO>(g, j), e1_hi = fb_coef<NS, FWD, TOPO>(j, g);
     const bool xi_lo = (j == 3 || j == 4), xo_lo = (g == 3 || g == 4), xi_hi = xo_lo, xo_hi = xi_lo;
     const int e2_lo = X && xi_lo ? fb_coef<NS, FWD>(g, j + 5) : FbDims<NS>::pad, e2_hi = X && xi_hi ? fb_coef<NS, FWD>(j, g + 5) : FbDims<NS>::pad;
     const int f1_lo = X && xo_lo && xi_lo ? fb_coef<NS, FWD>(g + 5, j + 5) : FbDims<NS>::pad, f1_hi = X && xo_hi && xi_hi ? fb_coef<NS, FWD>(j + 5, g + 5) : FbDims<NS>::pad;
@@ -147,11 +156,11 @@ __device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const in
         const int cnt = (q & 63) + 1, q0 = q & ~63;
         if (lane < cnt) {
             const int qq = q0 + lane;
-            double *dst = vec + (size_t)(FWD ? qq + 1 : Tb - 1 - qq) * NS;
+            double *dst = vec + (size_t)(FWD ? qq + 1 : Tb - 1 - qq) * RS;
             const double2 *src = (const double2 *)&stage[lane][0];
             double2 *d2 = (double2 *)dst;
 #pragma unroll
-            for (int k = 0; k < NS / 2; k++) d2[k] = src[k];
+            for (int k = 0; k < RS / 2; k++) d2[k] = src[k];
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -182,26 +191,28 @@ __device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const in
             const double eh2 = eh2_n, fh1 = fh1_n, fh2 = fh2_n;
             read_pair(q + 2);
             {   // lo step
-                if (FWD) { msum = msum + ml; K += sx; }
+                if (FWD || ABS) { msum = msum + ml; K += sx; }
                 if (X) {
                     const double t = __builtin_fma(el2, x, el * a), tx = __builtin_fma(fl1, x, fl2 * a);
                     a = sum_lo3(t); x = sum_lo3(tx);
                 } else a = sum_lo3(el * a);
                 if (store) {
                     if (j == 0) stage[q & 63][g] = a;
+                    if (ABS && lane == 0) stage[q & 63][8] = 0.693147180559945309417232121458 * (double)K + msum;
                     if (X && j == 0 && xo_lo) stage[q & 63][g + 5] = x;
                     if ((q & 63) == 63 || q == Tb - 1) flush(q);
                 }
             }
             if (q + 1 < q1) {   // hi step
                 const int qh = q + 1;
-                if (FWD) msum = msum + mh;
+                if (FWD || ABS) msum = msum + mh;
                 if (X) {
                     const double t = __builtin_fma(eh2, x, eh * a), tx = __builtin_fma(fh1, x, fh2 * a);
                     a = sum_hi3(t); x = sum_hi3(tx);
                 } else a = sum_hi3(eh * a);
                 if (store) {
                     if (lane < 8) stage[qh & 63][lane] = a;
+                    if (ABS && lane == 8) stage[qh & 63][8] = 0.693147180559945309417232121458 * (double)K + msum;
                     if (X && (lane == 3 || lane == 4)) stage[qh & 63][lane + 5] = x;
                     if ((qh & 63) == 63 || qh == Tb - 1) flush(qh);
                 }
@@ -224,29 +235,29 @@ __device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const in
 
 // The two chains of a read: wave 0 forwards (and logZ), wave 1 backwards (flags & 2: the vectors are wanted).
 // `wide` (optional): per-read flag of k_crf_exp "score range too wide for the linear form": such a read is left to the log-space kernels.
-template <int NS>
+template <int NS, int TOPO = 0>
 __global__ void __launch_bounds__(128)
 k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__restrict__ bwdbuf, int TbS, double *__restrict__ logz_out,
          const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
-    constexpr int Pd = FbDims<NS>::Pd;
+    constexpr int Pd = FbDims<NS, TOPO>::Pd, RS = TOPO == 1 ? 10 : NS;
     __shared__ double ebuf[2][kFbChunk * Pd];
-    __shared__ double stage[2][64][NS];
+    __shared__ double stage[2][64][RS];
     __shared__ double s_logz;
     if (wide && wide[blockIdx.x]) return;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;
     if (Tb <= 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
-    double *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * NS;
-    double *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * NS;
+    double *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * RS;
+    double *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * RS;
     const bool want_post = (flags & 2) != 0;
     if (wave == 0) {
-        if (want_post && lane < NS) F[lane] = 1.0;
-        fb_chain<NS, true>(Er, Tb, ebuf[0], stage[0], F, want_post, &s_logz);
+        if (want_post && lane < RS) F[lane] = lane < NS ? 1.0 : 0.0;              // (run-length rows: offset C = 0 in [8])
+        fb_chain<NS, true, TOPO>(Er, Tb, ebuf[0], stage[0], F, want_post, &s_logz);
         if (lane == 0 && logz_out) logz_out[blockIdx.x] = s_logz;
     } else if (want_post) {
-        if (lane < NS) Bw[(size_t)Tb * NS + lane] = 1.0;
-        fb_chain<NS, false>(Er, Tb, ebuf[1], stage[1], Bw, true, nullptr);
+        if (lane < RS) Bw[(size_t)Tb * RS + lane] = lane < NS ? 1.0 : 0.0;
+        fb_chain<NS, false, TOPO>(Er, Tb, ebuf[1], stage[1], Bw, true, nullptr);
     }
 }
 
@@ -323,6 +334,56 @@ k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__r
     }
 }
 
+// transpost_crf_runlength's output (decode.c:1102-1135) from the vectors of k_crf_fb<8, 1>: sixteen lanes a block, four of its 40 values each -- the shape / scale
+// rows copied, entry r = 8 tb + from of the transition rows = (fwd[from] + bwd[to]) + score with to = move state tb, or stay state 4 + tb for the two sources of
+// its own base; fwd / bwd = log of the stored vector + its offset, formed in fp64 and rounded once
+__global__ void __launch_bounds__(256)
+k_rle_post8(const float *__restrict__ param, float *__restrict__ post, const double *__restrict__ fwdbuf, const double *__restrict__ bwdbuf, int TbS,
+            const int *__restrict__ tbs) {
+    constexpr int Ps = 40, RS = 10;
+    const int read = blockIdx.y;
+    const int Tb = tbs ? tbs[read] : TbS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
+    if ((int)blockIdx.x * kPostBlocks >= Tb) return;
+    const bool has = sub < 10;
+    int lf_src[4], lb_src[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int r = max(0, min(4 * sub + e, Ps - 1) - 8), from = r & 7, tb = r >> 3;
+        const int to = ((from & 3) != tb) ? tb : tb + 4;
+        lf_src[e] = 4 * (16 * grp + from); lb_src[e] = 4 * (16 * grp + to);
+    }
+    for (int round = 0; round < 4; round++) {
+        const int blk = blockIdx.x * kPostBlocks + (round * 4 + wave) * 4 + grp;
+        const bool live = blk < Tb;
+        const int bc = min(blk, Tb - 1);
+        const float4 x = *((const float4 *)(param + ((size_t)read * TbS + bc) * Ps) + min(sub, 9));
+        const int st = min(sub, 7);
+        const double *fr = fwdbuf + ((size_t)read * (TbS + 1) + bc) * RS, *br = bwdbuf + ((size_t)read * (TbS + 1) + bc + 1) * RS;
+        const double va = fr[st], vb = br[st], ca = fr[8], cb = br[8];
+        // log(v) = log(mantissa) + e ln2 (a zero: -inf, an unreachable state)
+        const float lf = va > 0.0 ? (float)((double)__builtin_amdgcn_frexp_exp(va) * 0.693147180559945309417232121458 + (double)logf((float)__builtin_amdgcn_frexp_mant(va)) + ca) : -INFINITY;
+        const float lb = vb > 0.0 ? (float)((double)__builtin_amdgcn_frexp_exp(vb) * 0.693147180559945309417232121458 + (double)logf((float)__builtin_amdgcn_frexp_mant(vb)) + cb) : -INFINITY;
+        const float xs[4] = { x.x, x.y, x.z, x.w };
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float f = __int_as_float(__builtin_amdgcn_ds_bpermute(lf_src[e], __float_as_int(lf)));
+            const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(lb_src[e], __float_as_int(lb)));
+            v[e] = (4 * sub + e < 8) ? xs[e] : (f + b) + xs[e];
+        }
+        if (live && has) *((float4 *)(post + ((size_t)read * TbS + blk) * Ps) + sub) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// run-length posterior of nbase = 4, stride-40 reads: E (k_crf_exp of the 32 transition rows, stride 40 doubles), the two chains, the assembly
+void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E, double *fwd, int nread, int Tb, const int *tbs) {
+    launch_crf_exp(s, param, E, nread, Tb, 4, 40, tbs, nullptr, 0.0f, 8, 32);
+    double *bwd = fwd + (size_t)nread * (Tb + 1) * 10;
+    hipLaunchKernelGGL((k_crf_fb<8, 1>), dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, (double *)nullptr, tbs, 2, (const int *)nullptr);
+    hipLaunchKernelGGL(k_rle_post8, dim3((Tb + kPostBlocks - 1) / kPostBlocks, nread), dim3(256), 0, s, param, post, fwd, bwd, Tb, tbs);
+}
+
 // flags: 1 = subtract (float)(logZ / Tb) from the scores, 2 = posterior wanted; logz: device doubles per read (required with flags & 1)
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
                    int flags, const int *wide) {
@@ -350,6 +411,13 @@ void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, floa
 //      segment maps, each lane then walks its segment from its known end state.
 constexpr int kVitChunk = 2048;          // blocks whose traceback words stay in LDS (a multiple of 8)
 
+// TOPO 1: the run-length model's 8 states (4 move + 4 stay, decode.c:927-1013 decode_crf_runlength) on the same chain.  Its 32 transition scores sit behind
+// the 8 shape / scale rows of a block; move state b1 is entered from every state of another base (score 8 b1 + from), stay state b from the move and
+// the stay state of its own base (score 8 b + from) -- the 8 x 8 square again, with other entries masked.  Its scan visits the sources of a move state
+// in the order move b2, stay b2 (b2 ascending) and replaces on a strict > starting from -HUGE_VAL with traceback 0; a stay state takes "stay" only
+// if strictly greater than "move".  Its path holds the state AFTER every block (and 0 behind the last), no qpath.
+
+template <int TOPO>
 __global__ void __launch_bounds__(64)
 k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
             float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
@@ -358,7 +426,7 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
     __shared__ unsigned careful[kVitChunk / 8 / 32];        // bit per group of 8 blocks: its words are one-hot in the lo layout
     __shared__ uint8_t path_lds[kVitChunk + 1];
     const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
-    const float *T = M + (size_t)blockIdx.x * TbS * Ps;
+    const float *T = M + (size_t)blockIdx.x * TbS * Ps + (TOPO == 1 ? 2 * nbase : 0);      // (run-length: the transition rows of a block)
     unsigned long long *tbg = (unsigned long long *)(tbbuf + (size_t)blockIdx.x * TbS * kMaxState);       // 16 bytes a block: room for the 8
     int *pth = path + (size_t)blockIdx.x * (TbS + 1);
     float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
@@ -366,8 +434,8 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
     if (Tb <= 0) return;
     const float NEG = -INFINITY;
     // lo step: (to g, from j); hi step: (to j, from g)
-    const int i_lo = ff8_entry(g, j), i_hi = ff8_entry(j, g);
-    const bool v_lo = ff8_has(g, j), v_hi = ff8_has(j, g);
+    const int i_lo = vit_entry<TOPO>(g, j), i_hi = vit_entry<TOPO>(j, g);
+    const bool v_lo = vit_has<TOPO>(g, j), v_hi = vit_has<TOPO>(j, g);
     const int nchunk = (Tb + kVitChunk - 1) / kVitChunk;
     const int ngroup_all = Tb / 8;                          // whole groups of the read; the rest (< 8 blocks) goes the literal way
     float pv = 0.0f;                                        // column form: value of state lane & 7
@@ -377,6 +445,28 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
         const float cand = v_lo ? x + pv : NEG;
         float v;
         int arg;
+        if constexpr (TOPO == 1) {
+            if (g < nbase) {
+                // curr = -HUGE_VAL, traceback 0; candidates in the order move b2, stay b2 (b2 ascending, b2 != g), each on a strict >: the first
+                // maximum among those greater than -inf, NaNs skipped
+                float mx = fmaxf(cand, dpp_f<0x141>(cand));
+                mx = fmaxf(mx, dpp_f<0xB1>(mx));
+                mx = fmaxf(mx, dpp_f<0x4E>(mx));
+                const unsigned eq = (unsigned)(__ballot(v_lo && cand == mx) >> (8 * g)) & 0xffu;
+                v = NEG; arg = 0;
+                if (mx > NEG && eq) {
+                    v = mx;
+                    bool found = false;
+#pragma unroll
+                    for (int pp = 0; pp < 8; pp++) { const int f = (pp >> 1) + 4 * (pp & 1); if (!found && ((eq >> f) & 1u)) { arg = f; found = true; } }
+                }
+            } else {
+                const float stay = __shfl(cand, 8 * g + g), move = __shfl(cand, 8 * g + g - nbase);
+                const bool stayed = stay > move;
+                v = stayed ? stay : move;
+                arg = stayed ? g : g - nbase;
+            }
+        } else
         if (g < nbase) {
             // the scan starts from the from-state-0 candidate and replaces on a strict >: a NaN there stays, NaNs elsewhere are skipped
             float mx = fmaxf(cand, dpp_f<0x141>(cand));
@@ -416,7 +506,7 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
 #pragma unroll
             for (int k = 0; k < 8; k++) cur[k] = r[k];
             fetch_group(r, gi + 3);
-            bool bad = pv != pv;
+            bool bad = TOPO == 1 ? !(fabsf(pv) < INFINITY) : (pv != pv);      // (run-length: an all -inf destination keeps traceback 0 -- only the literal scan knows)
 #pragma unroll
             for (int k = 0; k < 8; k++) bad = bad || (((k & 1) ? v_hi : v_lo) && !(fabsf(cur[k]) < INFINITY));
             const int slot0 = 8 * gi;
@@ -461,14 +551,23 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
 #pragma unroll
             for (int s2 = 0; s2 < ns; s2++) {
                 int arg;
-                if (!hi_layout) {
-                    const unsigned byte = (unsigned)(w >> (8 * s2)) & 0xffu;
+                // bits of destination s2 by from-state, whichever layout the word has
+                unsigned byte;
+                if (!hi_layout) byte = (unsigned)(w >> (8 * s2)) & 0xffu;
+                else {
+                    const unsigned long long col = (w >> s2) & 0x0101010101010101ull;
+                    byte = (unsigned)((col * 0x0102040810204080ull) >> 56);           // bit 8 f of col -> bit f
+                }
+                if constexpr (TOPO == 1) {
+                    if (s2 < nbase) {
+                        arg = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int pp = 0; pp < 8; pp++) { const int f = (pp >> 1) + 4 * (pp & 1); if (!found && ((byte >> f) & 1u)) { arg = f; found = true; } }
+                    } else arg = (((byte >> s2) & 1u) && !((byte >> (s2 - nbase)) & 1u)) ? s2 : s2 - nbase;      // stay only if strictly greater than move
+                } else {
                     if (s2 < nbase) arg = byte ? __builtin_ctz(byte) : 0;
                     else arg = ((byte >> s2) & 1u) ? s2 : s2 - nbase;
-                } else {
-                    const unsigned long long col = (w >> s2) & 0x0101010101010101ull;
-                    if (s2 < nbase) arg = col ? (__builtin_ctzll(col) >> 3) : 0;
-                    else arg = ((col >> (8 * s2)) & 1ull) ? s2 : s2 - nbase;
                 }
                 out |= (unsigned long long)arg << (8 * s2);
             }
@@ -487,7 +586,7 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
         const float v = __shfl(pv, s2);
         if (v > score) { score = v; last = s2; }
     }
-    if (lane == 0) { score_out[blockIdx.x] = score; qp[0] = NAN; }
+    if (lane == 0) { score_out[blockIdx.x] = score; if (TOPO == 0) qp[0] = NAN; }
     // ---- 3. traceback, last chunk first (its words are still in LDS)
     for (int c = nchunk - 1; c >= 0; c--) {
         const int c0 = c * kVitChunk, n = min(kVitChunk, Tb - c0), c1 = c0 + n;
@@ -531,12 +630,17 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
             }
         }
         __syncthreads();
+        if constexpr (TOPO == 1) {                             // decode.c:1000-1006: path[blk] = the state after block blk; this engine's extra slot holds 0 / NaN
+            if (c1 == Tb && lane == 0) { pth[Tb] = 0; qp[Tb] = NAN; }
+            for (int i = lane; i < n; i += 64) { pth[c0 + i] = path_lds[i + 1]; qp[c0 + i] = NAN; }
+        } else {
         if (c1 == Tb && lane == 0) pth[Tb] = path_lds[n];
         for (int i = lane; i < n; i += 64) {
             const int from = path_lds[i], to = path_lds[i + 1];
             pth[c0 + i] = from;
             const int idx = (to < nbase) ? (to * ns + from) : (off + from);      // trans_lookup, decode.c:104-114
             qp[c0 + i + 1] = T[(size_t)(c0 + i) * Ps + idx];
+        }
         }
     }
 }
@@ -766,7 +870,11 @@ void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *
 }
 
 void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs) {
-    hipLaunchKernelGGL(k_viterbi8x, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+    hipLaunchKernelGGL(k_viterbi8x<0>, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+}
+// decode_crf_runlength for nbase = 4, stride 40 (param: shape / scale rows + 32 transition scores a block)
+void launch_rle_viterbi8x(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs) {
+    hipLaunchKernelGGL(k_viterbi8x<1>, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, tbs);
 }
 
 }  // namespace ffhip

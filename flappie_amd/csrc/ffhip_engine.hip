@@ -1045,7 +1045,9 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
         const float *scores = b->trans;
         if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
-            if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);       // decode.c:1037-1159
+            if (rle && m->nbase == 4 && m->Ps == 40 && 10.0f / temperature <= kFbRange && !getenv("FFHIP_DECODE_R2"))
+                launch_rle_post8(s, b->trans, b->post, b->crf_e, (double *)b->fwd, b->nread, Tb, tbs);              // fp64 linear-space chains (ffhip_decode.hip)
+            else if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);       // decode.c:1037-1159
             else if (!post_done) launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);
             scores = b->post;
             b->launches[4]++;

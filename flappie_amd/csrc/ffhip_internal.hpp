@@ -141,11 +141,14 @@ void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd
                       double *E = nullptr, int *wide = nullptr);
 constexpr size_t kFwdRowBytes = 10 * sizeof(double);   // per block and direction of the forward / backward workspace: kMaxState floats (log-space kernels) or up to 10 doubles (ffhip_decode.hip)
 constexpr float kFbRange = 100.0f;       // max - min of a block's scores the scaled linear-space recursions take (fp64 range, scaling one pair of blocks behind)
-void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit);
+// row_off / P_override: the run-length model's 32 transition scores sit behind 8 other rows of its 40-float blocks
+void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit, int row_off = 0, int P_override = 0);
+void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E, double *fwd, int nread, int Tb, const int *tbs);
 // ffhip_decode.hip: partition function (+ subtraction, flags & 1) and posterior (flags & 2) of 8- or 10-state reads from E in one launch; fwd = 2*nread*(Tb+1)*(2*nbase) doubles
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
                     int flags, const int *wide);
 void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
+void launch_rle_viterbi8x(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
 void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
 // Viterbi + traceback + qpath
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,

@@ -722,12 +722,13 @@ __device__ __forceinline__ int ff10_src_lane(int s) { return s < 5 ? 8 * s : 40 
 constexpr int kExpBlocks = 64;
 __global__ void __launch_bounds__(256)
 k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t nblk /*nread*TbS*/, int P, int Ps, int Pd, int TbS,
-          const int *__restrict__ tbs, int *__restrict__ wide, float limit) {
+          const int *__restrict__ tbs, int *__restrict__ wide, float limit, int row_off) {
     __shared__ float sc[kExpBlocks * 64];
     __shared__ float mx[kExpBlocks];
     const size_t b0 = (size_t)blockIdx.x * kExpBlocks;
     const int nb = (int)min((size_t)kExpBlocks, nblk - b0);
-    for (int i = threadIdx.x; i < nb * Ps; i += 256) sc[i] = trans[b0 * Ps + i];
+    const size_t last = nblk * Ps - 1;
+    for (int i = threadIdx.x; i < nb * Ps; i += 256) sc[i] = trans[min(b0 * Ps + i + row_off, last)];      // (row_off: the entries start behind other rows of the block)
     __syncthreads();
     if (threadIdx.x < nb) {
         const float *S = sc + threadIdx.x * Ps;
@@ -987,17 +988,17 @@ k_crf_chain10(const double *__restrict__ E, int TbS, int Pd, int R, double *__re
     if (lane == 0) logz_out[blockIdx.x] = logZ;
 }
 
-void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit) {
-    const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
+void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit, int row_off, int P_override) {
+    const int P = P_override ? P_override : 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
     const size_t nblk = (size_t)nread * Tb;
-    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, wide, limit);
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, wide, limit, row_off);
 }
 
 void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, int Tb, int nbase, int Ps, int R,
                             double *logz, int subtract, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1), Pd = crf_exp_stride(P);
     const size_t nblk = (size_t)nread * Tb;
-    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, (int *)nullptr, 0.0f);
+    hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, (int *)nullptr, 0.0f, 0);
     const int Rr = R < 1 ? 1 : R;
     if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
         hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);

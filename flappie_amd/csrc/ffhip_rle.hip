@@ -13,6 +13,7 @@
 // posteriors run on two concurrent waves.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "ffhip_internal.hpp"
 #include "ffhip_math.hpp"
@@ -416,6 +417,7 @@ void launch_rle_transpost(hipStream_t s, const float *param, float *post, float 
 }
 
 void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs) {
+    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2")) { launch_rle_viterbi8x(s, param, tb, path, qpath, score, nread, Tb, tbs); return; }      // ffhip_decode.hip
     hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps, tbs);
 }
 
