@@ -384,6 +384,92 @@ void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E,
     hipLaunchKernelGGL(k_rle_post8, dim3((Tb + kPostBlocks - 1) / kPostBlocks, nread), dim3(256), 0, s, param, post, fwd, bwd, Tb, tbs);
 }
 
+// ---- runlengthV2_partition_function (layers.c:1255-1302) on the alternating layouts, in LOG space -----------------------------------------------
+// The reference folds a move state's 2 (nbase - 1) sources with pairwise fp64 logsumexp and rounds every STAY update through the float logsumexpf
+// (layers.c:1288-1290); the host-API test holds the operator to 1e-9 of that number, so the stay states keep exactly that float arithmetic and the
+// recursion stays in log space -- per block an fp64 max, exp, sum and log for the move states (any association: 1e-16) and the float logsumexpf for
+// the stay states, both on the lane layouts of the chains above instead of five LDS round trips per block (k_rle_partition, ffhip_rle.hip).
+__device__ __forceinline__ double fmax_lo3_d(double v) { v = fmax(v, dpp_d<0x141>(v)); v = fmax(v, dpp_d<0xB1>(v)); return fmax(v, dpp_d<0x4E>(v)); }
+__device__ __forceinline__ double fmax_hi3_d(double v) {
+    v = fmax(v, dpp_d<0x128>(v));
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const v2u_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+    }
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const v2u_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+}
+
+__global__ void __launch_bounds__(64)
+k_rle_partition8x(const float *__restrict__ param, int TbS, double *__restrict__ logz, const int *__restrict__ tbs) {
+    constexpr int Ps = 40, nbase = 4;
+    const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
+    const float *T = param + (size_t)blockIdx.x * TbS * Ps + 2 * nbase;
+    const int Tb = tbs ? tbs[blockIdx.x] : TbS;
+    if (Tb <= 0) return;
+    const double NEG = -HUGE_VAL;
+    // lo step: (to g, from j), hi step: (to j, from g)
+    const int i_lo = vit_entry<1>(g, j), i_hi = vit_entry<1>(j, g);
+    const bool v_lo = vit_has<1>(g, j), v_hi = vit_has<1>(j, g);
+    double v = 0.0;                                          // all eight states start at 0; column form (state lane & 7)
+    auto lse_f = [](float x, float y) { return logsumexpf_ref(x, y); };
+    auto step_lo = [&](float x) {                            // v: column form -> row form
+        const double cand = v_lo ? v + (double)x : NEG;
+        // move destinations (groups 0..3)
+        const double m = fmax_lo3_d(cand);
+        const double e = exp(cand - m);
+        const double mv = m + log(sum_lo3(e));
+        // stay destinations (groups 4..7): the two sources sit four lanes apart in the group
+        const float xf = (float)cand;
+        const float pf = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xf), 0x104, 0xf, 0x5, false) |      // row_shl:4 into banks 0, 2 ..
+                                        __builtin_amdgcn_update_dpp(0, __float_as_int(xf), 0x114, 0xf, 0xA, false));      // .. row_shr:4 into banks 1, 3
+        const double sv = v_lo ? (double)lse_f(xf, pf) : NEG;
+        v = g < nbase ? mv : fmax_lo3_d(sv);
+    };
+    auto step_hi = [&](float x) {                            // v: row form -> column form
+        const double cand = v_hi ? v + (double)x : NEG;
+        const double m = fmax_hi3_d(cand);
+        const double e = exp(cand - m);
+        const double mv = m + log(sum_hi3(e));
+        const float xf = (float)cand;
+        const v2u_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(xf), false, false);       // { low half twice, high half twice }
+        const float pf = __uint_as_float(lane < 32 ? r.y : r.x);                 // the lane 32 away: source group g ^ 4
+        const double sv = v_hi ? (double)lse_f(xf, pf) : NEG;
+        v = j < nbase ? mv : fmax_hi3_d(sv);
+    };
+    constexpr int kDepth = 8;
+    float ring[kDepth];
+    auto fetch = [&](int blk) { return T[(size_t)min(blk, Tb - 1) * Ps + ((blk & 1) ? i_hi : i_lo)]; };
+#pragma unroll
+    for (int k = 0; k < kDepth; k++) ring[k] = fetch(k);
+    for (int b0 = 0; b0 < Tb; b0 += kDepth) {
+        float cur[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) cur[k] = ring[k];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) ring[k] = fetch(b0 + kDepth + k);
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            if (b0 + k >= Tb) break;
+            if (k & 1) step_hi(cur[k]); else step_lo(cur[k]);
+        }
+    }
+    // final states: an odd block count ends in row form (state s in group s), an even one in column form (state s in lane s)
+    double z = 0.0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2 * nbase; s2++) {
+        const double val = __shfl(v, (Tb & 1) ? 8 * s2 : s2);
+        z = s2 == 0 ? val : (fmax(z, val) + log1p(exp(-fabs(z - val))));           // layers.c:1296-1299, in order
+    }
+    if (lane == 0) logz[blockIdx.x] = z;
+}
+
+void launch_rle_partition8x(hipStream_t s, const float *param, double *logz, int nread, int Tb, const int *tbs) {
+    hipLaunchKernelGGL(k_rle_partition8x, dim3(nread), dim3(64), 0, s, param, Tb, logz, tbs);
+}
+
 // flags: 1 = subtract (float)(logZ / Tb) from the scores, 2 = posterior wanted; logz: device doubles per read (required with flags & 1)
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
                    int flags, const int *wide) {

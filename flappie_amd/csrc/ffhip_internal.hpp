@@ -143,6 +143,7 @@ constexpr size_t kFwdRowBytes = 10 * sizeof(double);   // per block and directio
 constexpr float kFbRange = 100.0f;       // max - min of a block's scores the scaled linear-space recursions take (fp64 range, scaling one pair of blocks behind)
 // row_off / P_override: the run-length model's 32 transition scores sit behind 8 other rows of its 40-float blocks
 void launch_crf_exp(hipStream_t s, const float *trans, double *E, int nread, int Tb, int nbase, int Ps, const int *tbs, int *wide, float limit, int row_off = 0, int P_override = 0);
+void launch_rle_partition8x(hipStream_t s, const float *param, double *logz, int nread, int Tb, const int *tbs);
 void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E, double *fwd, int nread, int Tb, const int *tbs);
 // ffhip_decode.hip: partition function (+ subtraction, flags & 1) and posterior (flags & 2) of 8- or 10-state reads from E in one launch; fwd = 2*nread*(Tb+1)*(2*nbase) doubles
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
