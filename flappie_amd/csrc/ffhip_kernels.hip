@@ -577,9 +577,18 @@ k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__res
             v4f v = acc[i][j];
             float *o = trans + ((size_t)read * Tb + blk) * Ps + p;
             const float vv[4] = { v.x, v.y, v.z, v.w };
+            float rr[4];
+            if (raw) { rr[0] = vv[0]; rr[1] = vv[1]; rr[2] = vv[2]; rr[3] = vv[3]; }
+            else {
+                const ffv4 t = apply_act4((ffv4){ vv[0], vv[1], vv[2], vv[3] }, 2);      // tanh_ref's bits, four at a time through the lean logistic (ffhip_math.hpp)
+                rr[0] = (t.x - 0.0f) / scale; rr[1] = (t.y - 0.0f) / scale; rr[2] = (t.z - 0.0f) / scale; rr[3] = (t.w - 0.0f) / scale;
+            }
+            if (p + 3 < P && (Ps & 3) == 0) *(float4 *)o = make_float4(rr[0], rr[1], rr[2], rr[3]);      // one 16-byte store a lane (P and Ps are multiples of 4 for every model: 40, 60)
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (p + e < P) o[e] = raw ? vv[e] : (tanh_ref(vv[e]) - 0.0f) / scale;
+                for (int e = 0; e < 4; e++)
+                    if (p + e < P) o[e] = rr[e];
+            }
         }
     }
 }
