@@ -1,12 +1,15 @@
-// ffhip_decode.hip -- the decode chains of the 8-state (ACGT) flip-flop models without a lane gather on the chain.
+// ffhip_decode.hip -- the decode chains of the 8- and 10-state flip-flop models and of the run-length model without a lane gather on the chain.
 //
 // Reference functions replaced (paths relative to /root/reference/src):
-//   k_crf_fb8     crf_manystay_partition_function + the subtraction of globalnorm_flipflop (layers.c:1035-1096)
-//                 AND transpost_crf_flipflop + log_row_normalise_inplace (decode.c:377-497, flappie_matrix.c:450-467)
-//   k_viterbi8x   decode_crf_flipflop (decode.c:119-204)
+//   k_crf_fb<8|10> + k_post_fb   crf_manystay_partition_function + the subtraction of globalnorm_flipflop (layers.c:1035-1096)
+//                                AND transpost_crf_flipflop + log_row_normalise_inplace (decode.c:377-497, flappie_matrix.c:450-467)
+//   k_viterbi8x<0>, k_viterbi10x decode_crf_flipflop (decode.c:119-204)
+//   k_rle_partition8x            runlengthV2_partition_function (layers.c:1255-1302)
+//   k_crf_fb<8, 1> + k_rle_post8 transpost_crf_runlength (decode.c:1037-1159)
+//   k_viterbi8x<1>               decode_crf_runlength (decode.c:927-1013)
 //
 // Both are recursions over the blocks of one read, one wavefront per read and direction: what bounds them is the dependent chain
-// of one block, not bytes or flops.  The kernels of ffhip_kernels.hip (k_crf_chain8, k_transpost8, k_viterbi8) hold the 40
+// of one block, not bytes or flops.  Round 2's kernels in ffhip_kernels.hip (k_crf_chain8, k_transpost8, k_viterbi8) hold the 40
 // transition entries of a block one per lane, reduce per destination state with DPP moves and then GATHER the new state vector
 // back to the entries' source lanes with a ds_bpermute (an LDS-crossbar round trip) -- every block.  Here the 8 x 8 (to, from)
 // square of a block covers the 64 lanes and the lane <-> entry map ALTERNATES between blocks:
