@@ -63,6 +63,8 @@ __device__ __forceinline__ float max_hi3(float v) {
         : "=&v"(r), "=&v"(t) : "v"(v));
     return r;
 }
+// plain v_max_f32 of two values that are no NaNs (fmaxf would canonicalise both operands first: three instructions for one)
+__device__ __forceinline__ float max2_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double sum_lo3(double v) {
     v = v + dpp_d<0x141>(v);
     v = v + dpp_d<0xB1>(v);
@@ -835,11 +837,11 @@ k_viterbi10x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__re
             for (int k = 0; k < 8; k += 2) {
                 // lo step: pv, px in column form
                 const float c1 = cur[k][0] + pv, c2 = cur[k][1] + px, d1 = cur[k][2] + px, d2 = cur[k][3] + pv;
-                const float vr = max_lo3(fmaxf(c1, c2)), xr = max_lo3(fmaxf(d1, d2));            // row form
+                const float vr = max_lo3(max2_raw(c1, c2)), xr = max_lo3(max2_raw(d1, d2));      // row form
                 const unsigned long long a1 = __ballot(c1 == vr), a2 = __ballot(c2 == vr), a3 = __ballot(d1 == xr);
                 // hi step
                 const float h1 = cur[k + 1][0] + vr, h2 = cur[k + 1][1] + xr, k1 = cur[k + 1][2] + xr, k2 = cur[k + 1][3] + vr;
-                pv = max_hi3(fmaxf(h1, h2)); px = max_hi3(fmaxf(k1, k2));                          // column form
+                pv = max_hi3(max2_raw(h1, h2)); px = max_hi3(max2_raw(k1, k2));                    // column form
                 const unsigned long long b1 = __ballot(h1 == pv), b2 = __ballot(h2 == pv), b3 = __ballot(k1 == px);
                 if (lane == 0) {
                     tb0[slot0 + k] = a1; tb1[slot0 + k] = a2; tb2[slot0 + k] = a3;
