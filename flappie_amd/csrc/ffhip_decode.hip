@@ -531,7 +531,8 @@ k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
     const int ngroup_all = Tb / 8;                          // whole groups of the read; the rest (< 8 blocks) goes the literal way
     float pv = 0.0f;                                        // column form: value of state lane & 7
 
-    // the literal step, lo layout: candidates of block blk from the score x of entry (to g, from j)
+    // the literal step, lo layout: candidates of block blk from the score x of entry (to g, from j).  (The lane exchanges inside its branches read lanes of
+    // the SAME 8-lane group, which take the same branch: every source lane is active.)
     auto literal_step = [&](float x, int slot) {
         const float cand = v_lo ? x + pv : NEG;
         float v;

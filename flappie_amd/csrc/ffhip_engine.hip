@@ -1033,7 +1033,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
             mark(b, 4);       // the profile's "posterior" slot times the chain launch: partition function + normalisation + posterior together
             launch_crf_fb(s, m->nbase, b->crf_e, b->trans, b->post, (double *)b->fwd, b->nread, Tb, b->crf_logz, tbs, want_post ? 3 : 1, nullptr);
-            b->launches[3] += 2;
+            b->launches[3] += want_post ? 4 : 3;      // head, exp, chains, assembly (the subtraction alone: three)
         } else {
             if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz, 1, tbs);
             else launch_crf_norm(s, b->trans, b->nread, Tb, m->nbase, m->Ps, b->crf_logz, 1, tbs);
