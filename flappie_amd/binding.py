@@ -78,7 +78,7 @@ def lib():
     L.ffhip_model_upload.restype = vp
     L.ffhip_model_upload.argtypes = [vp, C.POINTER(CModelDesc)]
     L.ffhip_model_free.argtypes = [vp]
-    for fn in ("ffhip_model_hidden", "ffhip_model_nparam", "ffhip_model_nbase"):
+    for fn in ("ffhip_model_hidden", "ffhip_model_nparam", "ffhip_model_nbase", "ffhip_model_launch_reads"):
         getattr(L, fn).restype = C.c_size_t
         getattr(L, fn).argtypes = [vp]
     L.ffhip_model_nblock.restype = C.c_size_t
@@ -191,6 +191,11 @@ class DeviceModel:
         del keep
         if not self.h:
             raise FFHipError(lib().ffhip_last_error().decode())
+
+    @property
+    def launch_reads(self) -> int:
+        """reads per batch that keep every layer launch of this model full on this device (ffhip_model_launch_reads)"""
+        return int(lib().ffhip_model_launch_reads(self.h))
 
     def close(self):
         if self.h:

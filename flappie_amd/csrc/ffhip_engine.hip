@@ -347,7 +347,24 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
             const int S = (split_weight_exp(mx[0]) + ex < split_weight_exp(mx[1]) + eh) ? split_weight_exp(mx[0]) + ex : split_weight_exp(mx[1]) + eh;
             const int sw[2] = { S - ex, S - eh };
             r.split_S = kSplitF16 ? S : 0;
-            std::vector<uint16_t> sp3((size_t)2 * Ut * Hc * kSplitNS * 64 * 8);
+            // GRUmod at H = 256: the gate-major pack of the packed layer form follows -- row tile 3 mb + gate of member mb (16 units), row
+            // 4 q + c of a tile = unit 16 mb + 4 c + q (ffhip_rnn_split.hip, PACK)
+            const bool gpack = (G == 3 && Hp == 256);
+            const size_t classic = (size_t)2 * Ut * Hc * kSplitNS * 64 * 8, Vt = 3 * (Hp / 16);
+            std::vector<uint16_t> sp3(classic + (gpack ? (size_t)2 * Vt * Hc * kSplitNS * 64 * 8 : 0));
+            if (gpack)
+                for (int mat = 0; mat < 2; mat++)
+                    for (int vt = 0; vt < (int)Vt; vt++)
+                        for (int c = 0; c < Hc; c++)
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int e = 0; e < 8; e++) {
+                                    const int row = lane & 15, unit = 16 * (vt / 3) + 4 * (row & 3) + (row >> 2);
+                                    const float w = rowcol(mat == 0 ? iW : sW, 4 * unit + vt % 3, c * 32 + (lane >> 4) * 8 + e);
+                                    uint16_t sl[kSplitNS];
+                                    split_host_slices(w, sw[mat], sl);
+                                    const size_t base = classic + ((((size_t)mat * Vt + vt) * Hc + c) * kSplitNS) * 64 * 8 + (size_t)lane * 8 + e;
+                                    for (int k = 0; k < kSplitNS; k++) sp3[base + (size_t)k * 64 * 8] = sl[k];
+                                }
             for (int mat = 0; mat < 2; mat++)
                 for (int ut = 0; ut < Ut; ut++)
                     for (int c = 0; c < Hc; c++)
@@ -393,6 +410,14 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
 extern "C" size_t ffhip_model_hidden(const ffhip_model *m) { return m ? (size_t)m->H : 0; }
 extern "C" size_t ffhip_model_nparam(const ffhip_model *m) { return m ? (size_t)m->P : 0; }
 extern "C" size_t ffhip_model_nbase(const ffhip_model *m) { return m ? (size_t)m->nbase : 0; }
+// reads one FULL layer launch of this model takes on this device (the batch size that keeps every launch full): 1024 for GRUmod at 256 hidden
+// units (the packed form), 768 for an LSTM there, 512 at 384, else 256 -- on 256 CUs (ffhip_rnn_split.hip, split_next_launch_tiles)
+extern "C" size_t ffhip_model_launch_reads(const ffhip_model *m) {
+    if (!m) return 0;
+    const int ncu = m->eng->prop.multiProcessorCount;
+    if (m->H == m->Hp && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr) return (size_t)16 * split_next_launch_tiles(m->cell, m->Hp, 1 << 20, ncu);
+    return (size_t)16 * 2 * (ncu / 32);
+}
 extern "C" size_t ffhip_model_nblock(const ffhip_model *m, size_t nsample) {
     if (!m) return 0;
     size_t n = nsample;
@@ -858,7 +883,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     bool full_chip = b->pair_front != 0 || use_split2;
     if (use_split && !full_chip) {
         const int ncu_ = b->eng->prop.multiProcessorCount, beside_ = (b->eng->in_flight - (b->counted ? 1 : 0) > 0) ? 1 : 0;
-        const int nrt_ = split_next_launch_tiles(Hp, B16, ncu_);
+        const int nrt_ = split_next_launch_tiles(m->cell, Hp, B16, ncu_);
         full_chip = 2 * split_launch_workgroups(m->cell, Hp, nrt_, ncu_, beside_) > ncu_ * split_workgroups_per_cu(m->cell, Hp, nrt_, ncu_, beside_);
     }
     const int lean_conv = lean_env ? (lean_env[0] == '1') : (!full_chip && b->eng->in_flight - (b->counted ? 1 : 0) > 0);
@@ -935,7 +960,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
             float *out_f32 = (l == 4 || keep) ? out : nullptr;
             for (int rt0 = 0, nrt = 0; rt0 < B16; rt0 += nrt) {
-                nrt = split_next_launch_tiles(Hp, B16 - rt0, b->eng->prop.multiProcessorCount);
+                nrt = split_next_launch_tiles(m->cell, Hp, B16 - rt0, b->eng->prop.multiProcessorCount);
                 (void)maxt1; (void)maxt2;
                 // (the check-in words carry the launch's epoch: no fill between launches)
                 b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;

@@ -93,9 +93,10 @@ void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens,
 bool split_supported(int kind, int H);
 int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside);      // workgroups of one launch of nrt read tiles ...
 int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside);      // ... and how many of them share a CU
-int split_next_launch_tiles(int H, int remaining, int ncu);          // read tiles the next layer launch of a batch takes
+int split_next_launch_tiles(int kind, int H, int remaining, int ncu);          // read tiles the next layer launch of a batch takes
 int split_max_tiles(int ncu, int H = 512);                // read tiles (of 16) per launch: 32 workgroups per PAIR of tiles, one per CU (two at H <= 256)
 size_t split_flag_words(int nrt);
+size_t split_pack_offset(int H);           // 16-byte pieces in front of the gate-major weight pack of the packed GRUmod form
 inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 * kSplitNS; }      // 16 reads x H x 2 B x slices
 struct SplitLaunch {          // one batch's share of a paired layer launch
     const void *Wp; const float *bias; const void *xin; void *hout; float *hout_f32; unsigned *flags, *abort_word;

@@ -179,13 +179,21 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 // LDS (as in the one-tile form at N = 3) one tile after the other through ONE set of accumulators, the recurrent partials are
 // written over the landing zone they came from, the projection partials are single-buffered behind a per-(K quarter, tile)
 // "consumed" flag, and the x waves load x(t+1) just in time (it is L2-warm) instead of a step ahead across the gate phase.
-template <int KIND, int N, int TS, bool DN>
+// PACK (GRUmod, H = 256, dense): the cell has three gates, and a unit tile of 4 units x 4 rows carries an empty row per unit -- a quarter of the
+// MFMAs of both products.  Here a member owns 16 units (groups of 16) as THREE gate-major row tiles (z, r, candidate; no empty rows); inside a
+// tile row 4 q + c is unit 4 c + q, so that lane (q, read) of a tile's accumulator holds units q, 4 + q, 8 + q, 12 + q in its components: gate wave
+// (tile ts, component c) reads component c of the three gates and is, for the arithmetic and for the split / transpose / store of h(t), exactly
+// the 4-unit gate tile (units 4 c .. 4 c + 3) of the other forms.  The candidate's projection half travels as a fourth partial tile.
+template <int KIND, int N, int TS, bool DN, bool PACK = false>
 __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int block_index) {
     static_assert(!DN || TS == 2, "the dense form is a pair form");
-    __shared__ v4f px[DN ? 1 : 2][4][TS][N][64];     // projection partials, double-buffered (DN: single): [step parity][K quarter][tile of the group][unit tile][lane]
+    static_assert(!PACK || (DN && KIND == 1 && N == 2), "the packed form is the dense GRUmod form at H = 256");
+    constexpr int NRT = PACK ? 3 : N;           // row tiles of a wave
+    constexpr int MT = PACK ? 4 : N;            // unit tiles (of 4 units) of a member
+    __shared__ v4f px[DN ? 1 : 2][4][TS][NRT][64];     // projection partials, double-buffered (DN: single): [step parity][K quarter][tile of the group][unit tile][lane]
     __shared__ v4f ph_[DN ? 1 : 4][DN ? 1 : TS][DN ? 1 : N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial (DN: in the landing zone)
     __shared__ int pxc[4][2];               // DN: step (+1) whose projection partial of (K quarter, tile) the h wave has consumed
-    __shared__ v4f sbias[N][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
+    __shared__ v4f sbias[MT][4];             // bias of my rows: [unit tile][unit in tile] x 4 gates
     __shared__ unsigned short gsl[8][NS][16][4];   // per gate wave: bf16 slices of its tile's h(t), [slice][read][unit]
     __shared__ float gf32[8][16][4];        // per gate wave: fp32 h(t), [read][unit] (last layer's copy for the CRF head)
     __shared__ int lds_abort;
@@ -201,7 +209,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         if constexpr (DN) return (v4f *)&hland[w][ts][0][0][0] + j * 64;      // over the (consumed) first chunks of that tile's landing zone
         else return &ph_[w][ts][j][0];
     };
-    constexpr int G = 32, Hc = 4 * N, Ut = 32 * N;
+    constexpr int G = PACK ? 16 : 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,9 +229,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     const int Tb = TbA > TbB ? TbA : TbB;                 // steps of this pair of read tiles
     if (Tb <= 0) return;                                  // empty slots only (uniform for the whole group)
     const int ntl = (TbB > 0) ? 2 : 1;
-    const int ut0 = m * N;
+    const int ut0 = m * MT;
     if (threadIdx.x == 0) lds_abort = (__hip_atomic_load(a.abort_word, RLX_AGENT) != 0u) ? 1 : 0;      // an earlier layer of this batch gave up: leave at once
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * N) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * MT) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
     const int q = lane >> 4, rl = lane & 15;
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
@@ -238,10 +246,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     constexpr bool SGK = (KIND == 0 && N == 3 && TS == 2);
     const bool sg = SGK && ntl == 2 && a.split_gate != 0;
     const bool sg_front = sg && xw && wave < 2, sg_back = sg && xw && wave >= 2;
-    const int g6 = xw ? (sg ? 4 + (wave & 1) : 4 + wave) : kw;
-    const bool gate_wave = !(sg && xw) && g6 < ntl * N;      // works a whole tile
+    const int g6 = PACK ? wave : (xw ? (sg ? 4 + (wave & 1) : 4 + wave) : kw);      // PACK: 2 tiles x 4 components = the 8 waves
+    const bool gate_wave = !(sg && xw) && g6 < ntl * MT;     // works a whole tile
     const bool store_wave = gate_wave || sg_back;            // publishes a tile's h(t)
-    const int my_gts = g6 / N, my_gj = g6 % N;
+    const int my_gts = g6 / MT, my_gj = g6 % MT;             // (PACK: my_gj = the component = unit tile of the member)
     if (threadIdx.x < 2) cxflag[threadIdx.x] = 0;
     if (threadIdx.x < 8) pxc[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
@@ -291,18 +299,20 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     // tile over different lines and L2 channels instead of marching through them in lock step.
     int chunk[N];
 #pragma unroll
-    for (int cc = 0; cc < N; cc++) chunk[cc] = ((kw + m) & 3) * N + (cc + (m >> 2)) % N;
+    for (int cc = 0; cc < N; cc++) chunk[cc] = ((kw + m) & 3) * N + (cc + (PACK ? (m >> 1) : (m >> 2))) % N;      // (PACK: the order of the 8-unit members 2 m, 2 m + 1 of the other forms)
     // resident weights of this wave: rows of my N unit tiles, my N chunks, three slices
-    v4u wf[N][N][NS];
+    v4u wf[NRT][N][NS];
     {
-        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * Ut * Hc * NS * 64;
+        // (PACK: a.Wp is the gate-major pack, three row tiles a member, 3 * G of them a matrix)
+        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * (PACK ? 3 * G : Ut) * Hc * NS * 64;
+        const int rt_first = PACK ? 3 * m : ut0;
 #pragma unroll
-        for (int j = 0; j < N; j++)
+        for (int j = 0; j < NRT; j++)
 #pragma unroll
             for (int cc = 0; cc < N; cc++)
 #pragma unroll
                 for (int s = 0; s < NS; s++)
-                    wf[j][cc][s] = wp[(((size_t)(ut0 + j) * Hc + chunk[cc]) * NS + s) * 64 + lane];
+                    wf[j][cc][s] = wp[(((size_t)(rt_first + j) * Hc + chunk[cc]) * NS + s) * 64 + lane];
     }
     __syncthreads();
     if (lds_abort) return;
@@ -401,7 +411,31 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         h = ph_at(0, gts, gj)[lane].x * 1e-3f;
         if (false)
 #endif
-        if (KIND == 1) {
+        if constexpr (PACK) {
+            // as the GRUmod branch below, on component gj of the four partial tiles {z, r, u = (sW h)_c, x_c = (Wi x)_c} of read tile gts
+            // The K quarters are added in the order the other forms add them for these units (there they belong to member 2 m + (gj >> 1), whose
+            // wave w2 holds quarter (w2 + 2 m + (gj >> 1)) & 3; here wave w holds quarter (w + m) & 3): the results are bit-identical.
+            float sz = 0.f, sr = 0.f, su = 0.f, sx = 0.f;
+            const int rot = m + (gj >> 1);
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) {
+                const float *pz = (const float *)&ph_at((w2 + rot) & 3, gts, 0)[lane] + gj;
+                sz += pz[0]; sr += pz[64 * 4]; su += pz[128 * 4]; sx += pz[192 * 4];
+            }
+            sz = __builtin_ldexpf(sz, neg_exp); sr = __builtin_ldexpf(sr, neg_exp); su = __builtin_ldexpf(su, neg_exp); sx = __builtin_ldexpf(sx, neg_exp);
+            const v4f b = sbias[gj][q];
+            if (a.fast_gates) {
+                const float z = logistic_hw(sz + b.x), r = logistic_hw(sr + b.y);
+                const float hbar = tanh_hw(r * su + (sx + b.z));
+                h = z * c + (1.0f - z) * hbar;
+            } else {
+                const ffv2 L = logistic_ref2_lean((ffv2){ sz + b.x, sr + b.y });
+                float hbar = L.y * su + (sx + b.z);
+                hbar = tanh_ref_lean(hbar);
+                h = L.x * c + (1.0f - L.x) * hbar;
+            }
+            c = h;
+        } else if (KIND == 1) {
             // GRUmod (layers.c:690-714).  The accumulator rows are {z: x + h parts, r: x + h parts, u = (sW h)_c, x_c = (Wi x)_c}:
             // the candidate's two halves must stay apart (r multiplies only the recurrent one), and a unit's fourth row is free.
             // `c` carries this lane's own h(t-1).
@@ -502,16 +536,16 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         // Both tiles' partials are computed BEFORE the wait for the h wave's "consumed" flags -- those are raised at the end of its
         // recurrent pass, and a projection of the second tile started only then would stand between the h waves and the barrier.
         auto project_step = [&](int i, int want) {           // x(step i) of both tiles -> px[0][kw][*]; want = the step (+1) whose partials must have been consumed (0: none)
-            v4f acc[TS][N];
+            v4f acc[TS][NRT];
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
                 load_x_tile(i, ts);
 #pragma unroll
-                for (int j = 0; j < N; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+                for (int j = 0; j < NRT; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #if !(FFHIP_SPLIT_ABLATE & 1)          // 1 = x waves issue no MFMAs
 #pragma unroll
-                for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[cc], acc[ts]);
+                for (int cc = 0; cc < N; cc++) mm6<NRT, N>(wf, cc, xb[cc], acc[ts]);
 #endif
             }
 #pragma unroll
@@ -520,11 +554,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 if (want > 0)
                     for (unsigned spin = 0; *(volatile int *)&pxc[kw][ts] != want && 0 == *(volatile int *)&lds_abort && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                for (int j = 0; j < N; j++) px[0][kw][ts][j][lane] = acc[ts][j];
+                for (int j = 0; j < NRT; j++) px[0][kw][ts][j][lane] = acc[ts][j];
             }
         };
         constexpr int WARM = 3;
-        constexpr int LPM = (Hc * NS * 8 * TS + 31) / 32;    // 128-byte lines of the group's x(step) per member
+        constexpr int LPM = (Hc * NS * 8 * TS + G - 1) / G;  // 128-byte lines of the group's x(step) per member
         unsigned touched = 0, sink = 0;
         auto touch_x = [&](int i) {                          // L2 warming, spread over the group (see the classic loop below)
             const int line = m * LPM + lane;
@@ -595,7 +629,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
                 for (int j = 0; j < N; j++) acc[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-                for (int cc = 0; cc < N; cc++) mm6<N>(wf, cc, xb[ts][cc], acc);
+                for (int cc = 0; cc < N; cc++)
+                    if constexpr (!PACK) mm6<N>(wf, cc, xb[ts][cc], acc);
 #pragma unroll
                 for (int j = 0; j < N; j++) px[DN ? 0 : (i & 1)][kw][ts][j][lane] = acc[j];
             }
@@ -736,7 +771,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                             const v4u r = raw[k][s];
                             ok = ok && r.x != kSplitSentinel && r.y != kSplitSentinel && r.z != kSplitSentinel && r.w != kSplitSentinel;
                         }
-                        mm6<N>(wf, k % N, raw[k], acc[k / N]);
+                        if constexpr (!PACK) mm6<N>(wf, k % N, raw[k], acc[k / N]);
                         __builtin_amdgcn_sched_barrier(0);      // keep each chunk's check and MFMAs behind ITS loads only: the sweep streams under the MFMAs
                     }
 #if FFHIP_SPLIT_ABLATE & 2
@@ -776,7 +811,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[k & 1][0]), "+v"(r[k & 1][1]) :: "memory");
                             if (k + 1 < N) fetch(k + 1);
                             seen = sentinel_max(seen, r[k & 1]);
-                            mm6<N>(wf, k, r[k & 1], acc[0]);
+                            if constexpr (!PACK) mm6<N>(wf, k, r[k & 1], acc[0]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -816,11 +851,18 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                         fetch(0);
 #pragma unroll
                         for (int ts = 0; ts < 2; ts++) {
-                            v4f accd[N];
+                            v4f accd[NRT], xc = { 0.f, 0.f, 0.f, 0.f };
+                            if constexpr (PACK) {          // z and r start from their projection partials; the candidate's two halves stay apart
+                                accd[0] = px[0][kw][ts][0][lane];
+                                accd[1] = px[0][kw][ts][1][lane];
+                                accd[2] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+                                xc = px[0][kw][ts][2][lane];
+                            } else {
 #pragma unroll
-                            for (int j = 0; j < N; j++) {
-                                const v4f p = px[0][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
-                                accd[j] = KIND == 1 ? (v4f){ p.x, p.y, 0.0f, p.z } : p;
+                                for (int j = 0; j < N; j++) {
+                                    const v4f p = px[0][kw][ts][j][lane];      // (an absent second tile: stale LDS, dropped)
+                                    accd[j] = KIND == 1 ? (v4f){ p.x, p.y, 0.0f, p.z } : p;
+                                }
                             }
 #pragma unroll
                             for (int k = 0; k < N; k++) {
@@ -828,12 +870,13 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[c & 1][0]), "+v"(r[c & 1][1]) :: "memory");
                                 if (c + 1 < 2 * N) fetch(c + 1);
                                 seen = sentinel_max(seen, r[c & 1]);
-                                mm6<N>(wf, k, r[c & 1], accd);
+                                mm6<NRT, N>(wf, k, r[c & 1], accd);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if (ts < ntl) {
 #pragma unroll
-                                for (int j = 0; j < N; j++) ph_at(kw, ts, j)[lane] = accd[j];
+                                for (int j = 0; j < NRT; j++) ph_at(kw, ts, j)[lane] = accd[j];
+                                if constexpr (PACK) ph_at(kw, ts, 3)[lane] = xc;
                             }
                         }
                     }
@@ -868,12 +911,23 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             }
             if constexpr (DN) {
                 if (i == 0) {                                    // h(-1) = 0: the gate pre-activations are the projection alone
+                    if constexpr (PACK) {
+#pragma unroll
+                        for (int ts = 0; ts < TS; ts++) {
+                            if (ts >= ntl) continue;
+                            ph_at(kw, ts, 0)[lane] = px[0][kw][ts][0][lane];
+                            ph_at(kw, ts, 1)[lane] = px[0][kw][ts][1][lane];
+                            ph_at(kw, ts, 2)[lane] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+                            ph_at(kw, ts, 3)[lane] = px[0][kw][ts][2][lane];
+                        }
+                    } else {
                     init_acc();
 #pragma unroll
                     for (int ts = 0; ts < TS; ts++) {
                         if (ts >= ntl) continue;
 #pragma unroll
                         for (int j = 0; j < N; j++) ph_at(kw, ts, j)[lane] = acc[ts][j];
+                    }
                     }
                 }
                 // the projection partials of this step are consumed: the x wave of my K quarter may write the next ones
@@ -911,6 +965,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 template <int KIND, int N, int TS, bool DN = false>
 __global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
 k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN>(a, (int)blockIdx.x); }
+
+// the packed GRUmod form (H = 256): 128 registers, two workgroups a CU, 16 members a group
+__global__ void __launch_bounds__(512, 4)
+k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true>(a, (int)blockIdx.x); }
 
 // The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
 // others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
@@ -1361,14 +1419,19 @@ static bool split_dense256(int H) {
     const char *e = getenv("FFHIP_DENSE256");
     return H == 256 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS") && !getenv("FFHIP_NO_DENSE");
 }
+// GRUmod at H = 256: the packed form (lstm_split_body's PACK) -- 16 members a group, 128 registers, two workgroups a CU: a FULL launch takes
+// 8 * (ncu / 32) tiles, 1024 reads on 256 CUs; its weights are the second half of the layer's pack (FFHIP_NO_PACK: never)
+static bool split_pack256(int kind, int H) { return kind == 1 && split_dense256(H) && !getenv("FFHIP_NO_PACK"); }
+static bool split_launch_pack(int kind, int H, int nrt, int ncu) { return split_pack256(kind, H) && nrt == 8 * (ncu / 32); }
 int split_max_tiles(int ncu, int H) {
     if (split_dense256(H)) return 6 * (ncu / 32);
     return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32);
 }
 // tiles the next launch of a batch takes when `remaining` are left: the dense forms are for FULL launches only (a partly filled
 // one has a group count that is no multiple of the 8 XCDs and loses the one-L2 hand-off)
-int split_next_launch_tiles(int H, int remaining, int ncu) {
+int split_next_launch_tiles(int kind, int H, int remaining, int ncu) {
     const int unit = ncu / 32;
+    if (split_pack256(kind, H) && remaining >= 8 * unit) return 8 * unit;
     if (split_dense256(H) && remaining >= 6 * unit) return 6 * unit;
     if ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") && remaining >= 4 * unit) return 4 * unit;
     return remaining < 2 * unit ? remaining : 2 * unit;
@@ -1388,13 +1451,21 @@ static int split_launch_ts(int kind, int H, int nrt, int ncu, int beside) {
 }
 // workgroups of such a launch, and how many workgroups of its kernel share a CU: two launches (of two batches in flight) are
 // co-resident -- every workgroup of both must be, they wait for their peers -- iff together they fit
-int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside) { const int ts = split_launch_ts(kind, H, nrt, ncu, beside); return (nrt + ts - 1) / ts * 32; }
+int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside) {
+    if (split_launch_pack(kind, H, nrt, ncu)) return nrt / 2 * 16;
+    const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
+    return (nrt + ts - 1) / ts * 32;
+}
 int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside) {
     const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
+    if (split_launch_pack(kind, H, nrt, ncu)) return 2;
     if (split_launch_dense256(H, nrt, ncu)) return 3;
     return (ts == 1 || H <= 256 || split_launch_dense3(kind, H, nrt, ncu, beside)) ? 2 : 1;
 }
 size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
+// 16-byte pieces of a layer's classic pack [2 matrices][H / 4 unit tiles][H / 32 chunks][slices][64 lanes]: the gate-major pack of the packed
+// GRUmod form ([2][3 H / 16 row tiles][H / 32][slices][64]) follows it
+size_t split_pack_offset(int H) { return (size_t)2 * (H / 4) * (H / 32) * NS * 64; }
 int split_tiles_per_group(int kind, int H) {
     const char *force = getenv("FFHIP_SPLIT_TS");      // development: 1 or 2
     if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
@@ -1453,6 +1524,11 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     const int ngroup_l = (nrt + ts - 1) / ts;
 #ifndef FFHIP_SPLIT_BF16X3
     if (split_launch_dense3(kind, H, nrt, ncu, beside)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
+    if (split_launch_pack(kind, H, nrt, ncu)) {
+        a.Wp += split_pack_offset(H);
+        hipLaunchKernelGGL(k_grumod_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
+        return true;
+    }
     if (split_launch_dense256(H, nrt, ncu)) {
         if (kind == 0) hipLaunchKernelGGL((k_lstm_split<0, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_lstm_split<1, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
