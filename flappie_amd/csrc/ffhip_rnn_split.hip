@@ -190,6 +190,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     static_assert(!PACK || (DN && KIND == 1 && N == 2), "the packed form is the dense GRUmod form at H = 256");
     constexpr int NRT = PACK ? 3 : N;           // row tiles of a wave
     constexpr int MT = PACK ? 4 : N;            // unit tiles (of 4 units) of a member
+    // PACK has registers to spare (two workgroups a CU: 128) and spends 24 of them on the step's latency chain: the h waves take their projection
+    // partials into registers at the top of the step and release them at once -- the x waves never wait for the "consumed" flags, and the barrier
+    // behind the recurrent pass never waits for the x waves (-4.7 % layer time; profiles/r03_pack_experiments.txt).
+    // (Measured and dropped there: the first tile's four gate jobs worked by the x waves UNDER the second tile's MFMAs, as soon as the h waves
+    // have its partials in LDS -- a gate chain is twice as long as half a recurrent pass, the h waves then wait at the barrier for it: +11 %.)
     __shared__ v4f px[DN ? 1 : 2][4][TS][NRT][64];     // projection partials, double-buffered (DN: single): [step parity][K quarter][tile of the group][unit tile][lane]
     __shared__ v4f ph_[DN ? 1 : 4][DN ? 1 : TS][DN ? 1 : N][64];        // gate pre-activations by K quarter: projection partial + recurrent partial (DN: in the landing zone)
     __shared__ int pxc[4][2];               // DN: step (+1) whose projection partial of (K quarter, tile) the h wave has consumed
@@ -228,7 +233,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     const int TbB = haveB ? (a.tbt ? a.tbt[rtA + 1] : a.Tb) : 0;
     const int Tb = TbA > TbB ? TbA : TbB;                 // steps of this pair of read tiles
     if (Tb <= 0) return;                                  // empty slots only (uniform for the whole group)
-    const int ntl = (TbB > 0) ? 2 : 1;
+    const int ntl = PACK ? __builtin_amdgcn_readfirstlane((TbB > 0) ? 2 : 1) : ((TbB > 0) ? 2 : 1);      // (PACK: said to be scalar -- a test on it lived in a spilled vector register)
     const int ut0 = m * MT;
     if (threadIdx.x == 0) lds_abort = (__hip_atomic_load(a.abort_word, RLX_AGENT) != 0u) ? 1 : 0;      // an earlier layer of this batch gave up: leave at once
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * MT) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
@@ -417,9 +422,12 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             // wave w2 holds quarter (w2 + 2 m + (gj >> 1)) & 3; here wave w holds quarter (w + m) & 3): the results are bit-identical.
             float sz = 0.f, sr = 0.f, su = 0.f, sx = 0.f;
             const int rot = m + (gj >> 1);
+            unsigned lv = (unsigned)lane;          // (an opaque copy: the four addresses are recomputed per step instead of living in -- spilled -- registers)
+            asm volatile("" : "+v"(lv));
+            const char *pbase = (const char *)&hland[0][gts][0][0][0] + lv * 16u + (unsigned)gj * 4u;
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) {
-                const float *pz = (const float *)&ph_at((w2 + rot) & 3, gts, 0)[lane] + gj;
+                const float *pz = (const float *)(pbase + ((w2 + rot) & 3) * (int)sizeof(hland[0]));
                 sz += pz[0]; sr += pz[64 * 4]; su += pz[128 * 4]; sx += pz[192 * 4];
             }
             sz = __builtin_ldexpf(sz, neg_exp); sr = __builtin_ldexpf(sr, neg_exp); su = __builtin_ldexpf(su, neg_exp); sx = __builtin_ldexpf(sx, neg_exp);
@@ -592,7 +600,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 gate_front(i, my_gts, my_gj, c, my_tb);
                 __builtin_amdgcn_s_setprio(0);
             } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
-            else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            else if (gate_wave) {
+                if (PACK) __builtin_amdgcn_s_setprio(3);      // every wave works a gate job: the x waves' at the h waves' priority (-1.7 %)
+                gate_tile(i, my_gts, my_gj, c, my_tb);
+                if (PACK) __builtin_amdgcn_s_setprio(0);
+            }
             if (aborted) return;
             TL(4);
             raw_barrier();                                   // closes the gate phase
@@ -709,6 +721,15 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     }
             };
             if constexpr (!DN) init_acc();
+            v4f pc[PACK ? 2 : 1][3];           // PACK: the projection partials move to registers at the top of the step and are released at once
+            if constexpr (PACK) {
+#pragma unroll
+                for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) pc[ts][j] = px[0][kw][ts][j][lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;
+            }
             if (i > 0) {
                 const int tp = step_t(i - 1);
                 const unsigned char *hp = tile_ptr(a.hout, tp, 0);          // the pair's two tiles are adjacent
@@ -853,10 +874,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                         for (int ts = 0; ts < 2; ts++) {
                             v4f accd[NRT], xc = { 0.f, 0.f, 0.f, 0.f };
                             if constexpr (PACK) {          // z and r start from their projection partials; the candidate's two halves stay apart
-                                accd[0] = px[0][kw][ts][0][lane];
-                                accd[1] = px[0][kw][ts][1][lane];
-                                accd[2] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-                                xc = px[0][kw][ts][2][lane];
+                                accd[0] = pc[ts][0]; accd[1] = pc[ts][1]; accd[2] = (v4f){ 0.f, 0.f, 0.f, 0.f }; xc = pc[ts][2];
                             } else {
 #pragma unroll
                                 for (int j = 0; j < N; j++) {
@@ -915,10 +933,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
                         for (int ts = 0; ts < TS; ts++) {
                             if (ts >= ntl) continue;
-                            ph_at(kw, ts, 0)[lane] = px[0][kw][ts][0][lane];
-                            ph_at(kw, ts, 1)[lane] = px[0][kw][ts][1][lane];
+                            ph_at(kw, ts, 0)[lane] = pc[ts][0];
+                            ph_at(kw, ts, 1)[lane] = pc[ts][1];
                             ph_at(kw, ts, 2)[lane] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-                            ph_at(kw, ts, 3)[lane] = px[0][kw][ts][2][lane];
+                            ph_at(kw, ts, 3)[lane] = pc[ts][2];
                         }
                     } else {
                     init_acc();
@@ -932,7 +950,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 }
                 // the projection partials of this step are consumed: the x wave of my K quarter may write the next ones
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;
+                if (!PACK && lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;      // (PACK: released at the top of the step)
             } else {
 #pragma unroll
                 for (int ts = 0; ts < TS; ts++) {

@@ -11,7 +11,7 @@ using namespace ffhip;
 int main(int argc, char **argv) {
     const int H = argc > 2 ? atoi(argv[2]) : 384, B16 = argc > 1 ? atoi(argv[1]) : 16, Tb = 400;
     void *Wp, *xin, *hout; float *bias; unsigned *flags, *ab; unsigned long long *dbg;
-    const size_t wbytes = (size_t)2 * 4 * H * H * 6, abytes = split_bytes((size_t)Tb * B16, H);
+    const size_t wbytes = (size_t)2 * 4 * H * H * 8, abytes = split_bytes((size_t)Tb * B16, H);
     hipMalloc(&Wp, wbytes); hipMemset(Wp, 0, wbytes);
     hipMalloc(&bias, 4 * H * 4); hipMemset(bias, 0, 4 * H * 4);
     hipMalloc(&xin, abytes); hipMemset(xin, 0, abytes);
@@ -23,12 +23,13 @@ int main(int argc, char **argv) {
     g_split_dbg = dbg;
     const int mode = argc > 3 ? atoi(argv[3]) : 0;
     const int nrep = argc > 4 ? atoi(argv[4]) : 40;      // enough launches for the clocks to settle: the first ones run ~40 % slower
+    const int kind = argc > 5 ? atoi(argv[5]) : 0;          // 1: GRUmod (H = 256 and B16 = 64: the packed form)
     for (int rep = 0; rep < nrep; rep++) {
         hipMemsetD32((hipDeviceptr_t)hout, 0xFFFFFFFF, abytes / 4);
         hipMemset(flags, 0, 4096 * 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        launch_lstm_split(0, 0, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode, 0, 0, nullptr, nullptr, 256, (unsigned)(rep + 1), 0);   // B16 = 32 at H = 384: the dense form, two workgroups per CU
+        launch_lstm_split(0, kind, Wp, bias, xin, hout, nullptr, flags, ab, Tb, B16, H, 0, B16, 1, mode, 0, 0, nullptr, nullptr, 256, (unsigned)(rep + 1), 0);   // B16 = 32 at H = 384: the dense form, two workgroups per CU
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep < 2 || rep >= nrep - 2) printf("rep %d: layer %.3f ms = %.3f us/step = %.0f cycles/step\n", rep, ms, ms * 1e3 / Tb, ms * 1e3 / Tb * 2400);
