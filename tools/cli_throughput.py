@@ -18,7 +18,11 @@ counts = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["25
 readers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["4"]      # --readers values to time (0 = the reader thread in the process)
 d = tempfile.mkdtemp(prefix="flappie_cli_")
 t0 = time.time()
-M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native"))
+grumod = len(sys.argv) > 4 and sys.argv[4] == "grumod"              # the r941_5mC model (GRUmod5, stride 2, 10 states) instead of r941_native
+if grumod:
+    M.write_mdl(os.path.join(d, "flipflop_r941native5mC.h"), M.synthetic_model(M.NET_GRUMOD5, hidden, seed=1, ident="r941native5mC"))
+else:
+    M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, hidden, seed=1, ident="r941native"))
 print("model file written in %.1f s" % (time.time() - t0), flush=True)
 tool = os.path.join(ROOT, "flappie_amd", "fast5_tool")
 nmax = max(counts)
@@ -38,7 +42,7 @@ for nr in readers:
         dt = None
         for rep in range(int(os.environ.get("CLI_REPEATS", "3"))):                        # the best of a few runs: a single run's wall varies by +-5 %
             t0 = time.time()
-            r = subprocess.run(wrap + [os.path.join(ROOT, "flappie_amd", "flappie"), "--readers", nr, "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
+            r = subprocess.run(wrap + [os.path.join(ROOT, "flappie_amd", "flappie")] + (["--model", "r941_5mC"] if grumod else []) + ["--readers", nr, "--limit", str(n), "-o", os.path.join(d, "out.fq"), reads], env=env,
                                capture_output=True, text=True)
             dt = min(dt, time.time() - t0) if dt is not None else time.time() - t0
         nrec = sum(1 for ln in open(os.path.join(d, "out.fq")) if ln.startswith("@uuid"))
