@@ -35,9 +35,9 @@ CONFIGS = {
     "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, pair=1, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
-    "h256": dict(kind=0, hidden=256, nread=768, nsample=4000, steps=100, warmup=5, ident="r941native",
+    "h256": dict(kind=0, hidden=256, nread=1024, nsample=4000, steps=100, warmup=5, ident="r941native",
                  metric="Msamples/s basecalled (r941_native 20200220-size model, 4k-sample chunks)",
-                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=768 synthetic 4000-sample reads per GPU (what one layer launch takes at H = 256: three workgroups per CU), posterior decode + trace"),
+                 label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=1024 synthetic 4000-sample reads per GPU (what one layer launch of the packed form takes at H = 256: 16 members a group, two workgroups per CU), posterior decode + trace"),
     "c4":   dict(kind=1, hidden=256, nread=1024, nsample=4000, steps=40, warmup=3, ident="r941_5mC",
                  metric="Msamples/s basecalled (r941_5mC, 4k-sample chunks)",
                  label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=1024 synthetic 4000-sample reads per GPU (what one layer launch of the packed GRUmod form takes: "
@@ -443,7 +443,7 @@ def main():
     nblock_, rnn_path_ = batches[0].nblock, batches[-1].rnn_path()      # (the batches are closed before the line is put together)
     paired_ = (not stub) and pair and batches[0].paired()
     # GRUmod at H = 256 in batches of whole 1024-read launches: the packed form of the layer kernel (ffhip_rnn_split.hip, PACK)
-    packed_ = (not stub) and cfg["kind"] == M.NET_GRUMOD5 and H == 256 and dm is not None and dm.launch_reads == 1024 and NREAD % 1024 == 0
+    packed_ = (not stub) and cfg["kind"] in (M.NET_GRUMOD5, M.NET_LSTM5) and H == 256 and dm is not None and dm.launch_reads == 1024 and NREAD % 1024 == 0
 
     # second leg, reported beside `value`, never as it: the same steps with the batch's signal handed over as a HOST buffer
     # every step (SURVEY.md section 8d counts "from first H2D")
@@ -502,7 +502,8 @@ def main():
             # tests/test_split_numerics.py).  `achieved` counts the ALGORITHMIC fp32 FLOPs; the ceiling of this
             # formulation is the dense fp16/bf16 MFMA peak / 3.
             if rnn_path == 3 and packed_:
-                kname = "k_grumod_pack (GRUmod input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, gate-major row tiles: no empty accumulator rows; %d dependent steps)" % nblock
+                kname = ("k_grumod_pack (GRUmod input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, gate-major row tiles: no empty accumulator rows; %d dependent steps)" if G == 3 else
+                         "k_lstm_pack (LSTM input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, gate-major row tiles, 16 members a group; %d dependent steps)") % nblock
             elif rnn_path == 3:
                 kname = "k_lstm_split%s<%d,%d> (%s input projection + recurrence of one layer on fp16 MFMAs over 2-way split operands, %d dependent steps%s)" % (
                     "_pair" if paired_ else "", 1 if G == 3 else 0, H // 128, cell, nblock, "; ONE launch for the layer of two %d-read batches" % NREAD if paired_ else "")

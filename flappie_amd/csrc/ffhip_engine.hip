@@ -347,10 +347,10 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
             const int S = (split_weight_exp(mx[0]) + ex < split_weight_exp(mx[1]) + eh) ? split_weight_exp(mx[0]) + ex : split_weight_exp(mx[1]) + eh;
             const int sw[2] = { S - ex, S - eh };
             r.split_S = kSplitF16 ? S : 0;
-            // GRUmod at H = 256: the gate-major pack of the packed layer form follows -- row tile 3 mb + gate of member mb (16 units), row
-            // 4 q + c of a tile = unit 16 mb + 4 c + q (ffhip_rnn_split.hip, PACK)
-            const bool gpack = (G == 3 && Hp == 256);
-            const size_t classic = (size_t)2 * Ut * Hc * kSplitNS * 64 * 8, Vt = 3 * (Hp / 16);
+            // H = 256: the gate-major pack of the packed layer forms follows -- row tile G mb + gate of member mb (16 units; G = 3 gates for GRUmod,
+            // 4 for the LSTM), row 4 q + c of a tile = unit 16 mb + 4 c + q (ffhip_rnn_split.hip, PACK)
+            const bool gpack = ((G == 3 || G == 4) && Hp == 256);
+            const size_t classic = (size_t)2 * Ut * Hc * kSplitNS * 64 * 8, Vt = G * (Hp / 16);
             std::vector<uint16_t> sp3(classic + (gpack ? (size_t)2 * Vt * Hc * kSplitNS * 64 * 8 : 0));
             if (gpack)
                 for (int mat = 0; mat < 2; mat++)
@@ -358,8 +358,8 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
                         for (int c = 0; c < Hc; c++)
                             for (int lane = 0; lane < 64; lane++)
                                 for (int e = 0; e < 8; e++) {
-                                    const int row = lane & 15, unit = 16 * (vt / 3) + 4 * (row & 3) + (row >> 2);
-                                    const float w = rowcol(mat == 0 ? iW : sW, 4 * unit + vt % 3, c * 32 + (lane >> 4) * 8 + e);
+                                    const int row = lane & 15, unit = 16 * (vt / G) + 4 * (row & 3) + (row >> 2);
+                                    const float w = rowcol(mat == 0 ? iW : sW, 4 * unit + vt % G, c * 32 + (lane >> 4) * 8 + e);
                                     uint16_t sl[kSplitNS];
                                     split_host_slices(w, sw[mat], sl);
                                     const size_t base = classic + ((((size_t)mat * Vt + vt) * Hc + c) * kSplitNS) * 64 * 8 + (size_t)lane * 8 + e;
@@ -410,8 +410,8 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
 extern "C" size_t ffhip_model_hidden(const ffhip_model *m) { return m ? (size_t)m->H : 0; }
 extern "C" size_t ffhip_model_nparam(const ffhip_model *m) { return m ? (size_t)m->P : 0; }
 extern "C" size_t ffhip_model_nbase(const ffhip_model *m) { return m ? (size_t)m->nbase : 0; }
-// reads one FULL layer launch of this model takes on this device (the batch size that keeps every launch full): 1024 for GRUmod at 256 hidden
-// units (the packed form), 768 for an LSTM there, 512 at 384, else 256 -- on 256 CUs (ffhip_rnn_split.hip, split_next_launch_tiles)
+// reads one FULL layer launch of this model takes on this device (the batch size that keeps every launch full): 1024 at 256 hidden units (the
+// packed forms), 512 at 384, else 256 -- on 256 CUs (ffhip_rnn_split.hip, split_next_launch_tiles)
 extern "C" size_t ffhip_model_launch_reads(const ffhip_model *m) {
     if (!m) return 0;
     const int ncu = m->eng->prop.multiProcessorCount;

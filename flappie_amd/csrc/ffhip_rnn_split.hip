@@ -187,8 +187,11 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 template <int KIND, int N, int TS, bool DN, bool PACK = false>
 __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int block_index) {
     static_assert(!DN || TS == 2, "the dense form is a pair form");
-    static_assert(!PACK || (DN && KIND == 1 && N == 2), "the packed form is the dense GRUmod form at H = 256");
-    constexpr int NRT = PACK ? 3 : N;           // row tiles of a wave
+    static_assert(!PACK || (DN && N == 2), "the packed forms are dense forms at H = 256");
+    // PACK with the LSTM (KIND 0): the same regrouping -- 16 members of 16 units, FOUR gate-major row tiles a member -- without a row to save: what
+    // it buys there is 1024 reads a launch from two fat workgroups a CU instead of 768 from three (the sweep of h(t-1) enters a CU twice, not thrice)
+    constexpr bool PG = PACK && KIND == 1;      // the GRUmod one: three row tiles, the candidate's projection half as a fourth partial tile
+    constexpr int NRT = PACK ? (KIND == 1 ? 3 : 4) : N;      // row tiles of a wave
     constexpr int MT = PACK ? 4 : N;            // unit tiles (of 4 units) of a member
     // PACK has registers to spare (two workgroups a CU: 128) and spends 24 of them on the step's latency chain: the h waves take their projection
     // partials into registers at the top of the step and release them at once -- the x waves never wait for the "consumed" flags, and the barrier
@@ -308,9 +311,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     // resident weights of this wave: rows of my N unit tiles, my N chunks, three slices
     v4u wf[NRT][N][NS];
     {
-        // (PACK: a.Wp is the gate-major pack, three row tiles a member, 3 * G of them a matrix)
-        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * (PACK ? 3 * G : Ut) * Hc * NS * 64;
-        const int rt_first = PACK ? 3 * m : ut0;
+        // (PACK: a.Wp is the gate-major pack, NRT row tiles a member, NRT * G of them a matrix)
+        const v4u *wp = a.Wp + (size_t)(xw ? 0 : 1) * (PACK ? NRT * G : Ut) * Hc * NS * 64;
+        const int rt_first = PACK ? NRT * m : ut0;
 #pragma unroll
         for (int j = 0; j < NRT; j++)
 #pragma unroll
@@ -416,7 +419,34 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         h = ph_at(0, gts, gj)[lane].x * 1e-3f;
         if (false)
 #endif
-        if constexpr (PACK) {
+        if constexpr (PACK && KIND == 0) {
+            // as the LSTM branch below, on component gj of the four partial tiles {i, f, g, o} of read tile gts; quarters in the other forms' order (see below)
+            const v4f b = sbias[gj][q];
+            float s0 = b.x, s1 = b.y, s2 = b.z, s3 = b.w;
+            const int rot = m + (gj >> 1);
+            unsigned lv = (unsigned)lane;
+            asm volatile("" : "+v"(lv));
+            const char *pbase = (const char *)&hland[0][gts][0][0][0] + lv * 16u + (unsigned)gj * 4u;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) {
+                const float *pz = (const float *)(pbase + ((w2 + rot) & 3) * (int)sizeof(hland[0]));
+                s0 += pz[0]; s1 += pz[64 * 4]; s2 += pz[128 * 4]; s3 += pz[192 * 4];
+            }
+            const v4f s = unscale4((v4f){ s0, s1, s2, s3 });
+            if (a.fast_gates) {
+                const float forget = logistic_hw(s.y) * c;
+                const float update = logistic_hw(s.x) * tanh_hw(s.z);
+                c = forget + update;
+                h = logistic_hw(s.w) * tanh_hw(c);
+            } else {
+                const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
+                const float tanh_g = (L.z + L.z) - 1.0f;
+                const float forget = L.y * c;
+                const float update = L.x * tanh_g;
+                c = forget + update;
+                h = L.w * tanh_ref_lean(c);
+            }
+        } else if constexpr (PACK) {
             // as the GRUmod branch below, on component gj of the four partial tiles {z, r, u = (sW h)_c, x_c = (Wi x)_c} of read tile gts
             // The K quarters are added in the order the other forms add them for these units (there they belong to member 2 m + (gj >> 1), whose
             // wave w2 holds quarter (w2 + 2 m + (gj >> 1)) & 3; here wave w holds quarter (w + m) & 3): the results are bit-identical.
@@ -548,12 +578,24 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
-                load_x_tile(i, ts);
+                if constexpr (!(PACK && KIND == 0)) load_x_tile(i, ts);
 #pragma unroll
                 for (int j = 0; j < NRT; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #if !(FFHIP_SPLIT_ABLATE & 1)          // 1 = x waves issue no MFMAs
+                if constexpr (PACK && KIND == 0) {
+                    // 64 weight + 32 accumulator registers: x(t) comes a chunk at a time (8 registers; the x waves have the slack for the second wait)
+                    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.xin, step_t(i), ts), 0, (int)tileB, 0x00020000);
+#pragma unroll
+                    for (int cc = 0; cc < N; cc++) {
+#pragma unroll
+                        for (int s = 0; s < NS; s++) xb[0][s] = __builtin_amdgcn_raw_buffer_load_b128(rx, lane_off, ((chunk[cc] * NS + s) * 64) * 16, 0);
+                        mm6<NRT, N>(wf, cc, xb[0], acc[ts]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int cc = 0; cc < N; cc++) mm6<NRT, N>(wf, cc, xb[cc], acc[ts]);
+                }
 #endif
             }
 #pragma unroll
@@ -569,7 +611,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         constexpr int LPM = (Hc * NS * 8 * TS + G - 1) / G;  // 128-byte lines of the group's x(step) per member
         unsigned touched = 0, sink = 0;
         auto touch_x = [&](int i) {                          // L2 warming, spread over the group (see the classic loop below)
-            const int line = m * LPM + lane;
+            unsigned lt = (unsigned)lane;
+            if constexpr (PACK && KIND == 0) asm volatile("" : "+v"(lt));      // (an opaque copy: no 64-bit lane address held -- spilled -- across the step)
+            const int line = m * LPM + (int)lt;
             unsigned t = 0;
             if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb && !(FFHIP_EXP & 16))      // EXP 16: no L2 warming (counter calibration)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
@@ -721,8 +765,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     }
             };
             if constexpr (!DN) init_acc();
-            v4f pc[PACK ? 2 : 1][3];           // PACK: the projection partials move to registers at the top of the step and are released at once
-            if constexpr (PACK) {
+            v4f pc[PG ? 2 : 1][3];             // PACK (GRUmod): the projection partials move to registers at the top of the step and are released at once
+            if constexpr (PG) {
 #pragma unroll
                 for (int ts = 0; ts < 2; ts++)
 #pragma unroll
@@ -873,7 +917,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
                         for (int ts = 0; ts < 2; ts++) {
                             v4f accd[NRT], xc = { 0.f, 0.f, 0.f, 0.f };
-                            if constexpr (PACK) {          // z and r start from their projection partials; the candidate's two halves stay apart
+                            if constexpr (PACK && KIND == 0) {
+#pragma unroll
+                                for (int j = 0; j < NRT; j++) accd[j] = px[0][kw][ts][j][lane];
+                            } else if constexpr (PACK) {          // z and r start from their projection partials; the candidate's two halves stay apart
                                 accd[0] = pc[ts][0]; accd[1] = pc[ts][1]; accd[2] = (v4f){ 0.f, 0.f, 0.f, 0.f }; xc = pc[ts][2];
                             } else {
 #pragma unroll
@@ -894,7 +941,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                             if (ts < ntl) {
 #pragma unroll
                                 for (int j = 0; j < NRT; j++) ph_at(kw, ts, j)[lane] = accd[j];
-                                if constexpr (PACK) ph_at(kw, ts, 3)[lane] = xc;
+                                if constexpr (PG) ph_at(kw, ts, 3)[lane] = xc;
                             }
                         }
                     }
@@ -929,7 +976,14 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             }
             if constexpr (DN) {
                 if (i == 0) {                                    // h(-1) = 0: the gate pre-activations are the projection alone
-                    if constexpr (PACK) {
+                    if constexpr (PACK && KIND == 0) {
+#pragma unroll
+                        for (int ts = 0; ts < TS; ts++) {
+                            if (ts >= ntl) continue;
+#pragma unroll
+                            for (int j = 0; j < NRT; j++) ph_at(kw, ts, j)[lane] = px[0][kw][ts][j][lane];
+                        }
+                    } else if constexpr (PACK) {
 #pragma unroll
                         for (int ts = 0; ts < TS; ts++) {
                             if (ts >= ntl) continue;
@@ -950,7 +1004,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 }
                 // the projection partials of this step are consumed: the x wave of my K quarter may write the next ones
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!PACK && lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;      // (PACK: released at the top of the step)
+                if (!PG && lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;      // (the packed GRUmod form: released at the top of the step)
             } else {
 #pragma unroll
                 for (int ts = 0; ts < TS; ts++) {
@@ -987,6 +1041,8 @@ k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN>(a, (int)blockIdx.x)
 // the packed GRUmod form (H = 256): 128 registers, two workgroups a CU, 16 members a group
 __global__ void __launch_bounds__(512, 4)
 k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true>(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(512, 4)
+k_lstm_pack(SplitArgs a) { lstm_split_body<0, 2, 2, true, true>(a, (int)blockIdx.x); }
 
 // The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
 // others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
@@ -1437,9 +1493,9 @@ static bool split_dense256(int H) {
     const char *e = getenv("FFHIP_DENSE256");
     return H == 256 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS") && !getenv("FFHIP_NO_DENSE");
 }
-// GRUmod at H = 256: the packed form (lstm_split_body's PACK) -- 16 members a group, 128 registers, two workgroups a CU: a FULL launch takes
-// 8 * (ncu / 32) tiles, 1024 reads on 256 CUs; its weights are the second half of the layer's pack (FFHIP_NO_PACK: never)
-static bool split_pack256(int kind, int H) { return kind == 1 && split_dense256(H) && !getenv("FFHIP_NO_PACK"); }
+// H = 256: the packed forms (lstm_split_body's PACK; k_grumod_pack, k_lstm_pack) -- 16 members a group, 128 registers, two workgroups a CU: a
+// FULL launch takes 8 * (ncu / 32) tiles, 1024 reads on 256 CUs; their weights are the second half of the layer's pack (FFHIP_NO_PACK: never)
+static bool split_pack256(int kind, int H) { return (kind == 0 || kind == 1) && split_dense256(H) && !getenv("FFHIP_NO_PACK"); }
 static bool split_launch_pack(int kind, int H, int nrt, int ncu) { return split_pack256(kind, H) && nrt == 8 * (ncu / 32); }
 int split_max_tiles(int ncu, int H) {
     if (split_dense256(H)) return 6 * (ncu / 32);
@@ -1544,7 +1600,8 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     if (split_launch_dense3(kind, H, nrt, ncu, beside)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
     if (split_launch_pack(kind, H, nrt, ncu)) {
         a.Wp += split_pack_offset(H);
-        hipLaunchKernelGGL(k_grumod_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
+        if (kind == 1) hipLaunchKernelGGL(k_grumod_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(k_lstm_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
         return true;
     }
     if (split_launch_dense256(H, nrt, ncu)) {

@@ -63,7 +63,7 @@ static struct argp_option options[] = {
     {"hdf5-chunk", 13, "size", 0, "Chunk size for HDF5 output"},
     {"uuid", 14, 0, 0, "Output UUID"},
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
-    {"batch", 16, "nreads", 0, "Reads per GPU batch (default: what one layer launch takes -- 768 at up to 256 hidden units (1024: GRUmod), 512 up to 384, else 256)"},
+    {"batch", 16, "nreads", 0, "Reads per GPU batch (default: what one layer launch takes -- 1024 at up to 256 hidden units, 512 up to 384, else 256)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
     {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 12; 0 reads in this process)"},
     {0}
@@ -864,8 +864,8 @@ int main(int argc, char *argv[]) {
     reader_state rs;
     memset(&rs, 0, sizeof(rs));
     rs.fl = &fl;
-    /* reads per batch = what one layer launch takes (ffhip_rnn_split.hip, dense forms): 768 at H <= 256 (three workgroups per CU; 1024 for
-     * GRUmod, the packed form), 512 at H <= 384 (two), else 256 */
+    /* reads per batch = what one layer launch takes (ffhip_rnn_split.hip): 1024 at H = 256 (the packed forms), 512 at H <= 384 (the dense
+     * form), else 256 */
     if (0 == args.batch) args.batch = (int)ffhip_model_launch_reads(mdl);
     rs.chunk_cap = 4 * args.batch;
     for (int k = 0; k < NCHUNKBUF; k++) {

@@ -93,7 +93,7 @@ void ffhip_model_free(ffhip_model *mdl);
 size_t ffhip_model_hidden(const ffhip_model *mdl);
 size_t ffhip_model_nparam(const ffhip_model *mdl);       /* nstate * (nbase + 1), rows of `trans` */
 size_t ffhip_model_nbase(const ffhip_model *mdl);
-size_t ffhip_model_launch_reads(const ffhip_model *mdl);  /* reads per batch that keep every layer launch of this model full on this device */
+size_t ffhip_model_launch_reads(const ffhip_model *mdl);  /* reads per batch that keep every layer launch of this model full on this device (MI355X: 1024 at 256 hidden units, 512 at 384, else 256) */
 size_t ffhip_model_nblock(const ffhip_model *mdl, size_t nsample);   /* iceil chain, layers.c:204 */
 
 /* ---- batch: `nread` reads of `nsample` samples each, workspace resident in HBM -------------- */

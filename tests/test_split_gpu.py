@@ -131,14 +131,15 @@ def test_split_kernel_agrees_with_f32_kernel(B, engine, kind, hidden, nread, T):
 
 
 @pytest.mark.parametrize("kind,nread", [(M.NET_LSTM5, 512), (M.NET_GRUMOD5, 400), (M.NET_LSTM5, 768), (M.NET_GRUMOD5, 768), (M.NET_GRUMOD5, 1040), (M.NET_LSTM5, 1040),
-                                        (M.NET_GRUMOD5, 2064)])
+                                        (M.NET_GRUMOD5, 2064), (M.NET_LSTM5, 2064)])
 def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monkeypatch):
     """H <= 256 and more than 256 reads: one launch carries up to 512 reads (pair form, two workgroups per CU) or -- round 3 -- 768
     (the dense form in 79 registers: THREE workgroups per CU) instead of launches of 256 -- same arithmetic, so every score must be
     IDENTICAL to what the one-tile launches give (FFHIP_NO_DENSE=1); ragged lengths, the last pair of the 400-read batch has one
-    member, the 1040-read LSTM batch is a 768-read launch, a 256-read launch and a 16-read one.
-    GRUmod from 1024 reads on: the PACKED form (16 members a group, three gate-major row tiles a member, no empty accumulator rows; 1024 reads a
-    launch) -- another tiling of the same sums in the same order, so identical as well; 1040 reads = one packed launch + 16 reads, 2064 = two + 16"""
+    member.
+    From 1024 reads on: the PACKED forms (16 members a group, gate-major row tiles -- three a member for GRUmod, no empty accumulator rows, four
+    for the LSTM; 1024 reads a launch) -- another tiling of the same sums in the same order, so identical as well; 1040 reads = one packed launch
+    + 16 reads, 2064 = two + 16"""
     mdl = M.synthetic_model(kind, 256, seed=5 + kind)
     dm = B.DeviceModel(engine, mdl)
     rng = np.random.default_rng(nread)
@@ -164,7 +165,7 @@ def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monk
 
 
 # (384 x 512 and 256 x 768: every layer launch fills the chip -- such batches run one after the other on the GPU, ffhip_engine.hip "whole batches")
-@pytest.mark.parametrize("kind,hidden,nread", [(M.NET_LSTM5, 384, 256), (M.NET_LSTM5, 256, 512), (M.NET_GRUMOD5, 256, 256), (M.NET_LSTM5, 384, 512), (M.NET_LSTM5, 256, 768), (M.NET_GRUMOD5, 256, 1024)])
+@pytest.mark.parametrize("kind,hidden,nread", [(M.NET_LSTM5, 384, 256), (M.NET_LSTM5, 256, 512), (M.NET_GRUMOD5, 256, 256), (M.NET_LSTM5, 384, 512), (M.NET_LSTM5, 256, 768), (M.NET_GRUMOD5, 256, 1024), (M.NET_LSTM5, 256, 1024)])
 def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, nread):
     """bench.py's default at c2 and the flappie binary keep two batches in flight (one stream each; the persistent layer launches of
     the two are chained, every other kernel overlaps the other batch's layers).  Three rounds of run / run / finish / finish with
@@ -198,10 +199,10 @@ def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, 
 
 
 def test_launch_reads_is_what_a_full_layer_launch_takes(B, engine):
-    """ffhip_model_launch_reads (the flappie binary's default batch size): per 32 CUs 8 read tiles for GRUmod at H = 256 (the packed
-    form), 6 for an LSTM there, 4 at H = 384, 2 at H = 512 and for the shapes outside the split kernels"""
+    """ffhip_model_launch_reads (the flappie binary's default batch size): per 32 CUs 8 read tiles at H = 256 (the packed forms), 4 at
+    H = 384, 2 at H = 512 and for the shapes outside the split kernels"""
     unit = engine.info()["ncu"] // 32
-    for kind, hidden, tiles in ((M.NET_GRUMOD5, 256, 8), (M.NET_LSTM5, 256, 6), (M.NET_LSTM5, 384, 4), (M.NET_LSTM5, 512, 2), (M.NET_LSTM5, 96, 2)):
+    for kind, hidden, tiles in ((M.NET_GRUMOD5, 256, 8), (M.NET_LSTM5, 256, 8), (M.NET_LSTM5, 384, 4), (M.NET_LSTM5, 512, 2), (M.NET_LSTM5, 96, 2)):
         dm = B.DeviceModel(engine, M.synthetic_model(kind, hidden, seed=1))
         assert dm.launch_reads == 16 * tiles * unit, (kind, hidden)
         dm.close()

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-RECURRENT = ("k_lstm_split", "k_grumod_pack", "k_rnn_split", "k_lstm_fused", "k_rnn_persist")
+RECURRENT = ("k_lstm_split", "k_grumod_pack", "k_lstm_pack", "k_rnn_split", "k_lstm_fused", "k_rnn_persist")
 
 
 def find(scratch, tag, leg, suffix):
@@ -99,7 +99,7 @@ def main():
         H, nread, T = cfg["hidden"], cfg["nread"], cfg["nsample"]
         from flappie_amd import model as M
         Tb = M.synthetic_model(cfg["kind"], 128, seed=1).nblock(T)
-        rnn_path = 3 if ("k_lstm_split" in dom or "k_grumod_pack" in dom) else (4 if "k_rnn_split" in dom else (2 if "fused" in dom else 1))
+        rnn_path = 3 if ("k_lstm_split" in dom or "k_grumod_pack" in dom or "k_lstm_pack" in dom) else (4 if "k_rnn_split" in dom else (2 if "fused" in dom else 1))
         G = 3 if cfg["kind"] == 1 else 4
         # algorithmic bytes per launch: split layer kernel reads x and writes h at 4 B per value (two fp16 slices); f32 fused 4 + 4;
         # recurrence-only kernels read the projected gates (G*H floats) and write h
