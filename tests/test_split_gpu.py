@@ -198,6 +198,31 @@ def test_two_batches_in_flight_give_the_results_of_one(B, engine, kind, hidden, 
     dm.close()
 
 
+@pytest.mark.parametrize("kind", [M.NET_LSTM5, M.NET_GRUMOD5])
+def test_packed_kernels_against_oracle(B, engine, kind):
+    """the packed layer kernels of H = 256 (k_lstm_pack / k_grumod_pack: full 1024-read launches only) against the oracle itself: a batch
+    of 1024 slots of which 28 hold a read (both tiles of a group, one tile only, the first and the last slot; whole groups empty), so that the
+    oracle's share stays a few seconds; profiles/r03_parity_packed.txt is the same on 2048 reads"""
+    mdl = M.synthetic_model(kind, 256, seed=31 + kind)
+    om = ffo.OracleModel(mdl)
+    dm = B.DeviceModel(engine, mdl)
+    assert dm.launch_reads == 1024
+    rng = np.random.default_rng(404 + kind)
+    slots = [0, 1, 15, 16, 17, 31, 40, 100, 101, 250, 255, 256, 300, 511, 512, 513, 600, 640, 655, 700, 767, 768, 900, 990, 1000, 1008, 1022, 1023]
+    sigs = [np.zeros(0, dtype=np.float32)] * 1024
+    for k in slots:
+        sigs[k] = rng.standard_normal(int(rng.integers(150, 700))).astype(np.float32)
+    sigs[0] = rng.standard_normal(700).astype(np.float32)
+    b = B.Batch(dm, 1024, 700)
+    b.set_signals_ragged(sigs)
+    b.run(); b.finish()
+    assert b.rnn_path() == 3
+    for k in slots:
+        check_read(b, k, om.basecall(sigs[k]))
+    b.close()
+    dm.close()
+
+
 def test_launch_reads_is_what_a_full_layer_launch_takes(B, engine):
     """ffhip_model_launch_reads (the flappie binary's default batch size): per 32 CUs 8 read tiles at H = 256 (the packed forms), 4 at
     H = 384, 2 at H = 512 and for the shapes outside the split kernels"""
