@@ -166,6 +166,10 @@ void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread
 void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
 void launch_rle_transpost(hipStream_t s, const float *param, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
 void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
+// first-generation run-length decoders (decode.c:552-892) on one matrix of 4 nbase rows; tb: 8 bytes a block, fwd / bwd: 8 floats a block (+1)
+void launch_rl1_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *score, int nblk, int nbase, int Ps);
+void launch_rl1_posterior(hipStream_t s, const float *param, float *post, float *fwd, float *bwd, int nblk, int nbase, int Ps);
+void launch_rl1_mean(hipStream_t s, const float *param, const int *path, int *runlength, unsigned long long *seqlen, int nblk, int nbase, int Ps);
 // tile-interleaved -> dense [Tb][H] of one read (debug tap)
 void launch_untile(hipStream_t s, const float *act, float *dense, int read, int Tb, int B16, int H);
 

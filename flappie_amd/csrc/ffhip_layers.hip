@@ -580,6 +580,71 @@ extern "C" int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *
     return FFHIP_OK;
 }
 
+// ---- decoders of the first run-length head (decode.c:552-892): param is [4 nbase x nblock]
+static bool rl1_dims(const ffhip_mat &param, int *nbase) {
+    if (!view_ok(param) || param.nr % 4 != 0 || param.nr / 4 < 1 || param.nr / 4 > 8) return false;
+    *nbase = (int)(param.nr / 4);
+    return true;
+}
+
+// decode_runlength (decode.c:694-767): path[nblock] = the base entered in a block, -1 while staying; the best score through *score
+extern "C" int ffhip_runlength_v1_viterbi(ffhip_engine *eng, ffhip_mat param, int *path, float *score) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!path || !rl1_dims(param, &nbase)) return set_err(FFHIP_EINVAL, "bad run-length (v1) decode arguments");
+    const size_t nblock = param.nc;
+    float *d_p = upload_img(tmp, param, s), *d_s = (float *)tmp.get(4);
+    uint8_t *d_tb = (uint8_t *)tmp.get(nblock * 8);
+    int *d_path = (int *)tmp.get(nblock * 4);
+    if (!d_p || !d_s || !d_tb || !d_path) OP_NOMEM();
+    launch_rl1_viterbi(s, d_p, d_tb, d_path, d_s, (int)nblock, nbase, (int)param.stride);
+    float sc = NAN;
+    HIP_TRY(hipMemcpyAsync(path, d_path, nblock * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(&sc, d_s, 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    if (score) *score = sc;
+    return FFHIP_OK;
+}
+
+// posterior_runlength (decode.c:793-892): post is [4 nbase x nblock + 1] with param's stride; everything but the move and stay rows of
+// blocks 0 .. nblock - 1 is zero
+extern "C" int ffhip_runlength_v1_posterior(ffhip_engine *eng, ffhip_mat param, ffhip_mat post) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!rl1_dims(param, &nbase) || !view_ok(post) || post.nr != param.nr || post.nc != param.nc + 1 || post.stride != param.stride)
+        return set_err(FFHIP_EINVAL, "bad run-length (v1) posterior arguments");
+    const size_t nblock = param.nc, n = (nblock + 1) * param.stride;
+    float *d_p = upload_img(tmp, param, s), *d_o = (float *)tmp.get(n * 4), *d_f = (float *)tmp.get(2 * (nblock + 1) * 8 * 4);
+    if (!d_p || !d_o || !d_f) OP_NOMEM();
+    HIP_TRY(hipMemsetAsync(d_o, 0, n * 4, s), FFHIP_EHIP);
+    launch_rl1_posterior(s, d_p, d_o, d_f, d_f + (nblock + 1) * 8, (int)nblock, nbase, (int)param.stride);
+    HIP_TRY(hipMemcpyAsync(post.data, d_o, n * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    return FFHIP_OK;
+}
+
+// runlengths_mean (decode.c:576-603): runlength[nblock] from the discrete-Weibull rows of the entered base, 0 while staying; the sum through *seqlen
+extern "C" int ffhip_runlength_v1_mean(ffhip_engine *eng, ffhip_mat param, const int *path, int *runlength, size_t *seqlen) {
+    OP_ENTER(eng);
+    int nbase;
+    if (!path || !runlength || !rl1_dims(param, &nbase)) return set_err(FFHIP_EINVAL, "bad run-length (v1) mean arguments");
+    const size_t nblock = param.nc;
+    for (size_t b = 0; b < nblock; b++) if (path[b] >= nbase) return set_err(FFHIP_EINVAL, "run-length (v1) mean: a path entry is not a base");
+    float *d_p = upload_img(tmp, param, s);
+    int *d_path = (int *)tmp.get(nblock * 4), *d_rl = (int *)tmp.get(nblock * 4);
+    unsigned long long *d_n = (unsigned long long *)tmp.get(8);
+    if (!d_p || !d_path || !d_rl || !d_n) OP_NOMEM();
+    HIP_TRY(hipMemcpyAsync(d_path, path, nblock * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(d_n, 0, 8, s), FFHIP_EHIP);
+    launch_rl1_mean(s, d_p, d_path, d_rl, d_n, (int)nblock, nbase, (int)param.stride);
+    unsigned long long tot = 0;
+    HIP_TRY(hipMemcpyAsync(runlength, d_rl, nblock * 4, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(&tot, d_n, 8, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    if (seqlen) *seqlen = (size_t)tot;
+    return FFHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------ sloika GRU layers and the first run-length head
 // gru_forward/backward/step (layers.c:412-568) and gru_relu_* (layers.c:718-874): the GRU of the sloika networks
 // (networks.c:403, :492).  No model in the reference's registry uses them (networks.c:85-99), so this is a

@@ -397,6 +397,213 @@ k_rle_viterbi(const float *__restrict__ param, uint8_t *__restrict__ tbbuf, int 
     }
 }
 
+
+// ---- decoders of the FIRST run-length head (globalnorm_runlength, layers.c:1197-1228: nparam = 4 nbase rows per block -- two run parameters,
+// a move weight and a stay weight per base).  No registry entry reaches them (networks.c:86-105); they complete decode.h's surface as
+// single-matrix operators, one workgroup a matrix, the param rows prefetched kV1Depth blocks ahead of the chains.
+constexpr int kV1Base = 8, kV1Depth = 8, kV1Chunk = 4096;
+
+// decode_runlength (decode.c:694-767).  Per block every state takes the best of the OTHER bases' scores -- the block's maximum, or for the
+// maximum's own base the runner-up ("prev[idx] = -HUGE_VAL; idx2 = argmaxf(prev)") -- plus its move weight, unless staying (prev[b] + stay
+// weight, strictly greater) wins.  path[blk] = the base that is entered in block blk, -1 while staying.  One wave: every lane scans the
+// nbase previous scores literally (first maximum wins, as argmaxf does), lane b then owns state b.
+__global__ void __launch_bounds__(64)
+k_rl1_viterbi(const float *__restrict__ param, int nblk, int nbase, int Ps, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ score_out) {
+    __shared__ float vs[2][kV1Base];
+    __shared__ float srow[2 * kV1Base];
+    __shared__ uint8_t tb_lds[kV1Chunk * kV1Base];
+    const int lane = threadIdx.x, nrow = 2 * nbase, lane_c = lane < nrow ? lane : nrow - 1;
+    if (lane < nbase) { vs[0][lane] = 0.0f; vs[1][lane] = 0.0f; }        // calloc'ed `mem` (decode.c:699)
+    __syncthreads();
+    float ring[kV1Depth];
+    auto fetch = [&](int blk) { return param[(size_t)(blk < nblk ? blk : nblk - 1) * Ps + 2 * nbase + lane_c]; };      // move weights, then stay weights
+#pragma unroll
+    for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(k);
+    int cur = 0;
+    const int nchunk = (nblk + kV1Chunk - 1) / kV1Chunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int c0 = c * kV1Chunk, n = min(kV1Chunk, nblk - c0);
+        for (int b0 = 0; b0 < n; b0 += kV1Depth) {
+            float curv[kV1Depth];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(c0 + b0 + kV1Depth + k);
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) {
+                if (b0 + k >= n) break;
+                if (lane < nrow) srow[lane] = curv[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const float *prev = vs[cur];
+                int idx = 0;                                   // argmaxf (util.c:17-31): the first maximum
+                float vmax = prev[0];
+                for (int i = 1; i < nbase; i++) if (prev[i] > vmax) { vmax = prev[i]; idx = i; }
+                int idx2 = 0;                                  // ... and again with prev[idx] = -HUGE_VAL
+                float v2 = (0 == idx) ? -HUGE_VALF : prev[0];
+                for (int i = 1; i < nbase; i++) {
+                    const float x = (i == idx) ? -HUGE_VALF : prev[i];
+                    if (x > v2) { v2 = x; idx2 = i; }
+                }
+                if (lane < nbase) {
+                    const int b = lane;
+                    float v = (b == idx) ? prev[idx2] : vmax;     // (decode.c:731: curr[idx] = prev[idx2], read after prev[idx] was restored)
+                    int arg = (b == idx) ? idx2 : idx;
+                    v += srow[b];
+                    const float stay_score = prev[b] + srow[nbase + b];
+                    if (stay_score > v) { v = stay_score; arg = b + nbase; }
+                    vs[cur ^ 1][b] = v;
+                    tb_lds[(b0 + k) * kV1Base + b] = (uint8_t)arg;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                cur ^= 1;
+            }
+        }
+        if (c + 1 < nchunk) {             // a longer matrix: this chunk's bytes leave LDS
+            __syncthreads();
+            for (int i = lane; i < n * (kV1Base / 4); i += 64) ((uint32_t *)(tbbuf + (size_t)c0 * kV1Base))[i] = ((const uint32_t *)tb_lds)[i];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    int last = 0;
+    for (int st = 1; st < nbase; st++) if (vs[cur][st] > vs[cur][last]) last = st;
+    if (lane == 0) score_out[0] = vs[cur][last];
+    // traceback, last chunk first (it is still in LDS): lane 0 walks, the path leaves in rows of 64 blocks
+    __shared__ int pl[kV1Chunk];
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int c0 = c * kV1Chunk, n = min(kV1Chunk, nblk - c0);
+        if (c != nchunk - 1) {
+            __syncthreads();
+            for (int i = lane; i < n * (kV1Base / 4); i += 64) ((uint32_t *)tb_lds)[i] = ((const uint32_t *)(tbbuf + (size_t)c0 * kV1Base))[i];
+            __syncthreads();
+        }
+        if (lane == 0) {
+            for (int i = n - 1; i >= 0; i--) {
+                const int state = tb_lds[i * kV1Base + last];
+                if (state < nbase) { pl[i] = last; last = state; }      // a base was entered here (decode.c:757-760)
+                else pl[i] = -1;
+            }
+        }
+        last = __shfl(last, 0);
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) path[c0 + i] = pl[i];
+    }
+}
+
+// posterior_runlength (decode.c:793-892): wave 0 runs the forward chain, wave 1 the backward one, then one block per thread.  The chains
+// add their terms in the reference's order (the other bases ascending, then the stay), so the values are the oracle's up to the device's
+// expf / log1pf.  post is [nparam x (nblk + 1)], zero outside the move and stay rows of blocks 0 .. nblk - 1 (make_flappie_matrix clears).
+__global__ void __launch_bounds__(256)
+k_rl1_posterior(const float *__restrict__ param, float *__restrict__ post, float *__restrict__ fwdbuf, float *__restrict__ bwdbuf, int nblk, int nbase, int Ps) {
+    __shared__ float fs[2][kV1Base], bs[2][kV1Base];
+    __shared__ float srow[2][2 * kV1Base];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nrow = 2 * nbase, lane_c = lane < nrow ? lane : nrow - 1;
+#define RL1_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+    if (wave == 0) {
+        if (lane < nbase) { fs[0][lane] = 0.0f; fwdbuf[lane] = 0.0f; }      // fwd column 0 (decode.c:803: zeros)
+        float ring[kV1Depth];
+        auto fetch = [&](int blk) { return param[(size_t)(blk < nblk ? blk : nblk - 1) * Ps + 2 * nbase + lane_c]; };
+#pragma unroll
+        for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(k);
+        int cur = 0;
+        for (int b0 = 0; b0 < nblk; b0 += kV1Depth) {
+            float curv[kV1Depth];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(b0 + kV1Depth + k);
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) {
+                const int blk = b0 + k;
+                if (blk >= nblk) break;
+                if (lane < nrow) srow[0][lane] = curv[k];
+                RL1_WAVE_SYNC();
+                if (lane < nbase) {
+                    const float *prev = fs[cur];
+                    float v = -HUGE_VALF;                                     // decode.c:822-830
+                    for (int b2 = 0; b2 < nbase; b2++) if (b2 != lane) v = logsumexpf_ref(v, prev[b2]);
+                    v += srow[0][lane];
+                    v = logsumexpf_ref(v, prev[lane] + srow[0][nbase + lane]);      // :833
+                    fs[cur ^ 1][lane] = v;
+                    fwdbuf[(size_t)(blk + 1) * kV1Base + lane] = v;
+                }
+                RL1_WAVE_SYNC();
+                cur ^= 1;
+            }
+        }
+    } else if (wave == 1) {
+        if (lane < nbase) { bs[0][lane] = 0.0f; bwdbuf[(size_t)nblk * kV1Base + lane] = 0.0f; }      // calloc'ed `mem` (decode.c:805)
+        float ring[kV1Depth];
+        auto fetch = [&](int blk) { return param[(size_t)(blk > 0 ? blk : 0) * Ps + 2 * nbase + lane_c]; };      // blk counts down
+#pragma unroll
+        for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(nblk - 1 - k);
+        int cur = 0;
+        for (int j0 = 0; j0 < nblk; j0 += kV1Depth) {
+            float curv[kV1Depth];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) curv[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) ring[k] = fetch(nblk - 1 - (j0 + kV1Depth + k));
+#pragma unroll
+            for (int k = 0; k < kV1Depth; k++) {
+                const int j = j0 + k;                  // block nblk - 1 - j
+                if (j >= nblk) break;
+                if (lane < nrow) srow[1][lane] = curv[k];
+                RL1_WAVE_SYNC();
+                if (lane < nbase) {
+                    const float *prev = bs[cur];
+                    float v = -HUGE_VALF;                                     // decode.c:853-861
+                    for (int b2 = 0; b2 < nbase; b2++) if (b2 != lane) v = logsumexpf_ref(v, prev[b2] + srow[1][b2]);
+                    v = logsumexpf_ref(v, prev[lane] + srow[1][nbase + lane]);      // :866
+                    bs[cur ^ 1][lane] = v;
+                    bwdbuf[(size_t)(nblk - 1 - j) * kV1Base + lane] = v;      // the vector in front of block nblk - 1 - j
+                }
+                RL1_WAVE_SYNC();
+                cur ^= 1;
+            }
+        }
+    }
+#undef RL1_WAVE_SYNC
+    __syncthreads();
+    for (int blk = threadIdx.x; blk < nblk; blk += 256) {
+        const float *x = param + (size_t)blk * Ps + 2 * nbase;
+        float *o = post + (size_t)blk * Ps + 2 * nbase;
+        const float *f = fwdbuf + (size_t)blk * kV1Base, *bb = bwdbuf + (size_t)(blk + 1) * kV1Base;      // `prev` of decode.c:839-850 at this block
+        for (int b1 = 0; b1 < nbase; b1++) {
+            float v = -HUGE_VALF;                                             // :855, :859
+            for (int b2 = 0; b2 < nbase; b2++) if (b2 != b1) v = logsumexpf_ref(v, f[b2]);
+            o[b1] = v + (bb[b1] + x[b1]);                                     // :862
+            o[nbase + b1] = f[b1] + x[nbase + b1] + bb[b1];                   // :867
+        }
+    }
+}
+
+// runlengths_mean (decode.c:576-603) with dwmean (:552-562): per entered base 1 + round(sum_{i=1..100} exp(-(i / scale)^shape)) from that base's
+// shape and scale rows.  The reference calls libm's powf / expf; here each is evaluated in double and rounded to float -- the same float
+// except where libm itself is not correctly rounded (its stated bound is 0.52 ulp), which can only move a sum that sits on a half-integer.
+__global__ void __launch_bounds__(256)
+k_rl1_mean(const float *__restrict__ param, const int *__restrict__ path, int *__restrict__ runlength, unsigned long long *__restrict__ seqlen, int nblk, int nbase, int Ps) {
+    const int blk = blockIdx.x * 256 + threadIdx.x;
+    int rl = 0;
+    if (blk < nblk && path[blk] >= 0) {
+        const size_t off = (size_t)blk * Ps + (size_t)path[blk];
+        const float shape = param[off], scale = param[off + nbase];
+        float m = 0.0f;
+        for (int i = 1; i <= 100; i++) {
+            const float t = (float)i / scale;
+            const float p = (float)pow((double)t, (double)shape);
+            m += (float)exp(-(double)p);
+        }
+        rl = (int)(1.0f + roundf(m));
+    }
+    if (blk < nblk) runlength[blk] = rl;
+    unsigned long long tot = (unsigned long long)rl;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(seqlen, tot);
+}
+
 }  // namespace
 
 void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs) {
@@ -421,6 +628,17 @@ void launch_rle_transpost(hipStream_t s, const float *param, float *post, float 
 void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs) {
     if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2")) { launch_rle_viterbi8x(s, param, tb, path, qpath, score, nread, Tb, tbs); return; }      // ffhip_decode.hip
     hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps, tbs);
+}
+
+// first-generation run-length decoders on ONE matrix (nparam = 4 nbase rows, nbase <= 8)
+void launch_rl1_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *score, int nblk, int nbase, int Ps) {
+    hipLaunchKernelGGL(k_rl1_viterbi, dim3(1), dim3(64), 0, s, param, nblk, nbase, Ps, tb, path, score);
+}
+void launch_rl1_posterior(hipStream_t s, const float *param, float *post, float *fwd, float *bwd, int nblk, int nbase, int Ps) {
+    hipLaunchKernelGGL(k_rl1_posterior, dim3(1), dim3(256), 0, s, param, post, fwd, bwd, nblk, nbase, Ps);
+}
+void launch_rl1_mean(hipStream_t s, const float *param, const int *path, int *runlength, unsigned long long *seqlen, int nblk, int nbase, int Ps) {
+    hipLaunchKernelGGL(k_rl1_mean, dim3((nblk + 255) / 256), dim3(256), 0, s, param, path, runlength, seqlen, nblk, nbase, Ps);
 }
 
 }  // namespace ffhip

@@ -140,3 +140,61 @@ flappie_matrix transpost_crf_runlength(const_flappie_matrix param) {
     flappie_matrix_sync(post);          /* (runnie.c:294-307 reads this matrix's data.f directly: it is returned with a current host image) */
     return post;
 }
+
+/* ---- decoders of the first-generation run-length head (decode.c:552-892) ---- */
+
+float decode_runlength(const_flappie_matrix param, int *path) {
+    if (NULL == param || NULL == path) return NAN;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    float score = NAN;
+    if (NULL == eng) return NAN;
+    if (0 != ffhip_runlength_v1_viterbi(eng, mview(param), path, &score)) { warnx("%s: %s", __func__, ffhip_last_error()); return NAN; }
+    return score;
+}
+
+flappie_matrix posterior_runlength(const_flappie_matrix param) {
+    if (NULL == param) return NULL;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    if (NULL == eng) return NULL;
+    flappie_matrix post = make_flappie_matrix(param->nr, param->nc + 1);
+    if (NULL == post) return NULL;
+    if (0 != ffhip_runlength_v1_posterior(eng, mview(param), mview(post))) { warnx("%s: %s", __func__, ffhip_last_error()); return free_flappie_matrix(post); }
+    flappie_matrix_sync(post);
+    return post;
+}
+
+size_t runlengths_mean(const_flappie_matrix param, const int *path, int *runlength) {
+    if (NULL == param || NULL == path || NULL == runlength) return 0;
+    struct ffhip_engine *eng = flappie_hip_engine();
+    size_t seqlen = 0;
+    if (NULL == eng) return 0;
+    if (0 != ffhip_runlength_v1_mean(eng, mview(param), path, runlength, &seqlen)) { warnx("%s: %s", __func__, ffhip_last_error()); return 0; }
+    return seqlen;
+}
+
+/* decode.c:616-635: bookkeeping on the caller's arrays, no arithmetic */
+size_t runlengths_unit(const_flappie_matrix param, const int *path, int *runlength) {
+    if (NULL == param || NULL == path || NULL == runlength) return 0;
+    size_t seqlen = 0;
+    for (size_t blk = 0; blk < param->nc; blk++) {
+        runlength[blk] = (path[blk] >= 0) ? 1 : 0;
+        seqlen += (size_t)runlength[blk];
+    }
+    return seqlen;
+}
+
+/* decode.c:646-672 */
+char *runlength_to_basecall(const int *path, const int *runlength, size_t nblk) {
+    if (NULL == path || NULL == runlength) return NULL;
+    size_t seqlen = 0;
+    for (size_t blk = 0; blk < nblk; blk++) seqlen += (size_t)runlength[blk];
+    char *seq = calloc(seqlen + 1, sizeof(char));
+    if (NULL == seq) return NULL;
+    size_t at = 0;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        if (path[blk] < 0) continue;
+        memset(seq + at, base_lookup[path[blk]], (size_t)runlength[blk]);
+        at += (size_t)runlength[blk];
+    }
+    return seq;
+}

@@ -1,6 +1,6 @@
 /*  decode.h -- flip-flop decoding entry points of the drop-in boundary.
- *  Same signatures and semantics as /root/reference/src/decode.h:16-38 for the flip-flop functions
- *  (the run-length half belongs to runnie and is out of scope).
+ *  Same signatures and semantics as /root/reference/src/decode.h:16-38: the flip-flop functions, runnie's run-length
+ *  decoders and the first-generation run-length decoders no registry entry reaches.
  */
 #ifndef FFHIP_DECODE_H
 #define FFHIP_DECODE_H
@@ -44,6 +44,18 @@ flappie_imatrix trace_from_posterior(flappie_matrix tpost);
 float decode_crf_runlength(const_flappie_matrix transparam, int *path);
 /* decode.c:1037-1159: transition posteriors (not normalised per block); shape/scale rows copied through */
 flappie_matrix transpost_crf_runlength(const_flappie_matrix trans);
+
+/* ---- decoders of the first-generation run-length head (param: [4 nbase x nblock], globalnorm_runlength's output) ----
+ * decode.c:694-767: Viterbi; path needs nblock ints: the base entered in a block, -1 while staying; returns the best score or NAN */
+float decode_runlength(const_flappie_matrix param, int *path);
+/* decode.c:576-603: runlength[blk] = 1 + round(mean of the entered base's discrete Weibull), 0 where path is -1; returns the sum */
+size_t runlengths_mean(const_flappie_matrix param, const int *path, int *runlength);
+/* decode.c:616-635: runlength[blk] = 1 where a base is entered; returns their number */
+size_t runlengths_unit(const_flappie_matrix param, const int *path, int *runlength);
+/* decode.c:646-672: the base of every entered block repeated runlength[blk] times; NUL-terminated, owned by the caller */
+char *runlength_to_basecall(const int *path, const int *runlength, size_t nblk);
+/* decode.c:793-892: log posteriors of the move and stay weights, [4 nbase x nblock + 1] (other entries zero) */
+flappie_matrix posterior_runlength(const_flappie_matrix param);
 
 
 #ifdef __cplusplus

@@ -263,6 +263,11 @@ int ffhip_op_globalnorm_runlength_v1(ffhip_engine *eng, ffhip_mat X, ffhip_mat W
 int ffhip_op_runlength_partition_function_v1(ffhip_engine *eng, ffhip_mat S, double *logZ);
 int ffhip_runlength_transpost(ffhip_engine *eng, ffhip_mat param, ffhip_mat post);
 int ffhip_runlength_viterbi(ffhip_engine *eng, ffhip_mat param, int *path /* nblock */, float *score);
+/* decoders of the first-generation head on [4 nbase x nblock] matrices: decode_runlength (decode.c:694-767), posterior_runlength
+ * (decode.c:793-892; post is [4 nbase x nblock + 1]), runlengths_mean (decode.c:576-603) */
+int ffhip_runlength_v1_viterbi(ffhip_engine *eng, ffhip_mat param, int *path /* nblock: base entered, -1 = stay */, float *score);
+int ffhip_runlength_v1_posterior(ffhip_engine *eng, ffhip_mat param, ffhip_mat post);
+int ffhip_runlength_v1_mean(ffhip_engine *eng, ffhip_mat param, const int *path, int *runlength /* nblock */, size_t *seqlen);
 
 /* ---- signal preparation on the GPU ------------------------------------------------------------------
  * trim_and_segment_raw (flappie_common.c:13-81) followed by medmad_normalise_array (util.c:198-212) or the

@@ -1134,6 +1134,145 @@ fo_mat *fo_transpost_crf_runlength(const fo_mat *param) {
     return post;
 }
 
+
+/* ---- decoders of the FIRST run-length head (globalnorm_runlength's [4 nbase x nblk] output: two run parameters, a move weight and a stay
+ * weight per base).  No registry entry reaches them; restated for the drop-in boundary's last five prototypes (decode.h:26-36). ---- */
+
+/* decode.c:552-562  approximate mean of a discrete Weibull: sum_{i=1..maxval} exp(-(i / scale)^shape), float arithmetic, libm powf / expf */
+float fo_dwmean(float shape, float scale, int maxval) {
+    float m = 0.0f;
+    for (int i = 1; i <= maxval; i++) m += expf(-powf((float)i / scale, shape));
+    return m;
+}
+
+/* decode.c:576-603  runlength[blk] = 1 + round(dwmean of the entered base's shape / scale rows), 0 where path[blk] < 0; returns the sum */
+size_t fo_runlengths_mean(const fo_mat *param, const int *path, int *runlength) {
+    if (!param || !path || !runlength) return 0;
+    const size_t nblk = param->nc, nbase = param->nr / 4;           /* nbase_from_runlength_nparam (layers.c:1115-1119) */
+    size_t seqlen = 0;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        runlength[blk] = 0;
+        if (path[blk] < 0) continue;
+        const float *col = param->f + blk * param->stride + path[blk];
+        runlength[blk] = 1 + roundf(fo_dwmean(col[0], col[nbase], 100));      /* (float sum, converted on assignment, as written there) */
+        seqlen += runlength[blk];
+    }
+    return seqlen;
+}
+
+/* decode.c:616-635 */
+size_t fo_runlengths_unit(const fo_mat *param, const int *path, int *runlength) {
+    if (!param || !path || !runlength) return 0;
+    size_t seqlen = 0;
+    for (size_t blk = 0; blk < param->nc; blk++) {
+        runlength[blk] = (path[blk] < 0) ? 0 : 1;
+        seqlen += runlength[blk];
+    }
+    return seqlen;
+}
+
+/* decode.c:646-672  caller frees */
+char *fo_runlength_to_basecall(const int *path, const int *runlength, size_t nblk) {
+    if (!path || !runlength) return NULL;
+    static const char lookup[5] = { 'A', 'C', 'G', 'T', 'Z' };      /* decode.h:16 */
+    int seqlen = 0;
+    for (size_t blk = 0; blk < nblk; blk++) seqlen += runlength[blk];
+    char *seq = calloc(seqlen + 1, sizeof(char));
+    if (!seq) return NULL;
+    size_t i = 0;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        if (path[blk] < 0) continue;
+        for (int rl = 0; rl < runlength[blk]; rl++) seq[i++] = lookup[path[blk]];
+    }
+    return seq;
+}
+
+/* decode.c:694-767  Viterbi.  A base is entered from the best OTHER base (the block's first maximum; for that base itself the first maximum
+ * of the rest), or kept through its stay weight when that is strictly better.  path[blk] = entered base, -1 while staying. */
+float fo_decode_runlength(const fo_mat *param, int *path) {
+    if (!param || !path) return NAN;
+    const size_t nblk = param->nc, nbase = param->nr / 4;
+    float *mem = calloc(2 * nbase, sizeof(float));
+    char *traceback = calloc(nbase * nblk, sizeof(char));
+    if (!mem || !traceback) { free(mem); free(traceback); return NAN; }
+    float *prev = mem, *curr = mem + nbase;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const float *move = param->f + blk * param->stride + 2 * nbase, *stay = move + nbase;
+        char *tb = traceback + blk * nbase;
+        { float *tmp = prev; prev = curr; curr = tmp; }
+        size_t idx = 0;                                          /* argmaxf (util.c:17-31): first maximum */
+        for (size_t i = 1; i < nbase; i++) if (prev[i] > prev[idx]) idx = i;
+        const float max_score = prev[idx];
+        prev[idx] = -HUGE_VAL;
+        size_t idx2 = 0;
+        for (size_t i = 1; i < nbase; i++) if (prev[i] > prev[idx2]) idx2 = i;
+        prev[idx] = max_score;
+        for (size_t b = 0; b < nbase; b++) { curr[b] = max_score; tb[b] = (char)idx; }
+        curr[idx] = prev[idx2];
+        tb[idx] = (char)idx2;
+        for (size_t b = 0; b < nbase; b++) curr[b] += move[b];
+        for (size_t b = 0; b < nbase; b++) {
+            const float stay_score = prev[b] + stay[b];
+            if (stay_score > curr[b]) { curr[b] = stay_score; tb[b] = (char)(b + nbase); }
+        }
+    }
+    for (size_t blk = 0; blk < nblk; blk++) path[blk] = -1;
+    size_t last_state = 0;
+    for (size_t st = 1; st < nbase; st++) if (curr[st] > curr[last_state]) last_state = st;
+    const float logscore = curr[last_state];
+    for (size_t blk = nblk; blk > 0; blk--) {
+        const char state = traceback[(blk - 1) * nbase + last_state];
+        if ((size_t)state < nbase) { path[blk - 1] = (int)last_state; last_state = (size_t)state; }
+    }
+    free(traceback);
+    free(mem);
+    return logscore;
+}
+
+/* decode.c:793-892  log posteriors of the move and stay weights; [nparam x nblk + 1], everything else zero */
+fo_mat *fo_posterior_runlength(const fo_mat *param) {
+    if (!param) return NULL;
+    const size_t nblk = param->nc, nparam = param->nr, nbase = nparam / 4;
+    fo_mat *fwd = fo_make_mat(nbase, nblk + 1), *post = fo_make_mat(nparam, nblk + 1);
+    float *mem = calloc(2 * nbase, sizeof(float));
+    if (!fwd || !post || !mem) { fo_free_mat(fwd); fo_free_mat(post); free(mem); return NULL; }
+    for (size_t blk = 0; blk < nblk; blk++) {                    /* forward */
+        const float *move = param->f + blk * param->stride + 2 * nbase, *stay = move + nbase;
+        const float *prev = fwd->f + blk * fwd->stride;
+        float *curr = fwd->f + (blk + 1) * fwd->stride;
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++) if (b1 != b2) curr[b1] = fo_logsumexpf(curr[b1], prev[b2]);
+            curr[b1] += move[b1];
+        }
+        for (size_t b = 0; b < nbase; b++) curr[b] = fo_logsumexpf(curr[b], prev[b] + stay[b]);
+    }
+    float *prev = mem, *curr = mem + nbase;
+    for (size_t blk = nblk; blk > 0; blk--) {                    /* backward, with the posterior of block blk - 1 on the way */
+        const float *move = param->f + (blk - 1) * param->stride + 2 * nbase, *stay = move + nbase;
+        const float *f = fwd->f + (blk - 1) * fwd->stride;
+        float *pm = post->f + (blk - 1) * post->stride + 2 * nbase, *ps = pm + nbase;
+        { float *tmp = curr; curr = prev; prev = tmp; }
+        for (size_t b1 = 0; b1 < nbase; b1++) {
+            curr[b1] = -HUGE_VAL;
+            pm[b1] = -HUGE_VAL;
+            for (size_t b2 = 0; b2 < nbase; b2++) {
+                if (b1 == b2) continue;
+                curr[b1] = fo_logsumexpf(curr[b1], prev[b2] + move[b2]);
+                pm[b1] = fo_logsumexpf(pm[b1], f[b2]);
+            }
+            pm[b1] += prev[b1] + move[b1];
+        }
+        for (size_t b = 0; b < nbase; b++) {
+            curr[b] = fo_logsumexpf(curr[b], prev[b] + stay[b]);
+            ps[b] = f[b] + stay[b] + prev[b];
+        }
+    }
+    free(mem);
+    fo_free_mat(fwd);
+    return post;
+}
+
 /* runnie.c:282-313  one record per called base: (base index, block of the call, dwell); returns the count */
 size_t fo_runlength_records(const int *path, size_t nblock, size_t nbase, int *base, int *block, int *dwell) {
     size_t n = 0;

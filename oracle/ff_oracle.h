@@ -121,6 +121,13 @@ double fo_runlengthV2_partition_function(const fo_mat *C);
 fo_mat *fo_globalnorm_runlengthV2(const fo_mat *X, const fo_mat *W, const fo_mat *b, float temperature);
 float fo_decode_crf_runlength(const fo_mat *param, int *path);
 fo_mat *fo_transpost_crf_runlength(const fo_mat *param);
+/* first-generation run-length decoders (decode.c:552-892) */
+float fo_dwmean(float shape, float scale, int maxval);
+size_t fo_runlengths_mean(const fo_mat *param, const int *path, int *runlength);
+size_t fo_runlengths_unit(const fo_mat *param, const int *path, int *runlength);
+char *fo_runlength_to_basecall(const int *path, const int *runlength, size_t nblk);
+float fo_decode_runlength(const fo_mat *param, int *path);
+fo_mat *fo_posterior_runlength(const fo_mat *param);
 size_t fo_runlength_records(const int *path, size_t nblock, size_t nbase, int *base, int *block, int *dwell);
 fo_mat *fo_transpost(const fo_mat *trans, int return_log);
 float fo_decode_viterbi(const fo_mat *trans, int combine_stays, int *path, float *qpath);

@@ -104,6 +104,18 @@ def lib():
     L.fo_decode_crf_runlength.argtypes = [P(FoMat), P(C.c_int)]
     L.fo_transpost_crf_runlength.restype = P(FoMat)
     L.fo_transpost_crf_runlength.argtypes = [P(FoMat)]
+    L.fo_dwmean.restype = C.c_float
+    L.fo_dwmean.argtypes = [C.c_float, C.c_float, C.c_int]
+    L.fo_runlengths_mean.restype = C.c_size_t
+    L.fo_runlengths_mean.argtypes = [P(FoMat), P(C.c_int), P(C.c_int)]
+    L.fo_runlengths_unit.restype = C.c_size_t
+    L.fo_runlengths_unit.argtypes = [P(FoMat), P(C.c_int), P(C.c_int)]
+    L.fo_runlength_to_basecall.restype = C.c_void_p          # (a malloc'ed string: freed through libc by the caller)
+    L.fo_runlength_to_basecall.argtypes = [P(C.c_int), P(C.c_int), C.c_size_t]
+    L.fo_decode_runlength.restype = C.c_float
+    L.fo_decode_runlength.argtypes = [P(FoMat), P(C.c_int)]
+    L.fo_posterior_runlength.restype = P(FoMat)
+    L.fo_posterior_runlength.argtypes = [P(FoMat)]
     L.fo_runlength_records.restype = C.c_size_t
     L.fo_runlength_records.argtypes = [P(C.c_int), C.c_size_t, C.c_size_t, P(C.c_int), P(C.c_int), P(C.c_int)]
     L.fo_transitions.restype = P(FoMat)

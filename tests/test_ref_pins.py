@@ -230,6 +230,68 @@ def test_runlength_decoders_match_compiled_reference(nblock, style):
     L.fo_free_mat(rb)
 
 
+def _v1_param(rng, nblock, nbase, style):
+    """[nblock x 4 nbase]: shape and scale rows of a discrete Weibull (positive), then move and stay weights"""
+    dense = _scores(rng, 4 * nbase, nblock, style)
+    dense[:, :nbase] = 0.5 + 2.5 * rng.random((nblock, nbase))          # shape
+    dense[:, nbase: 2 * nbase] = 0.3 + 8.0 * rng.random((nblock, nbase))      # scale
+    return dense.astype(np.float32)
+
+
+@pytest.mark.parametrize("nbase,nblock,style", [(4, 1, "normal"), (4, 2, "ties"), (4, 17, "ties"), (4, 64, "normal"), (4, 800, "tanh5"), (4, 300, "flat"),
+                                                (4, 500, "ties"), (5, 200, "normal"), (2, 50, "normal"), (4, 40, "some_nan")])
+def test_first_generation_runlength_decoders_match_compiled_reference(nbase, nblock, style):
+    """decode.h's last five prototypes (decode_runlength, posterior_runlength, runlengths_mean, runlengths_unit, runlength_to_basecall;
+    decode.c:552-892): the oracle's restatement against the reference's own object code -- paths, run lengths and strings identical, scores
+    and posteriors bit for bit"""
+    R = _decref()
+    L = ffo.lib()
+    M = P(ffo.FoMat)
+    ip = P(C.c_int)
+    R.decode_runlength.restype = C.c_float
+    R.decode_runlength.argtypes = [M, ip]
+    R.posterior_runlength.restype = M
+    R.posterior_runlength.argtypes = [M]
+    for fn in (R.runlengths_mean, R.runlengths_unit):
+        fn.restype = C.c_size_t
+        fn.argtypes = [M, ip, ip]
+    R.runlength_to_basecall.restype = C.c_void_p
+    R.runlength_to_basecall.argtypes = [ip, ip, C.c_size_t]
+    R.dwmean.restype = C.c_float
+    R.dwmean.argtypes = [C.c_float, C.c_float, C.c_int]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(77 * nbase + nblock)
+    for rep in range(3):
+        dense = _v1_param(rng, nblock, nbase, style)
+        hm = ffo.HostMat.from_dense(dense)
+        pa, pb = np.full(nblock, -7, np.int32), np.full(nblock, -7, np.int32)
+        sa = R.decode_runlength(hm.ptr, pa.ctypes.data_as(ip))
+        sb = L.fo_decode_runlength(hm.ptr, pb.ctypes.data_as(ip))
+        assert np.float32(sa).view(np.uint32) == np.float32(sb).view(np.uint32)
+        assert np.array_equal(pa, pb) and pa.min() >= -1 and pa.max() < nbase
+        for ref, mine in ((R.runlengths_mean, L.fo_runlengths_mean), (R.runlengths_unit, L.fo_runlengths_unit)):
+            ra, rb = np.full(nblock, -7, np.int32), np.full(nblock, -7, np.int32)
+            na = ref(hm.ptr, pa.ctypes.data_as(ip), ra.ctypes.data_as(ip))
+            nb_ = mine(hm.ptr, pb.ctypes.data_as(ip), rb.ctypes.data_as(ip))
+            assert na == nb_ == int(ra.sum()) and np.array_equal(ra, rb)
+            qa = R.runlength_to_basecall(pa.ctypes.data_as(ip), ra.ctypes.data_as(ip), nblock)
+            qb = L.fo_runlength_to_basecall(pb.ctypes.data_as(ip), rb.ctypes.data_as(ip), nblock)
+            assert C.string_at(qa) == C.string_at(qb) and len(C.string_at(qa)) == na
+            libc.free(qa)
+            libc.free(qb)
+        if style != "some_nan":      # (a NaN weight makes every later vector NaN in both; the bit patterns of those NaNs are libm's business)
+            ra = R.posterior_runlength(hm.ptr)
+            rb = L.fo_posterior_runlength(hm.ptr)
+            a, b = ffo.take(ra, free=False), ffo.take(rb, free=False)
+            assert a.shape == (nblock + 1, 4 * nbase) and _same_bits(a, b)[0] == 0
+            assert not a[:, : 2 * nbase].any() and not a[nblock].any()
+            R.free_flappie_matrix(ra)
+            L.fo_free_mat(rb)
+    for shape, scale in ((0.5, 0.3), (1.0, 1.0), (2.2, 7.5), (3.0, 0.01), (0.7, 50.0)):
+        assert np.float32(R.dwmean(shape, scale, 100)).view(np.uint32) == np.float32(L.fo_dwmean(shape, scale, 100)).view(np.uint32)
+
+
 def test_glue_row_normalise_known_answers():
     """The glue's row_normalise_inplace (the one arithmetic loop of ref_decode_glue.c that is not the reference's own
     inline code) against the definition, shapes with 0..3 pad lanes; columns then sum to one (test_flappie_matrix.c:32-46)."""

@@ -201,6 +201,69 @@ def test_runlength_host_api(B):
     assert np.isnan(L.decode_crf_runlength(None, path.ctypes.data_as(ip))) and not L.transpost_crf_runlength(None)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbase,T,style", [(4, 1, "normal"), (4, 3, "ties"), (4, 150, "normal"), (4, 777, "ties"), (4, 5000, "tanh"), (5, 300, "normal"), (4, 9000, "flat")])
+def test_first_generation_decoders_through_the_c_api(B, nbase, T, style):
+    """decode_runlength, posterior_runlength, runlengths_mean, runlengths_unit, runlength_to_basecall (decode.c:552-892; k_rl1_viterbi,
+    k_rl1_posterior, k_rl1_mean) against the oracle, which tests/test_ref_pins.py holds to the reference's object code: paths, run lengths and
+    strings identical, the Viterbi score bit for bit (additions and comparisons only), the posterior within the logsumexp tolerance of the
+    other decoders; 5000 and 9000 blocks cross the kernels' 4096-block traceback chunks"""
+    from test_host_layer import CMat, HOSTLIB, _f
+    PM = C.POINTER(CMat)
+    ip = C.POINTER(C.c_int)
+    L = C.CDLL(HOSTLIB)
+    L.mat_from_array.restype = PM
+    L.mat_from_array.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t]
+    L.decode_runlength.restype = C.c_float
+    L.decode_runlength.argtypes = [PM, ip]
+    L.posterior_runlength.restype = PM
+    L.posterior_runlength.argtypes = [PM]
+    for fn in (L.runlengths_mean, L.runlengths_unit):
+        fn.restype = C.c_size_t
+        fn.argtypes = [PM, ip, ip]
+    L.runlength_to_basecall.restype = C.c_void_p
+    L.runlength_to_basecall.argtypes = [ip, ip, C.c_size_t]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    lib = ffo.lib()
+    rng = np.random.default_rng(1000 * nbase + T)
+    if style == "ties":
+        w = rng.integers(-2, 3, (T, 2 * nbase)).astype(np.float32)
+    elif style == "flat":
+        w = np.zeros((T, 2 * nbase), dtype=np.float32)
+    elif style == "tanh":
+        w = (5 * np.tanh(rng.standard_normal((T, 2 * nbase)) * 2) - 1.5).astype(np.float32)
+    else:
+        w = (rng.standard_normal((T, 2 * nbase)) * 2).astype(np.float32)
+    param = np.concatenate([(0.5 + 2.5 * rng.random((T, nbase))).astype(np.float32), (0.3 + 8.0 * rng.random((T, nbase))).astype(np.float32), w], axis=1)
+    a = np.ascontiguousarray(param, dtype=np.float32)
+    cm = L.mat_from_array(_f(a), a.shape[1], a.shape[0])
+    pm = ffo.HostMat.from_dense(param)
+    path, want = np.full(T, -7, np.int32), np.full(T, -7, np.int32)
+    s = L.decode_runlength(cm, path.ctypes.data_as(ip))
+    sw = lib.fo_decode_runlength(pm.ptr, want.ctypes.data_as(ip))
+    assert np.array_equal(path, want)
+    assert np.float32(s).view(np.uint32) == np.float32(sw).view(np.uint32)
+    for mine, ref in ((L.runlengths_mean, lib.fo_runlengths_mean), (L.runlengths_unit, lib.fo_runlengths_unit)):
+        rl, rw = np.full(T, -7, np.int32), np.full(T, -7, np.int32)
+        n = mine(cm, path.ctypes.data_as(ip), rl.ctypes.data_as(ip))
+        nw = ref(pm.ptr, want.ctypes.data_as(ip), rw.ctypes.data_as(ip))
+        assert n == nw and np.array_equal(rl, rw)
+        q = L.runlength_to_basecall(path.ctypes.data_as(ip), rl.ctypes.data_as(ip), T)
+        qw = lib.fo_runlength_to_basecall(want.ctypes.data_as(ip), rw.ctypes.data_as(ip), T)
+        assert C.string_at(q) == C.string_at(qw) and len(C.string_at(q)) == n
+        libc.free(q)
+        libc.free(qw)
+    post = L.posterior_runlength(cm)
+    m = post.contents
+    got = np.ctypeslib.as_array(m.f, shape=(m.nc, m.stride))[:, : m.nr].copy()
+    ref = ffo.take(lib.fo_posterior_runlength(pm.ptr))
+    assert got.shape == ref.shape == (T + 1, 4 * nbase)
+    assert np.abs(got - ref).max() <= 2e-5 + 2e-6 * np.abs(ref).max()
+    assert not got[:, : 2 * nbase].any() and not got[T].any()
+    assert np.isnan(L.decode_runlength(None, path.ctypes.data_as(ip))) and not L.posterior_runlength(None) and 0 == L.runlengths_mean(None, None, None)
+
+
 # ------------------------------------------------------------------------------------ the first-generation head (layers.c:1115-1228)
 def _brute_force_v1(param, nbase):
     """log-sum over every state path s_-1, s_0 .. s_T-1 of: move[s_t] when the base changes, stay[s_t] when it does not
