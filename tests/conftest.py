@@ -24,3 +24,14 @@ def engine():
     eng = B.Engine(0)
     yield eng
     eng.close()
+
+
+def oracle_calls(mdl, sigs, workers=None, **kw):
+    """The oracle's basecall of every signal, on a thread pool (ctypes releases the interpreter lock, the oracle keeps no state in
+    dot mode 0; threads, not processes: nothing of a live HIP context is forked).  TEST INFRASTRUCTURE."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ffo
+    om = ffo.OracleModel(mdl)
+    workers = workers or min(64, os.cpu_count() or 1)
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(lambda s: om.basecall(s, **kw) if len(s) else None, sigs))

@@ -50,9 +50,12 @@ def part2():
     sig = np.load(os.path.join(HERE, "signal_fixtures.npz"))
     norm = sig["normalised"]
     rng = np.random.default_rng(20260928)
-    for tag, kind, hidden, T in (("lstm5_h64", M.NET_LSTM5, 64, 4000), ("grumod5_h64", M.NET_GRUMOD5, 64, 2000),
-                                 ("lstm5_h96_t1237", M.NET_LSTM5, 96, 1237)):
-        mdl = M.synthetic_model(kind, hidden, seed=7)
+    # the last four: the shapes bench.py times (seed 1 = bench.py's model), short enough for the oracle and the repository
+    for tag, kind, hidden, T, seed in (("lstm5_h64", M.NET_LSTM5, 64, 4000, 7), ("grumod5_h64", M.NET_GRUMOD5, 64, 2000, 7),
+                                       ("lstm5_h96_t1237", M.NET_LSTM5, 96, 1237, 7),
+                                       ("lstm5_h256_t1500", M.NET_LSTM5, 256, 1500, 1), ("lstm5_h384_t1500", M.NET_LSTM5, 384, 1500, 1),
+                                       ("lstm5_h512_t1000", M.NET_LSTM5, 512, 1000, 1), ("grumod5_h256_t1000", M.NET_GRUMOD5, 256, 1000, 1)):
+        mdl = M.synthetic_model(kind, hidden, seed=seed)
         om = ffo.OracleModel(mdl)
         reads = [norm[1000:1000 + T].copy(), rng.standard_normal(T).astype(np.float32)]
         out = {}
@@ -70,10 +73,11 @@ def part2():
             out["score%d" % i] = np.float32(res["score"])
             out["vit_basecall%d" % i] = np.frombuffer(resv["basecall"].encode(), dtype=np.uint8)
             out["vit_path%d" % i] = resv["path"]
-        np.savez_compressed(os.path.join(HERE, "oracle_net_%s.npz" % tag), kind=kind, hidden=hidden, seed=7,
+        np.savez_compressed(os.path.join(HERE, "oracle_net_%s.npz" % tag), kind=kind, hidden=hidden, seed=seed,
                             provenance="oracle/ff_oracle.c output (NOT reference output; parity unpinned)",
                             **out)
-        print(tag, "nblock", out["path0"].size - 1, "basecall len", out["basecall0"].size, out["basecall1"].size)
+        kmers = [len({bytes(out["basecall%d" % i][k:k + 5]) for k in range(out["basecall%d" % i].size - 4)}) for i in (0, 1)]
+        print(tag, "nblock", out["path0"].size - 1, "basecall len", out["basecall0"].size, out["basecall1"].size, "distinct 5-mers", kmers)
 
 
 if __name__ == "__main__":

@@ -111,3 +111,32 @@ def test_split_operand_packer_fp16_rounding(tmp_path):
         ref = x.astype(np.float16)
     assert np.array_equal(rec["h"], ref.view(np.uint16))
     assert np.array_equal(rec["b"], ref.astype(np.float32))
+
+
+def kmer_count(s, k=5):
+    return len({s[i:i + k] for i in range(len(s) - k + 1)})
+
+
+@pytest.mark.parametrize("kind,hidden,seed", [(M.NET_LSTM5, 64, 7), (M.NET_LSTM5, 128, 7), (M.NET_LSTM5, 256, 1), (M.NET_LSTM5, 384, 1), (M.NET_LSTM5, 384, 5),
+                                              (M.NET_LSTM5, 512, 1), (M.NET_GRUMOD5, 64, 7), (M.NET_GRUMOD5, 256, 1), (M.NET_GRUMOD5, 256, 3), (M.NET_LSTM5, 256, 3)])
+def test_synthetic_models_are_input_driven(kind, hidden, seed):
+    """The random models the parity tests and bench.py use must make the comparison mean something: on N(0,1)
+    reads of 4000 samples the oracle calls at least one base per 12 samples and at least 100 distinct 5-mers per read (input-driven,
+    no period), and the network is not chaotic -- a 1e-6 perturbation of the input moves the transition scores by less than 5e-5
+    (flappie_amd/model.py SYNTH_GAINS; searched with tools/dev/tune_gains.py).  The oracle's vectorised mode: this is about the model."""
+    from oracle import ffo
+    mdl = M.synthetic_model(kind, hidden, seed=seed)
+    om = ffo.OracleModel(mdl)
+    rng = np.random.default_rng(1234)
+    with ffo.dot_mode(2):
+        for _ in range(2):
+            sig = rng.standard_normal(4000).astype(np.float32)
+            a = om.basecall(sig)
+            other = om.transitions(sig + np.float32(1e-6) * rng.standard_normal(4000).astype(np.float32))
+            calls = a["basecall"]
+            assert len(calls) * 12 >= 4000, (len(calls), calls[:60])
+            assert kmer_count(calls) >= 100, (kmer_count(calls), calls[:60])
+            assert min(calls.count(c) for c in "ACGTZ"[: mdl.nbase]) >= 0.02 * len(calls)
+            stays = int(np.sum(a["path"][1:] == a["path"][:-1]))
+            assert 0 < stays < a["nblock"]                       # stays and moves both occur
+            assert float(np.abs(other - a["trans"]).max()) < 5e-5

@@ -21,6 +21,11 @@ MIN_READS = 20000
 # what the recorded build gives for this seed: reads whose two GPU paths differ by more than 1e-4 in a transition score / in a base
 # string / in a quality string.  A change may lower these; raising one needs a reason written here.
 RECORDED = dict(beyond_1e4=0, base_strings=1, quality_strings=2)      # 20 281 reads, 181 cases; worst |dtrans| 4.6e-5 (gpurun_out r03c9, profiles/r03_fuzz_slice.txt)
+# ... and a fixed subsample of the slice against the ORACLE (path-vs-path alone says nothing about either path): every
+# ORACLE_EVERY-th read, default path; bounds are north_star's with the recorded count of exceptions
+ORACLE_EVERY = 64
+MIN_ORACLE_READS = 200
+RECORDED_ORACLE = dict(beyond_1e4=0, base_strings=0, quality_strings=0)
 
 
 def test_fixed_seed_slice_of_the_differential_campaign(engine):
@@ -31,6 +36,7 @@ def test_fixed_seed_slice_of_the_differential_campaign(engine):
     beyond = nbase_diff = nqual_diff = 0
     worst = 0.0
     flagged = []
+    sample = []
     while nread_tot < MIN_READS:
         kind = int(rng.choice([M.NET_LSTM5, M.NET_LSTM5, M.NET_GRUMOD5]))
         H = int(rng.choice([128, 256, 384, 512] if kind == M.NET_LSTM5 else [128, 256]))
@@ -68,6 +74,8 @@ def test_fixed_seed_slice_of_the_differential_campaign(engine):
             nqual_diff += bad[2]
             if any(bad) and len(flagged) < 40:
                 flagged.append((kind, H, mseed, nread, cap, r, int(lens[r]), d, bad, sigs[r]))
+            if nread_tot % ORACLE_EVERY == 0:
+                sample.append((kind, H, mseed, sigs[r], a))
             nread_tot += 1
         ncase += 1
     for _, dm in models.values():
@@ -80,6 +88,32 @@ def test_fixed_seed_slice_of_the_differential_campaign(engine):
             ref = ffo.OracleModel(M.synthetic_model(kind, H, seed=mseed)).basecall(sig)
             print("  kind %d H %d model seed %d, batch %d x %d, read %d (%d samples): |dtrans| %.2e, flags beyond/base/quality %s; oracle has %d bases"
                   % (kind, H, mseed, nread, cap, r, n, d, bad, len(ref["basecall"])))
+    # the subsample against the oracle (threads: the oracle runs outside the interpreter lock, no HIP state is forked)
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    from oracle import ffo
+    oms = {}
+    for kind, H, mseed, _, _ in sample:
+        if (kind, H, mseed) not in oms:
+            oms[(kind, H, mseed)] = ffo.OracleModel(M.synthetic_model(kind, H, seed=mseed))
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(lambda t: oms[t[:3]].basecall(t[3]), sample))
+    o_beyond = o_base = o_qual = 0
+    o_worst = 0.0
+    nbases = 0
+    for (kind, H, mseed, sig, a), ref in zip(sample, refs):
+        d = float(np.abs(a[2] - ref["trans"]).max())
+        o_worst = max(o_worst, d)
+        o_beyond += d > 1e-4
+        o_base += a[0] != ref["basecall"]
+        o_qual += a[0] == ref["basecall"] and a[1] != ref["quality"]
+        nbases += len(ref["basecall"])
+        if d > 1e-4 or a[0] != ref["basecall"] or a[1] != ref["quality"]:
+            print("  vs oracle: kind %d H %d model seed %d, %d samples: |dtrans| %.2e, bases %s, qualities %s" % (kind, H, mseed, sig.size, d, a[0] == ref["basecall"], a[1] == ref["quality"]))
+    print("fuzz slice, every %d-th read against the oracle: %d reads, %d called bases; %d beyond 1e-4 (worst %.2e), %d with another base string, %d with another quality string"
+          % (ORACLE_EVERY, len(sample), nbases, o_beyond, o_worst, o_base, o_qual))
+    assert len(sample) >= MIN_ORACLE_READS
+    assert o_beyond <= RECORDED_ORACLE["beyond_1e4"] and o_base <= RECORDED_ORACLE["base_strings"] and o_qual <= RECORDED_ORACLE["quality_strings"]
     assert nread_tot >= MIN_READS
     assert beyond <= RECORDED["beyond_1e4"], "more reads beyond 1e-4 between the two GPU paths than the recorded build"
     assert nbase_diff <= RECORDED["base_strings"], "more reads with differing base strings than the recorded build"

@@ -30,7 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _oracle_job(job):
     kind, hidden, seed, signal, mode = job
     from oracle import ffo
-    mdl = M.synthetic_model(kind, hidden, seed=seed)
+    mdl = M.synthetic_model(kind, hidden, seed=seed, gains=M.SYNTH_GAINS_R3[kind])      # the reads were found on the round-3 model
     om = ffo.OracleModel(mdl)
     with ffo.dot_mode(mode):
         r = om.basecall(signal)
@@ -50,7 +50,7 @@ def test_fuzz_tail_reads_stay_within_the_documented_bound(engine):
         res = list(pool.map(_oracle_job, jobs))
     oracle, yard = res[0::2], res[1::2]
 
-    mdl = M.synthetic_model(kind, hidden, seed=seed)
+    mdl = M.synthetic_model(kind, hidden, seed=seed, gains=M.SYNTH_GAINS_R3[kind])
     dm = B.DeviceModel(engine, mdl)
     cap = max(r[3].size for r in reads)
     out = {}
@@ -91,3 +91,37 @@ def test_fuzz_tail_reads_stay_within_the_documented_bound(engine):
     # the default path is no further from the float32 network proper than the reference-order sums are (measured: 0.8x; the
     # f32-MFMA cross-check path sits at 1.9x on these reads -- every float32 evaluation order scatters by 1-2e-4 on this model)
     assert rows[0][2] <= max(1.5 * d_oy, 1.0e-4), (rows[0][2], d_oy)
+    # ... and, as a bound that means something beside the flat 3e-4: the default path is at most 2e-5 further from
+    # the float32 network proper than the reference-order oracle is on these very reads
+    assert rows[0][2] <= d_oy + 2.0e-5, (rows[0][2], d_oy)
+
+
+def test_recorded_near_tie_reads(engine):
+    """tests/golden/near_ties.npz: reads a campaign found called differently from the oracle on scores that agree to rounding (a near-tie
+    of the posterior decode).  Recorded so that a SECOND such read is noticed: the campaigns count what is not in this file.  Held here:
+    the scores stay within 1e-5 of the oracle's, the Viterbi paths part for no more blocks than recorded, and the all-f32 path keeps
+    calling the read as the oracle does."""
+    from flappie_amd import binding as B
+    from oracle import ffo
+    g = np.load(os.path.join(HERE, "golden", "near_ties.npz"))
+    for i in range(int(g["n"])):
+        kind, hidden, seed = int(g["kind%d" % i]), int(g["hidden%d" % i]), int(g["model_seed%d" % i])
+        mdl = M.synthetic_model(kind, hidden, seed=seed, gains=tuple(float(x) for x in g["gains%d" % i]))
+        sig = g["signal%d" % i]
+        ref = ffo.OracleModel(mdl).basecall(sig)
+        dm = B.DeviceModel(engine, mdl)
+        res = {}
+        for name, flags in (("default", 0), ("f32", B.RUN_F32_RNN)):
+            b = B.Batch(dm, 1, sig.size)
+            b.set_signals(sig[None, :])
+            b.run(1.0, flags); b.finish()
+            res[name] = (b.basecall(0), b.path(0)[0], b.transitions(0))
+            b.close()
+        dm.close()
+        d = float(np.abs(res["default"][2] - ref["trans"]).max())
+        apart = int((res["default"][1] != ref["path"]).sum())
+        print("near tie %d (%s): %d samples; default path %d bases, f32 path %d, oracle %d; |dtrans| %.2e; Viterbi paths apart in %d blocks"
+              % (i, str(g["source%d" % i]), sig.size, len(res["default"][0]), len(res["f32"][0]), len(ref["basecall"]), d, apart))
+        assert d <= 1e-5
+        assert apart <= int(g["blocks_apart%d" % i])
+        assert res["f32"][0] == ref["basecall"]

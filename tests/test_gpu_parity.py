@@ -132,7 +132,7 @@ def test_layer_by_layer_activations(B, ffo, engine):
         b.close(); dm.close()
 
 
-@pytest.mark.parametrize("tag", ["lstm5_h64", "grumod5_h64", "lstm5_h96_t1237"])
+@pytest.mark.parametrize("tag", ["lstm5_h64", "grumod5_h64", "lstm5_h96_t1237", "lstm5_h256_t1500", "lstm5_h384_t1500", "lstm5_h512_t1000", "grumod5_h256_t1000"])
 def test_against_committed_vectors(B, engine, golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "oracle_net_%s.npz" % tag))
     mdl = M.synthetic_model(int(g["kind"]), int(g["hidden"]), seed=int(g["seed"]))

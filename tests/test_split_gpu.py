@@ -203,7 +203,7 @@ def test_packed_kernels_against_oracle(B, engine, kind):
     """the packed layer kernels of H = 256 (k_lstm_pack / k_grumod_pack: full 1024-read launches only) against the oracle itself: a batch
     of 1024 slots of which 28 hold a read (both tiles of a group, one tile only, the first and the last slot; whole groups empty), so that the
     oracle's share stays a few seconds; profiles/r03_parity_packed.txt is the same on 2048 reads"""
-    mdl = M.synthetic_model(kind, 256, seed=31 + kind)
+    mdl = M.synthetic_model(kind, 256, seed=3)
     om = ffo.OracleModel(mdl)
     dm = B.DeviceModel(engine, mdl)
     assert dm.launch_reads == 1024
