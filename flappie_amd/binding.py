@@ -120,6 +120,9 @@ def lib():
     L.ffhip_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(C.c_int32)]
     L.ffhip_batch_get_activation.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.ffhip_batch_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ffhip_batch_f32_reruns.argtypes = [vp]
+    L.ffhip_engine_f32_reruns.restype = C.c_ulonglong
+    L.ffhip_engine_f32_reruns.argtypes = [vp]
     _LIB = L
     return L
 
@@ -150,6 +153,9 @@ class Engine:
 
     def synchronize(self):
         _check(lib().ffhip_engine_synchronize(self.h))
+
+    def f32_reruns(self) -> int:
+        return int(lib().ffhip_engine_f32_reruns(self.h))
 
     def set_profiling(self, on: bool):
         _check(lib().ffhip_engine_set_profiling(self.h, int(on)))
@@ -352,6 +358,10 @@ class Batch:
         L.ffhip_batch_rnn_path.argtypes = [C.c_void_p]
         L.ffhip_batch_rnn_path.restype = C.c_int
         return int(L.ffhip_batch_rnn_path(self.h))
+
+    def f32_reruns(self) -> int:
+        """reads of the last run that left the split operand format's range and were run again on the f32 path (ffhip_batch_finish)"""
+        return int(lib().ffhip_batch_f32_reruns(self.h))
 
     def profile(self):
         ms = (C.c_float * NGROUP)()

@@ -473,6 +473,13 @@ struct ffhip_batch {
     int counted = 0;                    // this batch is in the engine's in_flight count (between run and finish)
     const float **d_gsrc = nullptr; int *d_glen = nullptr;              // ffhip_batch_set_prepared: source rows of the gather
     unsigned *pflags = nullptr, *pabort = nullptr, *h_abort = nullptr;   // persistent-kernel XCC ids / abort word
+    // reads with a value beyond the split format's range (ffhip_split.hpp: the swish convolutions' outputs are clamped at +-4094 there, the
+    // reference's are unbounded, layers.c:24-33): one word per read, set by the producers of that format, looked at by ffhip_batch_finish,
+    // which runs such reads again on the f32 path (`side`) and puts their results in place
+    unsigned *sat = nullptr, *h_sat = nullptr;
+    ffhip_batch *side = nullptr;        // 16 slots of this batch's capacity, created when the first read needs it
+    bool is_side = false;
+    int reruns = 0;                     // reads of the last run that took that way
     int persist_concurrent_ok = 0;      // two such batches fit on the chip at once
     float *scratch = nullptr;           // dense [Tb][H] for debug taps
     // pinned host mirrors of the small results
@@ -550,6 +557,8 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->h_lens) hipHostFree(b->h_lens);
     if (b->h_score) hipHostFree(b->h_score);
     if (b->h_abort) hipHostFree(b->h_abort);
+    if (b->h_sat) hipHostFree(b->h_sat);
+    if (b->side) ffhip_batch_destroy(b->side);
     if (b->have_ev) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
@@ -616,6 +625,9 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->pabort = (unsigned *)dalloc(b, 4 * sizeof(unsigned), true))) BFAIL();      // [0] abort word, [1] development counter
     if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
     *b->h_abort = 0;
+    if (!(b->sat = (unsigned *)dalloc(b, (size_t)b->Bp * sizeof(unsigned), true))) BFAIL();
+    if (hipHostMalloc((void **)&b->h_sat, (size_t)b->Bp * sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
+    memset(b->h_sat, 0, (size_t)b->Bp * sizeof(unsigned));
     if (persist_supported(m->cell, (int)Hp, eng->prop.multiProcessorCount)) {
         const int maxt = persist_max_tiles(m->cell, (int)Hp, eng->prop.multiProcessorCount, fused_supported(m->cell, (int)Hp));
         b->persist_concurrent_ok = 2 * b->B16 <= maxt;      // two such launches fit on the chip together
@@ -871,6 +883,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
     }
     mark(b, 0);
+    HIP_TRY(hipMemsetAsync(b->sat, 0, (size_t)Bp * sizeof(unsigned), s), FFHIP_EHIP);
     // ---- convolutions (layers.c:189-276, activations :24-49)
     // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
     const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT_CONV") && !(flags & FFHIP_RUN_F32_RNN);
@@ -896,15 +909,15 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         if (l < m->nconv - 1) {
             launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
-                              b->ragged ? b->rag_tin[l] : nullptr, (conv_f16 && l == m->nconv - 2) ? kSplitExpX : -100000);
+                              b->ragged ? b->rag_tin[l] : nullptr, (conv_f16 && l == m->nconv - 2) ? kSplitExpX : -100000, b->sat);
         } else if (conv_f16) {
             launch_conv_split(s, b->sbuf[l], b->act[0], c.Wsplit, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
-                              conv_split ? b->actS[0] : nullptr, kSplitExpX, c.split_S, lean_conv);
+                              conv_split ? b->actS[0] : nullptr, kSplitExpX, c.split_S, lean_conv, b->sat);
         } else {
             launch_conv_mfma(s, b->sbuf[l], b->act[0], c.Wp, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                              b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.K16, m->act, b->ragged ? b->plan[l].Tout : 0,
-                             conv_split ? b->actS[0] : nullptr, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH);
+                             conv_split ? b->actS[0] : nullptr, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH, b->sat);
         }
         b->launches[0]++;
     }
@@ -916,7 +929,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     cur = 0;
     HIP_TRY(hipMemsetAsync(b->pabort, (use_persist && getenv("FFHIP_DEBUG_FORCE_ABORT")) ? 1 : 0, sizeof(unsigned), s), FFHIP_EHIP);      // (debug: pretend a wait timed out)
     if ((use_split || use_split2) && !conv_split) {
-        launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH);
+        launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH, b->sat, B16);
         b->launches[0]++;
     }
     b->run_cur = cur;
@@ -988,7 +1001,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                 // projection on the bf16 pipes over split operands (fp32-exact products): the layer input is
                 // converted to the split layout first
                 if (!b->actS[0] && !(b->actS[0] = dalloc(b, split_bytes((size_t)Tb * B16, Hp), false))) return FFHIP_ENOMEM;
-                launch_split_from_f32(s, in, b->actS[0], (size_t)Tb * B16, Hp, (l == 0 && m->act == ACT_SWISH) ? kSplitExpX : kSplitExpH);
+                launch_split_from_f32(s, in, b->actS[0], (size_t)Tb * B16, Hp, (l == 0 && m->act == ACT_SWISH) ? kSplitExpX : kSplitExpH, b->sat, B16);
                 launch_inproj_split(s, b->actS[0], b->xa, r.Wsplit, r.bias, Tb * B16, Hp, r.split_S);
                 b->launches[1] += 2;
             } else {
@@ -1175,6 +1188,58 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
 
 extern "C" int ffhip_batch_paired(const ffhip_batch *b) { return (b && b->paired_last) ? 1 : 0; }
 
+// Reads of a finished batch that left the split format's range (b->h_sat) again, 16 at a time, through the all-f32 kernels, which
+// have no bound (the reference has none: layers.c:24-33); their results replace the clamped ones in the batch's buffers.  Rare by
+// construction -- a normalised sample in the hundreds -- so this path is written for clarity: a side batch of 16 slots with the
+// same capacity (hence the same strides: a read's results are contiguous device-to-device copies), created on first use.
+static int rerun_on_f32_path(ffhip_batch *b, const std::vector<int> &reads) {
+    const ffhip_model *m = b->mdl;
+    if (!b->side) {
+        b->side = ffhip_batch_create(b->eng, m, 16, (size_t)b->T);
+        if (!b->side) return FFHIP_ENOMEM;
+        b->side->is_side = true;
+    }
+    ffhip_batch *sd = b->side;
+    const size_t Tb = b->Tb, L = Tb + 1, Ps = m->Ps, ns = m->nstate;
+    const unsigned fl = b->last_flags;
+    for (size_t k0 = 0; k0 < reads.size(); k0 += 16) {
+        const int n = (int)std::min<size_t>(16, reads.size() - k0);
+        std::vector<int> lens(16, 0);
+        for (int k = 0; k < n; k++) lens[k] = b->hT[reads[k0 + k]];
+        if (int rc = apply_lengths(sd, lens)) return rc;
+        if (int rc = clear_signals(sd)) return rc;
+        for (int k = 0; k < n; k++)
+            HIP_TRY(hipMemcpyAsync(sd->sbuf[0].p + (size_t)k * sd->sbuf[0].rs + kSamplePad, b->sbuf[0].p + (size_t)reads[k0 + k] * b->sbuf[0].rs + kSamplePad,
+                                   (size_t)lens[k] * 4, hipMemcpyDeviceToDevice, sd->stream), FFHIP_EHIP);
+        sd->ran = sd->finished = 0;
+        if (int rc = ffhip_batch_run(sd, b->last_temperature, (fl & ~(unsigned)FFHIP_RUN_KEEP_ACTS) | FFHIP_RUN_F32_RNN)) return rc;
+        if (int rc = ffhip_batch_finish(sd)) return rc;
+        hipStream_t s = b->stream;
+        for (int k = 0; k < n; k++) {
+            const size_t r = (size_t)reads[k0 + k];
+            HIP_TRY(hipMemcpyAsync(b->trans + r * Tb * Ps, sd->trans + (size_t)k * Tb * Ps, Tb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            if (fl & FFHIP_RUN_NO_DECODE) continue;
+            if (!(fl & FFHIP_RUN_VITERBI_ONLY)) HIP_TRY(hipMemcpyAsync(b->post + r * Tb * Ps, sd->post + (size_t)k * Tb * Ps, Tb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->path + r * L, sd->path + (size_t)k * L, L * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->qpath + r * L, sd->qpath + (size_t)k * L, L * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->score + r, sd->score + k, 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->bases + r * L, sd->bases + (size_t)k * L, L, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->quals + r * L, sd->quals + (size_t)k * L, L, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->lens + r, sd->lens + k, 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            if (!(fl & FFHIP_RUN_NO_TRACE) && m->kind != FFHIP_NET_LSTM5_RLE)
+                HIP_TRY(hipMemcpyAsync(b->trace + r * L * ns, sd->trace + (size_t)k * L * ns, L * ns * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            memcpy(b->h_bases + r * L, sd->h_bases + (size_t)k * L, L);
+            memcpy(b->h_quals + r * L, sd->h_quals + (size_t)k * L, L);
+            b->h_lens[r] = sd->h_lens[k];
+            b->h_score[r] = sd->h_score[k];
+        }
+        HIP_TRY(hipStreamSynchronize(s), FFHIP_EHIP);
+    }
+    b->reruns = (int)reads.size();
+    b->eng->f32_reruns += reads.size();
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     if (!b) return set_err(FFHIP_EINVAL, "null batch");
     if (!b->ran) return set_err(FFHIP_EINVAL, "ffhip_batch_run has not been called");
@@ -1187,6 +1252,7 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         HIP_TRY(hipMemcpyAsync(b->h_score, b->score, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     }
     HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->h_sat, b->sat, n * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
@@ -1205,8 +1271,17 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         return ffhip_batch_finish(b);
     }
     b->finished = 1;
+    b->reruns = 0;
+    if (!b->is_side) {
+        std::vector<int> over;
+        for (int r = 0; r < b->nread; r++) if (b->h_sat[r] && b->hT[r] > 0) over.push_back(r);
+        if (!over.empty()) if (int rc = rerun_on_f32_path(b, over)) { b->finished = 0; return rc; }
+    }
     return FFHIP_OK;
 }
+
+extern "C" int ffhip_batch_f32_reruns(const ffhip_batch *b) { return b ? b->reruns : -1; }
+extern "C" unsigned long long ffhip_engine_f32_reruns(const ffhip_engine *eng) { return eng ? eng->f32_reruns : 0; }
 
 static bool results_ok(const ffhip_batch *b, int read) {
     if (!b || !b->finished || read < 0 || read >= b->nread) { set_err(FFHIP_EINVAL, "results not available (finish the batch, check the read index)"); return false; }

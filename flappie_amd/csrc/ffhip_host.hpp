@@ -28,6 +28,7 @@ struct ffhip_engine {
     // co-tenancy becomes a slowdown, not FFHIP_ETIMEOUT.
     int stepwise_batches = 0;
     int fallbacks = 0;          // how often that happened (ffhip_debug_fallback_count)
+    unsigned long long f32_reruns = 0;      // reads that left the split format's range and were run again on the f32 path (ffhip_engine_f32_reruns)
     int in_flight = 0;          // batches between ffhip_batch_run and ffhip_batch_finish: kernels of a batch submitted beside another
                                 // take the shapes that fit next to a resident layer launch (k_conv_split<2, 2>)
     // Signal preparation (ffhip_prep.hip) runs on a stream of its own -- beside the batches, not queued behind one of them -- and

@@ -52,17 +52,18 @@ void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf ds
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
                        const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0,     // ldp: entries per read of a per-read window table (0 = shared)
                        const int *tin = nullptr,                                  // stride-1 layer of a ragged batch: per-read input lengths instead of a table
-                       int split_exp = -100000);                                  // > -1000 (16 output features): write fp16 slices of value * 2^split_exp for launch_conv_split
+                       int split_exp = -100000,                                   // > -1000 (16 output features): write fp16 slices of value * 2^split_exp for launch_conv_split
+                       unsigned *sat = nullptr);                                  // per-read word set to 1 when a value leaves the split format's range (ffhip_split.hpp: clamped there; the engine re-runs such a read on the f32 path)
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
                       const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp = 0,
-                      void *out_split = nullptr, int split_exp = 0);      // != nullptr: write the split layout of ffhip_rnn_split.hip (values * 2^split_exp) INSTEAD of `out` (M % 128 == 0)
+                      void *out_split = nullptr, int split_exp = 0, unsigned *sat = nullptr);      // != nullptr: write the split layout of ffhip_rnn_split.hip (values * 2^split_exp) INSTEAD of `out` (M % 128 == 0)
 
 // the same convolution on split operands (16 input features): `in` holds fp16 slices (launch_conv_small with split_exp = kSplitExpX),
 // Wp the split weight pack [M/16][ceil(winlen/2)][2][64] x 16 B scaled by 2^(acc_exp - kSplitExpX)
 void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
-                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean = 0);      // lean: the <= 128-VGPR shape
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean = 0, unsigned *sat = nullptr);      // lean: the <= 128-VGPR shape
 
 // Xa = Wi^T x + b for every (t, read); in tile-interleaved, out D-fragment order
 void launch_inproj(hipStream_t s, const float *in, float *xa, const float4 *Wp, const float *bias,
@@ -113,7 +114,7 @@ bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *
 // input projection GEMM on split operands: in_split = activations in the split layout, Wp = the split weight pack (its first
 // matrix is Wi), xa = D-fragment order like launch_inproj
 void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const void *Wp, const float *bias, int ntile, int H, int scale_exp);
-void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp);      // tile-interleaved fp32 -> split of in * 2^act_exp
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp, unsigned *sat = nullptr, int B16 = 1);      // tile-interleaved fp32 -> split of in * 2^act_exp
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H, int act_exp);
 void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad);      // adds the mismatch count to *bad
 

@@ -54,7 +54,7 @@ template <int MAXF>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp,
-             const int *__restrict__ tin, float split_scale) {
+             const int *__restrict__ tin, float split_scale, unsigned *__restrict__ sat) {
     extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
     const int Fin = in.F, Fout = out.F, K = winlen * Fin;
     for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
@@ -97,6 +97,7 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 #pragma unroll
         for (int f = 0; f < 16; f += 4) {
             const ffv4 y = apply_act4((ffv4){ acc[f], acc[f + 1], acc[f + 2], acc[f + 3] }, act) * split_scale;
+            if (sat && split_overflow(y)) sat[r] = 1u;      // beyond the split format: the engine re-runs this read on the f32 path (ffhip_batch_finish)
             unsigned s0[kSplitNS], s1[kSplitNS], s2[kSplitNS], s3[kSplitNS];
             split_slices<true>(y.x, s0); split_slices<true>(y.y, s1); split_slices<true>(y.z, s2); split_slices<true>(y.w, s3);
 #pragma unroll
@@ -124,16 +125,16 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin, int split_exp) {
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin, int split_exp, unsigned *sat) {
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
     if (out.F <= 4)
-        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f);
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
     else if (out.F <= 16)
-        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale);
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat);
     else
-        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f);
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -185,7 +186,7 @@ template <bool BVEC>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, const float *__restrict__ bias,
             const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act, int ldp,
-            unsigned char *__restrict__ out_split, float split_scale) {
+            unsigned char *__restrict__ out_split, float split_scale, unsigned *__restrict__ sat) {
     constexpr int TM = 4, TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -242,6 +243,7 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
                 unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 32 * kSplitNS) +
                                      (size_t)(((mt >> 1) * kSplitNS * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);
                 const float f[4] = { v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale };
+                if (sat && split_overflow((v4f){ f[0], f[1], f[2], f[3] })) sat[(nt % B16) * 16 + rl] = 1u;      // see k_conv_small
                 unsigned sb[4][kSplitNS];
 #pragma unroll
                 for (int e = 0; e < 4; e++) split_slices<true>(f[e], sb[e]);
@@ -255,16 +257,16 @@ k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, c
 }
 
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
-                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp, void *out_split, int split_exp) {
+                      const int *x0a, const int *x0b, int B16, int Tout, int M, int K16, int act, int ldp, void *out_split, int split_exp, unsigned *sat) {
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
     if (vec)
         hipLaunchKernelGGL(k_conv_mfma<true>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp));
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp), sat);
     else
         hipLaunchKernelGGL(k_conv_mfma<false>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
-                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp));
+                           x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp), sat);
 }
 
 // ---- last convolution on split operands ---------------------------------------------------------------------------
@@ -284,7 +286,7 @@ template <int TM, int TN>
 __global__ void __launch_bounds__(256, 2)      // (two waves per SIMD for both shapes; <4, 4> without a bound took 216 + 64 registers and ran ONE wave per SIMD.  Measured and dropped: <4, 2> and <2, 4> at three waves per SIMD, 0.39 and 0.52 ms against 0.30)
 k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int NC, int winlen, int act, int ldp,
-             unsigned char *__restrict__ out_split, float split_scale, float acc_scale) {
+             unsigned char *__restrict__ out_split, float split_scale, float acc_scale, unsigned *__restrict__ sat) {
     constexpr int NSL = 2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the weight tiles' addresses then are scalar bases + the lane)
     const int wm = wave & 1, wn = wave >> 1;
@@ -370,6 +372,7 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
                 unsigned char *dst = out_split + (size_t)nt * ((size_t)Mt * 16 * 32 * kSplitNS) +
                                      (size_t)(((mt >> 1) * kSplitNS * 64 + ((mt & 1) * 2 + (kq >> 1)) * 16 + rl) * 16 + (kq & 1) * 8);
                 const float f[4] = { v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale };
+                if (sat && split_overflow((v4f){ f[0], f[1], f[2], f[3] })) sat[(nt % B16) * 16 + rl] = 1u;      // see k_conv_small
                 unsigned sb[4][kSplitNS];
 #pragma unroll
                 for (int e = 0; e < 4; e++) split_slices<true>(f[e], sb[e]);
@@ -383,17 +386,17 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
 }
 
 void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
-                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean) {
+                       int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean, unsigned *sat) {
     const int Mt = M / 16, NC = (winlen + 1) / 2;
     if (lean) {
         const int nMblk = (Mt + 3) / 4, nNblk = (Tout * B16 + 3) / 4;
         hipLaunchKernelGGL((k_conv_split<2, 2>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
-                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
+                           (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp), sat);
         return;
     }
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     hipLaunchKernelGGL((k_conv_split<4, 4>), dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
-                       (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp));
+                       (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp), sat);
 }
 
 // ---- input projection: Xa[nt][mt] = Wp[mt] . act[nt] + b ----------------------------------

@@ -1383,7 +1383,7 @@ void launch_inproj_split(hipStream_t s, const void *in_split, float *xa, const v
 // ---- layout converters -------------------------------------------------------------------------
 // fp32 tile-interleaved [tile][Ut][16 reads][4] <-> split [tile][Hc][NS][64][8 bf16]; one thread per (tile, pair of unit tiles, read)
 __global__ void __launch_bounds__(256)
-k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, size_t npair, int Ut, float scale) {
+k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, size_t npair, int Ut, float scale, unsigned *__restrict__ sat, int B16) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= npair) return;
     const int rl = (int)(idx & 15);
@@ -1392,6 +1392,7 @@ k_split_from_f32(const float *__restrict__ in, unsigned char *__restrict__ out, 
     const size_t tile = pr / (Ut / 2);
     const float *src = in + (tile * Ut + 2 * up) * 64 + rl * 4;
     const v4f lo = *(const v4f *)src * scale, hi = *(const v4f *)(src + 64) * scale;
+    if (sat && (split_overflow(lo) || split_overflow(hi))) sat[(tile % B16) * 16 + rl] = 1u;      // clamped below: the engine re-runs this read on the f32 path
     unsigned char *dst = out + tile * ((size_t)Ut / 8 * NS * 1024);
     const int c = up >> 2, kq = up & 3;
 #pragma unroll
@@ -1430,9 +1431,9 @@ k_f32_from_split(const unsigned char *__restrict__ in, float *__restrict__ out, 
     *(v4f *)(dst + 64) = (v4f){ v[4], v[5], v[6], v[7] };
 }
 
-void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp) {
+void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t ntile, int H, int act_exp, unsigned *sat, int B16) {
     const size_t npair = ntile * (size_t)(H / 8) * 16;
-    hipLaunchKernelGGL(k_split_from_f32, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, in, (unsigned char *)out, npair, H / 4, split_pow2(act_exp));
+    hipLaunchKernelGGL(k_split_from_f32, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, in, (unsigned char *)out, npair, H / 4, split_pow2(act_exp), sat, B16 > 0 ? B16 : 1);
 }
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H, int act_exp) {
     const size_t npair = ntile * (size_t)(H / 8) * 16;

@@ -83,6 +83,16 @@ __device__ __forceinline__ void split_slices(float v, unsigned (&s)[kSplitNS]) {
 #endif
 }
 
+// does split_slices<true> clamp one of these four (already scaled) values?  A NaN is not clamped (it stays a NaN, as in the reference)
+template <typename V4>
+__device__ __forceinline__ bool split_overflow(V4 v) {
+#ifdef FFHIP_SPLIT_BF16X3
+    return false;
+#else
+    return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65504.0f;
+#endif
+}
+
 __device__ __forceinline__ float split_slice_value(unsigned bits16) {
 #ifdef FFHIP_SPLIT_BF16X3
     return __uint_as_float(bits16 << 16);

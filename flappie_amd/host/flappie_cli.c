@@ -615,7 +615,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
         while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);           /* may complete and write an earlier chunk */
         pipe_state.fifo[pipe_state.nfifo++] = cur;
-        pipe_state.slot = (pipe_state.slot + 1) % NINFLIGHT;
+        pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);       /* depth in flight + the one being set up: no more batch objects than that */
         i += g;
     }
     c->all_submitted = 1;
@@ -907,6 +907,10 @@ int main(int argc, char *argv[]) {
                 "files listed -> done", now_s() - t_listed);
         fprintf(stderr, "basecalled: %llu reads, %llu samples (trimmed ranges), %llu raw samples\n", n_called_reads, n_called_samples, n_raw_samples);
     }
+    /* reads with a sample so far out that the default path's operand format could not hold the convolution's output: none is returned
+     * clamped, the engine ran them again on its f32 kernels (include/ffhip.h, ffhip_engine_f32_reruns) */
+    if (ffhip_engine_f32_reruns(eng) > 0)
+        warnx("%llu read(s) held samples beyond the range of the default kernels' operand format and were evaluated on the f32 kernels", ffhip_engine_f32_reruns(eng));
     flappie_hip_shutdown();
     if (reader_failures) { warnx("%d reader process(es) failed; see the warnings above", reader_failures); return EXIT_FAILURE; }
     return EXIT_SUCCESS;

@@ -308,6 +308,12 @@ int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP], int launch
  * its peer workgroups (another tenant on the GPU); each occurrence also warns on stderr once per process and sends the next 64 runs
  * to those kernels directly */
 int ffhip_debug_fallback_count(const ffhip_engine *eng);
+/* Reads whose swish-convolution outputs left the range of the default path's operand format (two fp16 slices of value * 2^4: +-4094;
+ * the reference's swish_activation_inplace, layers.c:24-33, has no bound): the producing kernels flag them, ffhip_batch_finish runs
+ * them again through the all-f32 kernels (FFHIP_RUN_F32_RNN, no bound) and puts those results in place -- no read is returned
+ * clamped.  The count of the batch's last run / of the engine's lifetime (the flappie binary prints the latter in its summary). */
+int ffhip_batch_f32_reruns(const ffhip_batch *b);
+unsigned long long ffhip_engine_f32_reruns(const ffhip_engine *eng);
 
 #ifdef __cplusplus
 }

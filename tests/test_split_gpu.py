@@ -511,13 +511,14 @@ def test_timeout_falls_back_to_the_stepwise_kernels(B):
     b.close(); dm.close(); eng.close()
 
 
-def test_outlier_samples_beyond_the_split_format_saturate_and_the_f32_path_does_not(B, engine):
-    """the split operand format carries the swish convolutions' outputs as fp16 slices of value * 16, i.e. clamped at +-4094
-    (ffhip_split.hpp); a med-MAD normalised signal stays three orders of magnitude below what it takes to get there, but the behaviour
-    beyond is stated, not assumed: (a) outliers that keep the convolution outputs inside the range change nothing -- default path and
-    oracle agree as on any read; (b) a spike large enough to pass 4094 behind the second convolution makes the default path SATURATE:
-    finite scores, and they may differ from the oracle's around the spike (printed); (c) the all-f32 path (FFHIP_RUN_F32_RNN) has no
-    such bound and agrees with the oracle on the same read.  INTEGRATION.md section 4 lists this as a known deviation."""
+def test_outlier_samples_beyond_the_split_format_are_run_again_on_the_f32_path(B, engine):
+    """The split operand format carries the swish convolutions' outputs as fp16 slices of value * 16, i.e. up to +-4094 (ffhip_split.hpp); the
+    reference's swish has no bound (layers.c:24-33).  A med-MAD normalised signal stays orders of magnitude below that, but nothing is returned
+    clamped: the kernels that produce the format flag a read that passes the bound, and ffhip_batch_finish runs it again
+    through the all-f32 kernels and puts those results in place.  (a) outliers inside the range change nothing and no read is re-run; (b) a
+    spike that drives the second convolution beyond 4094: the DEFAULT path returns the oracle's call -- bit for bit what FFHIP_RUN_F32_RNN
+    gives for that read -- and counts one re-run; (c) in a ragged 40-read batch with three such reads, the other 37 are bit-identical to
+    the same batch without the spikes; (d) the same through ffhip_batch_run_pair."""
     from oracle import ffo
     mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=9)
     om = ffo.OracleModel(mdl)
@@ -528,6 +529,7 @@ def test_outlier_samples_beyond_the_split_format_saturate_and_the_f32_path_does_
     mild[[300, 301, 900]] = [60.0, -45.0, 80.0]                 # large for a normalised signal, far inside the format
     wild[[300, 301, 900]] = [6.0e4, -4.5e4, 8.0e4]              # drives the second convolution's output beyond 4094
     res = {}
+    before = engine.f32_reruns()
     for name, sig in (("mild", mild), ("wild", wild)):
         ref = om.basecall(sig)
         for tag, flags in (("split", 0), ("f32", B.RUN_F32_RNN)):
@@ -536,13 +538,59 @@ def test_outlier_samples_beyond_the_split_format_saturate_and_the_f32_path_does_
             b.run(1.0, flags); b.finish()
             tr = b.transitions(0)
             assert np.isfinite(tr).all()
-            res[(name, tag)] = (float(np.abs(tr - ref["trans"]).max()), b.basecall(0) == ref["basecall"])
+            res[(name, tag)] = (float(np.abs(tr - ref["trans"]).max()), b.basecall(0) == ref["basecall"] and b.quality(0) == ref["quality"], b.f32_reruns(), tr,
+                                np.array_equal(b.path(0)[0], ref["path"]), float(np.abs(b.posterior(0) - ref["post"]).max()), int(np.abs(b.trace(0) - ref["trace"]).max()))
             b.close()
-    dm.close()
-    print("max |dtrans| vs oracle, bases equal:", res)
-    assert res[("mild", "split")][0] <= 1e-4 and res[("mild", "split")][1]
+    print("max |dtrans| vs oracle, strings equal, reads re-run:", {k: v[:3] for k, v in res.items()})
+    assert res[("mild", "split")][0] <= 1e-4 and res[("mild", "split")][1] and res[("mild", "split")][2] == 0
     assert res[("mild", "f32")][0] <= 1e-4 and res[("mild", "f32")][1]
-    # no clamp on the f32 path: the same calls as the oracle; with activations of 1e4 behind the spikes the summation orders differ by
-    # more than on ordinary reads (measured 1.7e-4)
-    assert res[("wild", "f32")][0] <= 5e-4 and res[("wild", "f32")][1]
-    assert res[("wild", "split")][0] > 1e-3          # ... and this is the deviation the default path's saturation costs on such a read (measured 9.3)
+    # with activations of 1e4 behind the spikes the summation orders differ by more than on ordinary reads (measured 1.7e-4)
+    assert res[("wild", "f32")][0] <= 5e-4 and res[("wild", "f32")][1] and res[("wild", "f32")][2] == 0
+    w = res[("wild", "split")]
+    assert w[2] == 1 and engine.f32_reruns() == before + 1
+    assert np.array_equal(w[3], res[("wild", "f32")][3])                      # the default path's answer IS the f32 path's
+    assert w[0] <= 5e-4 and w[1] and w[4] and w[5] <= 1e-3 and w[6] <= 1     # ... and the oracle's call
+    # (c) a ragged batch: three of 40 reads carry a spike
+    lens = rng.integers(400, 1501, 40)
+    clean = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
+    spiked = [x.copy() for x in clean]
+    for r, at in ((3, 200), (16, 50), (39, 390)):
+        spiked[r][at] = 7.0e4
+    out = []
+    for sg in (clean, spiked):
+        b = B.Batch(dm, 40, 1500)
+        b.set_signals_ragged(sg)
+        b.run(); b.finish()
+        out.append(([b.transitions(r) for r in range(40)], [(b.basecall(r), b.quality(r), b.score(r)) for r in range(40)], b.f32_reruns()))
+        if sg is spiked:
+            for r in (3, 16, 39):
+                ref = om.basecall(sg[r])
+                assert float(np.abs(b.transitions(r) - ref["trans"]).max()) <= 5e-4
+                assert (b.basecall(r), b.quality(r)) == (ref["basecall"], ref["quality"]) and np.array_equal(b.path(r)[0], ref["path"])
+                assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
+        b.close()
+    assert out[0][2] == 0 and out[1][2] == 3
+    for r in range(40):
+        if r not in (3, 16, 39):
+            assert np.array_equal(out[0][0][r], out[1][0][r]) and out[0][1][r] == out[1][1][r], r
+    dm.close()
+    # (d) the paired launch of bench.py's shape: one read of the second batch carries a spike
+    mdl = M.synthetic_model(M.NET_LSTM5, 384, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    sig = [rng.standard_normal((256, 600)).astype(np.float32) for _ in range(2)]
+    sig[1][77, 300] = -9.0e4
+    bs = [B.Batch(dm, 256, 600) for _ in range(2)]
+    for b, sg in zip(bs, sig):
+        b.set_signals(sg)
+    bs[0].run_pair(bs[1])
+    for b in bs:
+        b.finish()
+        assert b.paired()
+    assert bs[0].f32_reruns() == 0 and bs[1].f32_reruns() == 1
+    ref = ffo.OracleModel(mdl).basecall(sig[1][77])
+    assert float(np.abs(bs[1].transitions(77) - ref["trans"]).max()) <= 5e-4 and bs[1].basecall(77) == ref["basecall"] and bs[1].quality(77) == ref["quality"]
+    ref = ffo.OracleModel(mdl).basecall(sig[1][78])
+    assert float(np.abs(bs[1].transitions(78) - ref["trans"]).max()) <= 1e-4 and bs[1].basecall(78) == ref["basecall"]
+    for b in bs:
+        b.close()
+    dm.close()
