@@ -54,39 +54,10 @@ CONFIGS = {
 SURVEY_OPENBLAS_PER_CORE = {(0, 384): 0.010, (0, 256): 0.035, (0, 512): 0.0046, (1, 256): 0.0185}   # Msamples/s/core, SURVEY.md section 6 [probe]
 
 
-def find_openblas():
-    """An LP64 OpenBLAS on this host, if any: the one scipy ships (`scipy_cblas_*` symbols), a distribution's libopenblas, conda's.
-    (numpy's own `libscipy_openblas64_` is the ILP64 build: other symbol names, 64-bit integers -- not taken.)"""
-    import glob
-    import sysconfig
-    roots = {sysconfig.get_paths().get("purelib", ""), sysconfig.get_paths().get("platlib", "")} | {p for p in sys.path if p.endswith("-packages")}
-    cands = []
-    for r in sorted(x for x in roots if x):
-        cands += sorted(glob.glob(os.path.join(r, "scipy.libs", "libscipy_openblas-*.so"))) + sorted(glob.glob(os.path.join(r, "scipy_openblas32", "lib", "*.so")))
-    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib/x86_64-linux-gnu/openblas-*/libopenblas.so*", "/usr/lib64/libopenblas.so*",
-                "/opt/conda/lib/libopenblas.so*"):
-        cands += sorted(glob.glob(pat))
-    return cands
-
-
 def _oracle_with_blas(mode):
     """the oracle library in dot mode `mode`; mode 3 (OpenBLAS) falls back to 2 (own vectorised kernels) when no library loads"""
-    import ctypes as C
     from oracle import ffo
-    L = ffo.lib()
-    used = None
-    if mode == 3:
-        L.fo_blas_open.restype = C.c_int
-        L.fo_blas_open.argtypes = [C.c_char_p]
-        L.fo_blas_config.restype = C.c_char_p
-        for path in find_openblas():
-            if L.fo_blas_open(path.encode()) == 0:
-                used = (os.path.basename(path), L.fo_blas_config().decode(errors="replace").strip())
-                break
-        if used is None:
-            mode = 2
-    L.fo_set_dot_mode(mode)
-    return mode, used
+    return ffo.use_dot_mode(mode)
 
 
 def _cpu_worker(job):

@@ -149,6 +149,42 @@ def lib():
     return L
 
 
+def find_openblas():
+    """An LP64 OpenBLAS on this host, if any: the one scipy ships (`scipy_cblas_*` symbols), a distribution's libopenblas, conda's.
+    (numpy's own `libscipy_openblas64_` is the ILP64 build: other symbol names, 64-bit integers -- not taken.)"""
+    import glob
+    import sys
+    import sysconfig
+    roots = {sysconfig.get_paths().get("purelib", ""), sysconfig.get_paths().get("platlib", "")} | {p for p in sys.path if p.endswith("-packages")}
+    cands = []
+    for r in sorted(x for x in roots if x):
+        cands += sorted(glob.glob(os.path.join(r, "scipy.libs", "libscipy_openblas-*.so"))) + sorted(glob.glob(os.path.join(r, "scipy_openblas32", "lib", "*.so")))
+    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib/x86_64-linux-gnu/openblas-*/libopenblas.so*", "/usr/lib64/libopenblas.so*",
+                "/opt/conda/lib/libopenblas.so*"):
+        cands += sorted(glob.glob(pat))
+    return cands
+
+
+def use_dot_mode(mode: int):
+    """Put the oracle library in dot mode `mode` (ff_oracle.c: 0 reference order, 1 double accumulators, 2 own vectorised kernels, 3 the
+    GEMV / GEMM calls of the reference -- cblas_sgemv at layers.c:1009, cblas_sgemm at flappie_matrix.c:384 -- through a real OpenBLAS
+    dlopen()ed from this host).  Mode 3 falls back to 2 when no library loads.  Returns (mode in force, (library file, its config) or None)."""
+    L = lib()
+    used = None
+    if mode == 3:
+        L.fo_blas_open.restype = C.c_int
+        L.fo_blas_open.argtypes = [C.c_char_p]
+        L.fo_blas_config.restype = C.c_char_p
+        for path in find_openblas():
+            if L.fo_blas_open(path.encode()) == 0:
+                used = (os.path.basename(path), L.fo_blas_config().decode(errors="replace").strip())
+                break
+        if used is None:
+            mode = 2
+    L.fo_set_dot_mode(mode)
+    return mode, used
+
+
 class dot_mode:
     """with ffo.dot_mode(1): ...  -- how the oracle sums dot products inside the block (ff_oracle.c: 0 reference order in
     float = the oracle, 1 double accumulator = yardstick, 2 vectorised kernels = cpu_baseline timing)."""

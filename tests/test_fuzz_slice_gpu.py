@@ -7,8 +7,8 @@ exact properties of the build, not statistics: the test FAILS when a kernel chan
 than the recorded build did (more reads beyond north_star's 1e-4 on the transition scores, more reads with a differing base or
 quality string).  Every flagged read is printed with its distance from the oracle, so that a failure says which path moved.
 
-Recorded on the round-3 build (MI355X): see RECORDED below; the reads beyond 1e-4 all come from the one barely contractive random
-model of the campaign (tests/test_fuzz_tail_gpu.py)."""
+Every 64th read of the slice is also compared with the ORACLE (317 reads): path-vs-path alone says nothing about either path.
+Recorded on the round-4 build (MI355X): see RECORDED / RECORDED_ORACLE below."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,11 @@ SEED = 20260928
 MIN_READS = 20000
 # what the recorded build gives for this seed: reads whose two GPU paths differ by more than 1e-4 in a transition score / in a base
 # string / in a quality string.  A change may lower these; raising one needs a reason written here.
-RECORDED = dict(beyond_1e4=0, base_strings=1, quality_strings=2)      # 20 281 reads, 181 cases; worst |dtrans| 4.6e-5 (gpurun_out r03c9, profiles/r03_fuzz_slice.txt)
+# Round 4: the synthetic models became input-driven (flappie_amd/model.py SYNTH_GAINS: 6-8x the called bases per read, every read aperiodic), so the
+# same 20 281 reads now hold ~2.4 million called bases instead of ~0.3 million and near-ties of the posterior decode are met in proportion: 3 reads with
+# another base string and 4 with another quality string between the two GPU paths (round 3, input-blind models: 1 and 2); the scores themselves moved
+# CLOSER -- worst |dtrans| 2.2e-5 (4.6e-5).  tools/parity_h384.py puts the rate beside that of two summation orders of the oracle itself.
+RECORDED = dict(beyond_1e4=0, base_strings=3, quality_strings=4)      # 20 281 reads, 181 cases; worst |dtrans| 2.2e-5 (gpurun_out/r04a_tests.log, profiles/r04_fuzz_slice.txt)
 # ... and a fixed subsample of the slice against the ORACLE (path-vs-path alone says nothing about either path): every
 # ORACLE_EVERY-th read, default path; bounds are north_star's with the recorded count of exceptions
 ORACLE_EVERY = 64

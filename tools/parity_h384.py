@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """Parity campaign at bench.py's headline shape THROUGH THE PAIRED LAUNCH: H = 384 LSTM (bench.py's model,
 synthetic_model(seed=1)), batches of 256 reads run two at a time through ffhip_batch_run_pair -- k_lstm_split_pair<0,3,2,true>, the kernel
-the driver times -- every read through the oracle (a process pool, started before the engine exists).  Half the pairs are uniform
-(every read `tmax` samples), half ragged (1500 .. tmax, sorted as the flappie binary sorts).  Counts base-string / quality-string /
-Viterbi-path mismatches and the largest transition-score difference; reads recorded in tests/golden/near_ties.npz would be named.
+the driver times.  Every read also goes through the oracle TWICE (process pools, started before the engine exists):
+
+  oracle       dot products float, term by term in index order (ff_oracle.c dot mode 0: what the parity tests use)
+  oracle+blas  the same algorithm with its GEMV / GEMM calls -- the reference's cblas_sgemv / cblas_sgemm shapes, layers.c:1009,
+               flappie_matrix.c:384 -- in a real OpenBLAS dlopen()ed from this host (dot mode 3): the arithmetic the reference
+               itself would do on this machine
+
+so that the engine's distance from the oracle stands beside the distance BETWEEN TWO SUMMATION ORDERS OF THE REFERENCE ALGORITHM on
+the same reads: a called base that flips between those two is a near-tie of the posterior decode, not a property of the engine.
+Half the pairs are uniform (every read `tmax` samples), half ragged (1500 .. tmax, sorted as the flappie binary sorts).
 Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500]"""
 import multiprocessing as mp
 import os
@@ -20,15 +27,51 @@ KIND, H, SEED = M.NET_LSTM5, 384, 1
 _om = None
 
 
-def _init():
+def _init(mode):
     global _om
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
     from oracle import ffo
     _om = ffo.OracleModel(M.synthetic_model(KIND, H, seed=SEED))
+    got, _ = ffo.use_dot_mode(mode)
+    assert got == mode, "no LP64 OpenBLAS on this host"
 
 
 def _call(x):
     r = _om.basecall(x)
     return dict(basecall=r["basecall"], quality=r["quality"], path=np.asarray(r["path"]), trans=np.asarray(r["trans"]))
+
+
+class Tally:
+    def __init__(self, what):
+        self.what = what
+        self.d = dict(reads=0, bases=0, base_mismatch=0, bases_apart=0, qual_mismatch=0, qual_chars_diff=0, path_mismatch=0, worst=0.0)
+        self.named = []
+
+    def add(self, tag, a, ref):
+        d = self.d
+        d["reads"] += 1
+        d["bases"] += len(ref["basecall"])
+        dt = float(np.abs(a["trans"] - ref["trans"]).max())
+        d["worst"] = max(d["worst"], dt)
+        if a["basecall"] != ref["basecall"]:
+            d["base_mismatch"] += 1
+            import difflib
+            sm = difflib.SequenceMatcher(None, a["basecall"], ref["basecall"], autojunk=False)
+            apart = max(len(a["basecall"]), len(ref["basecall"])) - sum(m.size for m in sm.get_matching_blocks())
+            d["bases_apart"] += apart
+            self.named.append("%s: %d bases against %d (%d apart), |dtrans| %.2e" % (tag, len(a["basecall"]), len(ref["basecall"]), apart, dt))
+        elif a["quality"] != ref["quality"]:
+            d["qual_mismatch"] += 1
+            d["qual_chars_diff"] += sum(1 for x, y in zip(a["quality"], ref["quality"]) if x != y)
+        if not np.array_equal(a["path"], ref["path"]):
+            d["path_mismatch"] += 1
+
+    def line(self):
+        d = self.d
+        return ("%-24s %d reads, %d bases: %d reads with another base string (%d bases apart in all = %.1f per million), %d more with another quality string "
+                "(%d characters), %d with another Viterbi path; worst |dtrans| %.2e"
+                % (self.what + ":", d["reads"], d["bases"], d["base_mismatch"], d["bases_apart"], 1e6 * d["bases_apart"] / max(1, d["bases"]), d["qual_mismatch"],
+                   d["qual_chars_diff"], d["path_mismatch"], d["worst"]))
 
 
 def main():
@@ -45,13 +88,21 @@ def main():
             lens = np.sort(rng.integers(1500, tmax + 1, 256))[::-1]
             sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
         batches.append(sigs)
-    with mp.Pool(min(128, os.cpu_count() or 1), initializer=_init) as pool:
-        refs = [pool.map(_call, sigs, chunksize=2) for sigs in batches]
-    print("oracle: %d reads, %d samples, %.0f s" % (nread, sum(x.size for s in batches for x in s), time.time() - t0), flush=True)
+    flat = [x for sigs in batches for x in sigs]
+    ncpu = min(128, os.cpu_count() or 1)
+    with mp.Pool(ncpu, initializer=_init, initargs=(0,)) as pool:
+        ref0 = pool.map(_call, flat, chunksize=2)
+    print("oracle: %d reads, %d samples, %.0f s" % (nread, sum(x.size for x in flat), time.time() - t0), flush=True)
+    with mp.Pool(ncpu, initializer=_init, initargs=(3,)) as pool:
+        ref3 = pool.map(_call, flat, chunksize=2)
+    from oracle import ffo
+    print("oracle+blas (%s): %.0f s" % (ffo.use_dot_mode(3)[1], time.time() - t0), flush=True)
+    ffo.use_dot_mode(0)
     from flappie_amd import binding as B
     eng = B.Engine(0)
     dm = B.DeviceModel(eng, M.synthetic_model(KIND, H, seed=SEED))
-    tot = dict(reads=0, samples=0, bases=0, base_mismatch=0, qual_mismatch=0, path_mismatch=0, qual_chars_diff=0, worst=0.0, min_kmers=10 ** 9, paired_batches=0)
+    t_eng0, t_eng3, t_00 = Tally("engine <-> oracle"), Tally("engine <-> oracle+blas"), Tally("oracle <-> oracle+blas")
+    min_kmers, paired = 10 ** 9, 0
     bs = [B.Batch(dm, 256, tmax) for _ in range(2)]
     for k in range(0, len(batches), 2):
         for j in (0, 1):
@@ -60,28 +111,28 @@ def main():
         for j in (0, 1):
             b = bs[j]
             b.finish()
-            tot["paired_batches"] += int(b.paired())
-            for r, ref in enumerate(refs[k + j]):
-                tot["reads"] += 1
-                tot["samples"] += batches[k + j][r].size
-                tot["bases"] += len(ref["basecall"])
-                s = ref["basecall"]
-                tot["min_kmers"] = min(tot["min_kmers"], len({s[i:i + 5] for i in range(len(s) - 4)}))
-                d = float(np.abs(b.transitions(r) - ref["trans"]).max())
-                tot["worst"] = max(tot["worst"], d)
-                if b.basecall(r) != ref["basecall"]:
-                    tot["base_mismatch"] += 1
-                    print("  batch %d read %d (%d samples): %d bases against the oracle's %d, |dtrans| %.2e" % (k + j, r, batches[k + j][r].size, len(b.basecall(r)), len(s), d))
-                elif b.quality(r) != ref["quality"]:
-                    tot["qual_mismatch"] += 1
-                    tot["qual_chars_diff"] += sum(1 for a, c in zip(b.quality(r), ref["quality"]) if a != c)
-                if not np.array_equal(b.path(r)[0], ref["path"]):
-                    tot["path_mismatch"] += 1
-        print("pair %d done (%.0f s): %s" % (k // 2, time.time() - t0, tot), flush=True)
+            paired += int(b.paired())
+            for r in range(256):
+                i = (k + j) * 256 + r
+                a = dict(basecall=b.basecall(r), quality=b.quality(r), path=b.path(r)[0], trans=b.transitions(r))
+                tag = "batch %d read %d (%d samples)" % (k + j, r, flat[i].size)
+                t_eng0.add(tag, a, ref0[i])
+                t_eng3.add(tag, a, ref3[i])
+                t_00.add(tag, ref0[i], ref3[i])
+                s = ref0[i]["basecall"]
+                min_kmers = min(min_kmers, len({s[q:q + 5] for q in range(len(s) - 4)}))
+        print("pair %d done (%.0f s)" % (k // 2, time.time() - t0), flush=True)
     for b in bs:
         b.close()
     dm.close()
-    print("campaign (H = 384, run_pair, %d of %d batches in a paired launch):" % (tot["paired_batches"], len(batches)), tot)
+    print("campaign: H = 384 through ffhip_batch_run_pair, %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
+          % (paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
+    for t in (t_eng0, t_eng3, t_00):
+        print(t.line())
+        for n in t.named:
+            print("     " + n)
+    both = set(n.split(":")[0] for n in t_eng0.named) & set(n.split(":")[0] for n in t_eng3.named)
+    print("reads the engine calls differently from BOTH evaluations of the reference algorithm: %d%s" % (len(both), (" -- " + "; ".join(sorted(both))) if both else ""))
 
 
 if __name__ == "__main__":
