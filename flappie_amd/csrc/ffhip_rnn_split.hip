@@ -52,13 +52,6 @@
 #include "ffhip_split.hpp"
 #include <stdlib.h>
 
-#ifndef FFHIP_EXP
-#define FFHIP_EXP 0               // development builds only (tools/dev/build_variants.sh): timing experiments on the hand-off, bit by bit
-#endif
-#ifndef FFHIP_SPLIT_ABLATE
-#define FFHIP_SPLIT_ABLATE 0      // development builds only (tools/dev/ablate.py): leave parts of the step out to time the rest
-#endif
-
 namespace ffhip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -358,9 +351,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     // every lane cost ~3x the VALU work.)
     auto publish_h = [&](int i, int gts, int gj, float h) {
         const int t = step_t(i);
-#if FFHIP_SPLIT_ABLATE & 32             // 32 = no gather / split / store of h (combine with 2)
-        if (h == 123.0f) a.flags[0] = 1; else return;
-#endif
         // The lane-dependent addresses of this block are recomputed every step from an OPAQUE copy of the lane number: hoisted out
         // of the step loop (where the compiler puts anything loop-invariant) they are six registers held for the whole layer, and
         // the 128-register forms of this kernel spill them; a dozen integer instructions per step cost nothing beside that.
@@ -369,35 +359,15 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         const unsigned q_ = lv >> 4, rl_ = lv & 15u;
         unsigned sl_[NS];
         split_slices(h * split_pow2(kSplitExpH), sl_);        // |h| <= 1: in range without a clamp
-#if defined(FFHIP_SPLIT_BF16X3) || !(FFHIP_EXP & 32)          // EXP 32: the transpose in registers instead (measured: 0.5-2 % slower, below)
         unsigned short (*gs)[16][4] = gsl[wave];
 #pragma unroll
         for (int k = 0; k < NS; k++) gs[k][rl_][q_] = (unsigned short)sl_[k];
-#else
-        // Built and measured, not the default (c2 98.2 against 98.7 Msamples/s, h256 154.1 against 157.7, same device, interleaved: the
-        // swaps cost more than the LDS round trip they replace).  The 4 x 4 transpose across the wave's quarters in registers (gfx950's row / half swaps):
-        // w = both slices of my unit; one v_permlane16_swap of two copies leaves [u0 u0 u2 u2] and [u1 u1 u3 u3] by rows of 16 lanes,
-        // a v_permlane32_swap of each with a copy of itself spreads them -- every lane then holds the packed slices of units 0..3 of its read.
-        v2u pieces;
-        {
-            const unsigned w = sl_[0] | (sl_[1] << 16);
-            const v2u r16 = __builtin_amdgcn_permlane16_swap(w, w, false, false);
-            const v2u a02 = __builtin_amdgcn_permlane32_swap(r16.x, r16.x, false, false);       // { u0 everywhere, u2 everywhere }
-            const v2u a13 = __builtin_amdgcn_permlane32_swap(r16.y, r16.y, false, false);       // { u1 everywhere, u3 everywhere }
-            const unsigned sel = (q_ == 0u) ? 0x05040100u : 0x07060302u;                        // quarter 0 stores slice 0 (low halves), quarter 1 slice 1
-            pieces = (v2u){ __builtin_amdgcn_perm(a13.x, a02.x, sel), __builtin_amdgcn_perm(a13.y, a02.y, sel) };
-        }
-#endif
         if (a.hout_f32) gf32[wave][rl_][q_] = h;
         asm volatile("" ::: "memory");                        // LDS operations of one wave execute in order
         const int ut = ut0 + gj;
         if (q_ < (unsigned)NS) {
             const unsigned off = (unsigned)((((ut >> 3) * NS) * 64 + ((ut & 7) >> 1) * 16) * 16 + (ut & 1) * 8) + q_ * 1024u + rl_ * 16u;      // = out_off(gj)
-#if defined(FFHIP_SPLIT_BF16X3) || !(FFHIP_EXP & 32)
             const v2u sl = *(const v2u *)&gs[q_][rl_][0];
-#else
-            const v2u sl = pieces;
-#endif
             unsigned char *tp_out = out_tile(t, gts);
             if (fast) {                                    // the group shares one L2: plain stores
                 store_plain(tp_out, off, sl);              // (the data first: it is what the consumers wait for)
@@ -415,10 +385,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     auto gate_tile = [&](int i, int gts, int gj, float &c, int my_tb) {
         const int t = step_t(i);
         float h;
-#if FFHIP_SPLIT_ABLATE & 4              // 4 = no gate math (one LDS read stands in for it)
-        h = ph_at(0, gts, gj)[lane].x * 1e-3f;
-        if (false)
-#endif
         if constexpr (PACK && KIND == 0) {
             // as the LSTM branch below, on component gj of the four partial tiles {i, f, g, o} of read tile gts; quarters in the other forms' order (see below)
             const v4f b = sbias[gj][q];
@@ -581,7 +547,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 if constexpr (!(PACK && KIND == 0)) load_x_tile(i, ts);
 #pragma unroll
                 for (int j = 0; j < NRT; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-#if !(FFHIP_SPLIT_ABLATE & 1)          // 1 = x waves issue no MFMAs
                 if constexpr (PACK && KIND == 0) {
                     // 64 weight + 32 accumulator registers: x(t) comes a chunk at a time (8 registers; the x waves have the slack for the second wait)
                     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.xin, step_t(i), ts), 0, (int)tileB, 0x00020000);
@@ -596,7 +561,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
                 for (int cc = 0; cc < N; cc++) mm6<NRT, N>(wf, cc, xb[cc], acc[ts]);
                 }
-#endif
             }
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
@@ -615,7 +579,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             if constexpr (PACK && KIND == 0) asm volatile("" : "+v"(lt));      // (an opaque copy: no 64-bit lane address held -- spilled -- across the step)
             const int line = m * LPM + (int)lt;
             unsigned t = 0;
-            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb && !(FFHIP_EXP & 16))      // EXP 16: no L2 warming (counter calibration)
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
@@ -625,12 +589,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         touch_x(2);
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
-#if FFHIP_EXP & 64                     // EXP 64 / 128: the x waves stay out of the memory pipe while the h waves poll and sweep (~1500 / ~3000 cycles)
-            __builtin_amdgcn_s_sleep(24);
-#endif
-#if FFHIP_EXP & 128
-            __builtin_amdgcn_s_sleep(48);
-#endif
             TL(0);
             if (i + 1 < Tb) project_step(i + 1, i + 1);
             sink ^= touched;
@@ -675,7 +633,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 for (int cc = 0; cc < N; cc++) {
 #pragma unroll
                     for (int s = 0; s < NS; s++) xb[ts][cc][s] = p[(chunk[cc] * NS + s) * 64];
-                    if (!(FFHIP_EXP & 4)) __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
+                    __builtin_amdgcn_s_sleep(2);       // the x waves have slack: their prefetch trickles into the memory pipe instead of
                                                        // occupying it with an 18 KiB burst per wave
                 }
             }
@@ -705,7 +663,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         auto touch_x = [&](int i) {
             const int line = m * LPM + lane;
             unsigned t = 0;                               // (not `touched` itself: keeping the old value would make this a use of the old load)
-            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb && !(FFHIP_EXP & 16))      // EXP 16: no L2 warming (counter calibration)
+            if (wave == 3 && lane < LPM && line < ntl * Hc * NS * 8 && i < Tb)
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
@@ -717,12 +675,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         for (int i = 0; i < Tb; i++) {
             TL(0);
             if (i + 1 < Tb) {
-#if !(FFHIP_SPLIT_ABLATE & 1)      // compile-time timing experiments (results wrong by construction): 1 = x waves issue no MFMAs
                 project(i + 1);
-#endif
-#if !(FFHIP_SPLIT_ABLATE & 16)     // 16 = no prefetch of x (stale operands)
                 if (i + 2 < Tb) load_x(i + 2);
-#endif
             }
             sink ^= touched;                                 // (keeps the touch a real load; it landed a step ago)
             touch_x(i + WARM);
@@ -787,8 +741,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     const int put = ((kw + m) & 3) * NPROD + ul;
                     const bool act = pts < ntl;
                     const unsigned poff = (unsigned)(pts * (int)tileB + ((put >> 3) * NS * 64 + ((put & 7) >> 1) * 16 + 15) * 16 + (put & 1) * 8);
-#if !(FFHIP_SPLIT_ABLATE & 2)          // 2 = no hand-off wait at all (timing of the compute pipeline alone)
-                    for (unsigned spin = 0; !((FFHIP_EXP & 1) && HL); spin++) {      // EXP 1: no light poll in the LDS-landing forms: the sweep itself is the poll
+                    for (unsigned spin = 0; ; spin++) {
                         const unsigned v = act ? __builtin_amdgcn_raw_buffer_load_b32(rs2, poff, 0, 16 /*sc1*/) : 0u;
                         if (__all(v != kSplitSentinel)) break;
                         if (spin > 6000000u || (spin & 511u) == 511u) {
@@ -796,7 +749,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                             if (ab != 0u || spin > 6000000u) { timed_out = true; break; }
                         }
                     }
-#endif
                 }
                 TL(1);
                 v4u raw[NCH][NS];
@@ -806,17 +758,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 const int offB = (TS > 1 && ntl > 1) ? (int)tileB : 0;
                 auto load_chunk = [&](int k) {          // k = ts*N + cc
                     const int ts = k / N, cc = k % N;
-#if FFHIP_SPLIT_ABLATE & 8              // 8 = no sweep: operands are whatever the registers hold
-                    if (i > 1) return;
-#endif
 #pragma unroll
                     for (int s = 0; s < NS; s++) {
-#if FFHIP_SPLIT_ABLATE & 64             // 64 = the second tile's operands are the first tile's lines again (L2 traffic of the sweep halved)
-                        if (ts) raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 0);
-                        else raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 16);
-#else
                         raw[k][s] = __builtin_amdgcn_raw_buffer_load_b128(rs2, ts * offB + ((chunk[cc] * NS + s) * 64) * 16 + lane_off, 0, 16 /*sc1*/);
-#endif
                     }
                 };
                 // acc += sW h over my K slice; false if a sentinel was among the operands
@@ -842,9 +786,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                         if constexpr (!PACK) mm6<N>(wf, k % N, raw[k], acc[k / N]);
                         __builtin_amdgcn_sched_barrier(0);      // keep each chunk's check and MFMAs behind ITS loads only: the sweep streams under the MFMAs
                     }
-#if FFHIP_SPLIT_ABLATE & 2
-                    return true;
-#endif
                     return __all(ok) != 0;
                 };
                 // HL form of the sweep: 2N one-KiB DMA loads into this wave's landing zone; per chunk a counted wait, two ds_read_b128
@@ -857,14 +798,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     if constexpr (HL && !DN) {
 #pragma unroll
                         for (int k = 0; k < N; k++) {
-#if FFHIP_SPLIT_ABLATE & 8              // 8 = no sweep: operands are whatever the landing zone holds
-                            if (i > 1) continue;
-#endif
 #pragma unroll
                             for (int s = 0; s < NS; s++)
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)&hland[kw][0][k][s][0], 16,
                                                                          lane_off, ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
-                            if (k + 1 < N && !(FFHIP_EXP & 2)) __builtin_amdgcn_s_sleep(1);
+                            if (k + 1 < N) __builtin_amdgcn_s_sleep(1);
                         }
                         const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
                         v4u r[2][NS];
@@ -884,9 +822,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                         }
                     }
 #endif
-#if FFHIP_SPLIT_ABLATE & 2
-                    return true;
-#endif
                     return __all(seen != kSplitSentinel) != 0;
                 };
                 // Dense form: both tiles' 2N KiB each land in this wave's zone; ONE set of accumulators takes tile A, then tile B (each
@@ -897,9 +832,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     unsigned seen = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
                     if constexpr (DN) {
-#if !(FFHIP_SPLIT_ABLATE & 8)          // 8 = no sweep: operands are whatever the landing zone holds
 #pragma unroll
-                        for (int ts = 0; ts < ((FFHIP_SPLIT_ABLATE & 128) ? 1 : 2); ts++)      // 128 = only the first tile is swept (the CU's L2 port carries half)
+                        for (int ts = 0; ts < 2; ts++)
 #pragma unroll
                             for (int k = 0; k < N; k++) {
 #pragma unroll
@@ -908,7 +842,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                                                              lane_off, ts * offB + ((chunk[k] * NS + s) * 64) * 16, 0, 16 /*sc1*/);
                                 if (ts * N + k + 1 < 2 * N) __builtin_amdgcn_s_sleep(1);
                             }
-#endif
                         const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][lane];
                         v4u r[2][NS];
                         auto fetch = [&](int c) {           // (tile, chunk) c = ts * N + k has landed -> issue its two LDS reads
@@ -949,9 +882,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                         }
                     }
 #endif
-#if FFHIP_SPLIT_ABLATE & 2
-                    return true;
-#endif
                     return __all(seen != kSplitSentinel) != 0;
                 };
                 auto recur_any = [&]() -> bool { if constexpr (DN) return recur_dn(); else if constexpr (HL) return recur_lds(); else return recur(); };
@@ -969,7 +899,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                 const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
                                 if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                             }
-                            if (!(FFHIP_EXP & 8)) __builtin_amdgcn_s_sleep(1);
+                            __builtin_amdgcn_s_sleep(1);
                             if constexpr (!DN) init_acc();
                             if (recur_any()) break;
                         }

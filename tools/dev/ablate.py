@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Layer-kernel ablation timings in the REAL engine.  Build one library per variant with
+    (apply tools/dev/experiments/lstm_split_ablation_switches.patch first: the switches are not in the product source)
     make -C flappie_amd/csrc CXXFLAGS="... -DFFHIP_SPLIT_ABLATE=<bits>" ffhip_rnn_split.o -B && make -C flappie_amd/csrc
 (bits: 1 no projection MFMAs, 2 no hand-off wait, 4 no gate math, 8 no sweep of h, 16 no prefetch of x), copy it over
 flappie_amd/libffhip.so on the GPU box and run this script: it prints the time of the five recurrent layers of the
