@@ -56,6 +56,7 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming), (delete e, nullptr));
+    ffhip::pool_engine_born(device);
     return e;
 }
 
@@ -66,11 +67,22 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
 namespace ffhip {
 namespace {
 std::mutex g_pool_mu;
-std::unordered_map<void *, int> g_pool_class;                 // every buffer the pool handed out or holds -> its size class
-std::vector<void *> g_pool_free[48];
+// every buffer the pool handed out or holds -> its rounded size and the device it lives on; free lists per (device, size)
+struct PoolBuf { size_t bytes; int device; };
+std::unordered_map<void *, PoolBuf> g_pool_buf;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_pool_free;
+std::unordered_map<int, int> g_pool_engines;                  // live engines per device: the last one to go trims that device's lists
+int g_pool_default_device = 0;                                // device of the most recently created engine (entry points without an engine argument)
+// matrices whose device image may be orphaned by a plain free() of the struct (flappie_matrix.c): struct address -> image
+std::unordered_map<const void *, void *> g_image_owner;
 std::atomic<unsigned long long> g_copy[5];
 std::atomic<int> g_matrix_policy{ -1 };
-int size_class(size_t bytes) { int c = 12; while (((size_t)1 << c) < bytes && c < 47) c++; return c; }
+// powers of two up to 64 MiB (few classes, quick reuse); beyond that multiples of 16 MiB -- a power of two wastes up to half of a multi-GB scratch
+size_t round_size(size_t bytes) {
+    if (bytes <= ((size_t)64 << 20)) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+    const size_t q = (size_t)16 << 20;
+    return (bytes + q - 1) / q * q;
+}
 void count_copy(size_t n, hipMemcpyKind kind) {
     if (kind == hipMemcpyHostToDevice) { g_copy[0]++; g_copy[1] += n; }
     else if (kind == hipMemcpyDeviceToHost) {
@@ -81,30 +93,70 @@ void count_copy(size_t n, hipMemcpyKind kind) {
 }
 }  // namespace
 void *pool_get(size_t bytes) {
-    const int c = size_class(bytes);
+    const size_t sz = round_size(bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (!g_pool_free[c].empty()) { void *p = g_pool_free[c].back(); g_pool_free[c].pop_back(); return p; }
+        auto it = g_pool_free.find({ dev, sz });
+        if (it != g_pool_free.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
     }
     void *d = nullptr;
-    if (hipMalloc(&d, (size_t)1 << c) != hipSuccess) return nullptr;
+    if (hipMalloc(&d, sz) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool_class[d] = c;
+    g_pool_buf[d] = PoolBuf{ sz, dev };
     return d;
 }
 void pool_put(void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_class.find(p);
-    if (it == g_pool_class.end()) { hipFree(p); return; }      // not ours (never happens): free it the plain way
-    g_pool_free[it->second].push_back(p);
+    // whoever releases an image, the owner table must not name it any more (a later address reuse would release it a second time)
+    for (auto it = g_image_owner.begin(); it != g_image_owner.end(); ) { if (it->second == p) it = g_image_owner.erase(it); else ++it; }
+    auto it = g_pool_buf.find(p);
+    if (it == g_pool_buf.end()) { hipFree(p); return; }      // not ours (never happens): free it the plain way
+    g_pool_free[{ it->second.device, it->second.bytes }].push_back(p);
 }
-void pool_trim() {
+// free what the pool holds for `device` (its last engine is going); buffers still with their owners stay recorded
+void pool_trim(int device) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto &v : g_pool_free) {
-        for (void *p : v) { g_pool_class.erase(p); hipFree(p); }
-        v.clear();
+    for (auto &kv : g_pool_free) {
+        if (kv.first.first != device) continue;
+        for (void *p : kv.second) { g_pool_buf.erase(p); hipFree(p); }
+        kv.second.clear();
     }
+}
+int pool_device_of(const void *p) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_buf.find((void *)p);
+    return it == g_pool_buf.end() ? -1 : it->second.device;
+}
+void pool_engine_born(int device) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_engines[device]++; g_pool_default_device = device; }
+bool pool_engine_gone(int device) { std::lock_guard<std::mutex> lk(g_pool_mu); return --g_pool_engines[device] <= 0; }
+int pool_default_device() { std::lock_guard<std::mutex> lk(g_pool_mu); return g_pool_default_device; }
+void pool_state(unsigned long long out[4]) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::unordered_map<void *, int> seen;
+    unsigned long long nfree = 0, dup = 0;
+    for (auto &kv : g_pool_free) for (void *p : kv.second) { nfree++; if (seen[p]++) dup++; }
+    out[0] = g_pool_buf.size(); out[1] = nfree; out[2] = g_image_owner.size(); out[3] = dup;
+}
+void image_remember(const void *owner, void *dev) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_image_owner[owner] = dev;
+    static bool warned = false;
+    if (g_image_owner.size() > 4096 && !warned) {
+        warned = true;
+        fprintf(stderr, "ffhip: more than 4096 transition matrices are alive with a device image, or were released with a plain free() whose addresses were never "
+                        "reused: their device buffers stay allocated (free_flappie_matrix releases them; FLAPPIE_HOST_MATRICES=1 avoids device images)\n");
+    }
+}
+void *image_forget(const void *owner) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_image_owner.find(owner);
+    if (it == g_image_owner.end()) return nullptr;
+    void *d = it->second;
+    g_image_owner.erase(it);
+    return d;
 }
 hipError_t counted_memcpy_async(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) { count_copy(n, kind); return ::hipMemcpyAsync(dst, src, n, kind, s); }
 hipError_t counted_memcpy(void *dst, const void *src, size_t n, hipMemcpyKind kind) { count_copy(n, kind); return ::hipMemcpy(dst, src, n, kind); }
@@ -128,13 +180,19 @@ extern "C" void ffhip_copy_counts(unsigned long long out[5], int reset) {
     for (int i = 0; i < 5; i++) { if (out) out[i] = ffhip::g_copy[i].load(); if (reset) ffhip::g_copy[i].store(0); }
 }
 extern "C" void ffhip_dev_release(void *dev) { ffhip::pool_put(dev); }
+extern "C" void ffhip_debug_pool_state(unsigned long long out[4]) { if (out) ffhip::pool_state(out); }
+extern "C" void ffhip_dev_remember(const void *owner, void *dev) { if (owner && dev) ffhip::image_remember(owner, dev); }
+extern "C" void *ffhip_dev_forget(const void *owner) { return owner ? ffhip::image_forget(owner) : nullptr; }
 extern "C" int ffhip_dev_download(const void *dev, float *host, size_t nfloat) {
     if (!dev || !host) return set_err(FFHIP_EINVAL, "null image");
+    const int on = ffhip::pool_device_of(dev);
+    if (on >= 0) hipSetDevice(on);
     HIP_TRY(hipMemcpy(host, dev, nfloat * sizeof(float), hipMemcpyDeviceToHost), FFHIP_EHIP);
     return FFHIP_OK;
 }
 extern "C" void *ffhip_dev_upload(const float *host, size_t nfloat) {
     if (!host || !nfloat) return nullptr;
+    hipSetDevice(ffhip::pool_default_device());      // (no engine argument: the device of the engine created last; the host layer has one engine)
     void *d = ffhip::pool_get(nfloat * sizeof(float));
     if (d && hipMemcpy(d, host, nfloat * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ffhip::pool_put(d); return nullptr; }
     return d;
@@ -144,7 +202,7 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     if (!e) return;
     hipSetDevice(e->device);
     hipDeviceSynchronize();
-    ffhip::pool_trim();
+    if (ffhip::pool_engine_gone(e->device)) ffhip::pool_trim(e->device);
     for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
     if (e->prep_stream) hipStreamDestroy(e->prep_stream);
     if (e->prep_pin) hipHostFree(e->prep_pin);
@@ -412,11 +470,12 @@ extern "C" size_t ffhip_model_nparam(const ffhip_model *m) { return m ? (size_t)
 extern "C" size_t ffhip_model_nbase(const ffhip_model *m) { return m ? (size_t)m->nbase : 0; }
 // reads one FULL layer launch of this model takes on this device (the batch size that keeps every launch full): 1024 at 256 hidden units (the
 // packed forms), 512 at 384, else 256 -- on 256 CUs (ffhip_rnn_split.hip, split_next_launch_tiles)
+// (a device with fewer than 32 CUs -- none exists in this family -- still gets a unit of 1: the layer loop must advance)
 extern "C" size_t ffhip_model_launch_reads(const ffhip_model *m) {
     if (!m) return 0;
     const int ncu = m->eng->prop.multiProcessorCount;
     if (m->H == m->Hp && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr) return (size_t)16 * split_next_launch_tiles(m->cell, m->Hp, 1 << 20, ncu);
-    return (size_t)16 * 2 * (ncu / 32);
+    return (size_t)16 * 2 * std::max(1, ncu / 32);
 }
 extern "C" size_t ffhip_model_nblock(const ffhip_model *m, size_t nsample) {
     if (!m) return 0;

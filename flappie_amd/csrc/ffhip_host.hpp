@@ -81,7 +81,14 @@ int build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::vector<i
 // synchronises the device.  A buffer goes back only when no enqueued work uses it (the single-matrix calls are synchronous).
 void *pool_get(size_t bytes);
 void pool_put(void *p);
-void pool_trim();                     // hipFree every unused buffer (engine destruction)
+void pool_trim(int device);           // hipFree every unused buffer of that device (its last engine is destroyed)
+void pool_engine_born(int device);
+bool pool_engine_gone(int device);    // true: it was the device's last engine
+int pool_default_device();
+int pool_device_of(const void *p);    // -1: not a pool buffer
+void pool_state(unsigned long long out[4]);
+void image_remember(const void *owner, void *dev);
+void *image_forget(const void *owner);
 
 // every host<->device copy of the library goes through these: ffhip_copy_counts (include/ffhip.h)
 hipError_t counted_memcpy_async(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s);

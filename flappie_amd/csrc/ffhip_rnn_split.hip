@@ -1438,7 +1438,7 @@ int split_max_tiles(int ncu, int H) {
 // tiles the next launch of a batch takes when `remaining` are left: the dense forms are for FULL launches only (a partly filled
 // one has a group count that is no multiple of the 8 XCDs and loses the one-L2 hand-off)
 int split_next_launch_tiles(int kind, int H, int remaining, int ncu) {
-    const int unit = ncu / 32;
+    const int unit = ncu / 32 > 0 ? ncu / 32 : 1;       // (never 0: the engine's layer loop advances by this, the binary sizes its batches by it)
     if (split_pack256(kind, H) && remaining >= 8 * unit) return 8 * unit;
     if (split_dense256(H) && remaining >= 6 * unit) return 6 * unit;
     if ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") && remaining >= 4 * unit) return 4 * unit;

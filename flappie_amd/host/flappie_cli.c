@@ -871,6 +871,7 @@ int main(int argc, char *argv[]) {
     /* reads per batch = what one layer launch takes (ffhip_rnn_split.hip): 1024 at H = 256 (the packed forms), 512 at H <= 384 (the dense
      * form), else 256 */
     if (0 == args.batch) args.batch = (int)ffhip_model_launch_reads(mdl);
+    if (args.batch <= 0) args.batch = 256;              /* (the query answered 0: no model; never an empty batch) */
     rs.chunk_cap = CHUNK_BATCHES * args.batch;
     for (int k = 0; k < NCHUNKBUF; k++) {
         rs.items[k] = calloc(rs.chunk_cap, sizeof(item));

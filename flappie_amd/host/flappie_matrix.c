@@ -39,28 +39,16 @@ void flappie_matrix_host_changed(flappie_matrix mat) {
 
 /* The reference's own calculate_post releases the transition matrix with a plain free() (flappie.c:281): the struct goes, its data
  * -- and here its device image -- would leak, one per read.  Matrices handed out with a device image by calculate_transitions are
- * therefore remembered by ADDRESS: when malloc returns the address of a remembered struct for a new matrix, the old one was freed
- * behind this library's back, and its device buffer goes back to the pool.  (The host image leaks as it does in the reference.) */
-#define NOWNER 64
-static struct { const void *mat; void *dev; } dev_owner[NOWNER];
-
+ * therefore remembered by ADDRESS in the engine library (ffhip_dev_remember: a mutex-guarded map, cleared by whoever releases the image):
+ * when malloc returns the address of a remembered struct for a new matrix, the old one was freed behind this library's back, and its
+ * device buffer goes back to the pool.  (The host image leaks as it does in the reference; an address malloc never hands out again
+ * keeps its buffer: the library warns once should such records pile up.) */
 void flappie_matrix_remember_device_image(const_flappie_matrix mat) {
     if (NULL == mat || NULL == mat->dev) return;
-    int slot = -1;
-    for (int i = 0; i < NOWNER; i++) {
-        if (dev_owner[i].mat == mat) { slot = i; break; }
-        if (slot < 0 && NULL == dev_owner[i].mat) slot = i;
-    }
-    if (slot < 0) return;                     /* table full: that matrix is not watched */
-    dev_owner[slot].mat = mat;
-    dev_owner[slot].dev = mat->dev;
+    ffhip_dev_remember(mat, mat->dev);
 }
 
-static void *forget_device_image(const void *mat) {
-    for (int i = 0; i < NOWNER; i++)
-        if (dev_owner[i].mat == mat) { void *d = dev_owner[i].dev; dev_owner[i].mat = NULL; dev_owner[i].dev = NULL; return d; }
-    return NULL;
-}
+static void *forget_device_image(const void *mat) { return ffhip_dev_forget(mat); }
 
 flappie_matrix make_flappie_matrix(size_t nr, size_t nc) {
     if (nr == 0 || nc == 0) return NULL;

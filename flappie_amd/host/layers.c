@@ -53,6 +53,8 @@ flappie_matrix embedding(int const *index, size_t n, const_flappie_matrix E, fla
     if (NULL == index || NULL == E || 0 == n) return NULL;
     C = remake_flappie_matrix(C, E->nr, n);
     if (NULL == C) return NULL;
+    flappie_matrix_sync(E);                     /* a host-side copy loop: it reads E's host image ... */
+    flappie_matrix_host_changed(C);             /* ... and writes C's: a device image C kept from an earlier use is stale */
     for (size_t c = 0; c < n; c++) {
         if (index[c] < 0 || (size_t)index[c] >= E->nc) { warnx("embedding: index %d out of range", index[c]); return free_flappie_matrix(C); }
         memcpy(C->data.f + c * C->stride, E->data.f + (size_t)index[c] * E->stride, E->stride * sizeof(float));

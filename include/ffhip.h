@@ -171,8 +171,17 @@ int ffhip_debug_pk_probe(ffhip_engine *eng, int iters, int nwg, int ballast, uns
  * there is one (no upload), and leave their result on the device (state 2, no download) when the matrix they are given was produced
  * there -- see INTEGRATION.md section 3 for the rules and FLAPPIE_HOST_MATRICES=1 for the reference's host-only behaviour. */
 typedef struct { float *data; size_t nr, nc, stride; void **dev; int *dev_state; } ffhip_mat;
-/* buffers of device images come from (and go back to) a process-wide pool: no hipMalloc / hipFree per matrix */
+/* buffers of device images come from (and go back to) a pool per device: no hipMalloc / hipFree per matrix */
 void ffhip_dev_release(void *dev);
+/* A matrix whose struct the caller may release with a plain free() (the reference's flappie.c:281 does that to the transition matrix):
+ * `owner` (the struct's address) is remembered with its image; ffhip_dev_forget(owner) returns the image still recorded for that address
+ * (NULL if none) and drops the record -- make_flappie_matrix calls it on every new struct, so an address handed out again returns the
+ * orphaned buffer.  Any release of an image (ffhip_dev_release, an operator replacing a stale image) drops its record as well.  Thread-safe. */
+void ffhip_dev_remember(const void *owner, void *dev);
+void *ffhip_dev_forget(const void *owner);
+/* the pool's books, for tests: {buffers it allocated and has not freed, of those in its free lists, remembered owners, buffers that sit
+ * TWICE in a free list (must be 0: such a buffer would be handed to two matrices)} */
+void ffhip_debug_pool_state(unsigned long long out[4]);
 /* device image -> host image (the whole [nc][stride] image); synchronous */
 int ffhip_dev_download(const void *dev, float *host, size_t nfloat);
 /* host image -> a new device image (pool buffer); NULL on failure */

@@ -321,6 +321,55 @@ def test_matrices_of_the_hot_path_stay_on_the_device(host, model_dir):
 
 
 @pytest.mark.gpu
+def test_transition_matrix_released_with_a_plain_free(host, model_dir):
+    """flappie.c:281 releases the transition matrix with free(), not free_flappie_matrix(): the device image of such a struct is found again
+    through its address (ffhip_dev_remember / ffhip_dev_forget, flappie_matrix.c).  The reference's calculate_post sequence 40 times: the
+    pool must not grow with the reads, no buffer may ever sit twice in a free list, and an image released by another path first
+    (a host-side write, an operator replacing a stale output image) must not be released again when its address comes back."""
+    d, mdls = model_dir
+    os.environ["FLAPPIE_MODEL_DIR"] = d
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    host.ffhip_debug_pool_state.argtypes = [C.POINTER(C.c_ulonglong)]
+    host.flappie_matrix_host_changed.argtypes = [C.POINTER(CMat)]
+
+    def state():
+        out = (C.c_ulonglong * 4)()
+        host.ffhip_debug_pool_state(out)
+        return dict(zip(("buffers", "free", "owners", "twice"), (int(v) for v in out)))
+
+    try:
+        host.ffhip_set_matrix_policy(1)
+        rng = np.random.default_rng(17)
+        seen = []
+        for it in range(40):
+            T = int(rng.integers(1500, 3000))
+            raw = rng.standard_normal(T).astype(np.float32)
+            rt = RawTable(None, raw.size, 0, T, _f(raw))
+            trans = host.calculate_transitions(rt, 1.0, 0)
+            assert trans and trans.contents.dev_state == 2
+            post = host.transpost_crf_flipflop(trans, True)
+            if it % 3 == 1:
+                host.flappie_matrix_host_changed(trans)          # the image goes back to the pool here; the record must go with it
+                assert not trans.contents.dev
+            elif it % 3 == 2:
+                host.tanh_activation_inplace(trans)              # (works on the image in place: still owned)
+            libc.free(C.cast(trans, C.c_void_p))                 # flappie.c:281 -- struct gone, data.f leaks as in the reference
+            path = np.zeros(T, dtype=np.int32)
+            qpath = np.zeros(T, dtype=np.float32)
+            host.decode_crf_flipflop(post, False, path.ctypes.data_as(C.POINTER(C.c_int)), _f(qpath))
+            host.free_flappie_matrix(post)
+            s = state()
+            assert s["twice"] == 0, (it, s)
+            seen.append(s)
+        print("pool after 40 reads:", seen[-1], "after 10:", seen[9])
+        assert seen[-1]["owners"] <= 3 and seen[-1]["buffers"] <= seen[9]["buffers"] + 4, (seen[9], seen[-1])
+    finally:
+        host.flappie_hip_shutdown()
+        del os.environ["FLAPPIE_MODEL_DIR"]
+
+
+@pytest.mark.gpu
 def test_flappie_lite_fastq(model_dir, tmp_path):
     """C driver end to end: float32 signal files -> FASTQ; compares calls with the oracle on the same
     prepared signal and checks the header fields of flappie_output.c:112-116."""
