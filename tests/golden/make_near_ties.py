@@ -7,6 +7,10 @@ re-runs them.
   0: profiles/r03_parity_packed.txt -- tools/parity_pack.py 1024 3000 (round 3): GRUmod H = 256, synthetic_model(seed=7) under the
      round-3 gains, read 99 of the batch (2743 samples): 222 bases against the oracle's 220, |dtrans| 7.6e-6, paths apart in blocks
      246-248.  The signal is regenerated exactly as that tool drew it.
+  1: profiles/r04_parity_h384.txt -- tools/parity_h384.py 2048 2500 (round 4, input-driven models): LSTM H = 384, bench.py's model
+     (seed 1, round-4 gains), batch 5 read 68 (2500 samples): 457 bases against 457, one base apart, |dtrans| 1.3e-5 -- the one read of
+     2048 that the engine calls differently from BOTH the scalar oracle and the oracle through OpenBLAS (which differ from each other on
+     two more reads of that campaign).
 """
 import os
 import sys
@@ -24,7 +28,19 @@ lens = np.sort(rng.integers(300, tmax + 1, nread))[::-1]
 sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
 assert sigs[99].size == 2743
 out.update(kind0=np.array(M.NET_GRUMOD5), hidden0=np.array(256), model_seed0=np.array(seed), gains0=np.array(M.SYNTH_GAINS_R3[M.NET_GRUMOD5], dtype=np.float64),
-           signal0=sigs[99], source0=np.array("profiles/r03_parity_packed.txt read 99"), blocks_apart0=np.array(3))
-out["n"] = np.array(1)
+           signal0=sigs[99], source0=np.array("profiles/r03_parity_packed.txt read 99"), blocks_apart0=np.array(3), dtrans_bound0=np.array(1e-5), f32_equals_oracle0=np.array(1))
+# read 1: parity_h384.py's batches (rng 3840; pairs of uniform batches and pairs of ragged ones alternate), batch 5 read 68
+rng = np.random.default_rng(3840)
+tmax = 2500
+batches = []
+for k in range(6):
+    if (k // 2) % 2 == 0:
+        batches.append([rng.standard_normal(tmax).astype(np.float32) for _ in range(256)])
+    else:
+        lens = np.sort(rng.integers(1500, tmax + 1, 256))[::-1]
+        batches.append([rng.standard_normal(int(n)).astype(np.float32) for n in lens])
+out.update(kind1=np.array(M.NET_LSTM5), hidden1=np.array(384), model_seed1=np.array(1), gains1=np.array(M.SYNTH_GAINS[M.NET_LSTM5], dtype=np.float64),
+           signal1=batches[5][68], source1=np.array("profiles/r04_parity_h384.txt batch 5 read 68"), blocks_apart1=np.array(4), dtrans_bound1=np.array(2e-5), f32_equals_oracle1=np.array(-1))
+out["n"] = np.array(2)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "near_ties.npz"), **out)
 print("near_ties.npz: %d reads" % int(out["n"]))
