@@ -105,17 +105,18 @@ def main():
         # recurrence-only kernels read the projected gates (G*H floats) and write h
         paired = 2 if "_pair" in dom else 1                 # k_lstm_split_pair: one launch carries the layer of two batches
         alg = Tb * nread * H * {3: 8, 2: 8, 1: 4 * G + 4, 4: 4 * G + 4}[rnn_path] * paired
-        # Round 3 calibrated FETCH_SIZE on the split layer kernel's own known byte count (profiles/r03_fetch_calibration.txt: the layer input is
-        # read exactly once; TCC_EA0_RDREQ counts one request per 64-byte sector of it): for these kernels the RAW value is the byte count, the
-        # doubling of MI355X_MICROARCH.md's streaming-read rule does not apply.  Both are recorded.
-        calibrated = rnn_path in (3, 4)
-        rd = res[dom][2] if calibrated else res[dom][0]
+        # Round 4 settled the rule with a microbenchmark in the kernel's own load forms (tools/dev/fetch_calib.cpp, profiles/r04_traffic_rule.txt):
+        # 314.6 MB streamed once through global_load_dwordx4, buffer_load_dwordx4 sc1, buffer_load ... lds sc1 and one dword per line reads as
+        # FETCH_SIZE 157.3 MB with TCC_EA0_RDREQ = one request per 128-byte LINE -- FETCH_SIZE is HALF the bytes for every read form of this
+        # kernel (MI355X_MICROARCH.md's rule; round 3's "raw" reading was wrong: its 4.92 M "sectors" were 2.46 M lines of x plus as many of h);
+        # WRITE_SIZE is the byte count (64-byte requests).  Traffic = 2 x FETCH_SIZE + WRITE_SIZE.
+        rd = res[dom][0]
         entry = {"config": cfgname, "kind": cfg["kind"], "hidden": H, "nread": nread, "nsample": T, "rnn_path": rnn_path, "fused": rnn_path in (2, 3), "kernel": dom,
                  "reads_per_launch": nread * paired,
                  "recurrent_layer_hbm_bytes_per_launch": int(rd + res[dom][1]),
                  "read_bytes": int(rd), "write_bytes": int(res[dom][1]),
                  "read_bytes_if_fetch_size_doubled": int(res[dom][0]), "hbm_bytes_if_fetch_size_doubled": int(res[dom][0] + res[dom][1]),
-                 "fetch_size_rule": "raw (64-byte requests: calibrated on this kernel, profiles/r03_fetch_calibration.txt)" if calibrated else "doubled (MI355X_MICROARCH.md, wide coalesced reads)",
+                 "fetch_size_rule": "2 x FETCH_SIZE + WRITE_SIZE (calibrated in this kernel's own load forms: profiles/r04_traffic_rule.txt)",
                  "algorithmic_bytes_per_launch": alg, "source": "profiles/%s_hbm_traffic_pmc.csv" % tag}
         json.dump([entry], open(os.path.join(outdir, "%s_traffic.json" % tag), "w"), indent=1)
         print(json.dumps(entry, indent=1))
