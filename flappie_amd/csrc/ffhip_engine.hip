@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 #include <vector>
 #include <map>
 #include <string>
@@ -536,6 +537,7 @@ struct ffhip_batch {
     // reference's are unbounded, layers.c:24-33): one word per read, set by the producers of that format, looked at by ffhip_batch_finish,
     // which runs such reads again on the f32 path (`side`) and puts their results in place
     unsigned *sat = nullptr, *h_sat = nullptr;
+    double rehearsal_done_at = 0.0;     // FFHIP_DEBUG_HOST_REHEARSAL_MSPS: when the emulated GPU is done with this batch
     ffhip_batch *side = nullptr;        // 16 slots of this batch's capacity, created when the first read needs it
     bool is_side = false;
     int reruns = 0;                     // reads of the last run that took that way
@@ -1179,8 +1181,47 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     return FFHIP_OK;
 }
 
+// ---- host-load rehearsal (TEST HOOK, tools/host_scaling.py) ---------------------------------------------------
+// FFHIP_DEBUG_HOST_REHEARSAL_MSPS=<rate>: this process evaluates NO network.  A run enqueues placeholder results (calls of 0.4 bases per
+// block, all 'A') and is "busy" for (samples of the batch) / rate on an emulated GPU that works its batches one after the other;
+// ffhip_batch_finish sleeps until then.  Everything around the kernels -- fast5 readers, signal preparation and its uploads, the batch's
+// device buffers, result copies, FASTQ formatting -- is the real thing: seven such processes beside one real one load the host as eight
+// ranks of a node would, on a box with one GPU.  Announced on stderr; never a fallback, never set by the library itself.
+static double rehearsal_rate() {
+    static double v = -2.0;
+    if (v == -2.0) {
+        const char *e = getenv("FFHIP_DEBUG_HOST_REHEARSAL_MSPS");
+        v = e ? atof(e) : -1.0;
+        if (v > 0) fprintf(stderr, "ffhip: FFHIP_DEBUG_HOST_REHEARSAL_MSPS=%g -- NO NETWORK IS EVALUATED in this process: every batch returns placeholder calls "
+                                   "after (its samples) / %g us (host-side load rehearsal, tools/host_scaling.py)\n", v, v);
+    }
+    return v;
+}
+static double now_seconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static int rehearsal_run(ffhip_batch *b, float temperature, unsigned flags) {
+    hipSetDevice(b->eng->device);
+    hipStream_t s = b->stream;
+    const size_t n = (size_t)b->nread, L = (size_t)b->Tb + 1;
+    int *lens = (int *)b->h_glen.get(n * 4);
+    if (!lens) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+    double samples = 0;
+    for (size_t r = 0; r < n; r++) { lens[r] = b->hTb[r] * 2 / 5; samples += b->hT[r]; }
+    HIP_TRY(hipMemsetAsync(b->bases, 'A', n * L, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->quals, '5', n * L, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->score, 0, n * 4, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->sat, 0, (size_t)b->Bp * sizeof(unsigned), s), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->lens, lens, n * 4, hipMemcpyHostToDevice, s), FFHIP_EHIP);
+    const double t = now_seconds(), start = t > b->eng->rehearsal_busy_until ? t : b->eng->rehearsal_busy_until;
+    b->eng->rehearsal_busy_until = b->rehearsal_done_at = start + samples / (rehearsal_rate() * 1e6);
+    b->last_flags = b->run_flags = flags; b->last_temperature = temperature;
+    b->ran = 1; b->finished = 0; b->paired_last = 0;
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags) {
     if (b) b->paired_last = 0;
+    if (b && rehearsal_rate() > 0) return rehearsal_run(b, temperature, flags);
     return batch_run_impl(b, temperature, flags, PH_ALL);
 }
 
@@ -1188,6 +1229,7 @@ extern "C" int ffhip_batch_run(ffhip_batch *b, float temperature, unsigned flags
 // H = 384 layer kernel, two workgroups per CU -- 512 reads in flight as with one 512-read batch).  Everything else of a run is
 // enqueued per batch on its own stream as ffhip_batch_run does; shapes this does not apply to simply run one after the other.
 extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temperature, unsigned flags) {
+    if (b0 && b1 && rehearsal_rate() > 0) { if (int rc = rehearsal_run(b0, temperature, flags)) return rc; return rehearsal_run(b1, temperature, flags); }
     if (!b0 || !b1 || b0 == b1) return set_err(FFHIP_EINVAL, "two distinct batches are needed");
     const ffhip_model *m = b0->mdl;
     ffhip_engine *eng = b0->eng;
@@ -1313,6 +1355,10 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipMemcpyAsync(b->h_sat, b->sat, n * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    if (rehearsal_rate() > 0) {                              // (test hook above: the emulated GPU finishes this batch at rehearsal_done_at)
+        const double left = b->rehearsal_done_at - now_seconds();
+        if (left > 0) { struct timespec ts = { (time_t)left, (long)((left - (double)(time_t)left) * 1e9) }; nanosleep(&ts, nullptr); }
+    }
     if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     if (*b->h_abort != 0) {

@@ -40,6 +40,7 @@ struct ffhip_engine {
     void *prep_scratch[4] = { nullptr, nullptr, nullptr, nullptr };
     size_t prep_scratch_cap[4] = { 0, 0, 0, 0 };
     std::vector<std::pair<void *, size_t>> prep_pool;       // free output buffers (pointer, bytes)
+    double rehearsal_busy_until = 0.0;                      // FFHIP_DEBUG_HOST_REHEARSAL_MSPS (ffhip_engine.hip): when the emulated GPU is free again
 };
 
 struct ffhip_prep;

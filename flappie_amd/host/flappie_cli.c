@@ -10,6 +10,7 @@
 #include <assert.h>
 #include <dirent.h>
 #include <err.h>
+#include <sys/stat.h>
 #include <glob.h>
 #include <libgen.h>
 #include <math.h>
@@ -66,6 +67,7 @@ static struct argp_option options[] = {
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default: what one layer launch takes -- 1024 at up to 256 hidden units, 512 up to 384, else 256)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
     {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 12; 0 reads in this process)"},
+    {"shard-by-size", 19, 0, 0, "With --shard: deal the files to the n shards by size (largest first, each to the lightest shard) instead of by index"},
     {0}
 };
 
@@ -96,6 +98,7 @@ static struct {
     int batch;
     int readers;
     int shard, nshard;
+    bool shard_by_size;
 } args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 12, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
 
 static void print_models(FILE *fh) {
@@ -186,6 +189,7 @@ static error_t parse_arg(int key, char *arg, struct argp_state *state) {
         if (2 != sscanf(arg, "%d/%d", &args.shard, &args.nshard) || args.nshard < 1 || args.shard < 0 || args.shard >= args.nshard)
             errx(EXIT_FAILURE, "--shard takes g/n with 0 <= g < n");
         break;
+    case 19: args.shard_by_size = true; break;
     case ARGP_KEY_NO_ARGS: argp_usage(state); break;
     case ARGP_KEY_ARG:
         args.files = &state->argv[state->next - 1];
@@ -647,6 +651,36 @@ typedef struct { char **path; size_t n, cap; } file_list;
 
 static int by_path(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
 
+/* --shard-by-size: the shard of every file of the sorted list, balanced by bytes (a single-read fast5 file's size follows its sample
+ * count): files in order of decreasing size, ties by position, each to the shard that holds the fewest bytes so far (lowest index on a
+ * tie) -- flappie_amd/shard.py::partition_reads, SURVEY.md section 8e.  Every process of a sharded run computes the same table. */
+typedef struct { off_t size; size_t idx; } sized_file;
+static int by_size_desc(const void *a, const void *b) {
+    const sized_file *x = a, *y = b;
+    if (x->size != y->size) return x->size < y->size ? 1 : -1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+static int *shards_by_size(char **path, size_t n, int nshard) {
+    sized_file *sf = malloc((n ? n : 1) * sizeof(*sf));
+    int *shard = malloc((n ? n : 1) * sizeof(int));
+    unsigned long long *load = calloc((size_t)nshard, sizeof(*load));
+    if (NULL == sf || NULL == shard || NULL == load) errx(EXIT_FAILURE, "out of memory");
+    for (size_t f = 0; f < n; f++) {
+        struct stat st;
+        sf[f].size = (0 == stat(path[f], &st)) ? st.st_size : 0;
+        sf[f].idx = f;
+    }
+    qsort(sf, n, sizeof(*sf), by_size_desc);
+    for (size_t k = 0; k < n; k++) {
+        int best = 0;
+        for (int g = 1; g < nshard; g++) if (load[g] < load[best]) best = g;
+        shard[sf[k].idx] = best;
+        load[best] += (unsigned long long)sf[k].size;
+    }
+    free(sf); free(load);
+    return shard;
+}
+
 static void list_files(file_list *fl) {
     const int reads_limit = (args.nshard >= 1) ? 0 : args.limit;      /* a shard is cut from the whole list, then limited */
     for (int fn = 0; args.files && args.files[fn]; fn++) {
@@ -675,11 +709,14 @@ static void list_files(file_list *fl) {
     if (args.nshard >= 1) {
         /* every process of a sharded run must see the same order: sort, keep every n-th file starting at g */
         qsort(fl->path, fl->n, sizeof(char *), by_path);
+        int *of = args.shard_by_size ? shards_by_size(fl->path, fl->n, args.nshard) : NULL;
         size_t kept = 0;
         for (size_t f = 0; f < fl->n; f++) {
-            if ((int)(f % (size_t)args.nshard) == args.shard && (args.limit <= 0 || (int)kept < args.limit)) fl->path[kept++] = fl->path[f];
+            const int g = of ? of[f] : (int)(f % (size_t)args.nshard);
+            if (g == args.shard && (args.limit <= 0 || (int)kept < args.limit)) fl->path[kept++] = fl->path[f];
             else free(fl->path[f]);
         }
+        free(of);
         fl->n = kept;
     }
 }
@@ -860,6 +897,10 @@ int main(int argc, char *argv[]) {
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
     const double t_listed = now_s();
+    if (getenv("FLAPPIE_LIST_ONLY")) {             /* the files this process would call, one per line -- no GPU touched (tests, tools/host_scaling.py) */
+        for (size_t f = 0; f < fl.n; f++) printf("%s\n", fl.path[f]);
+        return EXIT_SUCCESS;
+    }
     start_reader_procs(&fl, getenv("FLAPPIE_NO_READER_THREAD") ? 0 : args.readers);      /* before the HIP runtime and libhdf5 are touched here */
     const struct ffhip_model *mdl = flappie_hip_model(args.model);
     if (NULL == mdl) { stop_reader_procs(); errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model)); }

@@ -550,3 +550,41 @@ def test_reference_main_relinked_against_the_engine(cli_inputs):
         assert score_re.sub(r"\1S", a[1]) == score_re.sub(r"\1S", b[1])
         sa, sb = score_re.search(a[1]), score_re.search(b[1])
         assert sa and sb and abs(float(sa.group(2)) - float(sb.group(2))) <= 2e-6 * max(1.0, abs(float(sb.group(2)))), (a[1], b[1])
+
+
+def test_shard_by_size_balances_bytes_and_partitions_the_list(tmp_path):
+    """--shard g/n --shard-by-size (SURVEY.md section 8e "greedy by sum of samples"): every file lands in exactly one shard, the
+    shards' byte sums are within one largest file of each other where dealing by index is not, and the table is flappie_amd/shard.py::
+    partition_reads' (largest first, to the lightest shard).  No GPU: FLAPPIE_LIST_ONLY=1 prints the list and exits before the engine exists."""
+    from flappie_amd import shard as S
+    exe = os.path.join(ROOT, "flappie_amd", "flappie")
+    if not os.path.exists(exe):
+        pytest.fail("flappie binary not built")
+    d = tmp_path / "reads"
+    d.mkdir()
+    rng = np.random.default_rng(8)
+    sizes = {}
+    for k in range(203):
+        n = int(rng.integers(100, 5000)) * (40 if k % 8 == 0 else 1)          # every 8th file is fat: dealing by index puts them all in shard 0
+        p = d / ("r%04d.fast5" % k)
+        p.write_bytes(b"x" * n)
+        sizes[str(p)] = n
+    paths = sorted(sizes)
+    env = dict(os.environ, FLAPPIE_LIST_ONLY="1")
+
+    def listing(extra):
+        out = []
+        for g in range(8):
+            r = subprocess.run([exe, "--shard", "%d/8" % g] + extra + [str(d)], env=env, capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0, r.stderr
+            out.append(r.stdout.split())
+        return out
+
+    by_index, by_size = listing([]), listing(["--shard-by-size"])
+    for shards in (by_index, by_size):
+        assert sorted(p for s in shards for p in s) == paths                       # a partition of the list
+    want = S.partition_reads([sizes[p] for p in paths], 8)
+    assert [[paths[i] for i in s] for s in want] == by_size
+    load = lambda shards: [sum(sizes[p] for p in s) for s in shards]
+    assert max(load(by_size)) - min(load(by_size)) <= max(sizes.values())
+    assert max(load(by_index)) > 2 * min(load(by_index))

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Rehearsal of EIGHT ranks' host load on a box with ONE GPU (reference behaviour README.md:81-83,
+flappie.c:334-385: one process per shard of the file list, no traffic between them).
+
+Eight `flappie` processes run at the same time over the eight shards of one directory of single-read fast5 files, each with the readers a
+rank gets on a node (host cores / 8, at most 12): process 0 drives the real GPU; processes 1-7 run with FFHIP_DEBUG_HOST_REHEARSAL_MSPS set
+(flappie_amd/csrc/ffhip_engine.hip) -- no network is evaluated there, every batch "takes" its samples / that rate on an emulated GPU and
+returns placeholder calls, while the fast5 readers, the signal preparation with its uploads, the batch buffers, the result copies and
+the FASTQ writer are the real thing.  The host then carries what eight ranks put on it.  Reported per process: the MARGINAL host-fed rate
+(a long run minus a short run, both with all eight running), next to the rate of process 0 running ALONE; host CPU use during the long
+run; the same with the files on /dev/shm and on disk.   Run on the GPU box:  python tools/host_scaling.py [--hidden 384] [--files 12288]"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flappie_amd import model as M  # noqa: E402
+
+EXE, TOOL = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
+NSHARD = 8
+
+
+def cpu_times():
+    with open("/proc/stat") as fh:
+        v = [int(x) for x in fh.readline().split()[1:]]
+    return sum(v), v[3] + v[4]          # total, idle + iowait
+
+
+def run_set(d, n, readers, procs, gpu_rate, by_size):
+    """start one flappie per shard in `procs` at once; returns {shard: (wall, reads, raw samples, fallbacks)} and the host's CPU use"""
+    env0 = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE="0", FLAPPIE_CLI_TIMING="1")
+    c0 = cpu_times()
+    ps = {}
+    t0 = time.perf_counter()
+    for g in procs:
+        env = dict(env0)
+        if g != 0:
+            env["FFHIP_DEBUG_HOST_REHEARSAL_MSPS"] = str(gpu_rate)
+        cmd = [EXE, "--readers", str(readers), "--shard", "%d/%d" % (g, NSHARD)] + (["--shard-by-size"] if by_size else []) + ["--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % g), os.path.join(d, "reads")]
+        ps[g] = (subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), time.perf_counter())
+    out = {}
+    for g, (p, ts) in ps.items():
+        _, err = p.communicate()
+        dt = time.perf_counter() - ts
+        called = [ln for ln in err.splitlines() if ln.startswith("basecalled:")]
+        reads, raw = (int(called[-1].split()[1]), int(called[-1].split()[7])) if called else (0, 0)
+        out[g] = (dt, reads, raw, err.count("falling back"), p.returncode)
+    c1 = cpu_times()
+    busy = 1.0 - (c1[1] - c0[1]) / max(1, c1[0] - c0[0])
+    return out, busy, time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hidden", type=int, default=384)
+    ap.add_argument("--files", type=int, default=12288, help="files per shard in the long run (the short run takes a quarter)")
+    ap.add_argument("--gpu-rate", type=float, default=None, help="Msamples/s of the emulated GPUs (default: bench.py's value of the shape: 104 at H = 384, 203 at H = 256)")
+    ap.add_argument("--where", default="shm,disk")
+    a = ap.parse_args()
+    rate = a.gpu_rate or {384: 104.0, 256: 203.0}.get(a.hidden, 100.0)
+    ncore = len(os.sched_getaffinity(0))
+    readers = max(1, min(12, ncore // NSHARD - 2))
+    n_short = max(512, a.files // 4)
+    print("# tools/host_scaling.py --hidden %d --files %d: %d host cores, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s"
+          % (a.hidden, a.files, ncore, readers, rate))
+    for where in a.where.split(","):
+        base = "/dev/shm" if where == "shm" else tempfile.gettempdir()
+        d = tempfile.mkdtemp(prefix="ffhip_hostscale_", dir=base)
+        try:
+            os.mkdir(os.path.join(d, "reads"))
+            t0 = time.time()
+            gens = [subprocess.Popen([TOOL, "synth", os.path.join(d, "reads"), str(a.files), "3500", "5500", "20260928", str(g), str(NSHARD)], stdout=subprocess.DEVNULL) for g in range(NSHARD)]
+            assert all(p.wait() == 0 for p in gens)
+            M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, a.hidden, seed=1, ident="r941native"))
+            nbytes = sum(os.path.getsize(os.path.join(d, "reads", f)) for f in os.listdir(os.path.join(d, "reads")))
+            print("\n## files on %s (%s): %d files, %.2f GB, generated in %.0f s" % (where, base, NSHARD * a.files, nbytes / 1e9, time.time() - t0))
+            res = {}
+            for label, procs in (("alone", [0]), ("eight", list(range(NSHARD)))):
+                runs = []
+                for n in (n_short, a.files):
+                    best = None
+                    for _rep in range(2):
+                        r = run_set(d, n, readers, procs, rate, False)
+                        if best is None or r[2] < best[2]:
+                            best = r
+                    runs.append(best)
+                res[label] = runs
+                (s_out, _, _), (l_out, busy, wall) = runs
+                for g in procs:
+                    dt, raw = l_out[g][0] - s_out[g][0], l_out[g][2] - s_out[g][2]
+                    ok = l_out[g][4] == 0 and l_out[g][1] == a.files
+                    print("%-6s process %d (%s): marginal %.1f Msamples/s (%d raw samples in %.3f s; long run %.2f s, short %.2f s)%s%s"
+                          % (label, g, "real GPU" if g == 0 else "emulated GPU", raw / dt / 1e6 if dt > 0 else float("nan"), raw, dt, l_out[g][0], s_out[g][0],
+                             "" if ok else "  ** run failed or incomplete **", ("  [%d fall-backs to the step kernels]" % l_out[g][3]) if l_out[g][3] else ""))
+                print("%-6s host CPU busy during the long run: %.1f %% of %d cores (%.1f cores), wall %.2f s" % (label, 100 * busy, ncore, busy * ncore, wall))
+            r1 = (res["alone"][1][0][0][2] - res["alone"][0][0][0][2]) / (res["alone"][1][0][0][0] - res["alone"][0][0][0][0]) / 1e6
+            worst = min((res["eight"][1][0][g][2] - res["eight"][0][0][g][2]) / (res["eight"][1][0][g][0] - res["eight"][0][0][g][0]) / 1e6 for g in range(NSHARD))
+            r0 = (res["eight"][1][0][0][2] - res["eight"][0][0][0][2]) / (res["eight"][1][0][0][0] - res["eight"][0][0][0][0]) / 1e6
+            print("=> process 0 alone %.1f Msamples/s; with seven neighbours %.1f (%.2f of alone); slowest of the eight %.1f (%.2f of alone)" % (r1, r0, r0 / r1, worst, worst / r1))
+            # the same list dealt by size: the spread of the shards' sample sums (no run needed for that)
+            for flag in ([], ["--shard-by-size"]):
+                sums = []
+                for g in range(NSHARD):
+                    r = subprocess.run([EXE, "--shard", "%d/%d" % (g, NSHARD)] + flag + [os.path.join(d, "reads")], env=dict(os.environ, FLAPPIE_LIST_ONLY="1"), capture_output=True, text=True)
+                    sums.append(sum(os.path.getsize(p) for p in r.stdout.split()))
+                print("shard byte sums %s: min %.4f GB, max %.4f GB (max / min %.4f)" % ("by size " if flag else "by index", min(sums) / 1e9, max(sums) / 1e9, max(sums) / min(sums)))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
