@@ -513,7 +513,7 @@ struct ffhip_batch {
         }
         ~Pinned() { if (p) hipHostFree(p); }
     };
-    Pinned h_tin[3], h_ta[3], h_tq[3], h_tbs, h_tbt, h_glen, h_gsrc;
+    Pinned h_tin[3], h_ta[3], h_tq[3], h_tbs, h_tbt, h_glen, h_gsrc, h_rehearsal;
     int *d_tbs = nullptr, *d_tbt = nullptr;
     int *rag_x0a[3] = { nullptr, nullptr, nullptr }, *rag_x0b[3] = { nullptr, nullptr, nullptr };
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
@@ -1202,12 +1202,19 @@ static int rehearsal_run(ffhip_batch *b, float temperature, unsigned flags) {
     hipSetDevice(b->eng->device);
     hipStream_t s = b->stream;
     const size_t n = (size_t)b->nread, L = (size_t)b->Tb + 1;
-    int *lens = (int *)b->h_glen.get(n * 4);
+    int *lens = (int *)b->h_rehearsal.get(n * 4);       // (a buffer of its own: set_prepared's pinned tables may still be waiting for their copies)
     if (!lens) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
     double samples = 0;
-    for (size_t r = 0; r < n; r++) { lens[r] = b->hTb[r] * 2 / 5; samples += b->hT[r]; }
-    HIP_TRY(hipMemsetAsync(b->bases, 'A', n * L, s), FFHIP_EHIP);
-    HIP_TRY(hipMemsetAsync(b->quals, '5', n * L, s), FFHIP_EHIP);
+    int w = b->Tb;
+    for (size_t r = 0; r < n; r++) if (b->hTb[r] > 0 && b->hTb[r] < w) w = b->hTb[r];
+    w = w * 2 / 5;                                        // placeholder calls: 0.4 'A' per block of the batch's shortest read, NUL-terminated rows
+    for (size_t r = 0; r < n; r++) { lens[r] = b->hTb[r] > 0 ? w : 0; samples += b->hT[r]; }
+    HIP_TRY(hipMemsetAsync(b->bases, 0, n * L, s), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->quals, 0, n * L, s), FFHIP_EHIP);
+    if (w > 0) {
+        HIP_TRY(hipMemset2DAsync(b->bases, L, 'A', (size_t)w, n, s), FFHIP_EHIP);
+        HIP_TRY(hipMemset2DAsync(b->quals, L, '5', (size_t)w, n, s), FFHIP_EHIP);
+    }
     HIP_TRY(hipMemsetAsync(b->score, 0, n * 4, s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(b->pabort, 0, sizeof(unsigned), s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(b->sat, 0, (size_t)b->Bp * sizeof(unsigned), s), FFHIP_EHIP);
