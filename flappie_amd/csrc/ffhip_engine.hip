@@ -61,6 +61,30 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     return e;
 }
 
+// ---- host-load rehearsal (TEST HOOK, tools/host_scaling.py; VERDICT r3, next 3) ---------------------------------------------------
+// FFHIP_DEBUG_HOST_REHEARSAL_MSPS=<rate>: this process evaluates NO network.  A run produces placeholder results (calls of 0.4 bases per
+// block, all 'A') and is "busy" for (samples of the batch) / rate on an emulated GPU that works its batches one after the other;
+// ffhip_batch_finish sleeps until then.  With FFHIP_DEBUG_HOST_REHEARSAL_NOGPU=1 beside it the steady state touches the GPU not at all:
+// the signal preparation packs the chunk into its pinned staging buffer (the host's share of it) and stops there -- fixed trims instead
+// of the segmentation, no upload -- and the placeholder results are written on the host.  Eight processes that SHARE one physical GPU
+// otherwise measure that GPU's scheduler (32+ queues of 8 contexts, time-sliced), which a node with a GPU per process does not have.
+// Everything else -- fast5 reader processes, pipes, staging copies, batching, FASTQ formatting and writing -- is the real thing.
+// Announced on stderr; never a fallback, never set by the library itself.
+namespace ffhip {
+double rehearsal_rate() {
+    static double v = -2.0;
+    if (v == -2.0) {
+        const char *e = getenv("FFHIP_DEBUG_HOST_REHEARSAL_MSPS");
+        v = e ? atof(e) : -1.0;
+        if (v > 0) fprintf(stderr, "ffhip: FFHIP_DEBUG_HOST_REHEARSAL_MSPS=%g%s -- NO NETWORK IS EVALUATED in this process: every batch returns placeholder calls "
+                                   "after (its samples) / %g us (host-side load rehearsal, tools/host_scaling.py)\n", v,
+                           getenv("FFHIP_DEBUG_HOST_REHEARSAL_NOGPU") ? " without the GPU" : "", v);
+    }
+    return v;
+}
+bool rehearsal_nogpu() { return rehearsal_rate() > 0 && getenv("FFHIP_DEBUG_HOST_REHEARSAL_NOGPU") != nullptr; }
+}  // namespace ffhip
+
 // ---- device buffer pool and copy accounting (ffhip_host.hpp) ------------------------------------------------------
 #undef hipMemcpyAsync
 #undef hipMemcpy
@@ -863,6 +887,13 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
         if (!src[r] || len > (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: rejected by trimming, or longer than the batch's %d samples", reads[r], b->T);
         lens[r] = (int)len;
     }
+    if (rehearsal_nogpu()) {                                 // test hook (top of this file): the lengths, and nothing on the device
+        b->hT = lens;
+        b->hTb.assign(b->nread, 0);
+        for (int r = 0; r < b->nread; r++) b->hTb[r] = lens[r] > 0 ? (int)ffhip_model_nblock(b->mdl, (size_t)lens[r]) : 0;
+        b->ran = b->finished = 0;
+        return FFHIP_OK;
+    }
     if (int rc = apply_lengths(b, lens)) return rc;
     if (b->ragged) if (int rc = clear_signals(b)) return rc;
     SampleBuf &sb = b->sbuf[0];
@@ -1181,22 +1212,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     return FFHIP_OK;
 }
 
-// ---- host-load rehearsal (TEST HOOK, tools/host_scaling.py; VERDICT r3, next 3) ---------------------------------------------------
-// FFHIP_DEBUG_HOST_REHEARSAL_MSPS=<rate>: this process evaluates NO network.  A run enqueues placeholder results (calls of 0.4 bases per
-// block, all 'A') and is "busy" for (samples of the batch) / rate on an emulated GPU that works its batches one after the other;
-// ffhip_batch_finish sleeps until then.  Everything around the kernels -- fast5 readers, signal preparation and its uploads, the batch's
-// device buffers, result copies, FASTQ formatting -- is the real thing: seven such processes beside one real one load the host as eight
-// ranks of a node would, on a box with one GPU.  Announced on stderr; never a fallback, never set by the library itself.
-static double rehearsal_rate() {
-    static double v = -2.0;
-    if (v == -2.0) {
-        const char *e = getenv("FFHIP_DEBUG_HOST_REHEARSAL_MSPS");
-        v = e ? atof(e) : -1.0;
-        if (v > 0) fprintf(stderr, "ffhip: FFHIP_DEBUG_HOST_REHEARSAL_MSPS=%g -- NO NETWORK IS EVALUATED in this process: every batch returns placeholder calls "
-                                   "after (its samples) / %g us (host-side load rehearsal, tools/host_scaling.py)\n", v, v);
-    }
-    return v;
-}
+// ---- host-load rehearsal: the run side (see rehearsal_rate() at the top of this file)
 static double now_seconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static int rehearsal_run(ffhip_batch *b, float temperature, unsigned flags) {
     hipSetDevice(b->eng->device);
@@ -1209,6 +1225,16 @@ static int rehearsal_run(ffhip_batch *b, float temperature, unsigned flags) {
     for (size_t r = 0; r < n; r++) if (b->hTb[r] > 0 && b->hTb[r] < w) w = b->hTb[r];
     w = w * 2 / 5;                                        // placeholder calls: 0.4 'A' per block of the batch's shortest read, NUL-terminated rows
     for (size_t r = 0; r < n; r++) { lens[r] = b->hTb[r] > 0 ? w : 0; samples += b->hT[r]; }
+    if (rehearsal_nogpu()) {                              // the host mirrors ffhip_batch_finish would have filled
+        memset(b->h_bases, 0, n * L); memset(b->h_quals, 0, n * L);
+        for (size_t r = 0; r < n; r++) { memset(b->h_bases + r * L, 'A', (size_t)lens[r]); memset(b->h_quals + r * L, '5', (size_t)lens[r]); b->h_lens[r] = lens[r]; b->h_score[r] = 0.0f; }
+        *b->h_abort = 0; memset(b->h_sat, 0, (size_t)b->Bp * sizeof(unsigned));
+        const double t = now_seconds(), start = t > b->eng->rehearsal_busy_until ? t : b->eng->rehearsal_busy_until;
+        b->eng->rehearsal_busy_until = b->rehearsal_done_at = start + samples / (rehearsal_rate() * 1e6);
+        b->last_flags = b->run_flags = flags; b->last_temperature = temperature;
+        b->ran = 1; b->finished = 0; b->paired_last = 0;
+        return FFHIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(b->bases, 0, n * L, s), FFHIP_EHIP);
     HIP_TRY(hipMemsetAsync(b->quals, 0, n * L, s), FFHIP_EHIP);
     if (w > 0) {
@@ -1353,6 +1379,13 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     if (!b->ran) return set_err(FFHIP_EINVAL, "ffhip_batch_run has not been called");
     hipSetDevice(b->eng->device);
     const size_t n = (size_t)b->nread, L = (size_t)b->Tb + 1;
+    if (rehearsal_nogpu()) {                                 // test hook (top of this file): the results are on the host already
+        const double left = b->rehearsal_done_at - now_seconds();
+        if (left > 0) { struct timespec ts = { (time_t)left, (long)((left - (double)(time_t)left) * 1e9) }; nanosleep(&ts, nullptr); }
+        if (b->counted) { b->counted = 0; b->eng->in_flight--; }
+        b->finished = 1; b->reruns = 0;
+        return FFHIP_OK;
+    }
     if (!(b->last_flags & FFHIP_RUN_NO_DECODE)) {
         HIP_TRY(hipMemcpyAsync(b->h_bases, b->bases, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
         HIP_TRY(hipMemcpyAsync(b->h_quals, b->quals, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);

@@ -88,6 +88,8 @@ bool pool_engine_gone(int device);    // true: it was the device's last engine
 int pool_default_device();
 int pool_device_of(const void *p);    // -1: not a pool buffer
 void pool_state(unsigned long long out[4]);
+double rehearsal_rate();              // test hook FFHIP_DEBUG_HOST_REHEARSAL_MSPS (ffhip_engine.hip); <= 0: off
+bool rehearsal_nogpu();
 void image_remember(const void *owner, void *dev);
 void *image_forget(const void *owner);
 

@@ -358,6 +358,14 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     // one packed upload for the chunk: the reads are gathered in pinned memory first (a copy per read from pageable memory costs
     // 10-20 us of launch and staging each -- 30 ms for 2048 reads, during which nothing else was submitted)
     for (int r = 0; r < nread; r++) memcpy(pin + p->off[r], reads[r].raw, reads[r].n * 4);
+    if (rehearsal_nogpu()) {             // test hook (ffhip_engine.hip, "host-load rehearsal"): the host's share is done; fixed trims stand for the segmentation
+        for (int r = 0; r < nread; r++) {
+            p->start[r] = std::min(e_in[r], s_in[r] + trim_start);
+            p->end[r] = std::max(p->start[r], e_in[r] > trim_end ? e_in[r] - trim_end : (size_t)0);
+            p->stats[2 * (size_t)r] = 0.0f; p->stats[2 * (size_t)r + 1] = 1.0f;
+        }
+        return p;
+    }
     if (hipMemcpyAsync(d_raw, pin, total * 4, hipMemcpyHostToDevice, s) != hipSuccess) PFAIL(FFHIP_EHIP, "upload of raw signal failed");
     size_t *d_off = d_sz, *d_n = d_sz + nread, *d_s = d_sz + 2 * (size_t)nread, *d_e = d_sz + 3 * (size_t)nread, *d_so = d_sz + 4 * (size_t)nread, *d_eo = d_sz + 5 * (size_t)nread;
     bool ok = hipMemcpyAsync(d_off, p->off.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;

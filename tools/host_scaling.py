@@ -23,6 +23,7 @@ from flappie_amd import model as M  # noqa: E402
 
 EXE, TOOL = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
 NSHARD = 8
+NOGPU = True          # emulated processes keep off the physical GPU altogether (--emu-on-gpu: their signal preparation and copies run on it)
 
 
 def cpu_times():
@@ -41,6 +42,8 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
         env = dict(env0)
         if g not in real:
             env["FFHIP_DEBUG_HOST_REHEARSAL_MSPS"] = str(gpu_rate)
+            if NOGPU:
+                env["FFHIP_DEBUG_HOST_REHEARSAL_NOGPU"] = "1"
         cmd = [EXE, "--readers", str(readers), "--shard", "%d/%d" % (g, NSHARD)] + (["--shard-by-size"] if by_size else []) + ["--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % g), os.path.join(d, "reads")]
         ps[g] = (subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), time.perf_counter())
     out = {}
@@ -49,7 +52,7 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
         dt = time.perf_counter() - ts
         called = [ln for ln in err.splitlines() if ln.startswith("basecalled:")]
         reads, raw = (int(called[-1].split()[1]), int(called[-1].split()[7])) if called else (0, 0)
-        out[g] = (dt, reads, raw, err.count("falling back"), p.returncode)
+        out[g] = (dt, reads, raw, err.count("falling back"), p.returncode, [ln for ln in err.splitlines() if ln.endswith(" s") and not ln.startswith("ffhip")])
     c1 = cpu_times()
     busy = 1.0 - (c1[1] - c0[1]) / max(1, c1[0] - c0[0])
     return out, busy, time.perf_counter() - t0
@@ -61,13 +64,20 @@ def main():
     ap.add_argument("--files", type=int, default=32768, help="files per shard in the long run (the short run takes a quarter)")
     ap.add_argument("--gpu-rate", type=float, default=None, help="Msamples/s of the emulated GPUs (default: bench.py's value of the shape: 104 at H = 384, 203 at H = 256)")
     ap.add_argument("--where", default="shm,disk")
+    ap.add_argument("--phases", action="store_true", help="print the binary's own phase times of the last process of each leg")
+    ap.add_argument("--legs", default="real1,emu1,emu8,mixed")
+    ap.add_argument("--emu-on-gpu", action="store_true", help="the emulated processes run their signal preparation, uploads and result copies on the one physical GPU "
+                    "(eight contexts on one device: measures that device's scheduler more than the host)")
     a = ap.parse_args()
+    global NOGPU
+    NOGPU = not a.emu_on_gpu
     rate = a.gpu_rate or {384: 104.0, 256: 203.0}.get(a.hidden, 100.0)
     ncore = len(os.sched_getaffinity(0))
     readers = max(1, min(12, ncore // NSHARD - 2))
     n_short = max(512, a.files // 4)
-    print("# tools/host_scaling.py --hidden %d --files %d: %d host cores, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s"
-          % (a.hidden, a.files, ncore, readers, rate))
+    print("# tools/host_scaling.py --hidden %d --files %d%s: %d host cores, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s (%s)"
+          % (a.hidden, a.files, " --emu-on-gpu" if a.emu_on_gpu else "", ncore, readers, rate,
+             "their signal preparation and copies on the physical GPU" if a.emu_on_gpu else "emulated processes never touch the physical GPU in steady state"))
     for where in a.where.split(","):
         base = "/dev/shm" if where == "shm" else tempfile.gettempdir()
         d = tempfile.mkdtemp(prefix="ffhip_hostscale_", dir=base)
@@ -84,7 +94,9 @@ def main():
             # carries eight pipelines and the one physical GPU only their signal preparation and copies.  mixed: process 0 on the real GPU beside seven
             # emulated ones (there the emulated processes' small GPU operations queue behind process 0's chip-filling layer launches -- an artefact of
             # sharing ONE GPU that a node with eight does not have -- so their own rates say nothing; process 0's rate is the figure of that row).
-            for label, procs, real in (("real1", [0], (0,)), ("emu1", [1], ()), ("emu8", list(range(NSHARD)), ()), ("mixed", list(range(NSHARD)), (0,))):
+            for label, procs, real in (("real1", [0], (0,)), ("emu1", [1], ()), ("emu2", [0, 1], ()), ("emu4", [0, 1, 2, 3], ()), ("emu8", list(range(NSHARD)), ()), ("mixed", list(range(NSHARD)), (0,))):
+                if label not in a.legs.split(","):
+                    continue
                 runs = []
                 for n in (n_short, a.files):
                     best = None
@@ -101,10 +113,19 @@ def main():
                     print("%-6s process %d (%s): marginal %.1f Msamples/s (%d raw samples in %.3f s; long run %.2f s, short %.2f s)%s%s"
                           % (label, g, "real GPU" if g in real else "emulated GPU", raw / dt / 1e6 if dt > 0 else float("nan"), raw, dt, l_out[g][0], s_out[g][0],
                              "" if ok else "  ** run failed or incomplete **", ("  [%d fall-backs to the step kernels]" % l_out[g][3]) if l_out[g][3] else ""))
+                if a.phases:
+                    g = procs[-1]
+                    print("       phases of process %d in the long run (FLAPPIE_CLI_TIMING): %s" % (g, "; ".join(" ".join(ln.split()) for ln in l_out[g][5])))
                 print("%-6s host CPU busy during the long run: %.1f %% of %d cores (%.1f cores), wall %.2f s" % (label, 100 * busy, ncore, busy * ncore, wall))
             def marg(label, g):
                 (s_out, _, _), (l_out, _, _) = res[label]
                 return (l_out[g][2] - s_out[g][2]) / (l_out[g][0] - s_out[g][0]) / 1e6
+            for k in (2, 4):
+                if "emu%d" % k in res:
+                    ek = [marg("emu%d" % k, g) for g in range(k)]
+                    print("=> %d processes on emulated GPUs at once: %.1f ... %.1f each, %.0f in all" % (k, min(ek), max(ek), sum(ek)))
+            if not all(x in res for x in ("real1", "emu1", "emu8", "mixed")):
+                continue
             e1, e8 = marg("emu1", 1), [marg("emu8", g) for g in range(NSHARD)]
             print("=> host side alone (one process, emulated GPU): %.1f Msamples/s; eight at once: %.1f ... %.1f each (slowest %.2f of alone), %.0f in all"
                   % (e1, min(e8), max(e8), min(e8) / e1, sum(e8)))
