@@ -60,6 +60,36 @@ def _oracle_with_blas(mode):
     return ffo.use_dot_mode(mode)
 
 
+def effective_cpus():
+    """(CPUs this process may actually use, hardware threads it can be scheduled on, why): the affinity mask says where, the cgroup's CPU
+    bandwidth quota how much -- on the GPU boxes of this pool a container sees 256 hardware threads and is granted 16 CPUs' worth of time
+    (cpu.max `1600000 100000`); processes beyond the quota only throttle each other."""
+    try:
+        naff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        naff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                t = fh.read().split()
+            if path.endswith("cpu.max"):
+                if t and t[0] != "max":
+                    quota = float(t[0]) / float(t[1])
+            else:
+                q = float(t[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    p = float(fh.read().split()[0])
+                if q > 0:
+                    quota = q / p
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is None or quota >= naff:
+        return naff, naff, "affinity mask"
+    return max(1, int(quota + 0.5)), naff, "cgroup CPU quota %.1f of %d hardware threads" % (quota, naff)
+
+
 def _cpu_worker(job):
     """One host core: the oracle's whole path over its own reads until the time budget is spent."""
     kind, hidden, ident, nsample, seed, budget_s, max_reads, mode = job
@@ -87,11 +117,7 @@ def cpu_baseline(cfg, budget_s=12.0):
     sgemm for projections and convolutions) -- the shapes OpenBLAS would run, within ~1.5-2x of the survey's OpenBLAS probe
     on one core; the reference-order scalar oracle that the parity tests use is ~5x slower and is not what is timed."""
     import multiprocessing as mp
-    try:
-        ncore = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncore = os.cpu_count() or 1
-    ncore = max(1, ncore)                       # every host core, as the reference's README runs it (one process per core under GNU parallel)
+    ncore, nhw, why = effective_cpus()          # every CPU this container is GRANTED, as the reference's README runs it (one process per core under GNU parallel)
     nsample = min(cfg["nsample"], 20000)        # long-read configs: a 20 000-sample prefix per read keeps the sample bounded
     max_reads = max(2, int(400000 // nsample))
     mode, blas = _oracle_with_blas(3)                 # 3 = the GEMV / GEMM calls go to a real OpenBLAS when this host has one
@@ -107,17 +133,13 @@ def cpu_baseline(cfg, budget_s=12.0):
     wall = time.time() - t0
     nread = sum(r[0] for r in res)
     dt = max(r[1] for r in res)
-    at64 = None
-    if ncore > 64:                              # rounds 1-3 loaded 64 processes only: the same figure again, for comparison across rounds
-        with mp.get_context("spawn").Pool(64) as pool:
-            r64 = pool.map(_cpu_worker, [j[:5] + (budget_s / 2,) + j[6:] for j in jobs[:64]])
-        at64 = round(sum(r[0] for r in r64) * nsample / max(r[1] for r in r64) / 1e6, 6)
     return dict(value=round(nread * nsample / dt / 1e6, 6), unit="Msamples/s", cores=ncore, kind="port+openblas" if blas else "port",
                 sample="%d synthetic reads of %d samples over %d single-threaded processes (whole path: oracle algorithm, %s), slowest worker %.1f s, %.1f s wall"
                        % (nread, nsample, ncore, ("GEMV / GEMM through %s [%s], one thread each; element-wise loops oracle/cpu_ref.c" % blas) if blas else
                           "vectorised kernels of oracle/cpu_ref.c", dt, wall),
                 per_core=round(nread * nsample / dt / 1e6 / ncore, 6),
-                with_64_processes=at64,
+                hardware_threads=nhw, cores_limited_by=why,
+                whole_host_if_linear=round(nread * nsample / dt / 1e6 / ncore * nhw, 4),
                 one_core_alone=round(one[0] * nsample / one[1] / 1e6, 6),
                 one_core_alone_own_kernels=round(own[0] * nsample / own[1] / 1e6, 6),
                 blas_library=blas[0] if blas else None,
@@ -125,7 +147,8 @@ def cpu_baseline(cfg, budget_s=12.0):
                 note=("kind=port+openblas: the reference's layers.c / flappie_matrix.c cannot be built in this image (no <cblas.h>); this is the oracle's restatement of "
                       "them calling the SAME cblas_sgemv / cblas_sgemm shapes (layers.c:1009, :250, flappie_matrix.c:384) in an OpenBLAS found on this host, dlopen()ed. "
                       if blas else "kind=port: no LP64 OpenBLAS found on this host; the port's own vectorised kernels. ") +
-                     "per_core = all cores loaded (every step re-streams the recurrent matrix: the cores compete for memory bandwidth); one_core_alone = one process on an idle host; "
+                     "cores = the CPUs this container is granted (cgroup quota; rounds 1-3 started 64 processes under a 16-CPU quota and read the throttling as memory-bandwidth contention); "
+                     "per_core = value / cores; one_core_alone = one process alone; whole_host_if_linear = per_core x the host's hardware threads (an extrapolation, not a measurement); "
                      "reference_openblas_per_core_survey = the survey container's probe of the real reference (SURVEY.md section 6, other host)")
 
 
@@ -220,10 +243,7 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
     exe, tool = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
     if cfg["kind"] != M.NET_LSTM5 or not (os.path.exists(exe) and os.path.exists(tool)):
         return {"skipped": "needs the flappie binary + fast5_tool (libhdf5 at build time) and an LSTM5 flip-flop model"} if rank == 0 else None
-    try:
-        ncore = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncore = os.cpu_count() or 1
+    ncore = effective_cpus()[0]                 # what the container is granted, not what it can see
     readers = max(1, min(12, ncore // max(1, world) - 2))
     nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_HOSTFED_FILES", "32768"))      # per rank (the short run is a quarter of it: a steady-state marginal rate needs ~1 s of work)
     n_short = max(512, nfiles // 4)

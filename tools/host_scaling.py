@@ -11,6 +11,7 @@ the FASTQ writer are the real thing.  The host then carries what eight ranks put
 run; the same with the files on /dev/shm and on disk.   Run on the GPU box:  python tools/host_scaling.py [--hidden 384] [--files 12288]"""
 import argparse
 import os
+import resource
 import shutil
 import subprocess
 import sys
@@ -36,6 +37,7 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
     """start one flappie per shard in `procs` at once; returns {shard: (wall, reads, raw samples, fallbacks)} and the host's CPU use"""
     env0 = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE="0", FLAPPIE_CLI_TIMING="1")
     c0 = cpu_times()
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     ps = {}
     t0 = time.perf_counter()
     for g in procs:
@@ -54,8 +56,10 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
         reads, raw = (int(called[-1].split()[1]), int(called[-1].split()[7])) if called else (0, 0)
         out[g] = (dt, reads, raw, err.count("falling back"), p.returncode, [ln for ln in err.splitlines() if ln.endswith(" s") and not ln.startswith("ffhip")])
     c1 = cpu_times()
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     busy = 1.0 - (c1[1] - c0[1]) / max(1, c1[0] - c0[0])
-    return out, busy, time.perf_counter() - t0
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)       # this set's own processes (readers included), not the host's other tenants
+    return out, busy, time.perf_counter() - t0, cpu_s
 
 
 def main():
@@ -64,6 +68,7 @@ def main():
     ap.add_argument("--files", type=int, default=32768, help="files per shard in the long run (the short run takes a quarter)")
     ap.add_argument("--gpu-rate", type=float, default=None, help="Msamples/s of the emulated GPUs (default: bench.py's value of the shape: 104 at H = 384, 203 at H = 256)")
     ap.add_argument("--where", default="shm,disk")
+    ap.add_argument("--readers", type=int, default=0, help="reader processes per flappie process (default: what bench.py gives a rank: granted CPUs / 8 - 2, 1..12)")
     ap.add_argument("--phases", action="store_true", help="print the binary's own phase times of the last process of each leg")
     ap.add_argument("--legs", default="real1,emu1,emu8,mixed")
     ap.add_argument("--emu-on-gpu", action="store_true", help="the emulated processes run their signal preparation, uploads and result copies on the one physical GPU "
@@ -72,10 +77,11 @@ def main():
     global NOGPU
     NOGPU = not a.emu_on_gpu
     rate = a.gpu_rate or {384: 104.0, 256: 203.0}.get(a.hidden, 100.0)
-    ncore = len(os.sched_getaffinity(0))
-    readers = max(1, min(12, ncore // NSHARD - 2))
+    import bench
+    ncore, nhw, why = bench.effective_cpus()
+    readers = a.readers or max(1, min(12, ncore // NSHARD - 2))
     n_short = max(512, a.files // 4)
-    print("# tools/host_scaling.py --hidden %d --files %d%s: %d host cores, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s (%s)"
+    print("# tools/host_scaling.py --hidden %d --files %d%s: %d CPUs granted to this container, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s (%s)"
           % (a.hidden, a.files, " --emu-on-gpu" if a.emu_on_gpu else "", ncore, readers, rate,
              "their signal preparation and copies on the physical GPU" if a.emu_on_gpu else "emulated processes never touch the physical GPU in steady state"))
     for where in a.where.split(","):
@@ -102,11 +108,12 @@ def main():
                     best = None
                     for _rep in range(2):
                         r = run_set(d, n, readers, procs, rate, False, real)
-                        if best is None or r[2] < best[2]:
+                        if best is None or r[2] < best[2]:      # the faster of two
                             best = r
                     runs.append(best)
                 res[label] = runs
-                (s_out, _, _), (l_out, busy, wall) = runs
+                (s_out, _, _, s_cpu), (l_out, busy, wall, l_cpu) = runs
+                d_raw = sum(l_out[g][2] - s_out[g][2] for g in procs)
                 for g in procs:
                     dt, raw = l_out[g][0] - s_out[g][0], l_out[g][2] - s_out[g][2]
                     ok = l_out[g][4] == 0 and l_out[g][1] == a.files
@@ -116,9 +123,11 @@ def main():
                 if a.phases:
                     g = procs[-1]
                     print("       phases of process %d in the long run (FLAPPIE_CLI_TIMING): %s" % (g, "; ".join(" ".join(ln.split()) for ln in l_out[g][5])))
-                print("%-6s host CPU busy during the long run: %.1f %% of %d cores (%.1f cores), wall %.2f s" % (label, 100 * busy, ncore, busy * ncore, wall))
+                print("%-6s CPU time of these processes (readers included): %.2f s in the long run over %.2f s wall = %.1f CPUs; marginal %.3f CPU-s per million raw samples  "
+                      "[whole host, other tenants included: %.1f %% of %d hardware threads busy]" % (label, l_cpu, wall, l_cpu / wall, (l_cpu - s_cpu) / max(1.0, d_raw / 1e6), 100 * busy, nhw))
+                cost[label] = (l_cpu - s_cpu) / max(1.0, d_raw / 1e6)
             def marg(label, g):
-                (s_out, _, _), (l_out, _, _) = res[label]
+                (s_out, _, _, _), (l_out, _, _, _) = res[label]
                 return (l_out[g][2] - s_out[g][2]) / (l_out[g][0] - s_out[g][0]) / 1e6
             for k in (2, 4):
                 if "emu%d" % k in res:
@@ -129,6 +138,9 @@ def main():
             e1, e8 = marg("emu1", 1), [marg("emu8", g) for g in range(NSHARD)]
             print("=> host side alone (one process, emulated GPU): %.1f Msamples/s; eight at once: %.1f ... %.1f each (slowest %.2f of alone), %.0f in all"
                   % (e1, min(e8), max(e8), min(e8) / e1, sum(e8)))
+            c = cost.get("emu1", cost.get("real1"))
+            print("=> host CPU per million raw samples: %.3f CPU-s (one process) -- a rank at %.0f Msamples/s needs %.1f CPUs, eight need %.0f; this container is granted %d (%s)"
+                  % (c, rate, c * rate, 8 * c * rate, ncore, why))
             print("=> process 0 on the real GPU: alone %.1f Msamples/s; beside seven emulated neighbours %.1f (%.2f of alone)" % (marg("real1", 0), marg("mixed", 0), marg("mixed", 0) / marg("real1", 0)))
             # the same list dealt by size: the spread of the shards' sample sums (no run needed for that)
             for flag in ([], ["--shard-by-size"]):
