@@ -95,7 +95,7 @@ def main():
             M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(M.NET_LSTM5, a.hidden, seed=1, ident="r941native"))
             nbytes = sum(os.path.getsize(os.path.join(d, "reads", f)) for f in os.listdir(os.path.join(d, "reads")))
             print("\n## files on %s (%s): %d files, %.2f GB, generated in %.0f s" % (where, base, NSHARD * a.files, nbytes / 1e9, time.time() - t0))
-            res = {}
+            res, cost = {}, {}
             # real1: process 0 on the real GPU, alone.  emu1: one process on an emulated GPU, alone.  emu8: EIGHT processes on emulated GPUs -- the host
             # carries eight pipelines and the one physical GPU only their signal preparation and copies.  mixed: process 0 on the real GPU beside seven
             # emulated ones (there the emulated processes' small GPU operations queue behind process 0's chip-filling layer launches -- an artefact of
