@@ -395,13 +395,15 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
 // weights at all.  Two workgroups a CU (<= 256 registers): one's 60 MFMAs per tile run under the other's epilogue (the 848 VALU cycles a tile of
 // reference-exact swish, split and store costs).  Workgroups of one XCD (blockIdx mod 8) share their window tiles through that XCD's L2: the
 // M blocks of a column group sit on the same XCD.  Results bit-identical to k_conv_split (same products in the same order per accumulator).
-template <int NSL_ = 2>
+template <int NC>
 __global__ void __launch_bounds__(256, 2)
 k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restrict__ bias, const int *__restrict__ x0a, const int *__restrict__ x0b,
-                int B16, int Tout, int Mt, int NC, int winlen, int act, int ldp, unsigned char *__restrict__ out_split, float split_scale, float acc_scale,
+                int B16, int Tout, int Mt, int winlen, int ldp, unsigned char *__restrict__ out_split, float split_scale, float acc_scale,
                 unsigned *__restrict__ sat, int ngroup) {
-    constexpr int NSL = 2, TM = 2, MAXC = 10;                   // K chunks of 32 = two taps; 19 taps -> 10 chunks (launch_conv_split checks NC <= MAXC)
-    __shared__ v4u_t Bt[2][MAXC * NSL][64];                    // [buffer][piece = chunk * 2 + slice][lane]: 2 x 20 KiB
+    constexpr int act = 1;                                      // swish: the LSTM models' convolutions (the only ones with 16 input features)
+    constexpr int NSL = 2, TM = 2, NPIECE = NC * NSL, PPW = NPIECE / 4;      // K chunks of 32 = two taps; 19 taps -> NC = 10 chunks, 20 pieces, 5 a wave
+    static_assert(NPIECE % 4 == 0, "the pieces of a window tile are dealt evenly to the four waves");
+    __shared__ v4u_t Bt[2][NPIECE][64];                        // [buffer][piece = chunk * 2 + slice][lane]: 2 x 20 KiB
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kq = lane >> 4, rl = lane & 15;
     const int NMB = Mt / (4 * TM);
@@ -409,78 +411,83 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
     const int ntile = Tout * B16;
     const int mt0 = mb * 4 * TM + wave * TM;
     // my weights, for the whole layer
-    v4u_t A[TM][MAXC][NSL];
+    v4u_t A[TM][NC][NSL];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int c = 0; c < MAXC; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int sl = 0; sl < NSL; sl++)
-                A[i][c][sl] = (c < NC) ? Wp[((size_t)(mt0 + i) * NC + c) * NSL * 64 + sl * 64 + lane] : (v4u_t){ 0u, 0u, 0u, 0u };
+            for (int sl = 0; sl < NSL; sl++) A[i][c][sl] = Wp[((size_t)(mt0 + i) * NC + c) * NSL * 64 + sl * 64 + lane];
     v4f bv[TM];
 #pragma unroll
     for (int i = 0; i < TM; i++) bv[i] = *(const v4f *)(bias + (mt0 + i) * 16 + kq * 4) * acc_scale;
     const float inv_scale = 1.0f / acc_scale;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in.p, 0, (int)0xFFFFFFFFu, 0x00020000);
-    const int npiece = NC * NSL, ppw = (npiece + 3) / 4;        // pieces a wave gathers
-    // byte offset (from in.p) of this lane's 16 bytes of (window pass, tile nt, piece): the leading zero pad of read 0 for a tap beyond the window / a missing window
-    auto piece_offset = [&](int nt, int pass, int piece, bool &have) -> unsigned {
-        const int c = nt / B16, rt = nt % B16;
-        const size_t pi = (size_t)(rt * 16 + rl) * ldp + c;
-        const int x0 = pass == 0 ? x0a[pi] : x0b[pi];
-        have = (x0 != kNoWindow && x0 != kZeroCol);
-        const int ch = piece / NSL, sl = piece % NSL;
-        if (!have || 2 * ch + (kq >> 1) >= winlen) return (unsigned)((kq & 1) * 16 + sl * 32);      // zeros
-        return (unsigned)(((size_t)(rt * 16 + rl) * in.rs + (size_t)(kSamplePad + x0 + 2 * ch + (kq >> 1)) * 16) * 4 + sl * 32 + (kq & 1) * 16);
+    // window starts of a tile, this lane's read: both passes (x0b: the second window some columns accumulate, layers.c:257-271)
+    auto table = [&](int nt, int &xa, int &xb) {
+        const int t = nt < ntile ? nt : ntile - 1;
+        const size_t pi = (size_t)((t % B16) * 16 + rl) * ldp + t / B16;
+        xa = x0a[pi]; xb = x0b[pi];
     };
-    // gather my pieces of (tile, pass) into buffer `buf`; returns whether any lane of the tile has a window in this pass (the same answer in every wave)
-    auto gather = [&](int nt, int pass, int buf) -> bool {
-        bool any = false;
-        for (int k = 0; k < ppw; k++) {
-            const int piece = wave * ppw + k;
-            if (piece >= npiece) break;
-            bool have;
-            const unsigned off = piece_offset(nt, pass, piece, have);
-            any = any || have;
+    // gather my five pieces of (tile nt, window start x0 of this lane's read) into buffer `buf`: a tap beyond the window, or no window at
+    // all, reads the leading zero pad of read 0.  Offsets come from registers only: nothing here waits for memory.
+    auto gather = [&](int nt, int x0, int buf) {
+        const bool have = (x0 != kNoWindow && x0 != kZeroCol);
+        const unsigned row0 = (unsigned)(((size_t)((nt % B16) * 16 + rl) * in.rs + (size_t)(kSamplePad + (have ? x0 : 0)) * 16) * 4) + (unsigned)((kq >> 1) * 64 + (kq & 1) * 16);
+#pragma unroll
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wave * PPW + k, ch = piece / NSL, sl = piece % NSL;
+            const unsigned off = (!have || 2 * ch + (kq >> 1) >= winlen) ? (unsigned)((kq & 1) * 16 + sl * 32) : row0 + (unsigned)(ch * 128 + sl * 32);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)&Bt[buf][piece][0], 16, off, 0, 0, 0);
 #endif
         }
-        return __any(any) != 0;
     };
-    auto second_window = [&](int nt) -> bool {                   // does a read of this tile accumulate a second window into this column (layers.c:257-271)?
-        const size_t pi = (size_t)((nt % B16) * 16 + rl) * ldp + nt / B16;
-        const int x0 = x0b[pi];
-        return __any(x0 != kNoWindow && x0 != kZeroCol) != 0;
-    };
-    // work list of this workgroup: tiles g, g + ngroup, ...; a tile with a second window is two passes over the same accumulators
+    auto valid = [&](int x0) { return __any(x0 != kNoWindow && x0 != kZeroCol) != 0; };
+    // work list of this workgroup: tiles g, g + ngroup, ...; a tile with a second window is two passes over the same accumulators.
+    // The window table is read one tile AHEAD of the gather that uses it (cur_*: this tile, nxt_*: the next), the gather one item ahead of
+    // the MFMAs that use it: at the top of an iteration everything older than the last epilogue's four stores has arrived.
     int nt = g, pass = 0, buf = 0;
-    if (nt < ntile) gather(nt, 0, 0);
+    int cur_a, cur_b, nxt_a, nxt_b;
+    table(nt, cur_a, cur_b);
+    table(nt + ngroup, nxt_a, nxt_b);
+    if (nt < ntile) gather(nt, cur_a, 0);
     v4f acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; i++) acc[i] = bv[i];
+    bool stored = false;                                        // the previous iteration ended with an epilogue: 2 TM stores younger than my gather
     while (nt < ntile) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces have landed ...
-        __syncthreads();                                       // ... everybody's have, and nobody still reads the other buffer
-        // what comes after (tile, pass): its second pass, or the next tile's first
-        const bool two = (pass == 0) && second_window(nt);
-        const int nt_next = two ? nt : nt + ngroup, pass_next = two ? 1 : 0;
-        if (nt_next < ntile) gather(nt_next, pass_next, buf ^ 1);
-#pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            if (c < NC) {
-                const v4u_t b0 = Bt[buf][c * NSL][lane], b1 = Bt[buf][c * NSL + 1][lane];
-                // smallest terms first, as k_conv_split: w1 x0, w0 x1, w0 x0
-#pragma unroll
-                for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][1]), __builtin_bit_cast(v8h_t, b0), acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][0]), __builtin_bit_cast(v8h_t, b1), acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][0]), __builtin_bit_cast(v8h_t, b0), acc[i], 0, 0, 0);
-            }
+        // my pieces have landed: everything but the epilogue's stores, which were issued behind them and drain on their own (vector memory
+        // operations of a wave retire in order on this family)
+        if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(TM * kSplitNS == 4, "the counted wait above assumes four stores per epilogue");
+        // ... everybody's have, and nobody still reads the other buffer.  An LDS-only barrier: __syncthreads() drains vmcnt -- the stores again
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool two = (pass == 0) && valid(cur_b);
+        int nn_a = nxt_a, nn_b = nxt_b;
+        if (two) gather(nt, cur_b, buf ^ 1);
+        else {
+            if (nt + ngroup < ntile) gather(nt + ngroup, nxt_a, buf ^ 1);
+            table(nt + 2 * ngroup, nn_a, nn_b);                // (behind the gather: its wait is the next iteration's)
         }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const v4u_t b0 = Bt[buf][c * NSL][lane], b1 = Bt[buf][c * NSL + 1][lane];
+            // smallest terms first, as k_conv_split: w1 x0, w0 x1, w0 x0
+#pragma unroll
+            for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][1]), __builtin_bit_cast(v8h_t, b0), acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][0]), __builtin_bit_cast(v8h_t, b1), acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][0]), __builtin_bit_cast(v8h_t, b0), acc[i], 0, 0, 0);
+        }
+        stored = !two;
         if (!two) {
-            // epilogue of tile nt (k_conv_split's, value for value)
+            // epilogue of tile nt (k_conv_split's, value for value).  (Built and measured, not kept: the epilogue one iteration late in the MFMAs'
+            // own block, branch-free, for the scheduler to interleave -- it did not, 0.33 against 0.32 ms.)
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 const int mt = mt0 + i;
@@ -498,8 +505,10 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
                     *(uint2 *)(dst + (size_t)sl * 1024) = make_uint2(sb[0][sl] | (sb[1][sl] << 16), sb[2][sl] | (sb[3][sl] << 16));
                 acc[i] = bv[i];
             }
-        }
-        nt = nt_next; pass = pass_next; buf ^= 1;
+            nt += ngroup; pass = 0;
+            cur_a = nxt_a; cur_b = nxt_b; nxt_a = nn_a; nxt_b = nn_b;
+        } else pass = 1;
+        buf ^= 1;
     }
 }
 
@@ -508,14 +517,14 @@ void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, 
     const int Mt = M / 16, NC = (winlen + 1) / 2;
     // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_CONV_WS=0: the round-3 kernel)
     static const int ws_env = [] { const char *e = getenv("FFHIP_CONV_WS"); return e ? atoi(e) : 1; }();
-    if (!lean && out_split && kSplitNS == 2 && ws_env && Mt % 8 == 0 && NC <= 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
+    if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
         static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int NMB = Mt / 8;
         int ngroup = (2 * ncu / NMB) & ~7;                       // two workgroups a CU; whole XCD rounds of column groups
         if (ngroup < 8) ngroup = 8;
         const int ntile = Tout * B16;
         if (ngroup > ((ntile + 7) & ~7)) ngroup = (ntile + 7) & ~7;
-        hipLaunchKernelGGL((k_conv_split_ws<2>), dim3(NMB * ngroup), dim3(256), 0, s, in, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, NC, winlen, act, ldp,
+        hipLaunchKernelGGL((k_conv_split_ws<10>), dim3(NMB * ngroup), dim3(256), 0, s, in, (const v4u_t *)Wp, bias, x0a, x0b, B16, Tout, Mt, winlen, ldp,
                            (unsigned char *)out_split, split_pow2(split_exp), split_pow2(acc_exp), sat, ngroup);
         return;
     }
