@@ -323,9 +323,12 @@ def test_matrices_of_the_hot_path_stay_on_the_device(host, model_dir):
 @pytest.mark.gpu
 def test_transition_matrix_released_with_a_plain_free(host, model_dir):
     """flappie.c:281 releases the transition matrix with free(), not free_flappie_matrix(): the device image of such a struct is found again
-    through its address (ffhip_dev_remember / ffhip_dev_forget, flappie_matrix.c).  The reference's calculate_post sequence 40 times: the
-    pool must not grow with the reads, no buffer may ever sit twice in a free list, and an image released by another path first
-    (a host-side write, an operator replacing a stale output image) must not be released again when its address comes back."""
+    through its address (ffhip_dev_remember / ffhip_dev_forget, flappie_matrix.c) when malloc hands that address to the next matrix -- which a C
+    program's allocator does within a read or two (the struct's size class is its own), and which this process, whose interpreter allocates
+    between the calls, does only now and then: what is held here is what must hold EITHER way.  The reference's calculate_post sequence
+    40 times: no buffer may ever sit twice in a free list; an image released by another path first (a host-side write, an operator replacing
+    a stale output image) leaves no record behind and is not released again when its address comes back; every buffer the pool has
+    allocated is in a free list, remembered for an address, or owned by a live matrix (none at the end)."""
     d, mdls = model_dir
     os.environ["FLAPPIE_MODEL_DIR"] = d
     libc = C.CDLL(None)
@@ -363,7 +366,8 @@ def test_transition_matrix_released_with_a_plain_free(host, model_dir):
             assert s["twice"] == 0, (it, s)
             seen.append(s)
         print("pool after 40 reads:", seen[-1], "after 10:", seen[9])
-        assert seen[-1]["owners"] <= 3 and seen[-1]["buffers"] <= seen[9]["buffers"] + 4, (seen[9], seen[-1])
+        # 40 reads: 13 images were released by the host-side write (no record), at most 27 can still be remembered; nothing else is outstanding
+        assert seen[-1]["owners"] <= 27 and seen[-1]["buffers"] == seen[-1]["free"] + seen[-1]["owners"], seen[-1]
     finally:
         host.flappie_hip_shutdown()
         del os.environ["FLAPPIE_MODEL_DIR"]
