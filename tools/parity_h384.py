@@ -11,7 +11,9 @@ the driver times.  Every read also goes through the oracle TWICE (process pools,
 so that the engine's distance from the oracle stands beside the distance BETWEEN TWO SUMMATION ORDERS OF THE REFERENCE ALGORITHM on
 the same reads: a called base that flips between those two is a near-tie of the posterior decode, not a property of the engine.
 Half the pairs are uniform (every read `tmax` samples), half ragged (1500 .. tmax, sorted as the flappie binary sorts).
-Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500]"""
+Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500] [shape=c2]
+shape: c2 = LSTM H 384 in pairs of 256-read batches (the default, the headline); h256 / c4 = LSTM / GRUmod H 256 in full 1024-read launches of the
+packed kernels (k_lstm_pack / k_grumod_pack); c5 = LSTM H 512 in 256-read batches (k_lstm_split<0,4,2>).  bench.py's models (seed 1)."""
 import multiprocessing as mp
 import os
 import sys
@@ -23,7 +25,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from flappie_amd import model as M  # noqa: E402
 
-KIND, H, SEED = M.NET_LSTM5, 384, 1
+SHAPES = {"c2": (M.NET_LSTM5, 384, 256, True), "h256": (M.NET_LSTM5, 256, 1024, False), "c4": (M.NET_GRUMOD5, 256, 1024, False), "c5": (M.NET_LSTM5, 512, 256, False)}
+SHAPE = sys.argv[3] if len(sys.argv) > 3 else "c2"
+KIND, H, PER_BATCH, PAIRED = SHAPES[SHAPE]
+SEED = 1
 _om = None
 
 
@@ -77,15 +82,15 @@ class Tally:
 def main():
     nread = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     tmax = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
-    assert nread % 512 == 0
+    assert nread % (2 * PER_BATCH) == 0
     t0 = time.time()
     rng = np.random.default_rng(3840)
     batches = []
-    for k in range(nread // 256):
-        if (k // 2) % 2 == 0:
-            sigs = [rng.standard_normal(tmax).astype(np.float32) for _ in range(256)]
+    for k in range(nread // PER_BATCH):
+        if (k // 2) % 2 == 0 and SHAPE == "c2" or SHAPE != "c2" and k % 2 == 0:
+            sigs = [rng.standard_normal(tmax).astype(np.float32) for _ in range(PER_BATCH)]
         else:
-            lens = np.sort(rng.integers(1500, tmax + 1, 256))[::-1]
+            lens = np.sort(rng.integers(tmax * 3 // 5, tmax + 1, PER_BATCH))[::-1]
             sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
         batches.append(sigs)
     flat = [x for sigs in batches for x in sigs]
@@ -103,17 +108,21 @@ def main():
     dm = B.DeviceModel(eng, M.synthetic_model(KIND, H, seed=SEED))
     t_eng0, t_eng3, t_00 = Tally("engine <-> oracle"), Tally("engine <-> oracle+blas"), Tally("oracle <-> oracle+blas")
     min_kmers, paired = 10 ** 9, 0
-    bs = [B.Batch(dm, 256, tmax) for _ in range(2)]
+    bs = [B.Batch(dm, PER_BATCH, tmax) for _ in range(2)]
     for k in range(0, len(batches), 2):
         for j in (0, 1):
             bs[j].set_signals_ragged(batches[k + j])
-        bs[0].run_pair(bs[1])
+        if PAIRED:
+            bs[0].run_pair(bs[1])
+        else:
+            bs[0].run(); bs[1].run()
         for j in (0, 1):
             b = bs[j]
             b.finish()
             paired += int(b.paired())
-            for r in range(256):
-                i = (k + j) * 256 + r
+            assert b.rnn_path() == 3
+            for r in range(PER_BATCH):
+                i = (k + j) * PER_BATCH + r
                 a = dict(basecall=b.basecall(r), quality=b.quality(r), path=b.path(r)[0], trans=b.transitions(r))
                 tag = "batch %d read %d (%d samples)" % (k + j, r, flat[i].size)
                 t_eng0.add(tag, a, ref0[i])
@@ -125,8 +134,8 @@ def main():
     for b in bs:
         b.close()
     dm.close()
-    print("campaign: H = 384 through ffhip_batch_run_pair, %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
-          % (paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
+    print("campaign: shape %s (kind %d, H = %d, %d reads a batch%s), %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
+          % (SHAPE, KIND, H, PER_BATCH, ", through ffhip_batch_run_pair" if PAIRED else "", paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
     for t in (t_eng0, t_eng3, t_00):
         print(t.line())
         for n in t.named:
