@@ -286,6 +286,8 @@ struct ffhip_model {
     RnnDev rnn[5];
     float4 *FFp = nullptr;
     float *FFb = nullptr;
+    void *FFsplit = nullptr;    // the head's weights as fp16 slices in 16x16x32 A order (k_head_split: reads the last layer's split output)
+    int FF_split_S = 0;         // exponent its accumulators carry: weight exponent + kSplitExpH
     std::vector<void *> owned;
 };
 
@@ -485,6 +487,29 @@ extern "C" ffhip_model *ffhip_model_upload(ffhip_engine *eng, const ffhip_model_
         m->FFp = (float4 *)dev_upload(m, wp.data(), wp.size() * 4);
         m->FFb = (float *)dev_upload(m, bias.data(), bias.size() * 4);
         if (!m->FFp || !m->FFb) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        if (kSplitF16 && Hp % 32 == 0 && split_supported(m->cell, Hp)) {
+            // the same weights for the split-operand head: [mt][K chunk of 32][slice][lane][8 halves], row 16 mt + (lane & 15), k = 32 c + 8 (lane >> 4) + e
+            const int Hc = Hp / 32;
+            float mx = 0.0f;
+            for (int p = 0; p < P; p++)
+                for (int k = 0; k < H; k++) mx = fmaxf(mx, fabsf(W->data.f[(size_t)p * W->stride + k]));
+            const int sw = split_weight_exp(mx);
+            m->FF_split_S = sw + kSplitExpH;
+            std::vector<uint16_t> sp((size_t)Mt * Hc * kSplitNS * 64 * 8);
+            for (int mt = 0; mt < Mt; mt++)
+                for (int c = 0; c < Hc; c++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            const int row = mt * 16 + (lane & 15), k = c * 32 + (lane >> 4) * 8 + e;
+                            const float w = (row < P && k < H) ? W->data.f[(size_t)row * W->stride + k] : 0.0f;
+                            uint16_t sl[kSplitNS];
+                            split_host_slices(w, sw, sl);
+                            const size_t base = (((size_t)mt * Hc + c) * kSplitNS) * 64 * 8 + (size_t)lane * 8 + e;
+                            for (int q = 0; q < kSplitNS; q++) sp[base + (size_t)q * 64 * 8] = sl[q];
+                        }
+            m->FFsplit = dev_upload(m, sp.data(), sp.size() * 2);
+            if (!m->FFsplit) { set_err(FFHIP_ENOMEM, "device allocation failed"); ffhip_model_free(m); return nullptr; }
+        }
     }
 #undef FAIL
     return m;
@@ -958,6 +983,9 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                             rnn_split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
     // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
     const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
+    // the CRF head reads the last layer's SPLIT output (k_head_split): that layer then writes no fp32 copy (315 MB per headline batch, ~65 us of
+    // its launch) and the batch needs no fp32 activation buffer at all (FFHIP_NO_SPLIT_HEAD: the f32-MFMA head on the fp32 copy)
+    const bool split_head = use_split && !keep && m->FFsplit != nullptr && !getenv("FFHIP_NO_SPLIT_HEAD");
     const bool prof = b->eng->profiling != 0;
     const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
@@ -965,7 +993,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     int cur = b->run_cur;
     {
         const bool need0 = !conv_split;           // the convolution's fp32 output (every path but split layers behind a split-writing convolution)
-        for (int i = need0 ? 0 : 1; i < 2; i++)
+        for (int i = need0 ? 0 : 1; i < ((split_head && !need0) ? 1 : 2); i++)      // (act[1]: the last layer's fp32 copy for the f32 head)
             if (!b->act[i] && !(b->act[i] = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4, false))) return FFHIP_ENOMEM;
     }
   if (phases & PH_FRONT) {
@@ -1063,7 +1091,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             void *outS = b->actS[cur ^ 1];
             // (the output doubles as the hand-off flag; the kernel arms it itself a few steps ahead of its stores -- no fill)
             // the fp32 copy of a layer's output is needed by the CRF head (last layer) and by FFHIP_RUN_KEEP_ACTS
-            float *out_f32 = (l == 4 || keep) ? out : nullptr;
+            float *out_f32 = ((l == 4 && !split_head) || keep) ? out : nullptr;
             for (int rt0 = 0, nrt = 0; rt0 < B16; rt0 += nrt) {
                 nrt = split_next_launch_tiles(m->cell, Hp, B16 - rt0, b->eng->prop.multiProcessorCount);
                 (void)maxt1; (void)maxt2;
@@ -1146,12 +1174,14 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     bool post_done = false;                       // the posterior came out of the partition function's launch
     if (rle) {
         // ---- globalnorm_runlengthV2 (layers.c:1325-1358)
-        launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, 1.0f, 1);
+        if (split_head) launch_head_split(s, b->actS[cur], b->trans, m->FFsplit, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 32, 1.0f, m->FF_split_S, 1);
+        else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, 1.0f, 1);
         launch_rle_head_finish(s, b->trans, b->crf_logz, b->nread, Tb, m->nbase, m->Ps, temperature, tbs);
         b->launches[3] += 4;
     } else {
         // ---- globalnorm_flipflop (layers.c:1082-1106)
-        launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
+        if (split_head) launch_head_split(s, b->actS[cur], b->trans, m->FFsplit, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 32, temperature / 5.0f, m->FF_split_S, 0);
+        else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
         const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
@@ -1288,6 +1318,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     const char *pm_env = getenv("FFHIP_PERSIST_MODE");
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     ffhip_batch *bb[2] = { b0, b1 };
+    const bool split_head_pair = m->FFsplit != nullptr && !getenv("FFHIP_NO_SPLIT_HEAD");      // as batch_run_impl's split_head (a pair never keeps activations)
     bool paired = true;
     for (int l = 0; l < 5 && paired; l++) {
         const RnnDev &r = m->rnn[l];
@@ -1296,7 +1327,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
             ffhip_batch *b = bb[k];
             const int cur = b->run_cur;
             b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
-            p[k] = SplitLaunch{ r.Wsplit, r.bias, b->actS[cur], b->actS[cur ^ 1], (l == 4) ? b->act[cur ^ 1] : nullptr, b->pflags, b->pabort,
+            p[k] = SplitLaunch{ r.Wsplit, r.bias, b->actS[cur], b->actS[cur ^ 1], (l == 4 && !split_head_pair) ? b->act[cur ^ 1] : nullptr, b->pflags, b->pabort,
                                 b->Tb, b->B16, 0, b->B16, (l % 2 == 0) ? 1 : 0, persist_mode, r.split_S, fast_gates,
                                 b->ragged ? b->d_tbs : nullptr, b->ragged ? b->d_tbt : nullptr, b->split_epoch };
             if (prof) { hipEventRecord(b->lev[l][0], s); hipEventRecord(b->lev[l][1], s); }
@@ -1503,7 +1534,7 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
     const ffhip_model *m = b->mdl;
     const float *src = b->keep[layer + 1];
     if (!src) {
-        if (layer == 4) src = b->act[b->final_act];
+        if (layer == 4 && b->act[b->final_act] && !(b->rnn_path == 3 && b->mdl->FFsplit && !getenv("FFHIP_NO_SPLIT_HEAD"))) src = b->act[b->final_act];      // (the default path keeps no fp32 copy of the last layer: k_head_split)
         else return set_err(FFHIP_EINVAL, "activation of layer %d was not kept (run with flag 16)", layer);
     }
     hipSetDevice(b->eng->device);

@@ -118,6 +118,9 @@ void launch_split_from_f32(hipStream_t s, const float *in, void *out, size_t nti
 void launch_f32_from_split(hipStream_t s, const void *in, float *out, size_t ntile, int H, int act_exp);
 void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned long long *bad);      // adds the mismatch count to *bad
 
+// the same head on the last layer's split output (ffhip_rnn_split.hip layout), weights as fp16 slices scaled by 2^(acc_exp - kSplitExpH)
+void launch_head_split(hipStream_t s, const void *in_split, float *trans, const void *Wsplit, const float *bias,
+                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw);
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw = 0);      // raw = 1: W^T h + b only

@@ -736,6 +736,108 @@ k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__res
     }
 }
 
+// ---- the same head on the last layer's SPLIT output (round 4) ------------------------------------------------------------------
+// trans = tanh(W^T h + b) / (temperature / 5) with h read as the recurrent layer kernels leave it -- two fp16 slices of h * 2^12 in the
+// B-operand order of v_mfma_f32_16x16x32_f16, 1 KiB per (K chunk, slice) -- and W as fp16 slices of W * 2^sw: three products per chunk
+// (w1 h0, w0 h1, w0 h0: fp32-grade, ffhip_split.hpp), accumulators in the scaled space 2^S (bias pre-multiplied, result multiplied by
+// 2^-S: powers of two, no rounding).  The last layer then writes no fp32 copy of h.  A wave owns TM row tiles x 4 (block, read tile)
+// columns; operands of chunk c + 1 are loaded under the MFMAs of chunk c.  The epilogue is k_head's, value for value.
+template <int TM>
+__global__ void __launch_bounds__(256)
+k_head_split(const unsigned char *__restrict__ in, float *__restrict__ trans, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
+             int Tb, int B16, int nread, int P, int Ps, int Mt, int Hc, float scale, float acc_scale, int raw) {
+    constexpr int TN = 4, NSL = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntile = Tb * B16;
+    const int nt0 = (blockIdx.x * 4 + wave) * TN;
+    if (nt0 >= ntile) return;
+    const int q = lane >> 4, rl = lane & 15;
+    const size_t tileB = (size_t)Hc * NSL * 1024;
+    v4f acc[TM][TN];
+    const v4u_t *ap[TM];
+    const unsigned char *bp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = min(i, Mt - 1);
+        ap[i] = Wp + (size_t)mt * Hc * NSL * 64 + lane;
+        const v4f bv = *(const v4f *)(bias + mt * 16 + q * 4) * acc_scale;
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = bv;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) bp[j] = in + (size_t)min(nt0 + j, ntile - 1) * tileB + (size_t)lane * 16;
+    v4u_t A0[TM][NSL], B0[TN][NSL], A1[TM][NSL], B1[TN][NSL];
+    auto load = [&](v4u_t (&A)[TM][NSL], v4u_t (&B)[TN][NSL], int c) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int sl = 0; sl < NSL; sl++) A[i][sl] = ap[i][(size_t)(c * NSL + sl) * 64];
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int sl = 0; sl < NSL; sl++) B[j][sl] = *(const v4u_t *)(bp[j] + (size_t)(c * NSL + sl) * 1024);
+    };
+    auto mma = [&](v4u_t (&A)[TM][NSL], v4u_t (&B)[TN][NSL]) {
+        constexpr int WS[3] = { 1, 0, 0 }, XS[3] = { 0, 1, 0 };      // smallest terms first
+#pragma unroll
+        for (int term = 0; term < 3; term++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][WS[term]]), __builtin_bit_cast(v8h_t, B[j][XS[term]]), acc[i][j], 0, 0, 0);
+    };
+    load(A0, B0, 0);
+    for (int c = 0; c < Hc; c += 2) {
+        if (c + 1 < Hc) load(A1, B1, c + 1);
+        mma(A0, B0);
+        if (c + 1 < Hc) {
+            if (c + 2 < Hc) load(A0, B0, c + 2);
+            mma(A1, B1);
+        }
+    }
+    const float inv_scale = 1.0f / acc_scale;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int p = i * 16 + q * 4;
+        if (i >= Mt || p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            if (nt >= ntile) continue;
+            const int blk = nt / B16, read = (nt % B16) * 16 + rl;
+            if (read >= nread) continue;
+            const v4f v = acc[i][j] * inv_scale;
+            float *o = trans + ((size_t)read * Tb + blk) * Ps + p;
+            const float vv[4] = { v.x, v.y, v.z, v.w };
+            float rr[4];
+            if (raw) { rr[0] = vv[0]; rr[1] = vv[1]; rr[2] = vv[2]; rr[3] = vv[3]; }
+            else {
+                const ffv4 t = apply_act4((ffv4){ vv[0], vv[1], vv[2], vv[3] }, 2);
+                rr[0] = (t.x - 0.0f) / scale; rr[1] = (t.y - 0.0f) / scale; rr[2] = (t.z - 0.0f) / scale; rr[3] = (t.w - 0.0f) / scale;
+            }
+            if (p + 3 < P && (Ps & 3) == 0) *(float4 *)o = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (p + e < P) o[e] = rr[e];
+            }
+        }
+    }
+}
+
+void launch_head_split(hipStream_t s, const void *in_split, float *trans, const void *Wsplit, const float *bias,
+                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw) {
+    const int Mt = (P + 15) / 16;
+    const int ntile = Tb * B16;
+    if (Mt <= 3)
+        hipLaunchKernelGGL(k_head_split<3>, dim3((ntile + 15) / 16), dim3(256), 0, s, (const unsigned char *)in_split, trans, (const v4u_t *)Wsplit, bias, Tb, B16,
+                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw);
+    else
+        hipLaunchKernelGGL(k_head_split<4>, dim3((ntile + 15) / 16), dim3(256), 0, s, (const unsigned char *)in_split, trans, (const v4u_t *)Wsplit, bias, Tb, B16,
+                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw);
+}
+
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw) {
     const int Mt = (P + 15) / 16;
