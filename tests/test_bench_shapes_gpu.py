@@ -7,7 +7,7 @@
 
 The models are bench.py's (synthetic_model(kind, H, seed=1)); tests/test_cabi_and_model.py::test_synthetic_models_are_input_driven holds
 them to >= 1 base per 12 samples and >= 100 distinct 5-mers per 4000-sample read.  Bounds: north_star's -- base string, quality string and
-Viterbi path identical, transition scores within 1e-4; every test prints its worst |dtrans| and what it compared."""
+Viterbi path identical, transition scores within 5e-5 (half of north_star's 1e-4; measured worst 2.1e-5); every test prints its worst |dtrans| and what it compared."""
 import numpy as np
 import pytest
 
@@ -34,11 +34,13 @@ def compare(b, r, ref, stats):
     stats["reads"] += 1
     stats["bases"] += len(ref["basecall"])
     stats["kmers"] = min(stats["kmers"], kmers(ref["basecall"]))
-    assert d <= 1e-4, (r, d)
+    from conftest import note_parity
+    note_parity(d, np.abs(b.posterior(r) - ref["post"]).max())
+    assert d <= 5e-5, (r, d)
     assert b.basecall(r) == ref["basecall"], r
     assert b.quality(r) == ref["quality"], r
     assert np.array_equal(b.path(r)[0], ref["path"]), r
-    assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4          # (the scores' own deviation through two log-sum-exp recursions: tests/test_split_gpu.py)
+    assert np.abs(b.posterior(r) - ref["post"]).max() <= 1e-4          # (the scores' own deviation through two log-sum-exp recursions: tests/test_split_gpu.py)
     off = int((np.abs(b.trace(r) - ref["trace"]) > 0).sum())
     assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
     stats["trace_off"] += off

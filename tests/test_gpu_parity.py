@@ -2,8 +2,8 @@
 inputs, against the committed vectors, and -- at BASELINE.json's full size -- through
 size-independent properties.
 
-Tolerances (BASELINE.json north_star): transition scores within 1e-4 (absolute, fp32), called base
-string bit-exact.  Integer outputs (path, trace) are compared exactly except `trace`, whose
+Tolerances: BASELINE.json north_star asks for transition scores within 1e-4 (absolute, fp32) and a bit-exact called base
+string; the suite holds the scores to 5e-5 (measured worst: 2.1e-5).  Integer outputs (path, trace) are compared exactly except `trace`, whose
 round(255 p) may differ by one count where p sits on a rounding boundary."""
 import os
 
@@ -14,8 +14,10 @@ from flappie_amd import model as M
 
 pytestmark = pytest.mark.gpu
 
-TOL_SCORE = 1e-4
-TOL_POST = 2e-4          # log posterior END TO END (see compare_read); the kernel alone: 2e-5 + 2e-6 |x| (tests/test_decode_gpu.py)
+# Round 4: on the input-driven, well-conditioned models (flappie_amd/model.py SYNTH_GAINS) the whole GPU suite sees worst |dtrans| 2.1e-5 and worst
+# end-to-end |dlogpost| 4.0e-5 over 434 reads (printed at the end of every run: tests/conftest.py) -- the bounds are HALF north_star's now, not at it
+TOL_SCORE = 5e-5
+TOL_POST = 1e-4          # log posterior END TO END (see compare_read); the kernel alone: 2e-5 + 2e-6 |x| (tests/test_decode_gpu.py)
 _trace_cells = [0, 0]    # [cells compared, cells off by one count] of the current test
 
 
@@ -51,11 +53,13 @@ def run_batch(B, engine, mdl, sig, flags=0, temperature=1.0):
 def compare_read(b, r, ref, viterbi=False):
     tr = b.transitions(r)
     assert np.isfinite(tr).all()
+    from conftest import note_parity
+    note_parity(np.abs(tr - ref["trans"]).max(), None if viterbi else np.abs(b.posterior(r) - ref["post"]).max())
     assert np.abs(tr - ref["trans"]).max() <= TOL_SCORE
     path, qpath = b.path(r)
     assert np.array_equal(path, ref["path"])
     assert np.isnan(qpath[0])
-    assert np.abs(qpath[1:] - ref["qpath"][1:]).max() <= TOL_SCORE
+    assert np.abs(qpath[1:] - ref["qpath"][1:]).max() <= TOL_POST          # (the path's per-block scores ARE posterior entries unless viterbi-only)
     assert b.basecall(r) == ref["basecall"]
     assert b.quality(r) == ref["quality"]
     assert abs(b.score(r) - ref["score"]) <= 2e-3 * max(1.0, abs(ref["score"]) * 1e-2)

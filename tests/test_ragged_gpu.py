@@ -26,15 +26,17 @@ def engine(B):
 def check_read(b, r, ref, viterbi_only=False):
     assert b.read_nblock(r) == ref["nblock"]
     dtrans = float(np.abs(b.transitions(r) - ref["trans"]).max())
-    assert dtrans <= 1e-4
+    from conftest import note_parity
+    note_parity(dtrans, None if viterbi_only else np.abs(b.posterior(r) - ref["post"]).max())
+    assert dtrans <= 5e-5          # half of north_star's 1e-4 (measured worst over the suite: 2.1e-5)
     path, qpath = b.path(r)
     assert np.array_equal(path, ref["path"])
     assert b.basecall(r) == ref["basecall"] and b.quality(r) == ref["quality"]
     assert abs(b.score(r) - ref["score"]) <= 1e-3 * max(1.0, abs(ref["score"]))
     if not viterbi_only:
-        # end to end: the scores' own deviation (<= 1e-4) propagates through two log-sum-exp recursions -- measured up to 1.2e-4 at |dtrans| = 2.6e-5 --
-        # so this bound cannot be the posterior kernel's; THAT is held to 2e-5 + 2e-6 |x| on identical scores in tests/test_decode_gpu.py
-        assert np.abs(b.posterior(r) - ref["post"]).max() <= 2e-4
+        # end to end: the scores' own deviation propagates through two log-sum-exp recursions (measured worst 4.0e-5 at |dtrans| <= 2.1e-5);
+        # the posterior kernel alone is held to 2e-5 + 2e-6 |x| on identical scores in tests/test_decode_gpu.py
+        assert np.abs(b.posterior(r) - ref["post"]).max() <= 1e-4
         assert np.abs(b.trace(r) - ref["trace"]).max() <= 1
 
 
