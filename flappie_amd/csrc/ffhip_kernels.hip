@@ -447,6 +447,8 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
     // work list of this workgroup: tiles g, g + ngroup, ...; a tile with a second window is two passes over the same accumulators.
     // The window table is read one tile AHEAD of the gather that uses it (cur_*: this tile, nxt_*: the next), the gather one item ahead of
     // the MFMAs that use it: at the top of an iteration everything older than the last epilogue's four stores has arrived.
+    // (Measured and dropped: starting every other workgroup of a CU half an iteration late -- are the two in each other's way by running in
+    // phase? -- 0.305-0.308 ms per convolution group either way.)
     int nt = g, pass = 0, buf = 0;
     int cur_a, cur_b, nxt_a, nxt_b;
     table(nt, cur_a, cur_b);
