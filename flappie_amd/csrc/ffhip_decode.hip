@@ -105,11 +105,14 @@ template <int TOPO> __device__ __forceinline__ bool vit_has(int to, int from) { 
 //     main' = reduce(e1 * a + e2 * x)        e2: from the extra source carried at this lane's in-position into the lane's destination
 //     x'    = reduce(f1 * x + f2 * a)        in the lanes whose out-position is 3 or 4: f1 extra -> extra (stay), f2 main source -> extra
 // and x' lands at positions 3, 4 of the form main' lands in.  Two independent reductions per step; everything else as for NS = 8.
-constexpr int kFbChunk = 32;             // blocks of E staged in LDS per chunk and direction
 template <int NS, int TOPO = 0> struct FbDims {
     static constexpr int P = TOPO == 1 ? 32 : NS * (NS / 2 + 1);
     static constexpr int Pd = (P + 1 + 7) & ~7;               // crf_exp_stride(P): P entries, the block maximum at [P], zeros behind it
-    static constexpr int kStage = kFbChunk * Pd / 64;         // doubles per lane and chunk
+    // blocks of E staged in LDS per chunk and direction.  32 for the 8-state models; 16 for the 10-state ones, whose rows are 64 doubles: with 32
+    // the workgroup took 43 KB of LDS, three workgroups a CU, and the 1024 reads of a `c4` batch ran in two rounds -- with 16 (27 KB) all 1024
+    // chains are resident at once (four workgroups a CU, what their 176 registers allow)
+    static constexpr int kChunk = NS > 8 ? 16 : 32;
+    static constexpr int kStage = kChunk * Pd / 64;           // doubles per lane and chunk
     static constexpr int pad = P + 1;                         // an entry that reads as zero
 };
 
@@ -128,7 +131,7 @@ template <int NS, bool FWD, int TOPO = 0> __device__ __forceinline__ int fb_coef
 template <int NS, bool FWD, int TOPO = 0>
 __device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const int Tb, double *__restrict__ ebuf, double (*__restrict__ stage)[TOPO == 1 ? 10 : NS],
                                          double *__restrict__ vec, const bool store, double *__restrict__ logz) {
-    constexpr int Pd = FbDims<NS, TOPO>::Pd, P = FbDims<NS, TOPO>::P, kStage = FbDims<NS, TOPO>::kStage;
+    constexpr int Pd = FbDims<NS, TOPO>::Pd, P = FbDims<NS, TOPO>::P, kStage = FbDims<NS, TOPO>::kStage, kFbChunk = FbDims<NS, TOPO>::kChunk;
     constexpr bool ABS = TOPO == 1;
     constexpr int RS = ABS ? 10 : NS;                           // doubles per stored row
     constexpr bool X = NS > 8;                                 // states 8, 9 ride in the second vector
@@ -244,7 +247,7 @@ template <int NS, int TOPO = 0>
 __global__ void __launch_bounds__(128)
 k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__restrict__ bwdbuf, int TbS, double *__restrict__ logz_out,
          const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
-    constexpr int Pd = FbDims<NS, TOPO>::Pd, RS = TOPO == 1 ? 10 : NS;
+    constexpr int Pd = FbDims<NS, TOPO>::Pd, RS = TOPO == 1 ? 10 : NS, kFbChunk = FbDims<NS, TOPO>::kChunk;
     __shared__ double ebuf[2][kFbChunk * Pd];
     __shared__ double stage[2][64][RS];
     __shared__ double s_logz;
