@@ -35,15 +35,15 @@ CONFIGS = {
     "c2":   dict(kind=0, hidden=384, nread=256, nsample=4000, steps=200, warmup=5, inflight=2, pair=1, ident="r941native",
                  metric="Msamples/s basecalled (r941_native, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=384, batch=256 synthetic 4000-sample reads per GPU, posterior decode + trace (BASELINE.json configs[1])"),
-    "h256": dict(kind=0, hidden=256, nread=1024, nsample=4000, steps=100, warmup=5, ident="r941native",
+    "h256": dict(kind=0, hidden=256, nread=1024, nsample=4000, steps=100, warmup=5, inflight=2, ident="r941native",
                  metric="Msamples/s basecalled (r941_native 20200220-size model, 4k-sample chunks)",
                  label="r941_native-shape LSTM5 H=256 (the 41.8 MB model file), batch=1024 synthetic 4000-sample reads per GPU (what one layer launch of the packed form takes at H = 256: 16 members a group, two workgroups per CU), posterior decode + trace"),
-    "c4":   dict(kind=1, hidden=256, nread=1024, nsample=4000, steps=40, warmup=3, ident="r941_5mC",
+    "c4":   dict(kind=1, hidden=256, nread=1024, nsample=4000, steps=40, warmup=3, inflight=2, ident="r941_5mC",
                  metric="Msamples/s basecalled (r941_5mC, 4k-sample chunks)",
                  label="r941_5mC-shape GRUmod5 H=256, stride 2 (2000 blocks per read), 10 flip-flop states, batch=1024 synthetic 4000-sample reads per GPU (what one layer launch of the packed GRUmod form takes: "
                        "16 members a group, two workgroups per CU), "
                        "posterior decode + trace (BASELINE.json configs[3])"),
-    "c5":   dict(kind=0, hidden=512, nread=256, nsample=100000, steps=5, warmup=1, ident="r103native",
+    "c5":   dict(kind=0, hidden=512, nread=256, nsample=100000, steps=6, warmup=2, inflight=2, ident="r103native",
                  metric="Msamples/s basecalled (r103_native standing in for r10C_pcr, 100k-sample reads, trace on)",
                  label="r103_native-shape LSTM5 H=512 (SURVEY.md section 0.3: there is no r10C_pcr model), batch=256 synthetic 100000-sample reads per GPU, "
                        "posterior decode + trace (BASELINE.json configs[4])"),
@@ -550,9 +550,9 @@ def main():
             # what a step takes beyond its share of the layer launches: convolutions, head, decode and launch gaps that nothing hides
             "exposed_ms": round(dt / steps * 1e3 - rec["ms"] / (2.0 if paired_ else 1.0), 4),
             "kernel_ms_note": ("one batch in flight: the kernels of a step run back to back" if nfl == 1 else
-                               "two batches in flight: the convolution / head / decode kernels of one batch run BESIDE the other batch's layer launches, "
-                               "so their durations here overlap those and do not add up to ms_per_step; `--inflight 1` gives the serial breakdown "
-                               "(profiles/r02_c2_inflight1_bench.json)"),
+                               "two batches (or pairs) in flight: between two batches' layer launches the head / decode kernels of the one run BESIDE the "
+                               "convolutions of the next (ordered by the engine: FFHIP_FRONT_ORDER), so their durations here are stretched by each other, "
+                               "overlap, and do not add up to ms_per_step; `--inflight 1` gives the serial breakdown"),
             # decode side (posterior + Viterbi + assembly + trace): algorithmic bytes per block (SURVEY.md section 8d:
             # 4P read + nstate traceback + 8 path/qpath, plus 4P read + 4P write for the posterior) against HBM peak.
             # At 256 reads these kernels are latency-bound chains, not bandwidth-bound.  For the 8- and 10-state models the

@@ -31,6 +31,12 @@
 #include "ffhip_math.hpp"
 #include <stdlib.h>
 
+// a dependent chain: its wave goes first wherever another batch's convolutions share the SIMD
+#ifndef FFHIP_CHAIN_PRIO
+#define FFHIP_CHAIN_PRIO 3
+#endif
+#define FFHIP_CHAIN_PRIO_SET() __builtin_amdgcn_s_setprio(FFHIP_CHAIN_PRIO)
+
 namespace ffhip {
 
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
@@ -247,6 +253,7 @@ template <int NS, int TOPO = 0>
 __global__ void __launch_bounds__(128)
 k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__restrict__ bwdbuf, int TbS, double *__restrict__ logz_out,
          const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
+    FFHIP_CHAIN_PRIO_SET();
     constexpr int Pd = FbDims<NS, TOPO>::Pd, RS = TOPO == 1 ? 10 : NS, kFbChunk = FbDims<NS, TOPO>::kChunk;
     __shared__ double ebuf[2][kFbChunk * Pd];
     __shared__ double stage[2][64][RS];
@@ -412,6 +419,7 @@ __device__ __forceinline__ double fmax_hi3_d(double v) {
 
 __global__ void __launch_bounds__(64)
 k_rle_partition8x(const float *__restrict__ param, int TbS, double *__restrict__ logz, const int *__restrict__ tbs) {
+    FFHIP_CHAIN_PRIO_SET();
     constexpr int Ps = 40, nbase = 4;
     const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
     const float *T = param + (size_t)blockIdx.x * TbS * Ps + 2 * nbase;
@@ -515,6 +523,7 @@ template <int TOPO>
 __global__ void __launch_bounds__(64)
 k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
             float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
+    FFHIP_CHAIN_PRIO_SET();
     constexpr int Ps = 40, ns = 8, nbase = 4, off = 32;
     __shared__ unsigned long long tbw[kVitChunk];           // per block: first the ballot, then the 8 traceback bytes
     __shared__ unsigned careful[kVitChunk / 8 / 32];        // bit per group of 8 blocks: its words are one-hot in the lo layout
@@ -750,6 +759,7 @@ constexpr int kVit10Chunk = 1024;
 __global__ void __launch_bounds__(64)
 k_viterbi10x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
              float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
+    FFHIP_CHAIN_PRIO_SET();
     constexpr int NS = 10, Ps = 60, nbase = 5, off = 50, PAD = 0;
     __shared__ unsigned long long tb0[kVit10Chunk], tb1[kVit10Chunk], tb2[kVit10Chunk];    // ballots, then traceback bytes of states 0..7 | 8, 9
     __shared__ unsigned careful[kVit10Chunk / 8 / 32];

@@ -53,10 +53,12 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
         delete e;
         return nullptr;
     }
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
+    if (const char *ns = getenv("FFHIP_STREAMS")) e->nstreams = atoi(ns) < 2 ? 2 : (atoi(ns) > 4 ? 4 : atoi(ns));
+    for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming), (delete e, nullptr));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreateWithFlags(&e->done_ring[i], hipEventDisableTiming), (delete e, nullptr));
     ffhip::pool_engine_born(device);
     return e;
 }
@@ -228,19 +230,20 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     if (ffhip::pool_engine_gone(e->device)) ffhip::pool_trim(e->device);
-    for (int i = 0; i < 2; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
+    for (int i = 0; i < 4; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
     if (e->prep_stream) hipStreamDestroy(e->prep_stream);
     if (e->prep_pin) hipHostFree(e->prep_pin);
     for (int i = 0; i < 4; i++) if (e->prep_scratch[i]) hipFree(e->prep_scratch[i]);
     for (auto &b : e->prep_pool) hipFree(b.first);
     if (e->persist_done) hipEventDestroy(e->persist_done);
     if (e->batch_done) hipEventDestroy(e->batch_done);
+    for (int i = 0; i < 4; i++) if (e->done_ring[i]) hipEventDestroy(e->done_ring[i]);
     delete e;
 }
 
 extern "C" int ffhip_engine_synchronize(ffhip_engine *e) {
     if (!e) return set_err(FFHIP_EINVAL, "null engine");
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(e->streams[i]), FFHIP_EHIP);
+    for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamSynchronize(e->streams[i]), FFHIP_EHIP);
     return FFHIP_OK;
 }
 
@@ -608,6 +611,9 @@ struct ffhip_batch {
     int run_cur = 0;                    // which of act[] / actS[] holds the current activations between the phases of a run
     unsigned run_flags = 0;
     int paired_last = 0;                // the last run's layers were one launch with another batch's
+    ffhip_batch *prof_mate = nullptr;   // second batch of a profiled pair: the batch whose lev[][] events bracket the paired launches (two event records
+                                        // per launch instead of six: each is a packet between two layer launches, ~5 us of idle chip)
+    ffhip_batch *prof_ref = nullptr;    // ... and the first batch's way back, so that either can go first
     int pair_front = 0;                 // set by ffhip_batch_run_pair around the front phase: the layers to come are a paired (chip-filling) launch
     int profiled = 0;
 };
@@ -669,6 +675,8 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->h_abort) hipHostFree(b->h_abort);
     if (b->h_sat) hipHostFree(b->h_sat);
     if (b->side) ffhip_batch_destroy(b->side);
+    if (b->prof_ref && b->prof_ref->prof_mate == b) b->prof_ref->prof_mate = nullptr;
+    if (b->prof_mate && b->prof_mate->prof_ref == b) b->prof_mate->prof_ref = nullptr;
     if (b->have_ev) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
@@ -683,7 +691,7 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     ffhip_batch *b = new ffhip_batch();
     b->eng = eng; b->mdl = m;
     b->stream = eng->streams[eng->next_stream];
-    eng->next_stream ^= 1;
+    eng->next_stream = (eng->next_stream + 1) % eng->nstreams;
     b->nread = nread; b->B16 = (nread + 15) / 16; b->Bp = b->B16 * 16;
     b->T = (int)nsample;
 #define BFAIL() do { ffhip_batch_destroy(b); return nullptr; } while (0)
@@ -1002,8 +1010,6 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         for (int i = 0; i < 2; i++)
             if (!b->actS[i] && !(b->actS[i] = dalloc(b, bytes, false))) return FFHIP_ENOMEM;
     }
-    mark(b, 0);
-    HIP_TRY(hipMemsetAsync(b->sat, 0, (size_t)Bp * sizeof(unsigned), s), FFHIP_EHIP);
     // ---- convolutions (layers.c:189-276, activations :24-49)
     // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
     const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT_CONV") && !(flags & FFHIP_RUN_F32_RNN);
@@ -1023,7 +1029,19 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // Whole batches one after the other when this batch's layer launches fill the chip and it is not half of a pair: its convolutions
     // would otherwise run beside the other batch's layer launches, whose workgroups then wait for slots (h256 with two 768-read batches
     // in flight: 160 against 179 Msamples/s one at a time; c4: 65.5 against 75).  The host side still overlaps: this only orders the GPU.
-    if (full_chip && !b->pair_front && b->eng->batch_done_rec && !getenv("FFHIP_NO_BATCH_ORDER")) HIP_TRY(hipStreamWaitEvent(s, b->eng->batch_done, 0), FFHIP_EHIP);
+    // Round 4: the order is taken from the other batch's LAST LAYER LAUNCH instead of its last kernel -- this batch's convolutions then run
+    // beside that batch's head and decode (dependent chains of one wave a read: they leave the chip nearly empty), and a pair's front, on
+    // streams of its own (the engine hands out four), no longer queues behind the previous pair's decode: between two pairs' layer launches
+    // 1.33 ms of head + decode + copies + convolutions one after the other became max(...) of the two sides.  FFHIP_FRONT_ORDER=batch: round 3's.
+    const char *fo = getenv("FFHIP_FRONT_ORDER");
+    if (getenv("FFHIP_NO_BATCH_ORDER")) fo = "none";
+    const bool by_layers = !fo || fo[0] == 'l';
+    {
+        if (full_chip && by_layers && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
+        else if (full_chip && !by_layers && fo[0] == 'b' && !b->pair_front && b->eng->batch_done_rec) HIP_TRY(hipStreamWaitEvent(s, b->eng->batch_done, 0), FFHIP_EHIP);
+    }
+    mark(b, 0);                                        // (behind the wait: the convolution group's time is its kernels')
+    HIP_TRY(hipMemsetAsync(b->sat, 0, (size_t)Bp * sizeof(unsigned), s), FFHIP_EHIP);
     for (int l = 0; l < m->nconv; l++) {
         const ConvDev &c = m->conv[l];
         if (l < m->nconv - 1) {
@@ -1053,6 +1071,11 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         b->launches[0]++;
     }
     b->run_cur = cur;
+    // ... and this batch's LAYER launches follow the decode of the batches before it (the last two: a pair): a persistent launch that becomes
+    // resident piecemeal beside a running chain of decode kernels squeezes those onto the CUs it has not taken yet and cannot start before
+    // they are through (the run-length shape, whose head and decode are the longer side: 88 against 98 Msamples/s without this wait)
+    if (full_chip && by_layers && !getenv("FFHIP_NO_DECODE_WAIT"))
+        for (unsigned k = 1; k <= 2 && k <= b->eng->done_head; k++) HIP_TRY(hipStreamWaitEvent(s, b->eng->done_ring[(b->eng->done_head - k) & 3u], 0), FFHIP_EHIP);
   }      // PH_FRONT
   if (phases & PH_LAYERS) {
     for (int l = 0; l < 5; l++) {
@@ -1236,6 +1259,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     mark(b, 6);
     HIP_TRY(hipEventRecord(b->eng->batch_done, s), FFHIP_EHIP);
     b->eng->batch_done_rec = 1;
+    if (phases & PH_BACK) { HIP_TRY(hipEventRecord(b->eng->done_ring[b->eng->done_head & 3u], s), FFHIP_EHIP); b->eng->done_head++; }
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     b->ran = 1; b->finished = 0;
     if (!b->counted) { b->counted = 1; b->eng->in_flight++; }
@@ -1330,15 +1354,15 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
             p[k] = SplitLaunch{ r.Wsplit, r.bias, b->actS[cur], b->actS[cur ^ 1], (l == 4 && !split_head_pair) ? b->act[cur ^ 1] : nullptr, b->pflags, b->pabort,
                                 b->Tb, b->B16, 0, b->B16, (l % 2 == 0) ? 1 : 0, persist_mode, r.split_S, fast_gates,
                                 b->ragged ? b->d_tbs : nullptr, b->ragged ? b->d_tbt : nullptr, b->split_epoch };
-            if (prof) { hipEventRecord(b->lev[l][0], s); hipEventRecord(b->lev[l][1], s); }
         }
+        if (prof) hipEventRecord(b0->lev[l][1], s);
         if (eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, eng->persist_done, 0), FFHIP_EHIP);      // a paired launch fills the chip: after any other layer launch
         if (!launch_lstm_split_pair(s, m->cell, m->Hp, ncu, p[0], p[1])) { paired = false; break; }
         HIP_TRY(hipEventRecord(eng->persist_done, s), FFHIP_EHIP);
         eng->persist_chained = 1;
         eng->persist_last_half = 0;
+        if (prof) hipEventRecord(b0->lev[l][2], s);
         for (int k = 0; k < 2; k++) {
-            if (prof) hipEventRecord(bb[k]->lev[l][2], s);
             bb[k]->launches[2]++;
             bb[k]->run_cur ^= 1;
         }
@@ -1347,6 +1371,9 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     HIP_TRY(hipEventRecord(b0->pair_ev, s), FFHIP_EHIP);
     HIP_TRY(hipStreamWaitEvent(b1->stream, b0->pair_ev, 0), FFHIP_EHIP);     // the second batch's head and decode follow the paired layers
     b0->paired_last = b1->paired_last = 1;
+    if (b1->prof_mate && b1->prof_mate != b0 && b1->prof_mate->prof_ref == b1) b1->prof_mate->prof_ref = nullptr;
+    if (b0->prof_ref && b0->prof_ref != b1 && b0->prof_ref->prof_mate == b0) b0->prof_ref->prof_mate = nullptr;
+    b1->prof_mate = prof ? b0 : nullptr; b0->prof_ref = prof ? b1 : nullptr; b0->prof_mate = nullptr;
     if (int rc = batch_run_impl(b0, temperature, flags, PH_BACK)) return rc;
     return batch_run_impl(b1, temperature, flags, PH_BACK);
 }
@@ -1594,10 +1621,11 @@ extern "C" int ffhip_batch_profile(const ffhip_batch *b, float ms[FFHIP_NGROUP],
     hipEventElapsedTime(&t45, b->ev[4], b->ev[5]);
     hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
     float ms_inproj = 0.f, ms_rnn = 0.f;
+    const ffhip_batch *pb = (b->paired_last && b->prof_mate) ? b->prof_mate : b;      // a pair's launches are bracketed once, on the first batch (gone before its mate is asked: the layer time reads 0)
     for (int l = 0; l < 5; l++) {
         float a = 0.f, c = 0.f;
-        hipEventElapsedTime(&a, b->lev[l][0], b->lev[l][1]);
-        hipEventElapsedTime(&c, b->lev[l][1], b->lev[l][2]);
+        if (!b->paired_last) hipEventElapsedTime(&a, pb->lev[l][0], pb->lev[l][1]);
+        hipEventElapsedTime(&c, pb->lev[l][1], pb->lev[l][2]);
         if (b->launches[1] > 0) ms_inproj += a;      // a fused layer has no projection launch: that interval is the wait for the other batch's layer launches
         ms_rnn += c;
     }

@@ -11,8 +11,8 @@
 struct ffhip_engine {
     int device = 0;
     hipDeviceProp_t prop;
-    hipStream_t streams[2] = { nullptr, nullptr };
-    int next_stream = 0;
+    hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr };      // batches take them in turn (FFHIP_STREAMS = 2..4)
+    int nstreams = 4, next_stream = 0;
     int profiling = 0;
     // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.
     // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
@@ -21,6 +21,8 @@ struct ffhip_engine {
     int persist_chained = 0;
     hipEvent_t batch_done = nullptr;     // end of the last submitted batch (any stream): see batch_run_impl, "whole batches one after the other"
     int batch_done_rec = 0;
+    hipEvent_t done_ring[4] = { nullptr, nullptr, nullptr, nullptr };      // end of the decode of the last four submitted batches (before their copies to the host)
+    unsigned done_head = 0;
     int persist_last_half = 0;  // the engine's last persistent launch left room for a twin of its size: only then may the next half-chip launch run beside it
     // A persistent layer kernel whose workgroups are not all resident (another tenant on the GPU, e.g. a second flappie
     // process) gives up through its bounded waits (abort word).  ffhip_batch_finish then re-runs the batch on the

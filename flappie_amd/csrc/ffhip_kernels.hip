@@ -50,14 +50,18 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // is reproduced in index space; kNoWindow = none.  Input pads are zero, so partial windows at
 // either edge are plain full-length windows here.
 // ------------------------------------------------------------------------------------------
-template <int MAXF>
+// KT > 0 (round 4): the window length in floats is a compile-time constant and Fout == MAXF -- the window comes as KT / 4 vector loads
+// (one dword load per tap before), the weights lie tap-major in LDS and come four filters per ds_read_b128 (one ds_read_b32 per
+// multiply-add before: the kernel was bound by LDS issue), the loops are unrolled.  Same multiply-adds in the same order: bit-identical.
+template <int MAXF, int KT = 0>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp,
              const int *__restrict__ tin, float split_scale, unsigned *__restrict__ sat) {
-    extern __shared__ float w_lds[];          // [Fout][winlen*Fin] then bias [Fout]
-    const int Fin = in.F, Fout = out.F, K = winlen * Fin;
-    for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];          // [Fout][winlen*Fin] (KT > 0: [winlen*Fin][Fout]) then bias [Fout]
+    const int Fin = in.F, Fout = KT > 0 ? MAXF : out.F, K = KT > 0 ? KT : winlen * Fin;
+    if (KT > 0) for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[(i % K) * MAXF + i / K] = W[i];
+    else for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[i] = W[i];
     for (int i = threadIdx.x; i < Fout; i += blockDim.x) w_lds[Fout * K + i] = bias[i];
     __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +85,24 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
     for (int wdw = 0; wdw < 2; wdw++) {
         if (xs[wdw] == kNoWindow) continue;
         const float *x = in.row(r, xs[wdw]);
+        if constexpr (KT > 0) {
+            float xv[KT];
+            if constexpr (KT % 4 == 0) {              // (Fin = 4: a sample is 16 bytes, every window 16-byte aligned)
+#pragma unroll
+                for (int k = 0; k < KT; k += 4) { const float4 v = *(const float4 *)(x + k); xv[k] = v.x; xv[k + 1] = v.y; xv[k + 2] = v.z; xv[k + 3] = v.w; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; k++) xv[k] = x[k];
+            }
+#pragma unroll
+            for (int k = 0; k < KT; k++) {
+#pragma unroll
+                for (int f = 0; f < MAXF; f += 4) {
+                    const float4 w = *(const float4 *)__builtin_assume_aligned(&w_lds[k * MAXF + f], 16);
+                    acc[f] = acc[f] + w.x * xv[k]; acc[f + 1] = acc[f + 1] + w.y * xv[k]; acc[f + 2] = acc[f + 2] + w.z * xv[k]; acc[f + 3] = acc[f + 3] + w.w * xv[k];
+                }
+            }
+        } else
         for (int k = 0; k < K; k++) {
             const float xv = x[k];
 #pragma unroll
@@ -129,7 +151,12 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
-    if (out.F <= 4)
+    static const bool unrolled = !(getenv("FFHIP_CONV_SMALL_U") && getenv("FFHIP_CONV_SMALL_U")[0] == '0');      // (=0: the round-3 loops, for comparison)
+    if (unrolled && out.F == 4 && in.F == 1 && winlen == 5)
+        hipLaunchKernelGGL((k_conv_small<4, 5>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
+    else if (unrolled && out.F == 16 && in.F == 4 && winlen == 5)
+        hipLaunchKernelGGL((k_conv_small<16, 20>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat);
+    else if (out.F <= 4)
         hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
     else if (out.F <= 16)
         hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat);

@@ -1,7 +1,8 @@
-"""A/B of the last convolution: round-3 kernel (FFHIP_CONV_WS=0) against the weights-stationary one -- bit-identity of everything downstream and time."""
+"""A/B of a convolution switch -- bit-identity of everything downstream and time.  Default: the last convolution, round-3 kernel (FFHIP_CONV_WS=0)
+against the weights-stationary one; `conv_ab.py FFHIP_CONV_SMALL_U` the thin front layers, round-3 loops (=0) against the unrolled ones."""
 import os, sys, subprocess, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     from flappie_amd import binding as B, model as M
     eng = B.Engine(0)
@@ -33,10 +34,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     res = {}
+    var = sys.argv[1] if len(sys.argv) > 1 else "FFHIP_CONV_WS"
     for ws in ("0", "1"):
-        r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, FFHIP_CONV_WS=ws), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **{var: ws}), capture_output=True, text=True)
         if r.returncode != 0:
-            print("FFHIP_CONV_WS=%s failed:" % ws, r.stderr[-2000:]); sys.exit(1)
+            print("%s=%s failed:" % (var, ws), r.stderr[-2000:]); sys.exit(1)
         res[ws] = json.loads(r.stdout.strip().splitlines()[-1])
     for k in res["0"]:
         a, c = res["0"][k], res["1"][k]

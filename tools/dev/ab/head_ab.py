@@ -1,7 +1,7 @@
 """A/B of the CRF head: f32-MFMA head on the last layer's fp32 copy (FFHIP_NO_SPLIT_HEAD=1) against k_head_split -- scores vs oracle, time."""
 import os, sys, subprocess, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     from flappie_amd import binding as B, model as M
     from oracle import ffo
