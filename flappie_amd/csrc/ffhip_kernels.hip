@@ -94,14 +94,24 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 #pragma unroll
                 for (int k = 0; k < KT; k++) xv[k] = x[k];
             }
+            // (pairs of filters as 2-vectors: v_pk_mul_f32 + v_pk_add_f32 -- this file is built without the SLP vectoriser, DESIGN.md section 5.4;
+            // each component is the same multiply and the same add)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 a2[MAXF / 2];
+#pragma unroll
+            for (int f = 0; f < MAXF; f += 2) a2[f / 2] = (f2){ acc[f], acc[f + 1] };
 #pragma unroll
             for (int k = 0; k < KT; k++) {
+                const f2 xk = { xv[k], xv[k] };
 #pragma unroll
                 for (int f = 0; f < MAXF; f += 4) {
                     const float4 w = *(const float4 *)__builtin_assume_aligned(&w_lds[k * MAXF + f], 16);
-                    acc[f] = acc[f] + w.x * xv[k]; acc[f + 1] = acc[f + 1] + w.y * xv[k]; acc[f + 2] = acc[f + 2] + w.z * xv[k]; acc[f + 3] = acc[f + 3] + w.w * xv[k];
+                    a2[f / 2] = a2[f / 2] + (f2){ w.x, w.y } * xk;
+                    a2[f / 2 + 1] = a2[f / 2 + 1] + (f2){ w.z, w.w } * xk;
                 }
             }
+#pragma unroll
+            for (int f = 0; f < MAXF; f += 2) { acc[f] = a2[f / 2].x; acc[f + 1] = a2[f / 2].y; }
         } else
         for (int k = 0; k < K; k++) {
             const float xv = x[k];

@@ -129,3 +129,54 @@ def test_full_packed_launch_against_the_oracle(B, engine, kind):
         compare(b, r, ref, st)
     b.close(); dm.close()
     report("full packed launch, kind %d, H = 256" % kind, st)
+
+
+def test_front_order_changes_the_schedule_not_the_results(B, engine):
+    """bench.py's c2 pipeline -- two PAIRS in flight, the second pair's convolutions beside the first pair's head and decode
+    (FFHIP_FRONT_ORDER=layers, the default; batch_run_impl) -- against round 3's order and against no order at all: every read's
+    transition scores, calls and qualities byte for byte the same.  Three rounds through the same four batch objects, so that
+    a batch's buffers are reused while its neighbours are still in flight."""
+    import hashlib
+    import os
+    mdl = M.synthetic_model(M.NET_LSTM5, 384, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(4004)
+    T, nread = 1500, 256
+    sigs = [rng.standard_normal((nread, T)).astype(np.float32) for _ in range(4)]
+    batches = [B.Batch(dm, nread, T) for _ in range(4)]
+
+    def digest(b):
+        h = hashlib.sha256()
+        for r in range(nread):
+            h.update(b.transitions(r).tobytes()); h.update(b.basecall(r).encode()); h.update(b.quality(r).encode())
+        return h.hexdigest()
+
+    seen = {}
+    old = os.environ.get("FFHIP_FRONT_ORDER")
+    try:
+        for order in ("layers", "batch", "none"):
+            os.environ["FFHIP_FRONT_ORDER"] = order
+            got = []
+            for rnd in range(3):
+                for k in range(4):
+                    batches[k].set_signals(sigs[(k + rnd) % 4])
+                batches[0].run_pair(batches[1])
+                batches[2].run_pair(batches[3])
+                for b in batches:
+                    b.finish()
+                    assert b.paired()
+                got.append([digest(batches[k]) for k in range(4)])
+            # the same signal gives the same bytes in whichever batch object and round it ran
+            for rnd in range(3):
+                for k in range(4):
+                    seen.setdefault((k + rnd) % 4, set()).add(got[rnd][k])
+    finally:
+        if old is None:
+            os.environ.pop("FFHIP_FRONT_ORDER", None)
+        else:
+            os.environ["FFHIP_FRONT_ORDER"] = old
+    for b in batches:
+        b.close()
+    dm.close()
+    assert all(len(v) == 1 for v in seen.values()), {k: len(v) for k, v in seen.items()}
+    assert len({next(iter(v)) for v in seen.values()}) == 4

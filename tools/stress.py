@@ -2,7 +2,8 @@
 """Soak test of the engine on the GPU box: many uniform and ragged batches of the benchmark's shape through the persistent
 recurrent kernels -- TWO BATCHES IN FLIGHT, as bench.py and the flappie binary run them (argv[4] = 1 for one) -- checking for
 errors / timeouts and that the results of a fixed probe read, placed in a random slot of every batch, never change.
-usage: tools/stress.py [iterations] [kind] [hidden] [batches in flight] [reads per batch]"""
+usage: tools/stress.py [iterations] [kind] [hidden] [batches in flight] [reads per batch] [pair]
+`pair` = 1: the batches go out two at a time through ffhip_batch_run_pair (batches in flight: 4 = two pairs, as bench.py's default)."""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ kind = int(sys.argv[2]) if len(sys.argv) > 2 else M.NET_LSTM5
 hidden = int(sys.argv[3]) if len(sys.argv) > 3 else 384
 nfl = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 nread = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+pair = len(sys.argv) > 6 and sys.argv[6] == "1"
 import ctypes as C  # noqa: E402
 eng = B.Engine(0)
 B.lib().ffhip_debug_fallback_count.argtypes = [C.c_void_p]
@@ -69,7 +71,12 @@ for it in range(niter):
     sigs = [probe if i == slots[k] else rng.standard_normal(int(n)).astype(np.float32) for i, n in enumerate(lens)]
     nsamp += int(lens.sum())
     batches[k].set_signals_ragged(sigs)
-    batches[k].run()
+    if not pair:
+        batches[k].run()
+    elif k % 2 == 1:
+        batches[k - 1].run_pair(batches[k], 1.0, 0)       # (uniform lengths of equal capacity pair up; the engine decides)
+    elif it == niter - 1:
+        batches[k].run()
     pending.append(k)
     if it % 250 == 0:
         print("iteration %d ok (%.1f s)" % (it, time.time() - t0), flush=True)
