@@ -36,6 +36,9 @@
 #define FFHIP_CHAIN_PRIO 3
 #endif
 #define FFHIP_CHAIN_PRIO_SET() __builtin_amdgcn_s_setprio(FFHIP_CHAIN_PRIO)
+#ifndef FFHIP_FB_CHUNK8
+#define FFHIP_FB_CHUNK8 32
+#endif
 
 namespace ffhip {
 
@@ -117,7 +120,7 @@ template <int NS, int TOPO = 0> struct FbDims {
     // blocks of E staged in LDS per chunk and direction.  32 for the 8-state models; 16 for the 10-state ones, whose rows are 64 doubles: with 32
     // the workgroup took 43 KB of LDS, three workgroups a CU, and the 1024 reads of a `c4` batch ran in two rounds -- with 16 (27 KB) all 1024
     // chains are resident at once (four workgroups a CU, what their 176 registers allow)
-    static constexpr int kChunk = NS > 8 ? 16 : 32;
+    static constexpr int kChunk = NS > 8 ? 16 : FFHIP_FB_CHUNK8;
     static constexpr int kStage = kChunk * Pd / 64;           // doubles per lane and chunk
     static constexpr int pad = P + 1;                         // an entry that reads as zero
 };
