@@ -36,6 +36,10 @@
 #define FFHIP_CHAIN_PRIO 3
 #endif
 #define FFHIP_CHAIN_PRIO_SET() __builtin_amdgcn_s_setprio(FFHIP_CHAIN_PRIO)
+#ifndef FFHIP_DECODE_PRIO
+#define FFHIP_DECODE_PRIO 2
+#endif
+#define FFHIP_DECODE_PRIO_SET() __builtin_amdgcn_s_setprio(FFHIP_DECODE_PRIO)
 #ifndef FFHIP_FB_CHUNK8
 #define FFHIP_FB_CHUNK8 32
 #endif
@@ -301,6 +305,7 @@ template <int NS>
 __global__ void __launch_bounds__(256)
 k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__restrict__ fwdbuf, const double *__restrict__ bwdbuf, int TbS,
           const double *__restrict__ logz, const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
+    FFHIP_DECODE_PRIO_SET();
     constexpr int P = FbDims<NS>::P, Ps = P, nbase = NS / 2, off = nbase * NS;
     const int read = blockIdx.y;
     if (wide && wide[read]) return;
@@ -358,6 +363,7 @@ k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__r
 __global__ void __launch_bounds__(256)
 k_rle_post8(const float *__restrict__ param, float *__restrict__ post, const double *__restrict__ fwdbuf, const double *__restrict__ bwdbuf, int TbS,
             const int *__restrict__ tbs) {
+    FFHIP_DECODE_PRIO_SET();
     constexpr int Ps = 40, RS = 10;
     const int read = blockIdx.y;
     const int Tb = tbs ? tbs[read] : TbS;

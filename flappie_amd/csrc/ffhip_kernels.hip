@@ -19,6 +19,13 @@
 #include "ffhip_math.hpp"
 #include <stdlib.h>
 
+// Head and decode kernels run beside the NEXT batch's convolutions (batch_run_impl, FFHIP_FRONT_ORDER) and the next layer launches wait for them:
+// their waves go first on a shared SIMD (the convolutions stay at priority 0)
+#ifndef FFHIP_DECODE_PRIO
+#define FFHIP_DECODE_PRIO 2
+#endif
+#define FFHIP_DECODE_PRIO_SET() __builtin_amdgcn_s_setprio(FFHIP_DECODE_PRIO)
+
 namespace ffhip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -219,12 +226,16 @@ __device__ __forceinline__ void mma_tiles(const v4f *(&ap)[TM], const float *(&b
 // ---- last convolution (implicit GEMM over the window) -------------------------------------
 // N tile = (output column c, read tile rt); all 16 reads share the window start.  Columns with a
 // second window (or none) are irregular and rare: handled by re-running the loop for window b.
-template <bool BVEC>
-__global__ void __launch_bounds__(256)
+// TN (column tiles a wave; round 4).  A one-feature input (the r941_5mC model's only convolution: 19 taps, K16 = 2) has 8 MFMAs a tile against ~130
+// VALU instructions of swish + split in the epilogue, and at TN = 4 the kernel holds 230 registers: two waves a SIMD.  FFHIP_CONV1_TN=2 (156 registers,
+// three waves) is 13 % faster ALONE (1.00 -> 0.88 ms for a 1024-read batch) -- and slower in the pipeline, where this convolution runs beside the previous
+// batch's head and decode and the next layer launches wait for THOSE: 100.3 -> 99.0 Msamples/s at `c4` (TN = 1: 98.7).  Default 4; bit-identical all three.
+template <bool BVEC, int TN = 4, int WPS = 1>
+__global__ void __launch_bounds__(256, WPS)
 k_conv_mfma(SampleBuf in, float *__restrict__ out, const v4f *__restrict__ Wp, const float *__restrict__ bias,
             const int *__restrict__ x0a, const int *__restrict__ x0b, int B16, int Tout, int Mt, int K16, int act, int ldp,
             unsigned char *__restrict__ out_split, float split_scale, unsigned *__restrict__ sat) {
-    constexpr int TM = 4, TN = 4;
+    constexpr int TM = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int nMblk = (Mt + 2 * TM - 1) / (2 * TM);
@@ -298,7 +309,16 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
-    if (vec)
+    static const int thin_tn = getenv("FFHIP_CONV1_TN") ? atoi(getenv("FFHIP_CONV1_TN")) : 4;
+    if (!vec && K16 <= 2 && thin_tn < 4) {
+        const int tn = thin_tn <= 1 ? 1 : 2, nNb = (Tout * B16 + 2 * tn - 1) / (2 * tn);
+        if (tn == 1)
+            hipLaunchKernelGGL((k_conv_mfma<false, 1, 4>), dim3(nMblk * nNb), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
+                               x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp), sat);
+        else
+            hipLaunchKernelGGL((k_conv_mfma<false, 2, 3>), dim3(nMblk * nNb), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
+                               x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp), sat);
+    } else if (vec)
         hipLaunchKernelGGL(k_conv_mfma<true>, dim3(nMblk * nNblk), dim3(256), 0, s, in, out, (const v4f *)Wp, bias,
                            x0a, x0b, B16, Tout, Mt, K16, act, ldp, (unsigned char *)out_split, split_pow2(split_exp), sat);
     else
@@ -785,6 +805,7 @@ template <int TM>
 __global__ void __launch_bounds__(256)
 k_head_split(const unsigned char *__restrict__ in, float *__restrict__ trans, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
              int Tb, int B16, int nread, int P, int Ps, int Mt, int Hc, float scale, float acc_scale, int raw) {
+    FFHIP_DECODE_PRIO_SET();
     constexpr int TN = 4, NSL = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntile = Tb * B16;
@@ -1016,6 +1037,7 @@ constexpr int kExpBlocks = 64;
 __global__ void __launch_bounds__(256)
 k_crf_exp(const float *__restrict__ trans, double *__restrict__ E, size_t nblk /*nread*TbS*/, int P, int Ps, int Pd, int TbS,
           const int *__restrict__ tbs, int *__restrict__ wide, float limit, int row_off) {
+    FFHIP_DECODE_PRIO_SET();
     __shared__ float sc[kExpBlocks * 64];
     __shared__ float mx[kExpBlocks];
     const size_t b0 = (size_t)blockIdx.x * kExpBlocks;
@@ -2230,6 +2252,7 @@ void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *pat
 __global__ void __launch_bounds__(64)
 k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *__restrict__ bases,
            char *__restrict__ quals, int *__restrict__ lens, int TbS, int nbase, const int *__restrict__ tbs) {
+    FFHIP_DECODE_PRIO_SET();
     const int lane = threadIdx.x;
     const int *pth = path + (size_t)blockIdx.x * (TbS + 1);
     const float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
@@ -2273,6 +2296,7 @@ void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *b
 // both loops at full length; same sums in the same order here, 0.31 -> 0.25 ms for a 1024-read 10-state batch beside the next batch's convolution.)
 __global__ void __launch_bounds__(256)
 k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int TbS, int nbase, int P, int Ps, int is_log, const int *__restrict__ tbs) {
+    FFHIP_DECODE_PRIO_SET();
     const int ns = 2 * nbase, off = nbase * ns;
     const float *Pp = post + (size_t)blockIdx.y * TbS * Ps;
     int32_t *tr = trace + (size_t)blockIdx.y * (TbS + 1) * ns;

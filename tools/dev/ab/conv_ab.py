@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from flappie_amd import binding as B, model as M
     eng = B.Engine(0)
     out = {}
-    for kind, H, nread, T, ragged in ((0, 384, 256, 4000, False), (0, 384, 100, 1777, True), (0, 512, 48, 3001, False), (0, 256, 64, 999, True), (2, 384, 64, 2000, False), (0, 128, 33, 1234, True)):
+    for kind, H, nread, T, ragged in ((0, 384, 256, 4000, False), (0, 384, 100, 1777, True), (0, 512, 48, 3001, False), (0, 256, 64, 999, True), (2, 384, 64, 2000, False), (0, 128, 33, 1234, True), (1, 256, 64, 1500, True), (1, 128, 40, 999, False), (1, 256, 1024, 4000, False)):
         mdl = M.synthetic_model(kind, H, seed=1)
         dm = B.DeviceModel(eng, mdl)
         rng = np.random.default_rng(H + nread)
@@ -35,11 +35,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     res = {}
     var = sys.argv[1] if len(sys.argv) > 1 else "FFHIP_CONV_WS"
-    for ws in ("0", "1"):
+    for ws in ((sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("0", "1")):
         r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **{var: ws}), capture_output=True, text=True)
         if r.returncode != 0:
             print("%s=%s failed:" % (var, ws), r.stderr[-2000:]); sys.exit(1)
         res[ws] = json.loads(r.stdout.strip().splitlines()[-1])
-    for k in res["0"]:
-        a, c = res["0"][k], res["1"][k]
+    v0, v1 = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("0", "1")
+    for k in res[v0]:
+        a, c = res[v0][k], res[v1][k]
         print("%-28s digest %s / %s %s   conv group %.4f -> %.4f ms" % (k, a[0], c[0], "identical" if a[0] == c[0] else "** DIFFERENT **", a[1], c[1]))
