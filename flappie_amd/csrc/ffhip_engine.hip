@@ -662,6 +662,13 @@ int ffhip::build_conv_plan(int T, int winlen, int s, std::vector<int> &a, std::v
     return overflow ? -2 : Tout;
 }
 
+// a profiled pair's links (ffhip_batch::prof_mate / prof_ref), taken apart from either end
+static void prof_unlink(ffhip_batch *b) {
+    if (b->prof_ref && b->prof_ref->prof_mate == b) b->prof_ref->prof_mate = nullptr;
+    if (b->prof_mate && b->prof_mate->prof_ref == b) b->prof_mate->prof_ref = nullptr;
+    b->prof_ref = b->prof_mate = nullptr;
+}
+
 extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (!b) return;
     hipSetDevice(b->eng->device);
@@ -675,8 +682,7 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     if (b->h_abort) hipHostFree(b->h_abort);
     if (b->h_sat) hipHostFree(b->h_sat);
     if (b->side) ffhip_batch_destroy(b->side);
-    if (b->prof_ref && b->prof_ref->prof_mate == b) b->prof_ref->prof_mate = nullptr;
-    if (b->prof_mate && b->prof_mate->prof_ref == b) b->prof_mate->prof_ref = nullptr;
+    prof_unlink(b);
     if (b->have_ev) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
@@ -1371,9 +1377,8 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     HIP_TRY(hipEventRecord(b0->pair_ev, s), FFHIP_EHIP);
     HIP_TRY(hipStreamWaitEvent(b1->stream, b0->pair_ev, 0), FFHIP_EHIP);     // the second batch's head and decode follow the paired layers
     b0->paired_last = b1->paired_last = 1;
-    if (b1->prof_mate && b1->prof_mate != b0 && b1->prof_mate->prof_ref == b1) b1->prof_mate->prof_ref = nullptr;
-    if (b0->prof_ref && b0->prof_ref != b1 && b0->prof_ref->prof_mate == b0) b0->prof_ref->prof_mate = nullptr;
-    b1->prof_mate = prof ? b0 : nullptr; b0->prof_ref = prof ? b1 : nullptr; b0->prof_mate = nullptr;
+    prof_unlink(b0); prof_unlink(b1);                  // (whatever pairs they were part of before, in either role)
+    if (prof) { b1->prof_mate = b0; b0->prof_ref = b1; }
     if (int rc = batch_run_impl(b0, temperature, flags, PH_BACK)) return rc;
     return batch_run_impl(b1, temperature, flags, PH_BACK);
 }

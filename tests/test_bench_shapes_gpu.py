@@ -180,3 +180,32 @@ def test_front_order_changes_the_schedule_not_the_results(B, engine):
     dm.close()
     assert all(len(v) == 1 for v in seen.values()), {k: len(v) for k, v in seen.items()}
     assert len({next(iter(v)) for v in seen.values()}) == 4
+
+
+def test_profile_of_a_pair_survives_role_swaps_and_destruction_order(B, engine):
+    """a profiled pair brackets its layer launches once, on the first batch (two event records per launch, not six); the second batch reads
+    them through a link that either batch's destruction and any later pairing take apart: same layer time from both, roles swapped, and the
+    survivor's profile still answers after its mate is gone"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 384, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(77)
+    sig = rng.standard_normal((256, 1000)).astype(np.float32)
+    a, b, c = (B.Batch(dm, 256, 1000) for _ in range(3))
+    for x in (a, b, c):
+        x.set_signals(sig)
+    engine.set_profiling(True)
+    try:
+        for first, second in ((a, b), (b, a), (c, a), (b, c)):
+            first.run_pair(second)
+            first.finish(); second.finish()
+            p0, p1 = first.profile(), second.profile()
+            assert first.paired() and second.paired()
+            assert p0["recurrent"]["ms"] > 0.5 and p0["recurrent"]["ms"] == p1["recurrent"]["ms"]
+        b.close()                      # the first batch of the last pair goes first: the second one's link is taken apart with it
+        assert c.profile()["recurrent"]["ms"] >= 0.0
+        a.run(); a.finish()            # and a batch that was half of a pair runs alone again
+        assert not a.paired() and a.profile()["recurrent"]["ms"] > 0.5
+    finally:
+        engine.set_profiling(False)
+    a.close(); c.close()
+    dm.close()
