@@ -55,7 +55,6 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     }
     if (const char *ns = getenv("FFHIP_STREAMS")) e->nstreams = atoi(ns) < 2 ? 2 : (atoi(ns) > 4 ? 4 : atoi(ns));
     for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
-    if (!getenv("FFHIP_NO_AUX_STREAM")) for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming), (delete e, nullptr));
@@ -232,7 +231,6 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     hipDeviceSynchronize();
     if (ffhip::pool_engine_gone(e->device)) ffhip::pool_trim(e->device);
     for (int i = 0; i < 4; i++) if (e->streams[i]) hipStreamDestroy(e->streams[i]);
-    for (int i = 0; i < 4; i++) if (e->aux_streams[i]) hipStreamDestroy(e->aux_streams[i]);
     if (e->prep_stream) hipStreamDestroy(e->prep_stream);
     if (e->prep_pin) hipHostFree(e->prep_pin);
     for (int i = 0; i < 4; i++) if (e->prep_scratch[i]) hipFree(e->prep_scratch[i]);
@@ -246,7 +244,6 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
 extern "C" int ffhip_engine_synchronize(ffhip_engine *e) {
     if (!e) return set_err(FFHIP_EINVAL, "null engine");
     for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamSynchronize(e->streams[i]), FFHIP_EHIP);
-    for (int i = 0; i < e->nstreams; i++) if (e->aux_streams[i]) HIP_TRY(hipStreamSynchronize(e->aux_streams[i]), FFHIP_EHIP);
     return FFHIP_OK;
 }
 
@@ -611,8 +608,6 @@ struct ffhip_batch {
     int launches[FFHIP_NGROUP];
     hipEvent_t lev[5][3];
     hipEvent_t pair_ev = nullptr;       // ffhip_batch_run_pair: orders the two streams around the paired layer launches
-    hipStream_t aux = nullptr;          // the engine's side stream of this batch's slot: the trace runs there, beside Viterbi's chains
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int run_cur = 0;                    // which of act[] / actS[] holds the current activations between the phases of a run
     unsigned run_flags = 0;
     int paired_last = 0;                // the last run's layers were one launch with another batch's
@@ -692,8 +687,6 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
         for (int i = 0; i <= FFHIP_NGROUP; i++) hipEventDestroy(b->ev[i]);
         for (int l = 0; l < 5; l++) for (int i = 0; i < 3; i++) hipEventDestroy(b->lev[l][i]);
         if (b->pair_ev) hipEventDestroy(b->pair_ev);
-        if (b->fork_ev) hipEventDestroy(b->fork_ev);
-        if (b->join_ev) hipEventDestroy(b->join_ev);
     }
     delete b;
 }
@@ -704,7 +697,6 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     ffhip_batch *b = new ffhip_batch();
     b->eng = eng; b->mdl = m;
     b->stream = eng->streams[eng->next_stream];
-    b->aux = eng->aux_streams[eng->next_stream];
     eng->next_stream = (eng->next_stream + 1) % eng->nstreams;
     b->nread = nread; b->B16 = (nread + 15) / 16; b->Bp = b->B16 * 16;
     b->T = (int)nsample;
@@ -776,7 +768,6 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
         for (int i = 0; i < 3; i++)
             if (hipEventCreate(&b->lev[l][i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
     if (hipEventCreateWithFlags(&b->pair_ev, hipEventDisableTiming) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
-    if (hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
     b->have_ev = 1;
 #undef BFAIL
     return b;
@@ -1260,21 +1251,13 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             HIP_TRY(hipMemsetAsync(b->quals, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
             b->launches[5]++;
         } else {
-            // the trace reads the same scores as Viterbi and nothing of its results: it runs on the batch's side stream, beside Viterbi's
-            // dependent chains (one wave a read: they leave the chip to it), and the batch's stream takes it back in behind the assembly
-            const bool want_trace = !(flags & FFHIP_RUN_NO_TRACE), side = want_trace && b->aux != nullptr;
-            if (side) {
-                HIP_TRY(hipEventRecord(b->fork_ev, s), FFHIP_EHIP);
-                HIP_TRY(hipStreamWaitEvent(b->aux, b->fork_ev, 0), FFHIP_EHIP);
-                launch_trace(b->aux, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1, tbs);
-                HIP_TRY(hipEventRecord(b->join_ev, b->aux), FFHIP_EHIP);
-            }
             launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps, tbs);
             launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase, tbs);
             b->launches[5] += 2;
-            if (side) HIP_TRY(hipStreamWaitEvent(s, b->join_ev, 0), FFHIP_EHIP);
-            else if (want_trace) launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1, tbs);
-            if (want_trace) b->launches[5]++;
+            if (!(flags & FFHIP_RUN_NO_TRACE)) {
+                launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1, tbs);
+                b->launches[5]++;
+            }
         }
     } else {
         mark(b, 5);

@@ -13,7 +13,6 @@ struct ffhip_engine {
     hipDeviceProp_t prop;
     hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr };      // batches take them in turn (FFHIP_STREAMS = 2..4)
     int nstreams = 4, next_stream = 0;
-    hipStream_t aux_streams[4] = { nullptr, nullptr, nullptr, nullptr };  // one beside each: a batch's trace runs there while Viterbi's chains run on its own (FFHIP_NO_AUX_STREAM: none)
     int profiling = 0;
     // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.
     // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
