@@ -11,6 +11,9 @@ re-runs them.
      (seed 1, round-4 gains), batch 5 read 68 (2500 samples): 457 bases against 457, one base apart, |dtrans| 1.3e-5 -- the one read of
      2048 that the engine calls differently from BOTH the scalar oracle and the oracle through OpenBLAS (which differ from each other on
      two more reads of that campaign).
+  2: profiles/r04_parity_h384.txt -- tools/parity_h384.py 8192 2500 c2 on the round's FINAL tree (weights-stationary convolution, split head): same
+     model, batch 4 read 148 (2500 samples): 462 bases against 462, three apart, |dtrans| 1.3e-5 -- the one read of 8192 / 3.36 M bases called
+     differently from both evaluations of the reference algorithm (read 1 above no longer is: the scores moved in the last bits with the kernels).
 """
 import os
 import sys
@@ -41,6 +44,8 @@ for k in range(6):
         batches.append([rng.standard_normal(int(n)).astype(np.float32) for n in lens])
 out.update(kind1=np.array(M.NET_LSTM5), hidden1=np.array(384), model_seed1=np.array(1), gains1=np.array(M.SYNTH_GAINS[M.NET_LSTM5], dtype=np.float64),
            signal1=batches[5][68], source1=np.array("profiles/r04_parity_h384.txt batch 5 read 68"), blocks_apart1=np.array(4), dtrans_bound1=np.array(2e-5), f32_equals_oracle1=np.array(-1))
-out["n"] = np.array(2)
+out.update(kind2=np.array(M.NET_LSTM5), hidden2=np.array(384), model_seed2=np.array(1), gains2=np.array(M.SYNTH_GAINS[M.NET_LSTM5], dtype=np.float64),
+           signal2=batches[4][148], source2=np.array("profiles/r04_parity_h384.txt (8192 reads) batch 4 read 148"), blocks_apart2=np.array(48), dtrans_bound2=np.array(2e-5), f32_equals_oracle2=np.array(-1))
+out["n"] = np.array(3)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "near_ties.npz"), **out)
 print("near_ties.npz: %d reads" % int(out["n"]))
