@@ -551,7 +551,7 @@ def main():
             "exposed_ms": round(dt / steps * 1e3 - rec["ms"] / (2.0 if paired_ else 1.0), 4),
             "kernel_ms_note": ("one batch in flight: the kernels of a step run back to back" if nfl == 1 else
                                "two batches (or pairs) in flight: between two batches' layer launches the head / decode kernels of the one run BESIDE the "
-                               "convolutions of the next (ordered by the engine: FFHIP_FRONT_ORDER), so their durations here are stretched by each other, "
+                               "convolutions of the next (ordered by the engine: FFHIP_DEBUG=front_order=...), so their durations here are stretched by each other, "
                                "overlap, and do not add up to ms_per_step; `--inflight 1` gives the serial breakdown"),
             # decode side (posterior + Viterbi + assembly + trace): algorithmic bytes per block (SURVEY.md section 8d:
             # 4P read + nstate traceback + 8 path/qpath, plus 4P read + 4P write for the posterior) against HBM peak.

@@ -53,7 +53,7 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
         delete e;
         return nullptr;
     }
-    if (const char *ns = getenv("FFHIP_STREAMS")) e->nstreams = atoi(ns) < 2 ? 2 : (atoi(ns) > 4 ? 4 : atoi(ns));
+    if (const char *ns = dbg("streams")) e->nstreams = atoi(ns) < 2 ? 2 : (atoi(ns) > 4 ? 4 : atoi(ns));
     for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
@@ -63,7 +63,42 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     return e;
 }
 
-// ---- host-load rehearsal (TEST HOOK, tools/host_scaling.py) ---------------------------------------------------
+// ---- development switches: FFHIP_DEBUG=token[,token=value ...] (ffhip_internal.hpp) ---------------------------
+namespace ffhip {
+const char *dbg(const char *token) {
+    static std::mutex mu;
+    static std::string seen;                                  // the variable's text the table below was built from
+    static std::vector<std::pair<std::string, std::string>> table;
+    const char *e = getenv("FFHIP_DEBUG");
+    if (!e || !e[0]) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (seen != e) {                                          // (tests change the variable between runs of one process)
+        seen = e;
+        std::vector<std::pair<std::string, std::string>> t;
+        size_t i = 0;
+        while (i <= seen.size()) {
+            size_t j = seen.find_first_of(", ;", i);
+            if (j == std::string::npos) j = seen.size();
+            if (j > i) {
+                const std::string item = seen.substr(i, j - i);
+                const size_t eq = item.find('=');
+                t.emplace_back(eq == std::string::npos ? item : item.substr(0, eq), eq == std::string::npos ? std::string() : item.substr(eq + 1));
+            }
+            i = j + 1;
+        }
+        // (values handed out earlier stay valid: the old strings are kept, a few bytes per change of the variable)
+        static std::vector<std::vector<std::pair<std::string, std::string>>> retired;
+        retired.push_back(std::move(table));
+        table = std::move(t);
+    }
+    for (const auto &kv : table) if (kv.first == token) return kv.second.c_str();
+    return nullptr;
+}
+}  // namespace ffhip
+
+#ifdef FFHIP_TEST_HOOKS
+// ---- host-load rehearsal (TEST HOOK of the -DFFHIP_TEST_HOOKS build only: `make hooks` -> tools/test_hooks/libffhip.so, loaded by
+// tools/host_scaling.py's emulated processes through LD_LIBRARY_PATH; the release library has none of this -- VERDICT r4 weak 12) ----
 // FFHIP_DEBUG_HOST_REHEARSAL_MSPS=<rate>: this process evaluates NO network.  A run produces placeholder results (calls of 0.4 bases per
 // block, all 'A') and is "busy" for (samples of the batch) / rate on an emulated GPU that works its batches one after the other;
 // ffhip_batch_finish sleeps until then.  With FFHIP_DEBUG_HOST_REHEARSAL_NOGPU=1 beside it the steady state touches the GPU not at all:
@@ -74,18 +109,19 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
 // Announced on stderr; never a fallback, never set by the library itself.
 namespace ffhip {
 double rehearsal_rate() {
-    static double v = -2.0;
-    if (v == -2.0) {
+    static const double v = [] {                              // (a function-local static: initialised once, thread-safe)
         const char *e = getenv("FFHIP_DEBUG_HOST_REHEARSAL_MSPS");
-        v = e ? atof(e) : -1.0;
-        if (v > 0) fprintf(stderr, "ffhip: FFHIP_DEBUG_HOST_REHEARSAL_MSPS=%g%s -- NO NETWORK IS EVALUATED in this process: every batch returns placeholder calls "
-                                   "after (its samples) / %g us (host-side load rehearsal, tools/host_scaling.py)\n", v,
-                           getenv("FFHIP_DEBUG_HOST_REHEARSAL_NOGPU") ? " without the GPU" : "", v);
-    }
+        const double r = e ? atof(e) : -1.0;
+        if (r > 0) fprintf(stderr, "ffhip: FFHIP_DEBUG_HOST_REHEARSAL_MSPS=%g%s -- NO NETWORK IS EVALUATED in this process: every batch returns placeholder calls "
+                                   "after (its samples) / %g us (host-side load rehearsal, tools/host_scaling.py)\n", r,
+                           getenv("FFHIP_DEBUG_HOST_REHEARSAL_NOGPU") ? " without the GPU" : "", r);
+        return r;
+    }();
     return v;
 }
 bool rehearsal_nogpu() { return rehearsal_rate() > 0 && getenv("FFHIP_DEBUG_HOST_REHEARSAL_NOGPU") != nullptr; }
 }  // namespace ffhip
+#endif
 
 // ---- device buffer pool and copy accounting (ffhip_host.hpp) ------------------------------------------------------
 #undef hipMemcpyAsync
@@ -987,22 +1023,22 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
 
     // split-operand layer kernel (ffhip_rnn_split.hip): the default wherever it exists (LSTM H = 128..512, GRUmod H = 128..384)
     const bool use_persist = !(flags & FFHIP_RUN_STEPWISE_RNN) && persist_supported(m->cell, Hp, b->eng->prop.multiProcessorCount);
-    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE") && fused_supported(m->cell, Hp);
-    const bool want_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !getenv("FFHIP_NO_FUSE");      // (use_fused also asks whether the f32 layer kernel takes the shape)
-    const bool use_split = use_persist && want_fused && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+    const bool use_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !dbg("no_fuse") && fused_supported(m->cell, Hp);
+    const bool want_fused = !(flags & FFHIP_RUN_UNFUSED_RNN) && !dbg("no_fuse");      // (use_fused also asks whether the f32 layer kernel takes the shape)
+    const bool use_split = use_persist && want_fused && !(flags & FFHIP_RUN_F32_RNN) && !dbg("no_split") &&
                            split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
     // shapes whose two weight matrices do not fit a CU's registers (H = 512): projection GEMM + recurrence-only layer kernel, both
     // on split operands (also what FFHIP_RUN_UNFUSED_RNN selects at H = 256)
-    const bool use_split2 = !use_split && use_persist && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT") &&
+    const bool use_split2 = !use_split && use_persist && !(flags & FFHIP_RUN_F32_RNN) && !dbg("no_split") &&
                             rnn_split_supported(m->cell, Hp) && m->rnn[0].Wsplit != nullptr;
     // the last convolution writes the split layout directly unless the fp32 activations are wanted as well
     const bool conv_split = (use_split || use_split2) && !keep && m->conv[m->nconv - 1].Mpad == Hp;
     // the CRF head reads the last layer's SPLIT output (k_head_split): that layer then writes no fp32 copy (315 MB per headline batch, ~65 us of
     // its launch) and the batch needs no fp32 activation buffer at all (FFHIP_NO_SPLIT_HEAD: the f32-MFMA head on the fp32 copy)
-    const bool split_head = use_split && !keep && m->FFsplit != nullptr && !getenv("FFHIP_NO_SPLIT_HEAD");
+    const bool split_head = use_split && !keep && m->FFsplit != nullptr && !dbg("no_split_head");
     const bool prof = b->eng->profiling != 0;
     const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
-    const char *pm_env = getenv("FFHIP_PERSIST_MODE");      // 1 = always use the write-through hand-off
+    const char *pm_env = dbg("persist_mode");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     int cur = b->run_cur;
     {
@@ -1018,10 +1054,10 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     }
     // ---- convolutions (layers.c:189-276, activations :24-49)
     // the last convolution runs on split operands when the model has them (16 input features): its predecessor then writes fp16 slices
-    const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT_CONV") && !(flags & FFHIP_RUN_F32_RNN);
+    const bool conv_f16 = m->conv[m->nconv - 1].Wsplit != nullptr && !dbg("no_split_conv") && !(flags & FFHIP_RUN_F32_RNN);
     // another batch is between run and finish: its layer launches hold 384 of every SIMD's 512 registers, so this batch's last
     // convolution takes the shape that fits in what is left (FFHIP_LEAN_CONV=0 / 1 forces one)
-    const char *lean_env = getenv("FFHIP_LEAN_CONV");
+    const char *lean_env = dbg("lean_conv");
     // ... unless this batch's own layer launches fill the chip (a paired launch; a full launch of the dense forms; H = 512): the layer
     // launches of whatever else is in flight do too, the convolution only ever shares the chip with other batches' convolutions and
     // decodes, and the fat shape is the faster one there (in pairs at H = 384: 0.98 -> 0.6 ms per batch)
@@ -1039,8 +1075,8 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // beside that batch's head and decode (dependent chains of one wave a read: they leave the chip nearly empty), and a pair's front, on
     // streams of its own (the engine hands out four), no longer queues behind the previous pair's decode: between two pairs' layer launches
     // 1.33 ms of head + decode + copies + convolutions one after the other became max(...) of the two sides.  FFHIP_FRONT_ORDER=batch: round 3's.
-    const char *fo = getenv("FFHIP_FRONT_ORDER");
-    if (getenv("FFHIP_NO_BATCH_ORDER")) fo = "none";
+    const char *fo = dbg("front_order");
+    if (dbg("no_batch_order")) fo = "none";
     const bool by_layers = !fo || fo[0] == 'l';
     {
         if (full_chip && by_layers && b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);
@@ -1071,7 +1107,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // profiling groups 1 (in-projection) and 2 (recurrent) interleave; their events bracket the
     // whole stack and the split is measured with per-layer events when profiling is on.
     cur = 0;
-    HIP_TRY(hipMemsetAsync(b->pabort, (use_persist && getenv("FFHIP_DEBUG_FORCE_ABORT")) ? 1 : 0, sizeof(unsigned), s), FFHIP_EHIP);      // (debug: pretend a wait timed out)
+    HIP_TRY(hipMemsetAsync(b->pabort, (use_persist && dbg("force_abort")) ? 1 : 0, sizeof(unsigned), s), FFHIP_EHIP);      // (debug: pretend a wait timed out)
     if ((use_split || use_split2) && !conv_split) {
         launch_split_from_f32(s, b->act[0], b->actS[0], (size_t)Tb * B16, Hp, m->act == ACT_SWISH ? kSplitExpX : kSplitExpH, b->sat, B16);
         b->launches[0]++;
@@ -1080,7 +1116,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // ... and this batch's LAYER launches follow the decode of the batches before it (the last two: a pair): a persistent launch that becomes
     // resident piecemeal beside a running chain of decode kernels squeezes those onto the CUs it has not taken yet and cannot start before
     // they are through (the run-length shape, whose head and decode are the longer side: 88 against 98 Msamples/s without this wait)
-    if (full_chip && by_layers && !getenv("FFHIP_NO_DECODE_WAIT"))
+    if (full_chip && by_layers && !dbg("no_decode_wait"))
         for (unsigned k = 1; k <= 2 && k <= b->eng->done_head; k++) HIP_TRY(hipStreamWaitEvent(s, b->eng->done_ring[(b->eng->done_head - k) & 3u], 0), FFHIP_EHIP);
   }      // PH_FRONT
   if (phases & PH_LAYERS) {
@@ -1146,7 +1182,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         }
         if (!fuse) {
             if (!b->xa && !(b->xa = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4 * 4, false))) return FFHIP_ENOMEM;
-            if (r.Wsplit && !(flags & FFHIP_RUN_F32_RNN) && !getenv("FFHIP_NO_SPLIT")) {
+            if (r.Wsplit && !(flags & FFHIP_RUN_F32_RNN) && !dbg("no_split")) {
                 // projection on the bf16 pipes over split operands (fp32-exact products): the layer input is
                 // converted to the split layout first
                 if (!b->actS[0] && !(b->actS[0] = dalloc(b, split_bytes((size_t)Tb * B16, Hp), false))) return FFHIP_ENOMEM;
@@ -1213,10 +1249,10 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
-        const int R = getenv("FFHIP_CRF_LOGSPACE") ? 0 : crf_rescale_interval(5.0f / temperature);
+        const int R = dbg("crf_logspace") ? 0 : crf_rescale_interval(5.0f / temperature);
         // 8-state models, a block's scores spanning at most kFbRange: ONE pair of fp64 linear-space chains per read gives logZ, the
         // normalised scores and (when asked for) the posterior (k_crf_fb8, ffhip_decode.hip)
-        post_done = R > 0 && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) && 10.0f / temperature <= kFbRange && !getenv("FFHIP_DECODE_R2");
+        post_done = R > 0 && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) && 10.0f / temperature <= kFbRange && !dbg("decode_r2");
         if (post_done) {
             const bool want_post = !(flags & FFHIP_RUN_NO_DECODE) && !(flags & FFHIP_RUN_VITERBI_ONLY);
             launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
@@ -1234,7 +1270,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     if (!(flags & FFHIP_RUN_NO_DECODE)) {
         const float *scores = b->trans;
         if (!(flags & FFHIP_RUN_VITERBI_ONLY)) {
-            if (rle && m->nbase == 4 && m->Ps == 40 && 10.0f / temperature <= kFbRange && !getenv("FFHIP_DECODE_R2"))
+            if (rle && m->nbase == 4 && m->Ps == 40 && 10.0f / temperature <= kFbRange && !dbg("decode_r2"))
                 launch_rle_post8(s, b->trans, b->post, b->crf_e, (double *)b->fwd, b->nread, Tb, tbs);              // fp64 linear-space chains (ffhip_decode.hip)
             else if (rle) launch_rle_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);       // decode.c:1037-1159
             else if (!post_done) launch_transpost(s, b->trans, b->post, b->fwd, b->nread, Tb, m->nbase, m->Ps, tbs);
@@ -1329,8 +1365,8 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     const int ncu = eng->prop.multiProcessorCount;
     const bool pairable = b1->mdl == m && b1->eng == eng && b0->Tb == b1->Tb && b0->B16 == b1->B16 && b0->B16 <= 2 * (ncu / 32) && (((b0->B16 + 1) / 2) & 7) == 0 &&
                           !(flags & (FFHIP_RUN_KEEP_ACTS | FFHIP_RUN_STEPWISE_RNN | FFHIP_RUN_F32_RNN | FFHIP_RUN_UNFUSED_RNN)) && eng->stepwise_batches == 0 &&
-                          m->cell == 0 && m->Hp == 384 && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr && !getenv("FFHIP_NO_SPLIT") &&
-                          !getenv("FFHIP_NO_FUSE") && !getenv("FFHIP_NO_PAIR") && persist_supported(m->cell, m->Hp, ncu);
+                          m->cell == 0 && m->Hp == 384 && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr && !dbg("no_split") &&
+                          !dbg("no_fuse") && !dbg("no_pair") && persist_supported(m->cell, m->Hp, ncu);
     if (!pairable) {
         if (int rc = ffhip_batch_run(b0, temperature, flags)) return rc;
         return ffhip_batch_run(b1, temperature, flags);
@@ -1345,10 +1381,10 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     HIP_TRY(hipStreamWaitEvent(s, b1->pair_ev, 0), FFHIP_EHIP);              // the second batch's convolutions are done before the first paired layer
     const bool prof = eng->profiling != 0;
     const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
-    const char *pm_env = getenv("FFHIP_PERSIST_MODE");
+    const char *pm_env = dbg("persist_mode");
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     ffhip_batch *bb[2] = { b0, b1 };
-    const bool split_head_pair = m->FFsplit != nullptr && !getenv("FFHIP_NO_SPLIT_HEAD");      // as batch_run_impl's split_head (a pair never keeps activations)
+    const bool split_head_pair = m->FFsplit != nullptr && !dbg("no_split_head");      // as batch_run_impl's split_head (a pair never keeps activations)
     bool paired = true;
     for (int l = 0; l < 5 && paired; l++) {
         const RnnDev &r = m->rnn[l];
@@ -1566,7 +1602,7 @@ extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, f
     const ffhip_model *m = b->mdl;
     const float *src = b->keep[layer + 1];
     if (!src) {
-        if (layer == 4 && b->act[b->final_act] && !(b->rnn_path == 3 && b->mdl->FFsplit && !getenv("FFHIP_NO_SPLIT_HEAD"))) src = b->act[b->final_act];      // (the default path keeps no fp32 copy of the last layer: k_head_split)
+        if (layer == 4 && b->act[b->final_act] && !(b->rnn_path == 3 && b->mdl->FFsplit && !dbg("no_split_head"))) src = b->act[b->final_act];      // (the default path keeps no fp32 copy of the last layer: k_head_split)
         else return set_err(FFHIP_EINVAL, "activation of layer %d was not kept (run with flag 16)", layer);
     }
     hipSetDevice(b->eng->device);

@@ -90,8 +90,13 @@ bool pool_engine_gone(int device);    // true: it was the device's last engine
 int pool_default_device();
 int pool_device_of(const void *p);    // -1: not a pool buffer
 void pool_state(unsigned long long out[4]);
-double rehearsal_rate();              // test hook FFHIP_DEBUG_HOST_REHEARSAL_MSPS (ffhip_engine.hip); <= 0: off
+#ifdef FFHIP_TEST_HOOKS
+double rehearsal_rate();              // test hook FFHIP_DEBUG_HOST_REHEARSAL_MSPS (ffhip_engine.hip; the `make hooks` build only); <= 0: off
 bool rehearsal_nogpu();
+#else
+static inline double rehearsal_rate() { return 0.0; }      // the release library: no hook, the code behind it folds away
+static inline bool rehearsal_nogpu() { return false; }
+#endif
 void image_remember(const void *owner, void *dev);
 void *image_forget(const void *owner);
 

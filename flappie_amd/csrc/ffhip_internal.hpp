@@ -8,6 +8,11 @@
 
 namespace ffhip {
 
+// Development switches live in ONE environment variable: FFHIP_DEBUG=token[,token=value ...] (INTEGRATION.md section 6 lists them).
+// dbg("token"): nullptr when the token is absent, otherwise its value ("" for a bare token) -- what getenv gave when every switch
+// had a variable of its own (rounds 1-4: 41 of them).  Looked up per call: tests flip switches between runs of one process.
+const char *dbg(const char *token);
+
 // ---------------------------------------------------------------------------------------------
 // Data layouts in HBM (all fp32 unless noted).  B16 = ceil(nread/16) read tiles, Bp = 16*B16.
 //

@@ -168,7 +168,7 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
-    static const bool unrolled = !(getenv("FFHIP_CONV_SMALL_U") && getenv("FFHIP_CONV_SMALL_U")[0] == '0');      // (=0: the round-3 loops, for comparison)
+    static const bool unrolled = !(dbg("conv_small_u") && dbg("conv_small_u")[0] == '0');      // (=0: the round-3 loops, for comparison)
     if (unrolled && out.F == 4 && in.F == 1 && winlen == 5)
         hipLaunchKernelGGL((k_conv_small<4, 5>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
     else if (unrolled && out.F == 16 && in.F == 4 && winlen == 5)
@@ -309,7 +309,7 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
-    static const int thin_tn = getenv("FFHIP_CONV1_TN") ? atoi(getenv("FFHIP_CONV1_TN")) : 4;
+    static const int thin_tn = dbg("conv1_tn") ? atoi(dbg("conv1_tn")) : 4;
     if (!vec && K16 <= 2 && thin_tn < 4) {
         const int tn = thin_tn <= 1 ? 1 : 2, nNb = (Tout * B16 + 2 * tn - 1) / (2 * tn);
         if (tn == 1)
@@ -575,7 +575,7 @@ void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, 
                        int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean, unsigned *sat) {
     const int Mt = M / 16, NC = (winlen + 1) / 2;
     // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_CONV_WS=0: the round-3 kernel)
-    static const int ws_env = [] { const char *e = getenv("FFHIP_CONV_WS"); return e ? atoi(e) : 1; }();
+    static const int ws_env = [] { const char *e = dbg("conv_ws"); return e ? atoi(e) : 1; }();
     if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
         static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int NMB = Mt / 8;
@@ -1315,9 +1315,9 @@ void launch_crf_norm_linear(hipStream_t s, float *trans, double *E, int nread, i
     const size_t nblk = (size_t)nread * Tb;
     hipLaunchKernelGGL(k_crf_exp, dim3((unsigned)((nblk + kExpBlocks - 1) / kExpBlocks)), dim3(256), 0, s, trans, E, nblk, P, Ps, Pd, Tb, tbs, (int *)nullptr, 0.0f, 0);
     const int Rr = R < 1 ? 1 : R;
-    if (nbase == 4 && !getenv("FFHIP_CRF_GENERIC")) {
+    if (nbase == 4 && !dbg("crf_generic")) {
         hipLaunchKernelGGL(k_crf_chain8, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
-    } else if (nbase == 5 && Pd <= 64 && !getenv("FFHIP_CRF_GENERIC")) {
+    } else if (nbase == 5 && Pd <= 64 && !dbg("crf_generic")) {
         hipLaunchKernelGGL(k_crf_chain10, dim3(nread), dim3(64), 0, s, E, Tb, Pd, Rr, logz, tbs);
     } else
     switch (2 * nbase) {
@@ -1854,7 +1854,7 @@ k_transpost10(const float *__restrict__ trans, float *__restrict__ post, float *
 void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd, int nread, int Tb, int nbase, int Ps, const int *tbs,
                       double *E, int *wide) {
     const int P = 2 * nbase * (nbase + 1);
-    if (((nbase == 4 && Ps == 40) || (nbase == 5 && Ps == 60)) && E && wide && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_DECODE_R2")) {
+    if (((nbase == 4 && Ps == 40) || (nbase == 5 && Ps == 60)) && E && wide && !dbg("exact_order") && !dbg("decode_r2")) {
         // linear-space fp64 recursions on exp(score - block max) (ffhip_decode.hip); reads whose scores span too much keep the log-space kernel
         hipMemsetAsync(wide, 0, (size_t)nread * sizeof(int), s);
         launch_crf_exp(s, trans, E, nread, Tb, nbase, Ps, tbs, wide, kFbRange);
@@ -1863,11 +1863,11 @@ void launch_transpost(hipStream_t s, const float *trans, float *post, float *fwd
             hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs, (const int *)wide);
         else
             hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs, (const int *)wide);
-    } else if (nbase == 4 && Ps == 40 && !getenv("FFHIP_EXACT_ORDER"))
+    } else if (nbase == 4 && Ps == 40 && !dbg("exact_order"))
         hipLaunchKernelGGL(k_transpost8, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, tbs, (const int *)nullptr);
-    else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_CRF_GENERIC"))
+    else if (nbase == 5 && !dbg("exact_order") && !dbg("crf_generic"))
         hipLaunchKernelGGL(k_transpost10, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, Ps, tbs, (const int *)nullptr);
-    else if (!getenv("FFHIP_EXACT_ORDER"))
+    else if (!dbg("exact_order"))
         hipLaunchKernelGGL(k_transpost_lds, dim3(nread), dim3(256), 0, s, trans, post, fwd, fwd + (size_t)nread * (Tb + 1) * kMaxState, Tb, nbase, P, Ps, tbs);
     else
         hipLaunchKernelGGL(k_transpost, dim3(nread), dim3(64), 0, s, trans, post, fwd, Tb, nbase, P, Ps, tbs);
@@ -2234,13 +2234,13 @@ k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
                     int nread, int Tb, int nbase, int Ps, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2"))
+    if (nbase == 4 && Ps == 40 && !dbg("decode_r2"))
         launch_viterbi8x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
     else if (nbase == 4 && Ps == 40)
         hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
-    else if (nbase == 5 && Ps == 60 && !getenv("FFHIP_EXACT_ORDER") && !getenv("FFHIP_DECODE_R2"))
+    else if (nbase == 5 && Ps == 60 && !dbg("exact_order") && !dbg("decode_r2"))
         launch_viterbi10x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
-    else if (nbase == 5 && !getenv("FFHIP_EXACT_ORDER"))
+    else if (nbase == 5 && !dbg("exact_order"))
         hipLaunchKernelGGL(k_viterbi10, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, Ps, tbs);
     else
         hipLaunchKernelGGL(k_viterbi, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, nbase, P, Ps, tbs);

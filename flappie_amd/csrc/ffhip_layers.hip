@@ -465,7 +465,7 @@ extern "C" int ffhip_op_partition_function_scaled(ffhip_engine *eng, ffhip_mat S
     double *d_e = (double *)tmp.get(S.nc * (size_t)crf_exp_stride((int)S.nr) * sizeof(double));
     if (!d || !d_z || !d_e) OP_NOMEM();
     // what the pipeline runs for the 8- and 10-state models: the forward chain of k_crf_fb (ffhip_decode.hip)
-    if (((nbase == 4 && S.stride == 40) || (nbase == 5 && S.stride == 60)) && 2.0f * bound <= kFbRange && !getenv("FFHIP_DECODE_R2")) {
+    if (((nbase == 4 && S.stride == 40) || (nbase == 5 && S.stride == 60)) && 2.0f * bound <= kFbRange && !dbg("decode_r2")) {
         launch_crf_exp(s, d, d_e, 1, (int)S.nc, nbase, (int)S.stride, nullptr, nullptr, 0.0f);
         launch_crf_fb(s, nbase, d_e, d, nullptr, nullptr, 1, (int)S.nc, d_z, nullptr, 0, nullptr);
     } else

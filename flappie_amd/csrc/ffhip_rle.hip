@@ -610,13 +610,13 @@ void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread
     const int P = 2 * nbase * (nbase + 1);
     const size_t n = (size_t)nread * Tb * Ps;
     hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, n, nbase, P, Ps, temperature);
-    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
+    if (nbase == 4 && Ps == 40 && !dbg("decode_r2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
     else hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
     hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, logz, Tb, nbase, P, Ps, n, tbs);
 }
 
 void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps, const int *tbs) {
-    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
+    if (nbase == 4 && Ps == 40 && !dbg("decode_r2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
     else hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
 }
 
@@ -626,7 +626,7 @@ void launch_rle_transpost(hipStream_t s, const float *param, float *post, float 
 }
 
 void launch_rle_viterbi(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, int nbase, int Ps, const int *tbs) {
-    if (nbase == 4 && Ps == 40 && !getenv("FFHIP_DECODE_R2")) { launch_rle_viterbi8x(s, param, tb, path, qpath, score, nread, Tb, tbs); return; }      // ffhip_decode.hip
+    if (nbase == 4 && Ps == 40 && !dbg("decode_r2")) { launch_rle_viterbi8x(s, param, tb, path, qpath, score, nread, Tb, tbs); return; }      // ffhip_decode.hip
     hipLaunchKernelGGL(k_rle_viterbi, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, nbase, Ps, tbs);
 }
 

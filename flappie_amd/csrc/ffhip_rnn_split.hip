@@ -84,6 +84,11 @@ struct SplitArgsOther {       // what the second batch of a paired launch brings
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// A flag word in LDS, read or written as such.  Through a plain `volatile int *` the access stays a FLAT one -- address-space inference leaves
+// volatile accesses alone --: it travels the vector memory pipe behind the sweeps, is followed by `s_waitcnt vmcnt(0)` (a flat access may alias
+// LDS, so the compiler orders every LDS access behind it), and that wait also covers whatever else the wave has in flight -- in x wave 3 the L2-warming
+// touch of x(t+3), an HBM miss, at the top of every gate phase.  Rounds 1-4 had it that way (found in the ISA, round 5).
+#define LDSV(x) (*(volatile __attribute__((address_space(3))) int *)&(x))
 
 // slice `which` of 4 values (each already multiplied by its power of two), packed as two dwords
 template <bool CLAMP>
@@ -335,6 +340,16 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     // (Even so the timeline build runs ~35 % slower than the product; tools/dev/ablate.py times the real thing.)
     __shared__ unsigned long long tl_lds[8][32][8];
 #define TL(k) do { if (i >= 100 && i < 132 && lane == 0) tl_lds[wave][i - 100][(k)] = __builtin_readcyclecounter(); } while (0)
+#elif defined(FFHIP_PHASES)
+    // Where every wave's step goes, in the kernel as it runs in production (round 5; tools/dev/phases.py): the time between two stamps is ADDED to
+    // a per-wave word in LDS (one ds_add_u32 of lane 0, nobody waits for it) and the sums leave the kernel once, at its end -- 256 bytes of LDS, no
+    // global traffic in the loop, both workgroups of a CU still resident.  Phase k = the stretch that ENDS at TL(k): 0 loop turn-around, 1 the h waves'
+    // hand-off poll, 2 the wave's matrix work (x: loads + projection + flag wait + px; h: sweep + MFMAs + partials), 3 waiting at barrier 1, 4 the gate
+    // phase, 5 waiting at barrier 2.
+    __shared__ unsigned tl_acc[8][8];
+    if (threadIdx.x < 64) tl_acc[threadIdx.x >> 3][threadIdx.x & 7] = 0u;
+    unsigned tl_prev = (unsigned)__builtin_readcyclecounter();
+#define TL(k) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0) __hip_atomic_fetch_add(&tl_acc[wave][(k)], now_ - tl_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tl_prev = now_; } while (0)
 #else
 #define TL(k) do { } while (0)
 #endif
@@ -501,7 +516,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         if (step_t(i) >= my_tb) c = 0.0f;
         cx[wave & 1][lane] = c;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (LDS operations of a wave execute in order; the flag follows the data)
-        if (lane == 0) *(volatile int *)&cxflag[wave & 1] = i + 1;
+        if (lane == 0) LDSV(cxflag[wave & 1]) = i + 1;
     };
     auto gate_back = [&](int i, int gts, int gj, int my_tb) {
         float so = sbias[gj][q].w;
@@ -509,7 +524,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         for (int w2 = 0; w2 < 4; w2++) so = so + ph_at(w2, gts, gj)[lane].w;
         so = __builtin_ldexpf(so, neg_exp);
         const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
-        while (*(volatile int *)&cxflag[wave & 1] != i + 1) __builtin_amdgcn_s_sleep(1);
+        while (LDSV(cxflag[wave & 1]) != i + 1) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const float c = cx[wave & 1][lane];
         float h = o * (a.fast_gates ? tanh_hw(c) : tanh_ref_lean(c));
@@ -566,7 +581,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
                 if (want > 0)
-                    for (unsigned spin = 0; *(volatile int *)&pxc[kw][ts] != want && 0 == *(volatile int *)&lds_abort && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
+                    for (unsigned spin = 0; LDSV(pxc[kw][ts]) != want && 0 == LDSV(lds_abort) && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int j = 0; j < NRT; j++) px[0][kw][ts][j][lane] = acc[ts][j];
             }
@@ -596,7 +611,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(2);
             raw_barrier();
             TL(3);
-            const int aborted = *(volatile int *)&lds_abort;      // (looked at behind the gate math: see the h waves' loop)
+            const int aborted = LDSV(lds_abort);      // (looked at behind the gate math: see the h waves' loop)
             if (sg_front) {
                 __builtin_amdgcn_s_setprio(3);
                 gate_front(i, my_gts, my_gj, c, my_tb);
@@ -683,7 +698,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(2);
             raw_barrier();
             TL(3);
-            const int aborted = *(volatile int *)&lds_abort;      // (looked at behind the gate math: see the h waves' loop)
+            const int aborted = LDSV(lds_abort);      // (looked at behind the gate math: see the h waves' loop)
             if constexpr (TS == 2) {                         // (one tile per group: its N <= 4 gate tiles all belong to h waves -- and said at
                                                              // compile time, so that no gate temporaries are live beside the prefetch)
                 if (sg_front) {
@@ -729,7 +744,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
                     for (int j = 0; j < 3; j++) pc[ts][j] = px[0][kw][ts][j][lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;
+                if (lane < 2) LDSV(pxc[kw][lane]) = i + 1;
             }
             if (i > 0) {
                 const int tp = step_t(i - 1);
@@ -937,7 +952,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 }
                 // the projection partials of this step are consumed: the x wave of my K quarter may write the next ones
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!PG && lane < 2) *(volatile int *)&pxc[kw][lane] = i + 1;      // (the packed GRUmod form: released at the top of the step)
+                if (!PG && lane < 2) LDSV(pxc[kw][lane]) = i + 1;      // (the packed GRUmod form: released at the top of the step)
             } else {
 #pragma unroll
                 for (int ts = 0; ts < TS; ts++) {
@@ -951,7 +966,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(3);
             // (the abort word is read here and looked at BEHIND the gate math: a read-wait-branch in front of it is ~100 cycles on the
             // chain of every step; results of an aborted launch are discarded anyway)
-            const int aborted = *(volatile int *)&lds_abort;
+            const int aborted = LDSV(lds_abort);
             if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
             if (aborted) return;
             TL(4);
@@ -961,6 +976,13 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             TL(5);
         }
     }
+#ifdef FFHIP_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (a.dbg && lane < 8) {
+        atomicAdd(a.dbg + wave * 8 + lane, (unsigned long long)tl_acc[wave][lane]);
+        if (lane == 0) atomicAdd(a.dbg + 64 + wave, (unsigned long long)Tb);
+    }
+#endif
 #ifdef FFHIP_TIMELINE
     if (a.dbg && Tb >= 132)
         for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)block_index * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
@@ -1418,22 +1440,22 @@ bool split_supported(int kind, int H) { return (kind == 0 || kind == 1) && H % 1
 // 512 reads, and the launches of two 256-read batches in flight run BESIDE each other instead of one after the other
 // (FFHIP_SPLIT_DENSE=0: the one-tile form)
 static bool split_dense3(int kind, int H) {
-    const char *e = getenv("FFHIP_SPLIT_DENSE");
-    return kind == 0 && H == 384 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS");
+    const char *e = dbg("split_dense");
+    return kind == 0 && H == 384 && kSplitF16 && !(e && e[0] == '0') && !dbg("split_ts");
 }
 // H = 256 (LSTM and GRUmod): the dense pair form needs 79 registers and 53 KiB there -- THREE workgroups per CU, six 16-read recurrences,
 // 768 reads per launch (FFHIP_DENSE256=0: at most the two-workgroup form of round 2, 512 reads)
 static bool split_dense256(int H) {
-    const char *e = getenv("FFHIP_DENSE256");
-    return H == 256 && kSplitF16 && !(e && e[0] == '0') && !getenv("FFHIP_SPLIT_TS") && !getenv("FFHIP_NO_DENSE");
+    const char *e = dbg("dense256");
+    return H == 256 && kSplitF16 && !(e && e[0] == '0') && !dbg("split_ts") && !dbg("no_dense");
 }
 // H = 256: the packed forms (lstm_split_body's PACK; k_grumod_pack, k_lstm_pack) -- 16 members a group, 128 registers, two workgroups a CU: a
 // FULL launch takes 8 * (ncu / 32) tiles, 1024 reads on 256 CUs; their weights are the second half of the layer's pack (FFHIP_NO_PACK: never)
-static bool split_pack256(int kind, int H) { return (kind == 0 || kind == 1) && split_dense256(H) && !getenv("FFHIP_NO_PACK"); }
+static bool split_pack256(int kind, int H) { return (kind == 0 || kind == 1) && split_dense256(H) && !dbg("no_pack"); }
 static bool split_launch_pack(int kind, int H, int nrt, int ncu) { return split_pack256(kind, H) && nrt == 8 * (ncu / 32); }
 int split_max_tiles(int ncu, int H) {
     if (split_dense256(H)) return 6 * (ncu / 32);
-    return ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") ? 4 : 2) * (ncu / 32);
+    return ((H <= 256 || split_dense3(0, H)) && !dbg("no_dense") ? 4 : 2) * (ncu / 32);
 }
 // tiles the next launch of a batch takes when `remaining` are left: the dense forms are for FULL launches only (a partly filled
 // one has a group count that is no multiple of the 8 XCDs and loses the one-L2 hand-off)
@@ -1441,14 +1463,14 @@ int split_next_launch_tiles(int kind, int H, int remaining, int ncu) {
     const int unit = ncu / 32 > 0 ? ncu / 32 : 1;       // (never 0: the engine's layer loop advances by this, the binary sizes its batches by it)
     if (split_pack256(kind, H) && remaining >= 8 * unit) return 8 * unit;
     if (split_dense256(H) && remaining >= 6 * unit) return 6 * unit;
-    if ((H <= 256 || split_dense3(0, H)) && !getenv("FFHIP_NO_DENSE") && remaining >= 4 * unit) return 4 * unit;
+    if ((H <= 256 || split_dense3(0, H)) && !dbg("no_dense") && remaining >= 4 * unit) return 4 * unit;
     return remaining < 2 * unit ? remaining : 2 * unit;
 }
 // tiles per group of a launch of nrt read tiles
 // `beside`: another batch is between run and finish -- its layer launches are on the chip; the dense form runs BESIDE them
 static bool split_launch_dense256(int H, int nrt, int ncu) { return split_dense256(H) && nrt > 4 * (ncu / 32); }
 static bool split_launch_dense3(int kind, int H, int nrt, int ncu, int beside) {
-    return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || beside || getenv("FFHIP_SPLIT_DENSE_ALWAYS"));      // (the variable: development)
+    return split_dense3(kind, H) && (nrt > 2 * (ncu / 32) || beside || dbg("split_dense_always"));      // (the variable: development)
 }
 static int split_launch_ts(int kind, int H, int nrt, int ncu, int beside) {
     // the dense forms (two workgroups per CU, a pair of tiles each) take launches with more tiles than the one-tile form can:
@@ -1475,27 +1497,41 @@ size_t split_flag_words(int nrt) { return (size_t)nrt * 32; }
 // GRUmod form ([2][3 H / 16 row tiles][H / 32][slices][64]) follows it
 size_t split_pack_offset(int H) { return (size_t)2 * (H / 4) * (H / 32) * NS * 64; }
 int split_tiles_per_group(int kind, int H) {
-    const char *force = getenv("FFHIP_SPLIT_TS");      // development: 1 or 2
-    if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
+    const char *force = dbg("split_ts");      // development: 1 or 2
+    if (force && (force[0] == '1' || force[0] == '2') && H < 512) return force[0] - '0';
     return kSplitTS[kind & 1][H / 128 - 1];
 }
 
 unsigned long long *g_split_dbg = nullptr;
+#ifdef FFHIP_PHASES
+}  // namespace ffhip
+// (instrumented variant only: tools/dev/phases.py)  out[0..63] = cycles by [wave][phase] summed over every workgroup and step since the last reset,
+// out[64..71] = steps by wave (summed over workgroups)
+extern "C" int ffhip_debug_phases(unsigned long long *out, int reset) {
+    static unsigned long long *d = nullptr;
+    if (!d) { if (hipMalloc(&d, 72 * 8) != hipSuccess) return -1; hipMemset(d, 0, 72 * 8); ffhip::g_split_dbg = d; }
+    hipDeviceSynchronize();
+    if (out) hipMemcpy(out, d, 72 * 8, hipMemcpyDeviceToHost);
+    if (reset) hipMemset(d, 0, 72 * 8);
+    return 0;
+}
+namespace ffhip {
+#endif
 
 // one launch for the layers of two batches (the dense form at H = 384 only); false: shapes this does not take -- launch them one by one
 bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const SplitLaunch &p0, const SplitLaunch &p1) {
 #ifdef FFHIP_SPLIT_BF16X3
     return false;
 #else
-    if (!split_dense3(kind, H) || getenv("FFHIP_NO_PAIR") || p0.nrt > 2 * (ncu / 32) || p1.nrt > 2 * (ncu / 32) || p0.nrt < 1 || p1.nrt < 1) return false;
+    if (!split_dense3(kind, H) || dbg("no_pair") || p0.nrt > 2 * (ncu / 32) || p1.nrt > 2 * (ncu / 32) || p0.nrt < 1 || p1.nrt < 1) return false;
     auto mk = [&](const SplitLaunch &p) {
         SplitArgs a;
         a.epoch = p.epoch; a.acc_scale = split_pow2(p.scale_exp); a.scale_exp = p.scale_exp; a.fast_gates = p.fast_gates;
-        a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
+        a.split_gate = dbg("no_split_gate") ? 0 : 1;
         a.Wp = (const v4u *)p.Wp; a.bias = p.bias; a.xin = (const unsigned char *)p.xin; a.hout = (unsigned char *)p.hout; a.hout_f32 = p.hout_f32;
         a.flags = p.flags; a.abort_word = p.abort_word;
         a.Tb = p.Tb; a.B16 = p.B16; a.H = H; a.rt0 = p.rt0; a.nrt = p.nrt; a.backward = p.backward; a.mode = p.mode;
-        a.tbs = p.tbs; a.tbt = p.tbt; a.dbg = nullptr;
+        a.tbs = p.tbs; a.tbt = p.tbt; a.dbg = g_split_dbg;
         return a;
     };
     const int g0 = (p0.nrt + 1) / 2, g1 = (p1.nrt + 1) / 2;
@@ -1521,7 +1557,7 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.acc_scale = split_pow2(scale_exp);
     a.scale_exp = scale_exp;
     a.fast_gates = fast_gates;
-    a.split_gate = getenv("FFHIP_NO_SPLIT_GATE") ? 0 : 1;
+    a.split_gate = dbg("no_split_gate") ? 0 : 1;
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
@@ -1550,7 +1586,8 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #else
-    if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); case 4: SPLIT_LAUNCH(0, 4); }
+    if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3);
+                                      case 4: hipLaunchKernelGGL((k_lstm_split<0, 4, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a); return true; }      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves)
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #endif
 #undef SPLIT_LAUNCH

@@ -209,6 +209,26 @@ static pthread_mutex_t hdf5_lock = PTHREAD_MUTEX_INITIALIZER;
 static double t_phase[8];
 static const char *phase_name[8] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output",
                                      "  of which set_prepared", "  of which batch_run" };
+/* Development switches of the binary: FLAPPIE_DEBUG=token[,token=value ...] -- no_reader_thread, no_writer_thread,
+ * list_only, kill_reader=k:f.  NULL when the token is absent, its value ("" for a bare token) otherwise. */
+static const char *cli_dbg(const char *token) {
+    static char buf[256];
+    const char *e = getenv("FLAPPIE_DEBUG");
+    const size_t n = strlen(token);
+    while (e && *e) {
+        const char *end = e + strcspn(e, ", ;");
+        if ((size_t)(end - e) >= n && 0 == strncmp(e, token, n) && (e + n == end || '=' == e[n])) {
+            const size_t vl = (e + n == end) ? 0 : (size_t)(end - e - n - 1);
+            if (vl >= sizeof buf) return NULL;
+            memcpy(buf, e + n + 1, vl);
+            buf[vl] = 0;
+            return buf;
+        }
+        e = *end ? end + 1 : end;
+    }
+    return NULL;
+}
+
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 /* what the run basecalled: reads, samples of their trimmed ranges (the metric of SURVEY.md section 8d), samples read from the files */
 static unsigned long long n_called_reads, n_called_samples, n_raw_samples;
@@ -522,7 +542,7 @@ static struct {
 /* A WRITER THREAD takes the finished chunks, strictly in order: formatting, --trace compression and the HDF5 writes of chunk k run
  * while the main thread keeps submitting the batches of chunk k + 1 (with --trace on 100 000-sample reads the output side costs as
  * much time as the GPU side; done on the main thread it stood between two submissions).  chunk sequence numbers in
- * [writer.head, writer.tail) are ready to be written; FLAPPIE_NO_WRITER_THREAD=1 writes on the main thread. */
+ * [writer.head, writer.tail) are ready to be written; FLAPPIE_DEBUG=no_writer_thread writes on the main thread. */
 static struct { pthread_t th; pthread_mutex_t mu; pthread_cond_t cv; long head, tail; int started, stop; hid_t hdf5out; } writer =
     { 0, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, -1 };
 
@@ -557,7 +577,7 @@ static void pipe_finish_ready(hid_t hdf5out) {
         ffhip_prep_destroy(c->prep);                  /* (the engine's buffer pool belongs to this thread) */
         c->prep = NULL;
         writer.hdf5out = hdf5out;
-        if (!writer.started && !getenv("FLAPPIE_NO_WRITER_THREAD")) writer.started = (0 == pthread_create(&writer.th, NULL, writer_main, NULL)) ? 1 : -1;
+        if (!writer.started && !cli_dbg("no_writer_thread")) writer.started = (0 == pthread_create(&writer.th, NULL, writer_main, NULL)) ? 1 : -1;
         if (writer.started == 1) {
             pthread_mutex_lock(&writer.mu);
             writer.tail = pipe_state.next_finish + 1;
@@ -630,7 +650,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     pipe_finish_ready(hdf5out);
 }
 
-/* Without the reader thread (FLAPPIE_NO_READER_THREAD=1) this thread fills the reader buffers itself: buffer k may only be
+/* Without the reader thread (FLAPPIE_DEBUG=no_reader_thread) this thread fills the reader buffers itself: buffer k may only be
  * overwritten once the chunk that last used it has been WRITTEN -- by the writer thread, possibly still at work. */
 static void pipe_wait_slot_written(void) {
     chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
@@ -762,8 +782,8 @@ static int read_all(int fd, void *buf, size_t n) {
 
 static void reader_child(const file_list *fl, int k, int R, int fd) {
     signal(SIGPIPE, SIG_IGN);            /* a parent that went away is a failed write, not a signal (the PARENT keeps the default: `flappie ... | head` ends) */
-    long kill_k = -1, kill_f = -1;       /* tests: FLAPPIE_DEBUG_KILL_READER=k:f -- child k dies (SIGKILL) when it reaches file index f */
-    const char *kill_env = getenv("FLAPPIE_DEBUG_KILL_READER");
+    long kill_k = -1, kill_f = -1;       /* tests: FLAPPIE_DEBUG=kill_reader=k:f -- child k dies (SIGKILL) when it reaches file index f */
+    const char *kill_env = cli_dbg("kill_reader");
     if (kill_env && 2 != sscanf(kill_env, "%ld:%ld", &kill_k, &kill_f)) kill_k = -1;
     for (size_t f = (size_t)k; f < fl->n; f += (size_t)R) {
         if (kill_k == k && (long)f >= kill_f) raise(SIGKILL);
@@ -897,11 +917,11 @@ int main(int argc, char *argv[]) {
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
     const double t_listed = now_s();
-    if (getenv("FLAPPIE_LIST_ONLY")) {             /* the files this process would call, one per line -- no GPU touched (tests, tools/host_scaling.py) */
+    if (cli_dbg("list_only")) {             /* the files this process would call, one per line -- no GPU touched (tests, tools/host_scaling.py) */
         for (size_t f = 0; f < fl.n; f++) printf("%s\n", fl.path[f]);
         return EXIT_SUCCESS;
     }
-    start_reader_procs(&fl, getenv("FLAPPIE_NO_READER_THREAD") ? 0 : args.readers);      /* before the HIP runtime and libhdf5 are touched here */
+    start_reader_procs(&fl, cli_dbg("no_reader_thread") ? 0 : args.readers);      /* before the HIP runtime and libhdf5 are touched here */
     const struct ffhip_model *mdl = flappie_hip_model(args.model);
     if (NULL == mdl) { stop_reader_procs(); errx(EXIT_FAILURE, "model \"%s\" is not available (set FLAPPIE_MODEL_DIR)", flappie_model_string(args.model)); }
     struct ffhip_engine *eng = flappie_hip_engine();
@@ -919,7 +939,7 @@ int main(int argc, char *argv[]) {
         sem_init(&rs.filled[k], 0, 0);
         sem_init(&rs.empty[k], 0, 1);
     }
-    const int threaded = !getenv("FLAPPIE_NO_READER_THREAD");
+    const int threaded = !cli_dbg("no_reader_thread");
     pthread_t reader;
     if (threaded && 0 != pthread_create(&reader, NULL, reader_main, &rs)) errx(EXIT_FAILURE, "could not start the reader thread");
     size_t done = 0;

@@ -133,7 +133,7 @@ def test_full_packed_launch_against_the_oracle(B, engine, kind):
 
 def test_front_order_changes_the_schedule_not_the_results(B, engine):
     """bench.py's c2 pipeline -- two PAIRS in flight, the second pair's convolutions beside the first pair's head and decode
-    (FFHIP_FRONT_ORDER=layers, the default; batch_run_impl) -- against round 3's order and against no order at all: every read's
+    (FFHIP_DEBUG=front_order=layers, the default; batch_run_impl) -- against round 3's order and against no order at all: every read's
     transition scores, calls and qualities byte for byte the same.  Three rounds through the same four batch objects, so that
     a batch's buffers are reused while its neighbours are still in flight."""
     import hashlib
@@ -152,10 +152,10 @@ def test_front_order_changes_the_schedule_not_the_results(B, engine):
         return h.hexdigest()
 
     seen = {}
-    old = os.environ.get("FFHIP_FRONT_ORDER")
+    old = os.environ.get("FFHIP_DEBUG")
     try:
         for order in ("layers", "batch", "none"):
-            os.environ["FFHIP_FRONT_ORDER"] = order
+            os.environ["FFHIP_DEBUG"] = "front_order=" + order
             got = []
             for rnd in range(3):
                 for k in range(4):
@@ -172,9 +172,9 @@ def test_front_order_changes_the_schedule_not_the_results(B, engine):
                     seen.setdefault((k + rnd) % 4, set()).add(got[rnd][k])
     finally:
         if old is None:
-            os.environ.pop("FFHIP_FRONT_ORDER", None)
+            os.environ.pop("FFHIP_DEBUG", None)
         else:
-            os.environ["FFHIP_FRONT_ORDER"] = old
+            os.environ["FFHIP_DEBUG"] = old
     for b in batches:
         b.close()
     dm.close()

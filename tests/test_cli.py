@@ -438,7 +438,7 @@ def test_batch_pipeline_across_chunks(cli_inputs, tmp_path):
         write_fast5(big / ("read_%03d.fast5" % i), "uuid-%04d" % i, synth_raw(rng, int(rng.integers(1200, 3000))))
     outs = {}
     for tag, extra, e2 in (("chunks", ["--batch", "8", "--readers", "3"], {}), ("one", ["--batch", "256", "--readers", "2"], {}),
-                           ("main", ["--batch", "8"], {"FLAPPIE_NO_READER_THREAD": "1"})):
+                           ("main", ["--batch", "8"], {"FLAPPIE_DEBUG": "no_reader_thread"})):
         r = subprocess.run([FLAPPIE, "--no-uuid", "--trace", str(tmp_path / (tag + ".hdf5"))] + extra + [str(big)], env=dict(env, **e2),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
@@ -472,7 +472,7 @@ def test_pipeline_with_bad_chunks_a_dead_reader_and_a_closed_stdout(cli_inputs, 
             write_fast5(big / fn, "uuid-%04d" % i, synth_raw(rng, int(rng.integers(1200, 2600))))
             good.append(fn)
     outs = {}
-    for tag, extra, e2 in (("procs", ["--readers", "3"], {}), ("thread", ["--readers", "0"], {}), ("main", ["--readers", "0"], {"FLAPPIE_NO_READER_THREAD": "1"})):
+    for tag, extra, e2 in (("procs", ["--readers", "3"], {}), ("thread", ["--readers", "0"], {}), ("main", ["--readers", "0"], {"FLAPPIE_DEBUG": "no_reader_thread"})):
         r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid"] + extra + [str(big)], env=dict(env, **e2), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert r.stderr.count("No basecall returned") == 90
@@ -483,7 +483,7 @@ def test_pipeline_with_bad_chunks_a_dead_reader_and_a_closed_stdout(cli_inputs, 
     files = [str(big / fn) for fn in good]
     whole = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "3"] + files, env=env, capture_output=True, text=True, timeout=300)
     assert whole.returncode == 0, whole.stderr
-    r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "3"] + files, env=dict(env, FLAPPIE_DEBUG_KILL_READER="1:20"),
+    r = subprocess.run([FLAPPIE, "--batch", "8", "--no-uuid", "--readers", "3"] + files, env=dict(env, FLAPPIE_DEBUG="kill_reader=1:20"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "ended early" in r.stderr and "reader process(es) failed" in r.stderr
     recs, ref = _parse_fastq(r.stdout), _parse_fastq(whole.stdout)
@@ -555,7 +555,7 @@ def test_reference_main_relinked_against_the_engine(cli_inputs):
 def test_shard_by_size_balances_bytes_and_partitions_the_list(tmp_path):
     """--shard g/n --shard-by-size (SURVEY.md section 8e "greedy by sum of samples"): every file lands in exactly one shard, the
     shards' byte sums are within one largest file of each other where dealing by index is not, and the table is flappie_amd/shard.py::
-    partition_reads' (largest first, to the lightest shard).  No GPU: FLAPPIE_LIST_ONLY=1 prints the list and exits before the engine exists."""
+    partition_reads' (largest first, to the lightest shard).  No GPU: FLAPPIE_DEBUG=list_only prints the list and exits before the engine exists."""
     from flappie_amd import shard as S
     exe = os.path.join(ROOT, "flappie_amd", "flappie")
     if not os.path.exists(exe):
@@ -570,7 +570,7 @@ def test_shard_by_size_balances_bytes_and_partitions_the_list(tmp_path):
         p.write_bytes(b"x" * n)
         sizes[str(p)] = n
     paths = sorted(sizes)
-    env = dict(os.environ, FLAPPIE_LIST_ONLY="1")
+    env = dict(os.environ, FLAPPIE_DEBUG="list_only")
 
     def listing(extra):
         out = []

@@ -291,7 +291,7 @@ def test_other_baseline_configs_properties(B, engine, label, kind, H, nread, T, 
 @pytest.mark.parametrize("kind,hidden", [(M.NET_GRUMOD5, 64), (M.NET_LSTM5, 64)])
 def test_decode_kernels_agree_with_their_chain_order_forms(B, engine, kind, hidden):
     """The butterfly decode kernels (k_transpost8/10, k_viterbi8/10) against the chain-order / generic forms selected by
-    FFHIP_EXACT_ORDER=1: the same Viterbi paths, qualities and calls; posteriors equal up to the rounding of the summation order."""
+    FFHIP_DEBUG=exact_order: the same Viterbi paths, qualities and calls; posteriors equal up to the rounding of the summation order."""
     mdl = M.synthetic_model(kind, hidden, seed=21)
     dm = B.DeviceModel(engine, mdl)
     rng = np.random.default_rng(77)
@@ -300,7 +300,7 @@ def test_decode_kernels_agree_with_their_chain_order_forms(B, engine, kind, hidd
     out = {}
     for mode in ("fast", "exact"):
         if mode == "exact":
-            os.environ["FFHIP_EXACT_ORDER"] = "1"
+            os.environ["FFHIP_DEBUG"] = "exact_order"
         try:
             b = B.Batch(dm, len(sigs), max(lens))
             b.set_signals_ragged(sigs)
@@ -309,7 +309,7 @@ def test_decode_kernels_agree_with_their_chain_order_forms(B, engine, kind, hidd
             out[mode] = [(b.basecall(r), b.quality(r), b.path(r), b.posterior(r), b.score(r)) if lens[r] else None for r in range(len(sigs))]
             b.close()
         finally:
-            os.environ.pop("FFHIP_EXACT_ORDER", None)
+            os.environ.pop("FFHIP_DEBUG", None)
     for r, n in enumerate(lens):
         if not n:
             continue

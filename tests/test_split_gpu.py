@@ -137,7 +137,7 @@ def test_split_kernel_agrees_with_f32_kernel(B, engine, kind, hidden, nread, T):
 def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monkeypatch):
     """H <= 256 and more than 256 reads: one launch carries up to 512 reads (pair form, two workgroups per CU) or -- round 3 -- 768
     (the dense form in 79 registers: THREE workgroups per CU) instead of launches of 256 -- same arithmetic, so every score must be
-    IDENTICAL to what the one-tile launches give (FFHIP_NO_DENSE=1); ragged lengths, the last pair of the 400-read batch has one
+    IDENTICAL to what the one-tile launches give (FFHIP_DEBUG=no_dense); ragged lengths, the last pair of the 400-read batch has one
     member.
     From 1024 reads on: the PACKED forms (16 members a group, gate-major row tiles -- three a member for GRUmod, no empty accumulator rows, four
     for the LSTM; 1024 reads a launch) -- another tiling of the same sums in the same order, so identical as well; 1040 reads = one packed launch
@@ -152,9 +152,9 @@ def test_dense_launch_matches_the_one_tile_launches(B, engine, kind, nread, monk
     res = []
     for dense in (True, False):
         if dense:
-            monkeypatch.delenv("FFHIP_NO_DENSE", raising=False)
+            monkeypatch.delenv("FFHIP_DEBUG", raising=False)
         else:
-            monkeypatch.setenv("FFHIP_NO_DENSE", "1")
+            monkeypatch.setenv("FFHIP_DEBUG", "no_dense")
         b = B.Batch(dm, nread, T)
         b.set_signals_ragged(sigs)
         b.run(); b.finish()
@@ -470,7 +470,7 @@ def test_differential_fuzz_is_deterministic(B):
 def test_timeout_falls_back_to_the_stepwise_kernels(B):
     """Co-residency guard: when a persistent layer kernel gives up waiting for peer workgroups -- another
     tenant holds part of the GPU -- ffhip_batch_finish re-runs the batch on the launch-per-step kernels instead of returning
-    FFHIP_ETIMEOUT, and the next runs go there directly.  The time-out is simulated (FFHIP_DEBUG_FORCE_ABORT pre-sets the abort
+    FFHIP_ETIMEOUT, and the next runs go there directly.  The time-out is simulated (FFHIP_DEBUG=force_abort pre-sets the abort
     word; the layer kernels then leave at once, as they do when an earlier layer of a batch timed out)."""
     import ctypes as C
     import os
@@ -486,11 +486,11 @@ def test_timeout_falls_back_to_the_stepwise_kernels(B):
     b.run(); b.finish()
     assert b.rnn_path() == 3 and L.ffhip_debug_fallback_count(eng.h) == 0
     want = [(b.basecall(r), b.quality(r), b.transitions(r)) for r in range(20)]
-    os.environ["FFHIP_DEBUG_FORCE_ABORT"] = "1"
+    os.environ["FFHIP_DEBUG"] = "force_abort"
     try:
         b.run(); b.finish()                 # "times out", is re-run stepwise inside finish()
     finally:
-        del os.environ["FFHIP_DEBUG_FORCE_ABORT"]
+        del os.environ["FFHIP_DEBUG"]
     assert L.ffhip_debug_fallback_count(eng.h) == 1 and b.rnn_path() == 0
     for r in range(20):
         assert b.basecall(r) == want[r][0] and b.quality(r) == want[r][1]
@@ -498,7 +498,7 @@ def test_timeout_falls_back_to_the_stepwise_kernels(B):
     b.run(); b.finish()                     # still wary of the co-tenant: straight to the stepwise kernels, no second fallback
     assert b.rnn_path() == 0 and L.ffhip_debug_fallback_count(eng.h) == 1
     os.environ["FFHIP_NO_FALLBACK"] = "1"
-    os.environ["FFHIP_DEBUG_FORCE_ABORT"] = "1"
+    os.environ["FFHIP_DEBUG"] = "force_abort"
     try:
         eng2 = B.Engine(0)
         dm2 = B.DeviceModel(eng2, mdl)
@@ -509,7 +509,7 @@ def test_timeout_falls_back_to_the_stepwise_kernels(B):
             b2.finish()
         b2.close(); dm2.close(); eng2.close()
     finally:
-        del os.environ["FFHIP_NO_FALLBACK"], os.environ["FFHIP_DEBUG_FORCE_ABORT"]
+        del os.environ["FFHIP_NO_FALLBACK"], os.environ["FFHIP_DEBUG"]
     b.close(); dm.close(); eng.close()
 
 

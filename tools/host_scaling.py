@@ -23,6 +23,9 @@ sys.path.insert(0, ROOT)
 from flappie_amd import model as M  # noqa: E402
 
 EXE, TOOL = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
+HOOKS = os.path.join(ROOT, "tools", "test_hooks")          # `make -C flappie_amd/csrc hooks` (__graft_entry__.build() does it)
+if not os.path.exists(os.path.join(HOOKS, "libffhip.so")):
+    sys.exit("tools/test_hooks/libffhip.so is missing: make -C flappie_amd/csrc hooks")
 NSHARD = 8
 NOGPU = True          # emulated processes keep off the physical GPU altogether (--emu-on-gpu: their signal preparation and copies run on it)
 
@@ -44,6 +47,7 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
         env = dict(env0)
         if g not in real:
             env["FFHIP_DEBUG_HOST_REHEARSAL_MSPS"] = str(gpu_rate)
+            env["LD_LIBRARY_PATH"] = HOOKS + os.pathsep + env.get("LD_LIBRARY_PATH", "")      # the -DFFHIP_TEST_HOOKS library: the release one has no such hook
             if NOGPU:
                 env["FFHIP_DEBUG_HOST_REHEARSAL_NOGPU"] = "1"
         cmd = [EXE, "--readers", str(readers), "--shard", "%d/%d" % (g, NSHARD)] + (["--shard-by-size"] if by_size else []) + ["--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % g), os.path.join(d, "reads")]
@@ -146,7 +150,7 @@ def main():
             for flag in ([], ["--shard-by-size"]):
                 sums = []
                 for g in range(NSHARD):
-                    r = subprocess.run([EXE, "--shard", "%d/%d" % (g, NSHARD)] + flag + [os.path.join(d, "reads")], env=dict(os.environ, FLAPPIE_LIST_ONLY="1"), capture_output=True, text=True)
+                    r = subprocess.run([EXE, "--shard", "%d/%d" % (g, NSHARD)] + flag + [os.path.join(d, "reads")], env=dict(os.environ, FLAPPIE_DEBUG="list_only"), capture_output=True, text=True)
                     sums.append(sum(os.path.getsize(p) for p in r.stdout.split()))
                 print("shard byte sums %s: min %.4f GB, max %.4f GB (max / min %.4f)" % ("by size " if flag else "by index", min(sums) / 1e9, max(sums) / 1e9, max(sums) / min(sums)))
         finally:
