@@ -21,6 +21,8 @@ hidden = int(sys.argv[3]) if len(sys.argv) > 3 else 384
 nfl = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 nread = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 pair = len(sys.argv) > 6 and sys.argv[6] == "1"
+if pair and nfl % 2:
+    sys.exit("pairs need an even number of batches in flight (a batch waits for its partner before it is run: ADVICE r4)")
 import ctypes as C  # noqa: E402
 eng = B.Engine(0)
 B.lib().ffhip_debug_fallback_count.argtypes = [C.c_void_p]
