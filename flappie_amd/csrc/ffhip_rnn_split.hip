@@ -60,12 +60,6 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 constexpr int NS = kSplitNS;
-#ifndef FFHIP_XPRIO
-#define FFHIP_XPRIO 0      // priority of the dense forms' x waves while they project (the h waves and every gate job: 3)
-#endif
-#ifndef FFHIP_XPF
-#define FFHIP_XPF 0      // the x path through LDS (see XPF below): measured, not faster (-1.6 ... +0.6 % across boxes), and it raises the rate of the flag race above
-#endif
 
 struct SplitArgs {
     const v4u *Wp;            // [2][Ut][Hc][NS][64] 16 B; mat 0 = input weights, 1 = recurrent weights
@@ -222,7 +216,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     __shared__ int lds_fast;
     __shared__ float cx[2][64];             // split gate tiles: cell state c(t) from the front wave to the back wave of tiles 4 and 5
     __shared__ int cxflag[2];               // ... and the step it belongs to (+1)
-    __shared__ int xfree[FFHIP_XPF ? 4 : 1];   // XPF: the step whose x (tile A) x wave kw has taken out of h wave kw's landing zones
     // HL: the sweep of h(t-1) LANDS IN LDS (buffer_load ... lds: no destination registers) and feeds the MFMAs through ds_read_b128.
     // The one-tile kernel at N = 3 then fits 128 registers: TWO workgroups -- two independent recurrences -- share a CU.
     constexpr bool HL = (TS == 1 && N == 3) || DN;
@@ -234,7 +227,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     };
     constexpr int G = PACK ? 16 : 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
-    int lane = threadIdx.x & 63;                // (not const: the dense x waves re-derive it from an opaque copy every step, see XPF)
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool xw = wave < 4;
     const int kw = wave & 3;
@@ -255,7 +248,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     const int ut0 = m * MT;
     if (threadIdx.x == 0) lds_abort = (__hip_atomic_load(a.abort_word, RLX_AGENT) != 0u) ? 1 : 0;      // an earlier layer of this batch gave up: leave at once
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * MT) sbias[(threadIdx.x - 64) >> 2][threadIdx.x & 3] = *(const v4f *)(a.bias + (size_t)ut0 * 16 + (threadIdx.x - 64) * 4) * (KIND == 1 ? 1.0f : a.acc_scale);      // LSTM: the bias joins the accumulators in their scaled space (exact)
-    int q = lane >> 4, rl = lane & 15;
+    const int q = lane >> 4, rl = lane & 15;
     auto step_t = [&](int i) { return a.backward ? Tb - 1 - i : i; };
     // Gate tiles: the pair has ntl*N <= 6 of them; tile g6 = ts*N + j.  The h waves take tiles 0..3, x waves 0 and 1 take
     // tiles 4 and 5: at most two gate waves per SIMD, and each is a single dependency chain (two chains interleaved by
@@ -274,7 +267,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     const bool store_wave = gate_wave || sg_back;            // publishes a tile's h(t)
     const int my_gts = g6 / MT, my_gj = g6 % MT;             // (PACK: my_gj = the component = unit tile of the member)
     if (threadIdx.x < 2) cxflag[threadIdx.x] = 0;
-    if (FFHIP_XPF && threadIdx.x < 4) xfree[threadIdx.x] = 0;
     if (threadIdx.x < 8) pxc[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     // where quarter-wave q of a gate wave stores slice q of its 4 units x 16 reads: 8 bytes at k = 4*ut .. 4*ut+3
     auto out_off = [&](int gj) { const int ut = ut0 + gj; return (unsigned)((((ut >> 3) * NS + q) * 64 + ((ut & 7) >> 1) * 16 + rl) * 16 + (ut & 1) * 8); };
@@ -342,9 +334,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     if (lds_abort) return;
     const bool fast = lds_fast != 0;
     // the h waves are the critical path: their MFMAs go first, the projection fills the gaps (without priorities: +9 %)
-    if (xw) __builtin_amdgcn_s_setprio(DN ? FFHIP_XPRIO : 0); else __builtin_amdgcn_s_setprio(3);
+    if (xw) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
 
-    unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lane_off = (unsigned)lane * 16u;
     auto tile_ptr = [&](const unsigned char *base, int t, int ts) { return base + ((size_t)t * a.B16 + (rtA + ts)) * tileB; };
     auto raw_barrier = [&]() {               // LDS-only barrier: no vmcnt drain, prefetches stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -572,91 +564,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         };
         // Both tiles' partials are computed BEFORE the wait for the h wave's "consumed" flags -- those are raised at the end of its
         // recurrent pass, and a projection of the second tile started only then would stand between the h waves and the barrier.
-        // XPF -- the x path of a step (round 5).  The phase accounting of the production kernel (tools/dev/phases.py, profiles/r05_phases.txt) showed the h
-        // waves WAITING 2800 of a step's 10 750 cycles at barrier 1 for the x waves: load A -> MFMAs A -> load B -> MFMAs B, each load a round trip to L2
-        // behind the CU's busy memory pipe, all of it after the gate phase and at the lowest priority, took 7150 cycles against the h waves' 5300 of poll +
-        // sweep + MFMAs -- the projection, off the recurrence's chain by construction, WAS the longest chain of the step.  Now:
-        //   * x(i+2) of tile A is asked for at the END of step i's matrix phase and lands under the gate phase -- in LDS (buffer_load ... lds: no
-        //     registers), in the halves of the h waves' landing zones that hold no gate pre-activations (each (K quarter, tile) zone is 2N KiB, the
-        //     partials take the first N), free from the end of h wave kw's recurrent pass (the "consumed" flags this wave has just waited for) to its
-        //     next sweep (which waits for `xfree`: the x wave takes its six pieces out at the very top of the step);
-        //   * tile B's chunks 0 .. N-2 are asked for at the top of the step, straight into registers, and travel under tile A's LDS reads and MFMAs; its
-        //     last chunk follows into the registers tile A was staged through.
-        // Same products in the same order: bit-identical.
-        constexpr bool XPF = !PACK && FFHIP_XPF != 0;
-        const int xoffB = ntl > 1 ? (int)tileB : 0;         // (an absent second tile: the first one's lines again, products dropped -- no branch between the loads)
-        auto x_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.xin, step_t(i), 0), 0, (int)(TS * tileB), 0x00020000); };
-        auto x_zone = [&](int piece) -> v4u * { return (v4u *)&hland[kw][piece / N][0][0][0] + (N + piece % N) * 64; };      // piece = chunk * NS + slice
-        auto prefetch_a = [&](int i) {                       // x(step i) of tile A on its way to LDS
-#if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (XPF) {
-                __amdgpu_buffer_rsrc_t rx = x_rsrc(i);
-#pragma unroll
-                for (int cc = 0; cc < N; cc++)
-#pragma unroll
-                    for (int s = 0; s < NS; s++)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)x_zone(cc * NS + s), 16, lane_off, ((chunk[cc] * NS + s) * 64) * 16, 0, 0);
-            }
-#endif
-        };
-        v4u xq[2][NS];                                      // XPF: two chunk buffers -- 16 registers where the old schedule held a tile's 24
-        auto load_b_chunk = [&](__amdgpu_buffer_rsrc_t rx, int cc, int buf) {      // written out: the compiler sinks a load it knows to the MFMAs that use it
-            static_assert(NS == 2 || !XPF, "two slices");
-            asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %5 offen"
-                         : "=&v"(xq[buf][0]), "=&v"(xq[buf][NS - 1]) : "v"(lane_off), "s"(rx), "s"(xoffB + ((chunk[cc] * NS) * 64) * 16), "s"(xoffB + ((chunk[cc] * NS + 1) * 64) * 16) : "memory");
-        };
-        auto project_step_xpf = [&](int i, int want) {      // as project_step below; x(step i) of tile A is in LDS (prefetch_a)
-            static_assert(!XPF || (N >= 2 && N <= 3), "piece offsets and the buffer rotation below");
-            v4f acc[TS][NRT];
-            __amdgpu_buffer_rsrc_t rx = x_rsrc(i);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile A have landed (long ago: a gate phase has passed); nothing else of mine is in flight
-            load_b_chunk(rx, 0, 0);                           // tile B's chunk 0 travels under tile A's LDS reads and MFMAs
-#pragma unroll
-            for (int j = 0; j < NRT; j++) acc[0][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-            unsigned lvx = (unsigned)lane;
-            asm volatile("" : "+v"(lvx));
-            const unsigned zbase = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&hland[kw][0][0][0][0] + lvx * 16u;
-#pragma unroll
-            for (int cc = 0; cc < N; cc++) {
-                // one chunk of tile A at a time through buffer 1.  ONE address register, rebuilt per step from an opaque copy of the lane number, and
-                // immediate offsets: six loop-invariant piece addresses get hoisted and spilled (see publish_h)
-                constexpr int ZB = N * NS * 1024;            // bytes of one (K quarter, tile) landing zone
-#define XPF_OFF(p) (((p) / N) * ZB + (N + (p) % N) * 1024)
-                if (cc == 0) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xq[1][0]), "=&v"(xq[1][1]) : "v"(zbase), "n"(XPF_OFF(0)), "n"(XPF_OFF(1)) : "memory");
-                else if (cc == 1) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xq[1][0]), "=&v"(xq[1][1]) : "v"(zbase), "n"(XPF_OFF(2)), "n"(XPF_OFF(3)) : "memory");
-                else asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xq[1][0]), "=&v"(xq[1][1]) : "v"(zbase), "n"(XPF_OFF(N > 2 ? 4 : 0)), "n"(XPF_OFF(N > 2 ? 5 : 1)) : "memory");
-#undef XPF_OFF
-                mm6<NRT, N>(wf, cc, xq[1], acc[0]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (lane == 0) LDSV(xfree[FFHIP_XPF ? kw : 0]) = i;             // (LDS operations of a wave execute in order: the reads above are through)
-            load_b_chunk(rx, 1, 1);
-#pragma unroll
-            for (int j = 0; j < NRT; j++) acc[1][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-            // (loads return in order; since the wait at the top only tile B's are outstanding: chunk 0, chunk 1, and -- behind chunk 0's MFMAs, in its buffer -- chunk 2)
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(xq[0][0]), "+v"(xq[0][1]) :: "memory");
-            mm6<NRT, N>(wf, 0, xq[0], acc[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (N > 2) {
-                load_b_chunk(rx, 2, 0);
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(xq[1][0]), "+v"(xq[1][1]) :: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[1][0]), "+v"(xq[1][1]) :: "memory");
-            mm6<NRT, N>(wf, 1, xq[1], acc[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (N > 2) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[0][0]), "+v"(xq[0][1]) :: "memory");
-                mm6<NRT, N>(wf, 2, xq[0], acc[1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int ts = 0; ts < TS; ts++) {
-                if (ts >= ntl) continue;
-                if (want > 0)
-                    for (unsigned spin = 0; LDSV(pxc[kw][ts]) != want && 0 == LDSV(lds_abort) && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int j = 0; j < NRT; j++) px[0][kw][ts][j][lane] = acc[ts][j];
-            }
-        };
         auto project_step = [&](int i, int want) {           // x(step i) of both tiles -> px[0][kw][*]; want = the step (+1) whose partials must have been consumed (0: none)
             v4f acc[TS][NRT];
 #pragma unroll
@@ -702,28 +609,15 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             touched = t;
         };
         project_step(0, 0);
-        if constexpr (XPF) { if (Tb > 1) prefetch_a(1); }
-        if constexpr (!XPF) {
-            touch_x(1);
-            sink ^= touched;
-            touch_x(2);
-        }
+        touch_x(1);
+        sink ^= touched;
+        touch_x(2);
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
             TL(0);
-            if constexpr (XPF) {
-                // Everything this loop derives from the lane number is derived anew, every step, from an opaque copy: hoisted out of the loop (where the
-                // compiler puts anything invariant) the gate roles' and the partials' addresses are a dozen registers held across the projection, and with
-                // 72 weight + 24 operand + 24 accumulator registers there they are spilled -- or weights are (see publish_h).
-                asm volatile("" : "+v"(lane));
-                q = lane >> 4; rl = lane & 15; lane_off = (unsigned)lane * 16u;
-            }
-            if (i + 1 < Tb) { if constexpr (XPF) project_step_xpf(i + 1, i + 1); else project_step(i + 1, i + 1); }
-            if constexpr (XPF) { if (i + 2 < Tb) prefetch_a(i + 2); }      // (behind the "consumed" flags: h wave kw is through with its zones)
-            if constexpr (!XPF) {                                // (XPF: tile A's DMA takes its miss under the gate phase, tile B's loads have the h waves' 5000 cycles)
-                sink ^= touched;
-                touch_x(i + WARM);
-            }
+            if (i + 1 < Tb) project_step(i + 1, i + 1);
+            sink ^= touched;
+            touch_x(i + WARM);
             TL(2);
             raw_barrier();
             TL(3);
@@ -731,15 +625,15 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             if (sg_front) {
                 __builtin_amdgcn_s_setprio(3);
                 gate_front(i, my_gts, my_gj, c, my_tb);
-                __builtin_amdgcn_s_setprio(DN ? FFHIP_XPRIO : 0);
+                __builtin_amdgcn_s_setprio(0);
             } else if (sg_back) {
                 __builtin_amdgcn_s_setprio(3);           // (the back half publishes the tile's h(t): as much on the step's chain as the front half; -1.3 % launch time at c2)
                 gate_back(i, my_gts, my_gj, my_tb);
-                __builtin_amdgcn_s_setprio(DN ? FFHIP_XPRIO : 0);
+                __builtin_amdgcn_s_setprio(0);
             } else if (gate_wave) {
                 if (PACK) __builtin_amdgcn_s_setprio(3);      // every wave works a gate job: the x waves' at the h waves' priority (-1.7 %)
                 gate_tile(i, my_gts, my_gj, c, my_tb);
-                if (PACK) __builtin_amdgcn_s_setprio(DN ? FFHIP_XPRIO : 0);
+                if (PACK) __builtin_amdgcn_s_setprio(0);
             }
             if (aborted) return;
             TL(4);
@@ -1016,11 +910,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     return __all(seen != kSplitSentinel) != 0;
                 };
                 auto recur_any = [&]() -> bool { if constexpr (DN) return recur_dn(); else if constexpr (HL) return recur_lds(); else return recur(); };
-                if constexpr (DN && !PACK && FFHIP_XPF != 0) {
-                    // the free halves of my landing zones carried x(step i+1) of tile A: x wave kw has read it out (at the top of this step, long ago)
-                    if (i + 1 < Tb)
-                        for (unsigned spin = 0; LDSV(xfree[FFHIP_XPF ? kw : 0]) != i + 1 && 0 == LDSV(lds_abort) && spin < 40000000u; spin++) __builtin_amdgcn_s_sleep(1);
-                }
                 if (!timed_out) {
                     // gfx9 counts loads and stores on ONE counter and they complete out of order with respect to each other:
                     // while this wave's gate-phase stores of step i-1 may be pending the compiler can only wait vmcnt(0).
