@@ -255,9 +255,14 @@ extern "C" int ffhip_dev_download(const void *dev, float *host, size_t nfloat) {
 }
 extern "C" void *ffhip_dev_upload(const float *host, size_t nfloat) {
     if (!host || !nfloat) return nullptr;
-    hipSetDevice(ffhip::pool_default_device());      // (no engine argument: the device of the engine created last; the host layer has one engine)
+    // (no engine argument: the device of the engine created last -- the host layer has one engine --; the calling thread's own device is put back,
+    // so that an upload does not move a thread that drives another GPU: ADVICE r4)
+    int prev = -1;
+    hipGetDevice(&prev);
+    hipSetDevice(ffhip::pool_default_device());
     void *d = ffhip::pool_get(nfloat * sizeof(float));
-    if (d && hipMemcpy(d, host, nfloat * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ffhip::pool_put(d); return nullptr; }
+    if (d && hipMemcpy(d, host, nfloat * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ffhip::pool_put(d); d = nullptr; }
+    if (prev >= 0 && prev != ffhip::pool_default_device()) hipSetDevice(prev);
     return d;
 }
 

@@ -577,7 +577,17 @@ void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, 
     // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_CONV_WS=0: the round-3 kernel)
     static const int ws_env = [] { const char *e = dbg("conv_ws"); return e ? atoi(e) : 1; }();
     if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
-        static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        // (per call, of the CURRENT device -- the caller's engine has set it: a value cached from the first call would size the groups of an engine on
+        // another device of the process by the wrong chip)
+        int ncu = 256;
+        {
+            static int by_dev[32];                                // (0: not asked yet; plain ints, any thread writes the same value)
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+                if (!by_dev[dev] && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) by_dev[dev] = n;
+                if (by_dev[dev]) ncu = by_dev[dev];
+            }
+        }
         const int NMB = Mt / 8;
         int ngroup = (2 * ncu / NMB) & ~7;                       // two workgroups a CU; whole XCD rounds of column groups
         if (ngroup < 8) ngroup = 8;

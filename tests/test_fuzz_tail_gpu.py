@@ -84,9 +84,12 @@ def test_fuzz_tail_reads_stay_within_the_documented_bound(engine):
     for name, d_go, d_gy, nbase, nqual, npath, off1, offn, cells in rows:
         print("  GPU %-5s <-> oracle %.2e   <-> yardstick %.2e   reads with a different base string %d, quality string %d, Viterbi path %d (of %d);"
               " trace cells off by one %d, by more %d, of %d (%.4f %%)" % (name, d_go, d_gy, nbase, nqual, npath, n, off1, offn, cells, 100.0 * off1 / cells))
+    # (rounds 2-4 also asserted a flat 3e-4 here -- three times north_star's tolerance, and a bound on the MODEL: on these reads two float32 evaluations
+    # of the reference's own algorithm sit 1.1e-4 apart.  VERDICT r4, next 6: what is held is the engine's distance from the network proper RELATIVE to the
+    # oracle's own, below, for both GPU paths.)
     for name, d_go, d_gy, nbase, nqual, npath, off1, offn, cells in rows:
-        assert d_go <= 3.0e-4, (name, d_go)                       # the documented bound on these reads (1e-4 holds on every other model of the suite)
-        assert d_gy <= 3.0e-4, (name, d_gy)
+        assert d_gy <= 2.0 * d_oy + 2.0e-5, (name, d_gy, d_oy)      # (the f32-MFMA cross-check path: measured 1.9x on these reads)
+        assert d_go <= d_gy + d_oy + 1.0e-6, (name, d_go)           # (triangle: nothing but rounding stands between the three)
         assert offn == 0
     # the default path is no further from the float32 network proper than the reference-order sums are (measured: 0.8x; the
     # f32-MFMA cross-check path sits at 1.9x on these reads -- every float32 evaluation order scatters by 1-2e-4 on this model)
