@@ -348,6 +348,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # this rank, the flappie process of its host-fed leg and that one's reader children on the CPUs of the GPU's NUMA node (flappie_amd/shard.py;
+    # FFHIP_BENCH_SYSFS: a fake sysfs tree for the CPU tests; FFHIP_BENCH_NO_NUMA_BIND=1: off)
+    from flappie_amd import shard as _shard
+    numa_bound = (-1, 0) if os.environ.get("FFHIP_BENCH_NO_NUMA_BIND") else _shard.bind_to_gpu_numa(local_rank, os.environ.get("FFHIP_BENCH_SYSFS", "/sys"))
     import torch
     import torch.distributed as dist
     # FFHIP_BENCH_FORCE_DIST=1: take the RCCL code path (init, barrier, MAX all-reduce) with a single rank too --
@@ -564,6 +568,9 @@ def main():
                            "peak": 8000.0, "unit": "GB/s", "bytes_per_block": bytes_per_block, "ms": round(dec_ms, 4)},
         }
         out["per_rank_Msamples_per_s"] = per_rank
+        out["host_binding"] = {"rank0_numa_node": numa_bound[0], "rank0_cpus": numa_bound[1] or len(os.sched_getaffinity(0)),
+                               "note": "every rank binds itself (and the flappie process + reader children of its host-fed leg) to the CPUs of its GPU's NUMA node "
+                                       "that it may use; node -1 = not known or outside this container's CPU set: left alone"}
         out["max_over_ranks_s"] = round(dt, 6)
         if hostfed is not None:
             out["host_fed"] = hostfed

@@ -42,34 +42,52 @@ static char *string_attr(hid_t group, const char *name) {
     return str;
 }
 
+/* How a single-read file is opened for reading (round 5: the host's whole cost per read IS this function -- 115 us a file, 25 ns a sample, and eight
+ * ranks of a node ask for 23 CPUs of it, profiles/r04_host_scaling.txt).  A single-read fast5 is 15-40 KB of which libhdf5 touches a dozen places through a
+ * pread each, behind a 2 MB metadata cache it sets up per file: the CORE driver reads the file once into memory (no backing store: nothing is written),
+ * and the metadata cache starts at 64 KB.  Same bytes, same values.  FLAPPIE_DEBUG=plain_h5open keeps the default driver. */
+static hid_t read_fapl(void) {
+    static hid_t fapl = -2;
+    if (-2 == fapl) {
+        fapl = H5P_DEFAULT;
+        const char *dbg = getenv("FLAPPIE_DEBUG");
+        if (NULL == dbg || NULL == strstr(dbg, "plain_h5open")) {
+            hid_t p = H5Pcreate(H5P_FILE_ACCESS);
+            if (p >= 0 && H5Pset_fapl_core(p, 1 << 16, 0) >= 0) {
+                H5AC_cache_config_t mdc;
+                mdc.version = H5AC__CURR_CACHE_CONFIG_VERSION;
+                if (H5Pget_mdc_config(p, &mdc) >= 0) {
+                    mdc.set_initial_size = 1;
+                    mdc.initial_size = 1 << 16;
+                    mdc.min_size = 1 << 16;
+                    (void)H5Pset_mdc_config(p, &mdc);
+                }
+                fapl = p;
+            } else if (p >= 0) H5Pclose(p);
+        }
+    }
+    return fapl;
+}
+
 raw_table read_raw(const char *filename, bool scale_to_pA) {
     raw_table rawtbl = { NULL, 0, 0, 0, NULL };
     if (NULL == filename) return rawtbl;
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
-    hid_t file = H5Fopen(filename, H5F_ACC_RDONLY, H5P_DEFAULT);
+    hid_t file = H5Fopen(filename, H5F_ACC_RDONLY, read_fapl());
     if (file < 0) { warnx("Failed to open %s for reading.", filename); return rawtbl; }
-    static const char root[] = "/Raw/Reads/";
-    char first[256];                                          /* (one call when the name fits, as it always does: "Read_<n>") */
-    const ssize_t size = H5Lget_name_by_idx(file, root, H5_INDEX_NAME, H5_ITER_INC, 0, first, sizeof(first), H5P_DEFAULT);
-    if (size < 0) { warnx("Failed find read name under %s.", root); H5Fclose(file); return rawtbl; }
-    char *name = calloc((size_t)size + 1, 1);
-    if ((size_t)size < sizeof(first)) memcpy(name, first, (size_t)size);
-    else H5Lget_name_by_idx(file, root, H5_INDEX_NAME, H5_ITER_INC, 0, name, (size_t)size + 1, H5P_DEFAULT);
-    const size_t plen = sizeof(root) + (size_t)size + 8;
-    char *path = calloc(plen, 1);
-    snprintf(path, plen, "%s%s", root, name);
+    /* the one read group under /Raw/Reads, opened by index (one traversal; the reference asks for its name, builds the path and walks it again for the
+     * attribute and once more for the dataset: fast5_interface.c:249-283 -- the same objects) */
     char *uuid = NULL;
-    hid_t rgroup = H5Gopen(file, path, H5P_DEFAULT);
-    if (rgroup < 0) { warnx("Failed to find read_id under %s.", path); goto done; }
+    hid_t rgroup = H5Oopen_by_idx(file, "/Raw/Reads", H5_INDEX_NAME, H5_ITER_INC, 0, H5P_DEFAULT);
+    if (rgroup < 0) { warnx("Failed find read name under %s.", "/Raw/Reads/"); H5Fclose(file); return rawtbl; }
     uuid = string_attr(rgroup, "read_id");
-    H5Gclose(rgroup);
-    snprintf(path, plen, "%s%s/Signal", root, name);
-    hid_t dset = H5Dopen(file, path, H5P_DEFAULT);
-    if (dset < 0) { warnx("Failed to open dataset '%s' to read raw signal from.", path); free(uuid); goto done; }
+    hid_t dset = H5Dopen(rgroup, "Signal", H5P_DEFAULT);
+    if (dset < 0) { warnx("Failed to open dataset '%s' to read raw signal from.", "/Raw/Reads/<read>/Signal"); free(uuid); H5Oclose(rgroup); H5Fclose(file); return rawtbl; }
+    static const char path[] = "/Raw/Reads/<read>/Signal";
     hid_t space = H5Dget_space(dset);
     hsize_t nsample = 0;
     if (space >= 0) H5Sget_simple_extent_dims(space, &nsample, NULL);
-    float *raw = nsample ? calloc(nsample, sizeof(float)) : NULL;
+    float *raw = nsample ? malloc(nsample * sizeof(float)) : NULL;
     /* The reference asks libhdf5 for floats (fast5_interface.c:289) and lets its type-conversion path turn the stored 16-bit integers into
      * them, element by element through a background buffer -- a third of this function's time.  A 16-bit integer dataset (every fast5 file:
      * the Signal of a read is int16) is read as it is stored and converted here: (float)int16 is exact, the values are the same. */
@@ -102,9 +120,7 @@ raw_table read_raw(const char *filename, bool scale_to_pA) {
     }
     if (space >= 0) H5Sclose(space);
     H5Dclose(dset);
-done:
-    free(path);
-    free(name);
+    H5Oclose(rgroup);
     H5Fclose(file);
     return rawtbl;
 }

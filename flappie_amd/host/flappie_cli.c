@@ -6,6 +6,10 @@
  *  prepared on the host, grouped by trimmed length (the network never pads or splits a read) and sent to
  *  the HIP engine in batches; records are written in input order.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE      /* sched_setaffinity, CPU_SET (bind_to_gpu_numa) */
+#endif
+#include <sched.h>
 #include <argp.h>
 #include <assert.h>
 #include <dirent.h>
@@ -210,7 +214,7 @@ static double t_phase[8];
 static const char *phase_name[8] = { "fast5 read", "signal preparation", "batch create/destroy", "upload+network+decode", "fetch results", "write output",
                                      "  of which set_prepared", "  of which batch_run" };
 /* Development switches of the binary: FLAPPIE_DEBUG=token[,token=value ...] -- no_reader_thread, no_writer_thread,
- * list_only, kill_reader=k:f.  NULL when the token is absent, its value ("" for a bare token) otherwise. */
+ * list_only, kill_reader=k:f, no_numa_bind, sysfs_root=DIR.  NULL when the token is absent, its value ("" for a bare token) otherwise. */
 static const char *cli_dbg(const char *token) {
     static char buf[256];
     const char *e = getenv("FLAPPIE_DEBUG");
@@ -227,6 +231,60 @@ static const char *cli_dbg(const char *token) {
         e = *end ? end + 1 : end;
     }
     return NULL;
+}
+
+/* This process, the reader children it is about to fork and the pinned staging they fill, on the CPUs of the GPU's NUMA node (eight
+ * ranks of a node otherwise read their files wherever the scheduler puts them).  The node comes from sysfs -- the HIP runtime must not be up before the
+ * fork --: the device-th render node of vendor 0x1002 in minor order, HIP's numbering when no *_VISIBLE_DEVICES variable re-maps it.  Left alone when the
+ * node is unknown or none of its CPUs is in this process's set; FLAPPIE_DEBUG=no_numa_bind switches it off, sysfs_root=DIR is for the tests. */
+static int bind_to_gpu_numa(int device) {
+    const char *root = cli_dbg("sysfs_root");
+    char sys[256], path[512], buf[4096];
+    snprintf(sys, sizeof sys, "%s", (root && root[0]) ? root : "/sys");
+    int minors[64], nodes[64], n = 0;
+    snprintf(path, sizeof path, "%s/class/drm", sys);
+    DIR *d = opendir(path);
+    if (NULL == d) return -1;
+    for (struct dirent *e; n < 64 && NULL != (e = readdir(d));) {
+        int minor;
+        if (1 != sscanf(e->d_name, "renderD%d", &minor)) continue;
+        snprintf(path, sizeof path, "%s/class/drm/%s/device/vendor", sys, e->d_name);
+        FILE *fh = fopen(path, "r");
+        if (NULL == fh) continue;
+        const int amd = (NULL != fgets(buf, sizeof buf, fh) && 0 == strncasecmp(buf, "0x1002", 6));
+        fclose(fh);
+        if (!amd) continue;
+        snprintf(path, sizeof path, "%s/class/drm/%s/device/numa_node", sys, e->d_name);
+        int node = -1;
+        if (NULL != (fh = fopen(path, "r"))) { if (1 != fscanf(fh, "%d", &node)) node = -1; fclose(fh); }
+        int k = n++;
+        while (k > 0 && minors[k - 1] > minor) { minors[k] = minors[k - 1]; nodes[k] = nodes[k - 1]; k--; }
+        minors[k] = minor; nodes[k] = node;
+    }
+    closedir(d);
+    if (device < 0 || device >= n || nodes[device] < 0) return -1;
+    snprintf(path, sizeof path, "%s/devices/system/node/node%d/cpulist", sys, nodes[device]);
+    FILE *fh = fopen(path, "r");
+    if (NULL == fh) return -1;
+    const int got = NULL != fgets(buf, sizeof buf, fh);
+    fclose(fh);
+    if (!got) return -1;
+    cpu_set_t mine, want;
+    if (0 != sched_getaffinity(0, sizeof mine, &mine)) return -1;
+    CPU_ZERO(&want);
+    int nbound = 0;
+    for (char *p = buf; *p && *p != '\n';) {
+        char *end;
+        const long lo = strtol(p, &end, 10);
+        long hi = lo;
+        if (end == p) break;
+        if ('-' == *end) { p = end + 1; hi = strtol(p, &end, 10); }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) if (CPU_ISSET((int)c, &mine)) { CPU_SET((int)c, &want); nbound++; }
+        p = (',' == *end) ? end + 1 : end;
+    }
+    if (0 == nbound || 0 != sched_setaffinity(0, sizeof want, &want)) return -1;
+    if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "bound to %d CPUs of NUMA node %d (GPU %d)\n", nbound, nodes[device], device);
+    return nodes[device];
 }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -917,6 +975,7 @@ int main(int argc, char *argv[]) {
     file_list fl = { NULL, 0, 0 };
     list_files(&fl);
     const double t_listed = now_s();
+    if (!cli_dbg("no_numa_bind")) { const char *dev = getenv("FLAPPIE_HIP_DEVICE"); (void)bind_to_gpu_numa(dev ? atoi(dev) : 0); }
     if (cli_dbg("list_only")) {             /* the files this process would call, one per line -- no GPU touched (tests, tools/host_scaling.py) */
         for (size_t f = 0; f < fl.n; f++) printf("%s\n", fl.path[f]);
         return EXIT_SUCCESS;

@@ -63,3 +63,56 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def numa_cpus_of_gpu(index: int, sysfs: str = "/sys") -> Tuple[int, List[int]]:
+    """(NUMA node, its CPUs) of the index-th AMD GPU as the kernel lists them (render nodes of vendor 0x1002 in minor order -- the order HIP numbers
+    the devices in when no *_VISIBLE_DEVICES variable re-maps them); (-1, []) when the node is not known.  A rank binds itself, its reader
+    children and with them its pinned staging to these CPUs before it starts (`bind_to_gpu_numa`): eight ranks of a node otherwise run their
+    readers wherever the scheduler puts them, and half of every rank's host traffic crosses the socket link."""
+    import glob
+    import os
+    nodes = []
+    for path in glob.glob(os.path.join(sysfs, "class", "drm", "renderD*")):
+        try:
+            with open(os.path.join(path, "device", "vendor")) as fh:
+                if fh.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(path, "device", "numa_node")) as fh:
+                nodes.append((int(os.path.basename(path)[len("renderD"):]), int(fh.read().strip())))
+        except (OSError, ValueError):
+            continue
+    nodes.sort()
+    if not (0 <= index < len(nodes)) or nodes[index][1] < 0:
+        return -1, []
+    node = nodes[index][1]
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as fh:
+            return node, parse_cpulist(fh.read())
+    except (OSError, ValueError):
+        return node, []
+
+
+def bind_to_gpu_numa(index: int, sysfs: str = "/sys") -> Tuple[int, int]:
+    """restrict this process (and what it starts) to the CPUs it may use that sit on the GPU's NUMA node; (node, CPUs bound to), (-1, 0) = left alone
+    (node unknown, or none of its CPUs is in this process's set -- a container's quota may lie elsewhere)"""
+    import os
+    node, cpus = numa_cpus_of_gpu(index, sysfs)
+    if node < 0 or not cpus or not hasattr(os, "sched_setaffinity"):
+        return -1, 0
+    mine = os.sched_getaffinity(0) & set(cpus)
+    if not mine:
+        return -1, 0
+    os.sched_setaffinity(0, mine)
+    return node, len(mine)

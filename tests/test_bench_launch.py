@@ -26,7 +26,7 @@ def _line(r):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 8])
 def test_self_launch_with_a_stub_engine(n):
     env = {"FFHIP_BENCH_STUB": "1"}
     if n == 1:
@@ -57,3 +57,58 @@ def test_real_line_through_the_distributed_path_with_host_fed_leg():
     assert hf is not None
     if "skipped" not in hf:          # (needs libhdf5 at build time)
         assert hf["value"] and hf["value"] > 0.5 and len(hf["per_rank"]) == 1 and hf["files_per_rank"] == 1536
+
+
+def _fake_sysfs(tmp_path, nodes):
+    """a sysfs tree with one AMD render node per entry of `nodes` (its NUMA node), and two NUMA nodes that split this process's CPUs"""
+    cpus = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus) // 2)
+    lists = {0: cpus[:half], 1: cpus[half:] or cpus[:half]}
+    for k, node in enumerate(nodes):
+        d = tmp_path / "class" / "drm" / ("renderD%d" % (128 + k)) / "device"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n")
+        (d / "numa_node").write_text("%d\n" % node)
+    other = tmp_path / "class" / "drm" / "renderD200" / "device"
+    other.mkdir(parents=True)
+    (other / "vendor").write_text("0x10de\n")
+    (other / "numa_node").write_text("0\n")
+    for node, cl in lists.items():
+        d = tmp_path / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cl) + "\n")
+    return lists
+
+
+def test_numa_binding_of_a_rank(tmp_path):
+    """a rank binds itself (and what it starts) to the CPUs of its GPU's NUMA node -- flappie_amd/shard.py for bench.py's ranks, the
+    same walk over sysfs in the flappie binary (before it forks its readers).  Against a fake sysfs tree."""
+    sys.path.insert(0, ROOT)
+    from flappie_amd import shard
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    lists = _fake_sysfs(tmp_path, [0, 1, 1, -1])
+    assert shard.numa_cpus_of_gpu(0, str(tmp_path)) == (0, lists[0])
+    assert shard.numa_cpus_of_gpu(2, str(tmp_path)) == (1, lists[1])
+    assert shard.numa_cpus_of_gpu(3, str(tmp_path)) == (-1, []) and shard.numa_cpus_of_gpu(7, str(tmp_path)) == (-1, [])
+    code = ("import os, sys; sys.path.insert(0, %r); from flappie_amd import shard; r = shard.bind_to_gpu_numa(1, %r); "
+            "print(r[0], r[1], sorted(os.sched_getaffinity(0)))" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split(None, 2)
+    assert int(out[0]) == 1 and int(out[1]) == len(lists[1]) and eval(out[2]) == lists[1]
+    exe = os.path.join(ROOT, "flappie_amd", "flappie")
+    if os.path.exists(exe):
+        reads = tmp_path / "reads"
+        reads.mkdir()
+        (reads / "a.fast5").write_text("")
+        env = dict(os.environ, FLAPPIE_DEBUG="list_only,sysfs_root=%s" % tmp_path, FLAPPIE_HIP_DEVICE="2", FLAPPIE_CLI_TIMING="1")
+        r = subprocess.run([exe, str(reads)], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and "bound to %d CPUs of NUMA node 1 (GPU 2)" % len(lists[1]) in r.stderr, r.stderr
+        r = subprocess.run([exe, str(reads)], env=dict(env, FLAPPIE_DEBUG="list_only,no_numa_bind,sysfs_root=%s" % tmp_path), capture_output=True, text=True)
+        assert r.returncode == 0 and "bound to" not in r.stderr
+
+
+def test_bench_line_reports_the_binding(tmp_path):
+    _fake_sysfs(tmp_path, [1])
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"], {"FFHIP_BENCH_STUB": "1", "FFHIP_BENCH_SYSFS": str(tmp_path)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r)
+    assert d["host_binding"]["rank0_numa_node"] == 1 and d["host_binding"]["rank0_cpus"] >= 1

@@ -4,6 +4,8 @@
 #   tools/flappie_multi_gpu.sh NGPU OUT_PREFIX [flappie options ...] READS_DIR
 # writes OUT_PREFIX.<slice>.fq (and OUT_PREFIX.<slice>.trace.hdf5 when FLAPPIE_TRACE=1).  Slice g takes files g, g + NGPU, ... of the
 # sorted file list (flappie --shard g/NGPU), so `cat` of the slices is a permutation of the single-process output, each slice in input order.
+# Every process binds itself and its reader children to the CPUs of ITS GPU's NUMA node before it forks them (flappie_cli.c: bind_to_gpu_numa, from
+# FLAPPIE_HIP_DEVICE and /sys/class/drm/renderD*/device/numa_node; FLAPPIE_DEBUG=no_numa_bind leaves the placement to the scheduler).
 # Environment:  FLAPPIE_DEVICES=0,1,...  device of each slice (default: slice g -> GPU g)
 #               FLAPPIE_SERIAL=1         run the slices one after the other (several slices on ONE GPU: the persistent recurrent
 #                                        kernels of two processes cannot share a GPU)
