@@ -638,6 +638,9 @@ struct ffhip_batch {
     float *scratch = nullptr;           // dense [Tb][H] for debug taps
     // pinned host mirrors of the small results
     char *h_bases = nullptr, *h_quals = nullptr; int *h_lens = nullptr; float *h_score = nullptr;
+    // what ffhip_batch_finish brings down is ONE block on the device and one pinned block on the host, [sat | abort | lens | score | bases | quals]: one copy
+    // instead of six (round 5; a batch that was not decoded takes the first two parts only)
+    unsigned char *res_dev = nullptr, *res_host = nullptr; size_t res_bytes = 0, res_head = 0;
     std::vector<void *> owned;
     unsigned last_flags = 0;
     float last_temperature = 1.0f;
@@ -716,12 +719,7 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     hipStreamSynchronize(b->stream);
     if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     for (void *p : b->owned) hipFree(p);
-    if (b->h_bases) hipHostFree(b->h_bases);
-    if (b->h_quals) hipHostFree(b->h_quals);
-    if (b->h_lens) hipHostFree(b->h_lens);
-    if (b->h_score) hipHostFree(b->h_score);
-    if (b->h_abort) hipHostFree(b->h_abort);
-    if (b->h_sat) hipHostFree(b->h_sat);
+    if (b->res_host) hipHostFree(b->res_host);      // (h_sat, h_abort, h_lens, h_score, h_bases, h_quals point into it)
     if (b->side) ffhip_batch_destroy(b->side);
     prof_unlink(b);
     if (b->have_ev) {
@@ -781,27 +779,26 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->tb = (uint8_t *)dalloc(b, (size_t)nread * Tb * kMaxState, false))) BFAIL();
     if (!(b->path = (int *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
     if (!(b->qpath = (float *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
-    if (!(b->score = (float *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
-    if (!(b->bases = (char *)dalloc(b, (size_t)nread * (Tb + 1), true))) BFAIL();
-    if (!(b->quals = (char *)dalloc(b, (size_t)nread * (Tb + 1), true))) BFAIL();
-    if (!(b->lens = (int *)dalloc(b, (size_t)nread * 4, true))) BFAIL();
+    {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_sat = 0, o_abort = up((size_t)b->Bp * 4), o_lens = o_abort + 256, o_score = o_lens + up((size_t)nread * 4),
+                     o_bases = o_score + up((size_t)nread * 4), o_quals = o_bases + up((size_t)nread * (Tb + 1));
+        b->res_head = o_lens;
+        b->res_bytes = o_quals + up((size_t)nread * (Tb + 1));
+        if (!(b->res_dev = (unsigned char *)dalloc(b, b->res_bytes, true))) BFAIL();
+        if (hipHostMalloc((void **)&b->res_host, b->res_bytes) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
+        memset(b->res_host, 0, b->res_bytes);
+        b->sat = (unsigned *)(b->res_dev + o_sat); b->pabort = (unsigned *)(b->res_dev + o_abort); b->lens = (int *)(b->res_dev + o_lens);
+        b->score = (float *)(b->res_dev + o_score); b->bases = (char *)(b->res_dev + o_bases); b->quals = (char *)(b->res_dev + o_quals);
+        b->h_sat = (unsigned *)(b->res_host + o_sat); b->h_abort = (unsigned *)(b->res_host + o_abort); b->h_lens = (int *)(b->res_host + o_lens);
+        b->h_score = (float *)(b->res_host + o_score); b->h_bases = (char *)(b->res_host + o_bases); b->h_quals = (char *)(b->res_host + o_quals);
+    }
     if (!(b->trace = (int32_t *)dalloc(b, (size_t)nread * (Tb + 1) * ns * 4, true))) BFAIL();
     if (!(b->pflags = (unsigned *)dalloc(b, persist_flag_words((int)Hp, b->B16) * sizeof(unsigned), true))) BFAIL();
-    if (!(b->pabort = (unsigned *)dalloc(b, 4 * sizeof(unsigned), true))) BFAIL();      // [0] abort word, [1] development counter
-    if (hipHostMalloc((void **)&b->h_abort, sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
-    *b->h_abort = 0;
-    if (!(b->sat = (unsigned *)dalloc(b, (size_t)b->Bp * sizeof(unsigned), true))) BFAIL();
-    if (hipHostMalloc((void **)&b->h_sat, (size_t)b->Bp * sizeof(unsigned)) != hipSuccess) { set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL(); }
-    memset(b->h_sat, 0, (size_t)b->Bp * sizeof(unsigned));
+    // (pabort -- [0] abort word, [1] development counter -- and sat live in the result block above)
     if (persist_supported(m->cell, (int)Hp, eng->prop.multiProcessorCount)) {
         const int maxt = persist_max_tiles(m->cell, (int)Hp, eng->prop.multiProcessorCount, fused_supported(m->cell, (int)Hp));
         b->persist_concurrent_ok = 2 * b->B16 <= maxt;      // two such launches fit on the chip together
-    }
-    if (hipHostMalloc((void **)&b->h_bases, (size_t)nread * (Tb + 1)) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_quals, (size_t)nread * (Tb + 1)) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_lens, (size_t)nread * 4) != hipSuccess ||
-        hipHostMalloc((void **)&b->h_score, (size_t)nread * 4) != hipSuccess) {
-        set_err(FFHIP_ENOMEM, "pinned host allocation failed"); BFAIL();
     }
     for (int i = 0; i <= FFHIP_NGROUP; i++)
         if (hipEventCreate(&b->ev[i]) != hipSuccess) { set_err(FFHIP_EHIP, "hipEventCreate failed"); BFAIL(); }
@@ -1490,14 +1487,9 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         b->finished = 1; b->reruns = 0;
         return FFHIP_OK;
     }
-    if (!(b->last_flags & FFHIP_RUN_NO_DECODE)) {
-        HIP_TRY(hipMemcpyAsync(b->h_bases, b->bases, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
-        HIP_TRY(hipMemcpyAsync(b->h_quals, b->quals, n * L, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
-        HIP_TRY(hipMemcpyAsync(b->h_lens, b->lens, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
-        HIP_TRY(hipMemcpyAsync(b->h_score, b->score, n * 4, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
-    }
-    HIP_TRY(hipMemcpyAsync(b->h_abort, b->pabort, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
-    HIP_TRY(hipMemcpyAsync(b->h_sat, b->sat, n * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    // one copy: [sat | abort] and, when the batch was decoded, [lens | score | bases | quals] behind them (the block of ffhip_batch_create)
+    HIP_TRY(hipMemcpyAsync(b->res_host, b->res_dev, (b->last_flags & FFHIP_RUN_NO_DECODE) ? b->res_head : b->res_bytes, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    (void)n; (void)L;
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     if (rehearsal_rate() > 0) {                              // (test hook above: the emulated GPU finishes this batch at rehearsal_done_at)
         const double left = b->rehearsal_done_at - now_seconds();
