@@ -60,6 +60,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 constexpr int NS = kSplitNS;
+#ifndef FFHIP_SWAP_ROLES
+#define FFHIP_SWAP_ROLES 0      // 1: the h waves are the workgroup's waves 0-3 (the OLDER ones: between two MFMA streams of a SIMD the older wave runs, tools/dev/coissue_probe.cpp)
+#endif
 
 struct SplitArgs {
     const v4u *Wp;            // [2][Ut][Hc][NS][64] 16 B; mat 0 = input weights, 1 = recurrent weights
@@ -228,7 +231,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     constexpr int G = PACK ? 16 : 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + (FFHIP_SWAP_ROLES ? 4 : 0)) & 7);
     const bool xw = wave < 4;
     const int kw = wave & 3;
     const int ngroup = (a.nrt + TS - 1) / TS;

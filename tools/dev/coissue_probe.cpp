@@ -99,6 +99,8 @@ int main() {
         { { 1, 2, 0, 0 }, { 1, 0, 0, 0 }, "M (priority 3) + G (priority 0)" },
         { { 1, 1, 2, 2 }, { 1, 1, 1, 1 }, "M + M + G + G (the kernel's four waves a SIMD)" },
         { { 1, 1, 2, 2 }, { 0, 1, 1, 1 }, "M (0) + M (3) + G (3) + G (3)" },
+        { { 1, 1, 0, 0 }, { 0, 1, 0, 0 }, "M (older, priority 0) + M (younger, priority 3)" },
+        { { 2, 1, 0, 0 }, { 1, 1, 0, 0 }, "G (older) + M (younger)" },
         { { 13, 0, 0, 0 }, { 1, 0, 0, 0 }, "Mn3 alone: s_nop 3 behind every MFMA" },
         { { 17, 0, 0, 0 }, { 1, 0, 0, 0 }, "Mn7 alone" },
         { { 19, 0, 0, 0 }, { 1, 0, 0, 0 }, "Mn9 alone" },
