@@ -60,6 +60,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 constexpr int NS = kSplitNS;
+#ifndef FFHIP_SG_O_FRONT
+#define FFHIP_SG_O_FRONT 1      // split gate tiles: the front wave evaluates the output gate too (0: round 2-4's form, the back wave does)
+#endif
 #ifndef FFHIP_SWAP_ROLES
 #define FFHIP_SWAP_ROLES 0      // 1: the h waves are the workgroup's waves 0-3 (the OLDER ones: between two MFMA streams of a SIMD the older wave runs, tools/dev/coissue_probe.cpp)
 #endif
@@ -218,6 +221,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     __shared__ int lds_abort;
     __shared__ int lds_fast;
     __shared__ float cx[2][64];             // split gate tiles: cell state c(t) from the front wave to the back wave of tiles 4 and 5
+    __shared__ float ox[FFHIP_SG_O_FRONT ? 2 : 1][64];      // ... and the output gate o(t), evaluated by the front wave as well
     __shared__ int cxflag[2];               // ... and the step it belongs to (+1)
     // HL: the sweep of h(t-1) LANDS IN LDS (buffer_load ... lds: no destination registers) and feeds the MFMAs through ds_read_b128.
     // The one-tile kernel at N = 3 then fits 128 registers: TWO workgroups -- two independent recurrences -- share a CU.
@@ -517,6 +521,24 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
         s = unscale4(s);
         float forget, update;
+#if FFHIP_SG_O_FRONT
+        // The output gate is evaluated HERE, as the fourth lane of the packed logistic gate_tile uses (round 5): four logistics in packed instructions cost what two
+        // packed + one scalar evaluation cost, so this wave's instruction count stays and the back wave loses its own logistic, its four partial sums and their LDS
+        // reads -- ~45 VALU instructions a tile off a SIMD whose MFMA and VALU time add (profiles/r05_coissue_probe.txt).  The same operations on the same values.
+        float og;
+        if (a.fast_gates) {
+            forget = logistic_hw(s.y) * c;
+            update = logistic_hw(s.x) * tanh_hw(s.z);
+            og = logistic_hw(s.w);
+        } else {
+            const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
+            const float tanh_g = (L.z + L.z) - 1.0f;
+            forget = L.y * c;
+            update = L.x * tanh_g;
+            og = L.w;
+        }
+        ox[wave & 1][lane] = og;
+#else
         if (a.fast_gates) {
             forget = logistic_hw(s.y) * c;
             update = logistic_hw(s.x) * tanh_hw(s.z);
@@ -525,6 +547,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             forget = L.y * c;
             update = L.x * tanh_ref_lean(s.z);          // = 2 logistic(2 z) - 1, the form gate_tile evaluates
         }
+#endif
         c = forget + update;
         if (step_t(i) >= my_tb) c = 0.0f;
         cx[wave & 1][lane] = c;
@@ -532,14 +555,19 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         if (lane == 0) LDSV(cxflag[wave & 1]) = i + 1;
     };
     auto gate_back = [&](int i, int gts, int gj, int my_tb) {
+#if !FFHIP_SG_O_FRONT
         float so = sbias[gj][q].w;
 #pragma unroll
         for (int w2 = 0; w2 < 4; w2++) so = so + ph_at(w2, gts, gj)[lane].w;
         so = __builtin_ldexpf(so, neg_exp);
         const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
+#endif
         while (LDSV(cxflag[wave & 1]) != i + 1) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const float c = cx[wave & 1][lane];
+#if FFHIP_SG_O_FRONT
+        const float o = ox[wave & 1][lane];
+#endif
         float h = o * (a.fast_gates ? tanh_hw(c) : tanh_ref_lean(c));
         if (step_t(i) >= my_tb) h = 0.0f;
         publish_h(i, gts, gj, h);
