@@ -244,7 +244,9 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
     if cfg["kind"] != M.NET_LSTM5 or not (os.path.exists(exe) and os.path.exists(tool)):
         return {"skipped": "needs the flappie binary + fast5_tool (libhdf5 at build time) and an LSTM5 flip-flop model"} if rank == 0 else None
     ncore = effective_cpus()[0]                 # what the container is granted, not what it can see
-    readers = max(1, min(12, ncore // max(1, world) - 2))
+    # reader processes per rank: one reads ~50 Msamples/s of single-read files, and every reader beyond what the GPU consumes costs CPU for nothing (twelve of them:
+    # 0.026 CPU-s per million samples and 108 Msamples/s; two to four: 0.016 and 111-114 -- profiles/r05_host_scaling.txt).  Eight ranks inside a 16-CPU grant: two each.
+    readers = max(1, min(4, ncore // max(1, world)))
     nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_HOSTFED_FILES", "32768"))      # per rank (the short run is a quarter of it: a steady-state marginal rate needs ~1 s of work)
     n_short = max(512, nfiles // 4)
     obj = [None]

@@ -70,7 +70,7 @@ static struct argp_option options[] = {
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default: what one layer launch takes -- 1024 at up to 256 hidden units, 512 up to 384, else 256)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
-    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 12; 0 reads in this process)"},
+    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 4: one keeps up with ~50 Msamples/s, more only cost CPU; 0 reads in this process)"},
     {"shard-by-size", 19, 0, 0, "With --shard: deal the files to the n shards by size (largest first, each to the lightest shard) instead of by index"},
     {0}
 };
@@ -103,7 +103,7 @@ static struct {
     int readers;
     int shard, nshard;
     bool shard_by_size;
-} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 12, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
+} args = { 1, 200, 0.0f, NULL, FLAPPIE_OUTFORMAT_FASTQ, 0, DEFAULT_MODEL, NULL, "", false, 1.0f, 200, 10, 100, 0.0f, false, NULL, true, 0, 4, 0, 0 };      /* batch 0: by model (below); nshard 0: --shard not given */
 
 static void print_models(FILE *fh) {
     for (int mdl = 0; mdl < (int)flappie_nmodel; mdl++)

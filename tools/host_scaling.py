@@ -83,7 +83,7 @@ def main():
     rate = a.gpu_rate or {384: 104.0, 256: 203.0}.get(a.hidden, 100.0)
     import bench
     ncore, nhw, why = bench.effective_cpus()
-    readers = a.readers or max(1, min(12, ncore // NSHARD - 2))
+    readers = a.readers or max(1, min(4, ncore // NSHARD))       # (bench.py's rule: what a rank of an eight-rank job gets)
     n_short = max(512, a.files // 4)
     print("# tools/host_scaling.py --hidden %d --files %d%s: %d CPUs granted to this container, %d reader processes per flappie process, emulated GPUs at %.0f Msamples/s (%s)"
           % (a.hidden, a.files, " --emu-on-gpu" if a.emu_on_gpu else "", ncore, readers, rate,
