@@ -1247,17 +1247,19 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         b->launches[3] += 4;
     } else {
         // ---- globalnorm_flipflop (layers.c:1082-1106)
-        if (split_head) launch_head_split(s, b->actS[cur], b->trans, m->FFsplit, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 32, temperature / 5.0f, m->FF_split_S, 0);
-        else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
         // |score| <= 5/temperature (tanh bounded by 1): picks the rescaling interval of the linear-space form;
         // extreme temperatures (or FFHIP_CRF_LOGSPACE=1) take the log-space recursion
         const int R = dbg("crf_logspace") ? 0 : crf_rescale_interval(5.0f / temperature);
         // 8-state models, a block's scores spanning at most kFbRange: ONE pair of fp64 linear-space chains per read gives logZ, the
         // normalised scores and (when asked for) the posterior (k_crf_fb8, ffhip_decode.hip)
         post_done = R > 0 && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) && 10.0f / temperature <= kFbRange && !dbg("decode_r2");
+        // ... whose input E = exp(S - block max) the split head leaves behind from its own epilogue (round 5: k_crf_exp's launch and its pass over the scores are gone)
+        const bool head_e = split_head && post_done && head_split_writes_E(m->P);
+        if (split_head) launch_head_split(s, b->actS[cur], b->trans, m->FFsplit, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 32, temperature / 5.0f, m->FF_split_S, 0, head_e ? b->crf_e : nullptr);
+        else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
         if (post_done) {
             const bool want_post = !(flags & FFHIP_RUN_NO_DECODE) && !(flags & FFHIP_RUN_VITERBI_ONLY);
-            launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
+            if (!head_e) launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
             mark(b, 4);       // the profile's "posterior" slot times the chain launch: partition function + normalisation + posterior together
             launch_crf_fb(s, m->nbase, b->crf_e, b->trans, b->post, (double *)b->fwd, b->nread, Tb, b->crf_logz, tbs, want_post ? 3 : 1, nullptr);
             b->launches[3] += want_post ? 4 : 3;      // head, exp, chains, assembly (the subtraction alone: three)

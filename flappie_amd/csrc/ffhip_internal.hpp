@@ -125,7 +125,8 @@ void launch_lean_math_check(hipStream_t s, int exponent, int steps, unsigned lon
 
 // the same head on the last layer's split output (ffhip_rnn_split.hip layout), weights as fp16 slices scaled by 2^(acc_exp - kSplitExpH)
 void launch_head_split(hipStream_t s, const void *in_split, float *trans, const void *Wsplit, const float *bias,
-                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw);
+                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw, double *E = nullptr);
+bool head_split_writes_E(int P);       // the head can leave exp(S - block max) for the linear-space chains (drops k_crf_exp)
 // head: trans = tanh(W^T h + b) / (temperature/5)
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw = 0);      // raw = 1: W^T h + b only

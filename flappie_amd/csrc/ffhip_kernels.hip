@@ -814,7 +814,7 @@ k_head(const float *__restrict__ in, float *__restrict__ trans, const v4f *__res
 template <int TM>
 __global__ void __launch_bounds__(256)
 k_head_split(const unsigned char *__restrict__ in, float *__restrict__ trans, const v4u_t *__restrict__ Wp, const float *__restrict__ bias,
-             int Tb, int B16, int nread, int P, int Ps, int Mt, int Hc, float scale, float acc_scale, int raw) {
+             int Tb, int B16, int nread, int P, int Ps, int Mt, int Hc, float scale, float acc_scale, int raw, double *__restrict__ E, int Pd) {
     FFHIP_DECODE_PRIO_SET();
     constexpr int TN = 4, NSL = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -867,6 +867,58 @@ k_head_split(const unsigned char *__restrict__ in, float *__restrict__ trans, co
         }
     }
     const float inv_scale = 1.0f / acc_scale;
+    if (E) {
+        // ---- the same epilogue, column by column, and behind each column E = exp(S - max S) of the block for the fp64 chains of ffhip_decode.hip (round 5:
+        // k_crf_exp's pass over the scores -- one launch on the path between two pairs' layer launches, 26 MB read again -- is gone).  A block's P scores sit in
+        // the four quarter-waves of one read's lanes (rows 16 i + 4 q + e): the maximum is taken inside the lane, then across the quarters; every value is what
+        // k_crf_exp computes from the stored float, operation for operation (fmaxf over the same set, exp of the same double difference).
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nt = nt0 + j;
+            const bool live_t = nt < ntile;
+            const int ntc = live_t ? nt : ntile - 1;
+            const int blk = ntc / B16, read = (ntc % B16) * 16 + rl;
+            const bool live = live_t && read < nread;
+            float rr[TM][4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int p = i * 16 + q * 4;
+                const v4f v = acc[i][j] * inv_scale;
+                const ffv4 t = apply_act4((ffv4){ v.x, v.y, v.z, v.w }, 2);
+                rr[i][0] = (t.x - 0.0f) / scale; rr[i][1] = (t.y - 0.0f) / scale; rr[i][2] = (t.z - 0.0f) / scale; rr[i][3] = (t.w - 0.0f) / scale;
+                if (i < Mt && p < P) {
+                    float *o = trans + ((size_t)read * Tb + blk) * Ps + p;
+                    if (live) {
+                        if (p + 3 < P && (Ps & 3) == 0) *(float4 *)o = make_float4(rr[i][0], rr[i][1], rr[i][2], rr[i][3]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (p + e < P) o[e] = rr[i][e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (p + e < P) m = fmaxf(m, rr[i][e]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            double *Eo = E + ((size_t)read * Tb + blk) * Pd;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int p = i * 16 + q * 4;
+                if (!live || p >= Pd) continue;
+                double ev[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    ev[e] = (i < Mt && p + e < P) ? exp((double)rr[i][e] - (double)m) : ((p + e == P) ? (double)m : 0.0);      // [P]: the block's maximum; behind it zeros
+                *(double2 *)(Eo + p) = make_double2(ev[0], ev[1]);
+                *(double2 *)(Eo + p + 2) = make_double2(ev[2], ev[3]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int p = i * 16 + q * 4;
@@ -897,16 +949,20 @@ k_head_split(const unsigned char *__restrict__ in, float *__restrict__ trans, co
 }
 
 void launch_head_split(hipStream_t s, const void *in_split, float *trans, const void *Wsplit, const float *bias,
-                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw) {
+                       int Tb, int B16, int nread, int P, int Ps, int Hc, float scale, int acc_exp, int raw, double *E) {
     const int Mt = (P + 15) / 16;
     const int ntile = Tb * B16;
+    const int Pd = crf_exp_stride(P);
+    if (E && (raw || Pd > 16 * (Mt <= 3 ? 3 : 4))) E = nullptr;      // (the caller asks head_split_writes_E first)
     if (Mt <= 3)
         hipLaunchKernelGGL(k_head_split<3>, dim3((ntile + 15) / 16), dim3(256), 0, s, (const unsigned char *)in_split, trans, (const v4u_t *)Wsplit, bias, Tb, B16,
-                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw);
+                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw, E, Pd);
     else
         hipLaunchKernelGGL(k_head_split<4>, dim3((ntile + 15) / 16), dim3(256), 0, s, (const unsigned char *)in_split, trans, (const v4u_t *)Wsplit, bias, Tb, B16,
-                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw);
+                           nread, P, Ps, Mt, Hc, scale, split_pow2(acc_exp), raw, E, Pd);
 }
+// the head's epilogue can leave E = exp(S - max S) for the chains of ffhip_decode.hip: a block's row of crf_exp_stride(P) doubles must fit the head's row tiles
+bool head_split_writes_E(int P) { const int Mt = (P + 15) / 16; return !dbg("no_head_exp") && crf_exp_stride(P) <= 16 * (Mt <= 3 ? 3 : 4) && Mt <= 4; }
 
 void launch_head(hipStream_t s, const float *in, float *trans, const float4 *Wp, const float *bias,
                  int Tb, int B16, int nread, int P, int Ps, int K16, float scale, int raw) {
