@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a step of the layer kernel goes, per wave role, in the kernel AS IT RUNS IN PRODUCTION (round 5): the -DFFHIP_PHASES variant of libffhip.so
 (tools/dev/build_variants.sh phases="-DFFHIP_PHASES", copied over the tree's library by the caller) adds the time between its stamps to per-wave words
-in LDS and hands the sums out at the end of each launch.  usage: tools/dev/phases.py [config=c2|h256|c4] [pairs=6]"""
+in LDS and hands the sums out at the end of each launch.  usage: tools/dev/phases.py [config=c2|h256|c4] [pairs=6] [serial]   (serial: one batch at a time, run + finish -- a launch alone on the chip)"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +15,7 @@ from flappie_amd import model as M  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+serial = len(sys.argv) > 3 and sys.argv[3] == "serial"
 KIND, H, NREAD, T, PAIR = {"c2": (M.NET_LSTM5, 384, 256, 4000, True), "h256": (M.NET_LSTM5, 256, 1024, 4000, False),
                            "c4": (M.NET_GRUMOD5, 256, 1024, 4000, False)}[cfg]
 L = B.lib()
@@ -29,7 +30,10 @@ for b in bs:
 buf = (C.c_ulonglong * 72)()
 assert L.ffhip_debug_phases(buf, 1) == 0          # arms the buffer
 for rnd in range(rounds + 1):
-    if PAIR:
+    if serial:
+        for b in bs:
+            b.run(); b.finish()
+    elif PAIR:
         bs[0].run_pair(bs[1])
     else:
         bs[0].run(); bs[1].run()
