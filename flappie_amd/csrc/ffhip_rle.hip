@@ -30,17 +30,20 @@ __device__ __forceinline__ float softplus_ref(float x) { return log1pf(expf(-fab
 
 // rows of the head output after the affine map (k_head writes W^T h + b untouched in mode 1)
 __global__ void __launch_bounds__(256)
-k_rle_activate(float *__restrict__ param, size_t n /*nread*Tb*Ps*/, int nbase, int P, int Ps, float temperature) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int p = (int)(i % Ps);
-    if (p >= P) return;
-    const float x = param[i];
-    float r;
-    if (p < nbase) r = 1.0f + softplus_ref(x);
-    else if (p < 2 * nbase) r = 1e-8f + softplus_ref(x);
-    else r = 5.0f * tanhf(x) / temperature;
-    param[i] = r;
+k_rle_activate(float *__restrict__ param, int TbS, int nbase, int P, int Ps, float temperature) {
+    // block (64, 4): x = row of the block's parameter vector, y = block; grid (blocks / 4, read) -- 32-bit index arithmetic, no division
+    // (round 5: the flat 64-bit index with its `% Ps` cost 190 us per 256 x 800 blocks, on the decode chain of the run-length model)
+    const int blk = (int)blockIdx.x * 4 + (int)threadIdx.y;
+    if (blk >= TbS) return;
+    for (int p = (int)threadIdx.x; p < P; p += 64) {
+        float *v = param + ((size_t)blockIdx.y * TbS + blk) * Ps + p;
+        const float x = *v;
+        float r;
+        if (p < nbase) r = 1.0f + softplus_ref(x);
+        else if (p < 2 * nbase) r = 1e-8f + softplus_ref(x);
+        else r = 5.0f * tanhf(x) / temperature;
+        *v = r;
+    }
 }
 
 // runlengthV2_partition_function: one wave per read, lane = state
@@ -128,15 +131,12 @@ k_rle_partition(const float *__restrict__ param, int TbS, int nbase, int Ps, dou
 
 // rows [2*nbase, P) -= (float)(logZ / Tb)   (layers.c:1349-1356: `const float logZ = partition / (float)nc`)
 __global__ void __launch_bounds__(256)
-k_rle_sub(float *__restrict__ param, const double *__restrict__ logz, int TbS, int nbase, int P, int Ps, size_t n, const int *__restrict__ tbs) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int p = (int)(i % Ps);
-    if (p < 2 * nbase || p >= P) return;
-    const size_t r = i / ((size_t)TbS * Ps);
+k_rle_sub(float *__restrict__ param, const double *__restrict__ logz, int TbS, int nbase, int P, int Ps, const int *__restrict__ tbs) {
+    const int blk = (int)blockIdx.x * 4 + (int)threadIdx.y, r = (int)blockIdx.y;      // (as k_rle_activate)
     const int Tb = tbs ? tbs[r] : TbS;
-    if ((int)((i / Ps) % TbS) >= Tb) return;
-    param[i] -= (float)(logz[r] / (double)(float)Tb);
+    if (blk >= Tb) return;
+    const float z = (float)(logz[r] / (double)(float)Tb);
+    for (int p = 2 * nbase + (int)threadIdx.x; p < P; p += 64) param[((size_t)r * TbS + blk) * Ps + p] -= z;
 }
 
 // transpost_crf_runlength: wave 0 forward, wave 1 backward, then one block per thread
@@ -608,11 +608,10 @@ k_rl1_mean(const float *__restrict__ param, const int *__restrict__ path, int *_
 
 void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    const size_t n = (size_t)nread * Tb * Ps;
-    hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, n, nbase, P, Ps, temperature);
+    hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((Tb + 3) / 4), (unsigned)nread), dim3(64, 4), 0, s, param, Tb, nbase, P, Ps, temperature);
     if (nbase == 4 && Ps == 40 && !dbg("decode_r2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
     else hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
-    hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, logz, Tb, nbase, P, Ps, n, tbs);
+    hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((Tb + 3) / 4), (unsigned)nread), dim3(64, 4), 0, s, param, logz, Tb, nbase, P, Ps, tbs);
 }
 
 void launch_rle_partition(hipStream_t s, const float *param, double *logz, int nread, int Tb, int nbase, int Ps, const int *tbs) {

@@ -63,6 +63,9 @@ constexpr int NS = kSplitNS;
 #ifndef FFHIP_SG_O_FRONT
 #define FFHIP_SG_O_FRONT 1      // split gate tiles: the front wave evaluates the output gate too (0: round 2-4's form, the back wave does)
 #endif
+#ifndef FFHIP_PACK_X2
+#define FFHIP_PACK_X2 3         // the packed forms: the x waves' operand pieces double-buffered (1: k_lstm_pack, 2: k_grumod_pack too), 3: + the next step's first piece(s) across the gate phase; 0: one piece at a time, round 3-4's form
+#endif
 #ifndef FFHIP_SWAP_ROLES
 #define FFHIP_SWAP_ROLES 0      // 1: the h waves are the workgroup's waves 0-3 (the OLDER ones: between two MFMA streams of a SIMD the older wave runs, tools/dev/coissue_probe.cpp)
 #endif
@@ -595,8 +598,42 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         };
         // Both tiles' partials are computed BEFORE the wait for the h wave's "consumed" flags -- those are raised at the end of its
         // recurrent pass, and a projection of the second tile started only then would stand between the h waves and the barrier.
+#if FFHIP_PACK_X2
+        // pieces of the NEXT step that leave behind the last MFMAs of this one, in flight across the gate phase (FFHIP_PACK_X2 >= 3): both where the registers
+        // are there (GRUmod: 124), the first one otherwise (the LSTM form spills 9 registers with both)
+        constexpr int XPRE = FFHIP_PACK_X2 >= 3 ? ((KIND == 1 || FFHIP_PACK_X2 >= 5) ? 2 : 1) : 0;
+        v4u xq[2][NS];
+        auto ldq = [&](int i, int k, v4u (&dst)[NS]) {      // piece k = (tile, chunk) of x(step i)
+            const int ts = (k / N < ntl) ? k / N : 0, cc = k % N;
+            __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)tile_ptr(a.xin, step_t(i), ts), 0, (int)tileB, 0x00020000);
+#pragma unroll
+            for (int s = 0; s < NS; s++) dst[s] = __builtin_amdgcn_raw_buffer_load_b128(rx, lane_off, ((chunk[cc] * NS + s) * 64) * 16, 0);
+        };
+#endif
         auto project_step = [&](int i, int want) {           // x(step i) of both tiles -> px[0][kw][*]; want = the step (+1) whose partials must have been consumed (0: none)
             v4f acc[TS][NRT];
+#if FFHIP_PACK_X2
+            if constexpr (PACK && (KIND == 0 || FFHIP_PACK_X2 > 1)) {
+                // x(t) of the four (tile, chunk) pieces through TWO 8-register buffers, the load of piece k + 2 issued behind the MFMAs of piece k: two exposed L2
+                // round trips a step instead of four (the x waves closed every step of this form: the h waves waited 2960 of 11 640 cycles for them,
+                // profiles/r05_phases.txt).  An absent second tile re-reads the first and its products are dropped: the outstanding-load count stays static.
+                // FFHIP_PACK_X2 >= 3: pieces 0 and 1 of the NEXT step leave behind the last MFMAs of this one (in flight across the gate phase).
+                if constexpr (XPRE < 1) ldq(i, 0, xq[0]);
+                if constexpr (XPRE < 2) ldq(i, 1, xq[1]);
+#pragma unroll
+                for (int ts = 0; ts < TS; ts++)
+#pragma unroll
+                    for (int j = 0; j < NRT; j++) acc[ts][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int k = 0; k < TS * N; k++) {
+                    mm6<NRT, N>(wf, k % N, xq[k & 1], acc[k / N]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 2 < TS * N) ldq(i, k + 2, xq[k & 1]);
+                    else if (k + 2 - TS * N < XPRE) ldq(i + 1 < Tb ? i + 1 : i, k + 2 - TS * N, xq[k & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
+#endif
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
@@ -639,6 +676,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
+#if FFHIP_PACK_X2
+        if constexpr (PACK && (KIND == 0 || FFHIP_PACK_X2 > 1)) { if constexpr (XPRE >= 1) ldq(0, 0, xq[0]); if constexpr (XPRE >= 2) ldq(0, 1, xq[1]); }
+#endif
         project_step(0, 0);
         touch_x(1);
         sink ^= touched;
