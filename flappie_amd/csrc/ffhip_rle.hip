@@ -31,18 +31,18 @@ __device__ __forceinline__ float softplus_ref(float x) { return log1pf(expf(-fab
 // rows of the head output after the affine map (k_head writes W^T h + b untouched in mode 1)
 __global__ void __launch_bounds__(256)
 k_rle_activate(float *__restrict__ param, int TbS, int nbase, int P, int Ps, float temperature) {
-    // block (64, 4): x = row of the block's parameter vector, y = block; grid (blocks / 4, read) -- 32-bit index arithmetic, no division
-    // (round 5: the flat 64-bit index with its `% Ps` cost 190 us per 256 x 800 blocks, on the decode chain of the run-length model)
-    const int blk = (int)blockIdx.x * 4 + (int)threadIdx.y;
-    if (blk >= TbS) return;
-    for (int p = (int)threadIdx.x; p < P; p += 64) {
-        float *v = param + ((size_t)blockIdx.y * TbS + blk) * Ps + p;
-        const float x = *v;
-        float r;
-        if (p < nbase) r = 1.0f + softplus_ref(x);
-        else if (p < 2 * nbase) r = 1e-8f + softplus_ref(x);
-        else r = 5.0f * tanhf(x) / temperature;
-        *v = r;
+    // a workgroup takes 8 consecutive blocks of one read (grid: blocks / 8, read) and walks their rows BY KIND -- the 2 nbase^2 transition rows (tanh) of the 8 blocks,
+    // then their 2 nbase shape / scale rows (softplus) -- so that a wave evaluates one of the two functions, not both under a mask; 32-bit indices (round 5: the
+    // flat 64-bit index with its `% Ps` and the mixed rows cost 120 us per 256 x 800 blocks, on the decode chain of the run-length model)
+    const int blk0 = (int)blockIdx.x * 8, nt = P - 2 * nbase, ns = 2 * nbase;
+    float *base = param + ((size_t)blockIdx.y * TbS + blk0) * Ps;
+    for (int j = (int)threadIdx.x; j < 8 * nt; j += 256) {
+        const int bl = j / nt, pp = ns + j % nt;
+        if (blk0 + bl < TbS) { float *v = base + bl * Ps + pp; *v = 5.0f * tanhf(*v) / temperature; }
+    }
+    for (int j = (int)threadIdx.x; j < 8 * ns; j += 256) {
+        const int bl = j / ns, pp = j % ns;
+        if (blk0 + bl < TbS) { float *v = base + bl * Ps + pp; *v = (pp < nbase ? 1.0f : 1e-8f) + softplus_ref(*v); }
     }
 }
 
@@ -608,7 +608,7 @@ k_rl1_mean(const float *__restrict__ param, const int *__restrict__ path, int *_
 
 void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs) {
     const int P = 2 * nbase * (nbase + 1);
-    hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((Tb + 3) / 4), (unsigned)nread), dim3(64, 4), 0, s, param, Tb, nbase, P, Ps, temperature);
+    hipLaunchKernelGGL(k_rle_activate, dim3((unsigned)((Tb + 7) / 8), (unsigned)nread), dim3(256), 0, s, param, Tb, nbase, P, Ps, temperature);
     if (nbase == 4 && Ps == 40 && !dbg("decode_r2")) launch_rle_partition8x(s, param, logz, nread, Tb, tbs);      // ffhip_decode.hip
     else hipLaunchKernelGGL(k_rle_partition, dim3(nread), dim3(64), 0, s, param, Tb, nbase, Ps, logz, tbs);
     hipLaunchKernelGGL(k_rle_sub, dim3((unsigned)((Tb + 3) / 4), (unsigned)nread), dim3(64, 4), 0, s, param, logz, Tb, nbase, P, Ps, tbs);
