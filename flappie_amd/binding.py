@@ -54,7 +54,8 @@ class CRawTable(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libffhip.so")
+    # FFHIP_BINDING_LIBRARY: another build of the same C-ABI (tests only: tools/test_hooks/libffhip_resweep.so, the library whose layer kernels re-sweep on purpose)
+    return os.environ.get("FFHIP_BINDING_LIBRARY") or os.path.join(_HERE, "libffhip.so")
 
 
 def lib():

@@ -66,6 +66,9 @@ constexpr int NS = kSplitNS;
 #ifndef FFHIP_PACK_X2
 #define FFHIP_PACK_X2 3         // the packed forms: the x waves' operand pieces double-buffered (1: k_lstm_pack, 2: k_grumod_pack too), 3: + the next step's first piece(s) across the gate phase; 0: one piece at a time, round 3-4's form
 #endif
+#ifndef FFHIP_FORCE_RETRY
+#define FFHIP_FORCE_RETRY 0      // 1: every member re-sweeps h(t-1) once at every 32nd step (tools/test_hooks/libffhip_resweep.so, tests/test_resweep_gpu.py)
+#endif
 #ifndef FFHIP_SWAP_ROLES
 #define FFHIP_SWAP_ROLES 0      // 1: the h waves are the workgroup's waves 0-3 (the OLDER ones: between two MFMA streams of a SIMD the older wave runs, tools/dev/coissue_probe.cpp)
 #endif
@@ -986,7 +989,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     // while this wave's gate-phase stores of step i-1 may be pending the compiler can only wait vmcnt(0).
                     // They completed long ago (the poll above outlasts them) -- say so, and the sweep gets counted waits.
                     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                    if (!recur_any()) {
+                    if (!recur_any() || (FFHIP_FORCE_RETRY && (i & 31) == 5)) {      // (FFHIP_FORCE_RETRY: the test build that takes the re-sweep path on purpose, below)
 #ifdef FFHIP_COUNT_FALLBACK
                         if (lane == 0) atomicAdd(a.abort_word + 1, 1u);
 #endif
@@ -996,6 +999,13 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                 if (ab != 0u || spin > 3000000u) { timed_out = true; break; }
                             }
                             __builtin_amdgcn_s_sleep(1);
+                            // Round 5: the pass that just failed wrote its partial sums over the landing zones LAST -- the second tile's the very last thing it did -- and
+                            // the re-sweep's `buffer_load ... lds` pieces land in those zones again.  LDS writes of the DS path and of the DMA path are not ordered with
+                            // each other: a ds_write still queued when the sweep goes out can land AFTER the piece that replaces it, and the pass then multiplies stale
+                            // partial sums of the SECOND tile as if they were h(t-1) (no sentinel among them: the check passes).  One read tile wrong from that step
+                            // on, once in ~10^4 launches of k_grumod_pack (whose x waves do not slow its h waves down: the sweep meets a half-visible step more often);
+                            // taken on purpose (-DFFHIP_FORCE_RETRY) 199 launches of 200.  profiles/r05_pack_repeat.txt; tests/test_resweep_gpu.py keeps it fixed.
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                             if constexpr (!DN) init_acc();
                             if (recur_any()) break;
                         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a step of the layer kernel goes, per wave role, in the kernel AS IT RUNS IN PRODUCTION (round 5): the -DFFHIP_PHASES variant of libffhip.so
 (tools/dev/build_variants.sh phases="-DFFHIP_PHASES", copied over the tree's library by the caller) adds the time between its stamps to per-wave words
-in LDS and hands the sums out at the end of each launch.  usage: tools/dev/phases.py [config=c2|h256|c4] [pairs=6] [serial]   (serial: one batch at a time, run + finish -- a launch alone on the chip)"""
+in LDS and hands the sums out at the end of each launch.  usage: tools/dev/phases.py [config=c2|h256|c4|h512] [pairs=6] [serial]   (serial: one batch at a time, run + finish -- a launch alone on the chip)"""
 import ctypes as C
 import os
 import sys
@@ -17,7 +17,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 serial = len(sys.argv) > 3 and sys.argv[3] == "serial"
 KIND, H, NREAD, T, PAIR = {"c2": (M.NET_LSTM5, 384, 256, 4000, True), "h256": (M.NET_LSTM5, 256, 1024, 4000, False),
-                           "c4": (M.NET_GRUMOD5, 256, 1024, 4000, False)}[cfg]
+                           "c4": (M.NET_GRUMOD5, 256, 1024, 4000, False), "h512": (M.NET_LSTM5, 512, 256, 20000, False)}[cfg]
 L = B.lib()
 L.ffhip_debug_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 L.ffhip_debug_phases.restype = C.c_int
