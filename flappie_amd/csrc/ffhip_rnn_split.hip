@@ -96,15 +96,13 @@ struct SplitArgsOther {       // what the second batch of a paired launch brings
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-// A flag word in LDS.  Through a plain `volatile int *` the access is a FLAT one -- address-space inference leaves volatile accesses alone --: it travels
-// the vector memory pipe, and the compiler follows it with `s_waitcnt vmcnt(0)` (a flat access may alias LDS).  Round 5 turned these into LDS accesses
-// (-DFFHIP_LDS_FLAGS=1: `ds_read_b32` / `ds_write_b32`, +0.5 % at c2, +1 % at c4) and took that back: with them ONE read tile in ~1000 batches -- always the
-// pair's second tile, whose units 4..11 are gated by the x waves' front / back halves -- came out wrong when another pair's decode ran beside the layer
-// launch (`FFHIP_DEBUG=front_order=none`; 12 of 12 000 batches against 0 of 12 000 with the flat accesses, and 0 of 4 800 with either `cxflag` or
-// `lds_abort` alone flat: tools/dev/front_order_diag.py, profiles/r05_lds_flags.txt).  The cause was not found -- every hand-over reads correctly in the ISA --
-// so the slow form, which four rounds of stress and fuzz runs have behind them, stays.
+// A flag word in LDS.  Through a plain `volatile int *` the access is a FLAT one -- address-space inference leaves volatile accesses alone --: it travels the vector
+// memory pipe, and the compiler follows it with `s_waitcnt vmcnt(0)` (a flat access may alias LDS).  As LDS accesses (`ds_read_b32` / `ds_write_b32`) the flags cost less and
+// the x waves' polling no longer slows their h waves down: c2 +1.2 %, h256 +1.9 %, rle +0.6 % (profiles/r05_lds_flags.txt, last block).  Round 5 built this form first, saw ONE
+// read tile in ~1000 batches wrong with it -- always the pair's second tile -- and took it back; the cause turned out to be the re-sweep path (below: the faster h waves only took it
+// more often), and with that fixed the form is clean in 12 000 batches that showed 12 failures before (tools/dev/front_order_diag.py).  -DFFHIP_LDS_FLAGS=0: the flat accesses.
 #ifndef FFHIP_LDS_FLAGS
-#define FFHIP_LDS_FLAGS 0
+#define FFHIP_LDS_FLAGS 1
 #endif
 #if FFHIP_LDS_FLAGS
 #define LDSV(x) (*(volatile __attribute__((address_space(3))) int *)&(x))
