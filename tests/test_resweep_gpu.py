@@ -1,9 +1,9 @@
 """The layer kernels' RE-SWEEP path, taken on purpose.
 
-A sweep of h(t-1) that meets a sentinel (a producer's stores became visible line by line) is done again; by itself that happens about once in 10^4 layer launches, and
+A sweep of h(t-1) that meets a sentinel (a producer's stores became visible line by line) is done again; that happens ~10 times a layer launch (0.001 % of the h waves' steps, tools/dev/fallback_count.py), and
 for two rounds the path was wrong: the re-sweep's `buffer_load ... lds` pieces went out while the failed pass's last partial-sum `ds_write`s into the same landing
 zone -- the SECOND tile's -- were still queued, the two LDS write paths are not ordered, and a stale partial could replace an operand piece: one read tile wrong from
-that step on (round 5: found with tools/dev/pack_repeat.py, 2 of 10 000 launches of k_grumod_pack; 199 of 200 with the path forced; profiles/r05_pack_repeat.txt).
+that step on, about one launch in 10^4 (round 5: found with tools/dev/pack_repeat.py, 2 of 10 000 launches of k_grumod_pack; 199 of 200 with the path forced; profiles/r05_pack_repeat.txt).
 tools/test_hooks/libffhip_resweep.so is the release library with -DFFHIP_FORCE_RETRY=1 (every member re-sweeps once at every 32nd step): each dense / packed / paired
 form must give, bit for bit, what the release library gives."""
 import os
