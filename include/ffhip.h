@@ -72,6 +72,8 @@ typedef struct {
 #define FFHIP_RUN_UNFUSED_RNN   32u   /* separate input-projection GEMM + recurrent kernel (cross-check)      */
 #define FFHIP_RUN_F32_RNN       64u   /* f32-input MFMA recurrent kernel instead of the split-operand (two fp16 slices) one (cross-check) */
 #define FFHIP_RUN_KEEP_ACTS     16u   /* keep every layer's activations for ffhip_batch_get_activation        */
+/* (A read that left the default kernels' operand range and was evaluated again on the f32 kernels -- ffhip_batch_f32_reruns() -- returns
+ * the f32 run's scores, path and calls; its KEPT ACTIVATIONS are not refreshed: they stay those of the first, discarded evaluation.) */
 #define FFHIP_RUN_FAST_GATES   128u   /* split layer kernels: gate activations through the hardware exp / reciprocal (1 ulp) instead of the
                                        * instruction-for-instruction replay of the reference's exp_ps; opt-in, not bit-compatible */
 
