@@ -8,6 +8,7 @@
 #include <string.h>
 #include <math.h>
 #include <time.h>
+#include <ctype.h>
 #include <vector>
 #include <map>
 #include <string>
@@ -69,9 +70,24 @@ const char *dbg(const char *token) {
     static std::mutex mu;
     static std::string seen;                                  // the variable's text the table below was built from
     static std::vector<std::pair<std::string, std::string>> table;
+    std::lock_guard<std::mutex> lock(mu);                     // (getenv inside: a test's setenv in another thread must not race the read)
+    static bool legacy_checked = false;
+    if (!legacy_checked) {
+        // rounds 1-4 had one variable per switch; a script that still sets one now compares the default with itself -- say so, once
+        legacy_checked = true;
+        static const char *const legacy[] = { "FFHIP_NO_SPLIT_HEAD", "FFHIP_CONV_WS", "FFHIP_CONV_SMALL_U", "FFHIP_STREAMS", "FFHIP_FRONT_ORDER", "FFHIP_NO_DECODE_WAIT",
+            "FFHIP_CONV1_TN", "FFHIP_NO_PACK", "FFHIP_NO_SPLIT", "FFHIP_NO_FUSE", "FFHIP_NO_PAIR", "FFHIP_NO_DENSE", "FFHIP_PERSIST_MODE", "FFHIP_LEAN_CONV",
+            "FFHIP_NO_SPLIT_CONV", "FFHIP_NO_BATCH_ORDER", "FFHIP_CRF_LOGSPACE", "FFHIP_DECODE_R2", "FFHIP_EXACT_ORDER", "FFHIP_CRF_GENERIC", "FFHIP_SPLIT_TS",
+            "FFHIP_SPLIT_DENSE", "FFHIP_DENSE256", "FFHIP_NO_SPLIT_GATE", "FFHIP_NO_HEAD_EXP", "FFHIP_FORCE_ABORT" };
+        for (const char *name : legacy)
+            if (getenv(name)) {
+                std::string tok(name + 6);
+                for (auto &c : tok) c = (char)tolower((unsigned char)c);
+                fprintf(stderr, "libffhip: %s is no longer read (one variable since round 5: FFHIP_DEBUG=%s[=value], INTEGRATION.md section 6)\n", name, tok.c_str());
+            }
+    }
     const char *e = getenv("FFHIP_DEBUG");
     if (!e || !e[0]) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
     if (seen != e) {                                          // (tests change the variable between runs of one process)
         seen = e;
         std::vector<std::pair<std::string, std::string>> t;

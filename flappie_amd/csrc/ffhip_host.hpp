@@ -11,7 +11,7 @@
 struct ffhip_engine {
     int device = 0;
     hipDeviceProp_t prop;
-    hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr };      // batches take them in turn (FFHIP_STREAMS = 2..4)
+    hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr };      // batches take them in turn (FFHIP_DEBUG=streams=2..4)
     int nstreams = 4, next_stream = 0;
     int profiling = 0;
     // Persistent recurrent kernels spin on their peers: every workgroup of a launch must be resident.

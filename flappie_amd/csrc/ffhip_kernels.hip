@@ -19,7 +19,7 @@
 #include "ffhip_math.hpp"
 #include <stdlib.h>
 
-// Head and decode kernels run beside the NEXT batch's convolutions (batch_run_impl, FFHIP_FRONT_ORDER) and the next layer launches wait for them:
+// Head and decode kernels run beside the NEXT batch's convolutions (batch_run_impl, FFHIP_DEBUG=front_order=...) and the next layer launches wait for them:
 // their waves go first on a shared SIMD (the convolutions stay at priority 0)
 #ifndef FFHIP_DECODE_PRIO
 #define FFHIP_DECODE_PRIO 2
@@ -168,7 +168,8 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
-    static const bool unrolled = !(dbg("conv_small_u") && dbg("conv_small_u")[0] == '0');      // (=0: the round-3 loops, for comparison)
+    const char *su_env = dbg("conv_small_u");
+    const bool unrolled = !(su_env && su_env[0] == '0');      // (=0: the round-3 loops, for comparison)
     if (unrolled && out.F == 4 && in.F == 1 && winlen == 5)
         hipLaunchKernelGGL((k_conv_small<4, 5>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
     else if (unrolled && out.F == 16 && in.F == 4 && winlen == 5)
@@ -227,7 +228,7 @@ __device__ __forceinline__ void mma_tiles(const v4f *(&ap)[TM], const float *(&b
 // N tile = (output column c, read tile rt); all 16 reads share the window start.  Columns with a
 // second window (or none) are irregular and rare: handled by re-running the loop for window b.
 // TN (column tiles a wave; round 4).  A one-feature input (the r941_5mC model's only convolution: 19 taps, K16 = 2) has 8 MFMAs a tile against ~130
-// VALU instructions of swish + split in the epilogue, and at TN = 4 the kernel holds 230 registers: two waves a SIMD.  FFHIP_CONV1_TN=2 (156 registers,
+// VALU instructions of swish + split in the epilogue, and at TN = 4 the kernel holds 230 registers: two waves a SIMD.  FFHIP_DEBUG=conv1_tn=2 (156 registers,
 // three waves) is 13 % faster ALONE (1.00 -> 0.88 ms for a 1024-read batch) -- and slower in the pipeline, where this convolution runs beside the previous
 // batch's head and decode and the next layer launches wait for THOSE: 100.3 -> 99.0 Msamples/s at `c4` (TN = 1: 98.7).  Default 4; bit-identical all three.
 template <bool BVEC, int TN = 4, int WPS = 1>
@@ -309,7 +310,8 @@ void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp,
     const int Mt = M / 16;
     const int nMblk = (Mt + 7) / 8, nNblk = (Tout * B16 + 7) / 8;
     const bool vec = (in.F % 4 == 0);
-    static const int thin_tn = dbg("conv1_tn") ? atoi(dbg("conv1_tn")) : 4;
+    const char *tn_env = dbg("conv1_tn");
+    const int thin_tn = tn_env ? atoi(tn_env) : 4;
     if (!vec && K16 <= 2 && thin_tn < 4) {
         const int tn = thin_tn <= 1 ? 1 : 2, nNb = (Tout * B16 + 2 * tn - 1) / (2 * tn);
         if (tn == 1)
@@ -574,8 +576,9 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
 void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, const float *bias, const int *x0a, const int *x0b,
                        int B16, int Tout, int M, int winlen, int act, int ldp, void *out_split, int split_exp, int acc_exp, int lean, unsigned *sat) {
     const int Mt = M / 16, NC = (winlen + 1) / 2;
-    // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_CONV_WS=0: the round-3 kernel)
-    static const int ws_env = [] { const char *e = dbg("conv_ws"); return e ? atoi(e) : 1; }();
+    // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_DEBUG=conv_ws=0: the round-3 kernel)
+    const char *ws_txt = dbg("conv_ws");
+    const int ws_env = ws_txt ? atoi(ws_txt) : 1;
     if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
         // (per call, of the CURRENT device -- the caller's engine has set it: a value cached from the first call would size the groups of an engine on
         // another device of the process by the wrong chip)

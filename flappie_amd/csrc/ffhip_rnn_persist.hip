@@ -52,7 +52,6 @@ namespace ffhip {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-unsigned long long *g_persist_dbg = nullptr;     // development hook (FFHIP_PERSIST_TIMING / FFHIP_TIMELINE builds)
 
 struct PersistArgs {
     const v4f *sWp;        // [Ut][K16][64] float4, A-fragment order
@@ -64,7 +63,6 @@ struct PersistArgs {
     unsigned *flags;       // [nrt][G] XCC ids (zeroed before launch)
     unsigned *abort_word;  // != 0 -> a wait timed out
     int Tb, B16, Ut, K16, G, rt0, nrt, backward;
-    unsigned long long *dbg; // optional phase timestamps [Tb][4 waves][6]
     int fast_gates;        // opt-in (FFHIP_FAST_GATES=1): hardware exp2/rcp gate math, NOT bit-compatible with the reference's exp_ps
     const int *tbs;        // ragged batch: blocks of each read [16*B16] (nullptr = all Tb); a read's steps t >= tbs[r] give h = c = 0,
                            // which is a fresh start for backward layers and inert padding for forward ones
@@ -161,19 +159,11 @@ k_rnn_persist(PersistArgs a) {
     for (int i = 0; i < Tb; i++) {
         const int t = a.backward ? Tb - 1 - i : i;
         const int tp = a.backward ? t + 1 : t - 1;
-#ifdef FFHIP_PERSIST_TIMING
-#define STAMP(k) do { if (a.dbg && blockIdx.x == 8 && lane == 0) a.dbg[((size_t)i * 4 + wave) * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-        STAMP(0);
         const v4f x = x_next;
-#ifndef FFHIP_ABL_NOXA
         if (my_tile >= 0 && i + 1 < Tb) {      // Xa streams from HBM: fetch one step ahead
             const int tn = a.backward ? t - 1 : t + 1;
             x_next = a.xa[(((size_t)tn * a.B16 + rt) * Ut + ut0 + my_tile) * 64 + lane];
         }
-#endif
         if (i > 0) {
             v4f acc[UPC];
 #pragma unroll
@@ -205,7 +195,6 @@ k_rnn_persist(PersistArgs a) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                STAMP(1);
                 if (timed_out) {
                     if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
                 } else {
@@ -213,18 +202,10 @@ k_rnn_persist(PersistArgs a) {
                     for (int kk = 0; kk < KPW; kk++) {
                         const v4f bf = __builtin_bit_cast(v4f, raw[kk]);      // k16 beyond K16 reads 0 (buffer bounds)
 #pragma unroll
-#ifdef FFHIP_ABL_NOMFMA
-                        for (int j = 0; j < UPC; j++) acc[j] = acc[j] + bf * wreg[j][kk].x;
-#else
                         for (int j = 0; j < UPC; j++) acc[j] = mfma4p(wreg[j][kk], bf, acc[j]);
-#endif
                     }
                 }
             }
-#ifdef FFHIP_PERSIST_TIMING
-            asm volatile("s_nop 0" :: "v"(acc[0].x));
-#endif
-            STAMP(2);
 #pragma unroll
             for (int j = 0; j < UPC; j++) part[i & 1][wave][j][lane] = acc[j];
             // LDS-only barrier: __syncthreads() would also drain vmcnt and put the HBM latency of the
@@ -232,7 +213,6 @@ k_rnn_persist(PersistArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            STAMP(3);
             if (lds_abort) return;
         }
         if (my_tile >= 0) {
@@ -242,31 +222,16 @@ k_rnn_persist(PersistArgs a) {
                 for (int w2 = 0; w2 < 4; w2++) s = s + part[i & 1][w2][my_tile][lane];
             }
             float h;
-#ifdef FFHIP_ABL_NOGATE
-            s = s + x; c = c + s.y; h = s.x * 0.001f + s.z * 0.001f + s.w * 0.001f + c * 1e-9f; if (false)
-#endif
             if (KIND == 0) {
                 s = s + x;
                 // layers.c:1014-1025.  sigma(i), sigma(f), sigma(o) and tanh(g) = 2 sigma(2g) - 1 are
                 // four independent logistic evaluations: do them as one interleaved vector call.
-#if defined(FFHIP_ABL_FASTGATE)
-                auto sg = [](float v) { return __frcp_rn(1.0f + __expf(-v)); };
-                const float si = sg(s.x), sf = sg(s.y), so = sg(s.w), tg = 2.0f * sg(2.0f * s.z) - 1.0f;
-                c = sf * c + si * tg;
-                h = so * (2.0f * sg(2.0f * c) - 1.0f);
-#elif defined(FFHIP_GATE_OLD)
-                const float forget = logistic_ref(s.y) * c;
-                const float update = logistic_ref(s.x) * tanh_ref(s.z);
-                c = forget + update;
-                h = logistic_ref(s.w) * tanh_ref(c);
-#else
                 const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });      // bit-identical to logistic_ref4, fewer instructions (ffhip_math.hpp)
                 const float tanh_g = (L.z + L.z) - 1.0f;
                 const float forget = L.y * c;
                 const float update = L.x * tanh_g;
                 c = forget + update;
                 h = L.w * tanh_ref_lean(c);
-#endif
             } else {
                 // layers.c:690-714: x added to z,r before the logistic; candidate = tanh(r*u + x_c)
                 const float z = logistic_ref(s.x + x.x);
@@ -286,7 +251,6 @@ k_rnn_persist(PersistArgs a) {
             hv.z = __shfl(h, rl + 32);
             hv.w = __shfl(h, rl + 48);
             float *ho = a.hout + ((size_t)t * a.B16 + rt) * tile_floats + (size_t)(ut0 + my_tile) * 64 + rl * 4;
-            STAMP(4);
             if (lane < 16) {
                 if (fast) *(v4f *)ho = hv;                            // stays in the group's shared L2
                 else {
@@ -370,9 +334,6 @@ k_lstm_fused(PersistArgs a) {
     __syncthreads();
     const bool fast = lds_fast != 0;
     __builtin_amdgcn_s_setprio(3);
-#ifdef FFHIP_TIMELINE
-    if (a.mode >= 100 && g >= 8) { const unsigned long long t0 = __builtin_readcyclecounter(); while (__builtin_readcyclecounter() - t0 < (unsigned long long)(a.mode - 100) * 100ull) __builtin_amdgcn_s_sleep(8); }
-#endif
     const bool have_k = wave * KPW < K16;
 
     // x(t) slices are plain data from the previous kernel: ordinary coalesced loads, one step ahead
@@ -387,21 +348,9 @@ k_lstm_fused(PersistArgs a) {
         }
     }
 
-#ifdef FFHIP_TIMELINE
-#define TL(k) do { if (a.dbg && i >= 100 && i < 132 && lane == 0) a.dbg[64 * 512 + (((size_t)blockIdx.x * 4 + wave) * 32 + (i - 100)) * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
-    if (a.dbg && threadIdx.x == 0) {
-        unsigned hw, xc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));
-        a.dbg[blockIdx.x] = ((unsigned long long)xc << 32) | hw;
-    }
-#else
-#define TL(k) do { } while (0)
-#endif
     for (int i = 0; i < Tb; i++) {
         const int t = a.backward ? Tb - 1 - i : i;
         const int tp = a.backward ? t + 1 : t - 1;
-        TL(0);
         v4f acc[UPC];
         v4f accx[KIND == 1 ? UPC : 1];       // GRUmod keeps the projection apart: its candidate row must not mix with sW h
 #pragma unroll
@@ -448,7 +397,6 @@ k_lstm_fused(PersistArgs a) {
                 }
             }
         }
-        TL(1);
         // ---- recurrent half
         if (do_h) {
             bool timed_out = false;
@@ -469,7 +417,6 @@ k_lstm_fused(PersistArgs a) {
                     raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k16 * 256 + lane * 4) * 4, 0, 16 /*sc1*/);
                 }
             }
-            TL(2);
             if (timed_out) {
                 if (lane == 0) { __hip_atomic_store(a.abort_word, 1u, RLX_AGENT); lds_abort = 1; }
             } else {
@@ -481,10 +428,6 @@ k_lstm_fused(PersistArgs a) {
                 }
             }
         }
-#ifdef FFHIP_TIMELINE
-        asm volatile("s_nop 0" :: "v"(acc[0].x), "v"(acc[UPC - 1].w));
-#endif
-        TL(3);
         if (KIND == 1) {
             // rows (z, r, candidate, -): pack {z: x+h, r: x+h, u = (sW h)_c, x_c = (Wi x)_c}; row 3 is free
 #pragma unroll
@@ -496,7 +439,6 @@ k_lstm_fused(PersistArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (lds_abort) return;
-        TL(4);
         if (my_tile >= 0) {
             v4f s = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
@@ -541,7 +483,6 @@ k_lstm_fused(PersistArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hv), wr, ((ut0 + my_tile) * 64 + rl * 4) * 4, 0, 16 /*sc1*/);
                 }
             }
-            TL(5);
         }
     }
 }
@@ -671,7 +612,7 @@ bool launch_lstm_fused(hipStream_t s, int kind, const float4 *sWp, const float4 
     a.sWp = (const v4f *)sWp; a.iWp = (const v4f *)iWp; a.bias = bias; a.xin = xin; a.xa = nullptr; a.hout = hout;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.Ut = H / 4; a.K16 = H / 16; a.G = pick_group(a.Ut); a.rt0 = rt0; a.nrt = nrt;
-    a.backward = backward; a.mode = mode; a.dbg = g_persist_dbg;
+    a.backward = backward; a.mode = mode;
     a.tbs = tbs; a.tbt = tbt;
     a.fast_gates = getenv("FFHIP_FAST_GATES") ? 1 : 0;
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
@@ -705,7 +646,7 @@ bool launch_rnn_persist(hipStream_t s, int kind, const float4 *sWp, const float 
     a.mode = mode;
     a.tbs = tbs; a.tbt = tbt;
     a.fast_gates = 0;
-    a.dbg = g_persist_dbg;
+   
     const int UPC = a.Ut / a.G, kpw = pick_kpw(a.K16);
     if (kind == 0) {
         switch (UPC) {

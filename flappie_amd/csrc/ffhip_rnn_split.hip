@@ -32,9 +32,10 @@
 //   * after one LDS-only barrier six waves (the h waves and x waves 0, 1) do the gate math of one 16 x 16 tile each
 //     (4 gates of one unit of one read per lane, cell state in a register; ffhip_math.hpp *_lean forms, bit-identical
 //     to the reference-order arithmetic), split h(t) and store it; a second barrier closes the gate phase, so that no
-//     MFMA stream starts next to a gate wave on its SIMD (round 1's reason -- a VALU chain beside a dense f32-MFMA stream runs ~3x
-//     slower -- does not hold for the 16-bit MFMAs: 0.92-0.95, tools/dev/mfma_valu_probe2.cpp; the barrier still pays: without it the
-//     layer takes 2.40 instead of 2.29 ms);
+//     MFMA stream starts next to a gate wave on its SIMD: v_mfma_f32_16x16x32_f16 holds the SIMD's VALU issue port for its four
+//     passes, a gate wave beside a back-to-back stream makes NO progress (tools/dev/coissue_probe.cpp, profiles/r05_coissue_probe.txt;
+//     round 2's "0.92-0.95 beside a dense stream" came from a stream with a loop branch behind every three MFMAs and is withdrawn,
+//     DESIGN.md section 5.1.1); without the barrier the layer takes 2.40 instead of 2.29 ms;
 //   * hand-off: the payload is the flag.  A producer lane writes the sentinel 0xFFFFFFFF (two bf16 NaNs -- never a
 //     pair of slices of a finite value) to ITS slots of step t+3 when it publishes step t (and of steps 0..2 before
 //     the group's start barrier): no host-side fill of the reused buffer.  A consumer wave first polls ONE dword per
@@ -60,17 +61,8 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 constexpr int NS = kSplitNS;
-#ifndef FFHIP_SG_O_FRONT
-#define FFHIP_SG_O_FRONT 1      // split gate tiles: the front wave evaluates the output gate too (0: round 2-4's form, the back wave does)
-#endif
-#ifndef FFHIP_PACK_X2
-#define FFHIP_PACK_X2 3         // the packed forms: the x waves' operand pieces double-buffered (1: k_lstm_pack, 2: k_grumod_pack too), 3: + the next step's first piece(s) across the gate phase; 0: one piece at a time, round 3-4's form
-#endif
 #ifndef FFHIP_FORCE_RETRY
 #define FFHIP_FORCE_RETRY 0      // 1: every member re-sweeps h(t-1) once at every 32nd step (tools/test_hooks/libffhip_resweep.so, tests/test_resweep_gpu.py)
-#endif
-#ifndef FFHIP_SWAP_ROLES
-#define FFHIP_SWAP_ROLES 0      // 1: the h waves are the workgroup's waves 0-3 (the OLDER ones: between two MFMA streams of a SIMD the older wave runs, tools/dev/coissue_probe.cpp)
 #endif
 
 struct SplitArgs {
@@ -100,15 +92,8 @@ struct SplitArgsOther {       // what the second batch of a paired launch brings
 // memory pipe, and the compiler follows it with `s_waitcnt vmcnt(0)` (a flat access may alias LDS).  As LDS accesses (`ds_read_b32` / `ds_write_b32`) the flags cost less and
 // the x waves' polling no longer slows their h waves down: c2 +1.2 %, h256 +1.9 %, rle +0.6 % (profiles/r05_lds_flags.txt, last block).  Round 5 built this form first, saw ONE
 // read tile in ~1000 batches wrong with it -- always the pair's second tile -- and took it back; the cause turned out to be the re-sweep path (below: the faster h waves only took it
-// more often), and with that fixed the form is clean in 12 000 batches that showed 12 failures before (tools/dev/front_order_diag.py).  -DFFHIP_LDS_FLAGS=0: the flat accesses.
-#ifndef FFHIP_LDS_FLAGS
-#define FFHIP_LDS_FLAGS 1
-#endif
-#if FFHIP_LDS_FLAGS
+// more often), and with that fixed the form is clean in 12 000 batches that showed 12 failures before (tools/dev/front_order_diag.py).  The flat form is in tools/dev/experiments/lstm_split_round5_switches.patch.
 #define LDSV(x) (*(volatile __attribute__((address_space(3))) int *)&(x))
-#else
-#define LDSV(x) (*(volatile int *)&(x))
-#endif
 
 // slice `which` of 4 values (each already multiplied by its power of two), packed as two dwords
 template <bool CLAMP>
@@ -225,7 +210,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     __shared__ int lds_abort;
     __shared__ int lds_fast;
     __shared__ float cx[2][64];             // split gate tiles: cell state c(t) from the front wave to the back wave of tiles 4 and 5
-    __shared__ float ox[FFHIP_SG_O_FRONT ? 2 : 1][64];      // ... and the output gate o(t), evaluated by the front wave as well
+    __shared__ float ox[2][64];      // ... and the output gate o(t), evaluated by the front wave as well
     __shared__ int cxflag[2];               // ... and the step it belongs to (+1)
     // HL: the sweep of h(t-1) LANDS IN LDS (buffer_load ... lds: no destination registers) and feeds the MFMAs through ds_read_b128.
     // The one-tile kernel at N = 3 then fits 128 registers: TWO workgroups -- two independent recurrences -- share a CU.
@@ -239,7 +224,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     constexpr int G = PACK ? 16 : 32, Hc = 4 * N, Ut = 32 * N;
     constexpr size_t tileB = (size_t)Hc * NS * 1024;      // bytes of one (t, read tile) in the split layout
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + (FFHIP_SWAP_ROLES ? 4 : 0)) & 7);
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7);
     const bool xw = wave < 4;
     const int kw = wave & 3;
     const int ngroup = (a.nrt + TS - 1) / TS;
@@ -355,13 +340,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         asm volatile("" ::: "memory");
     };
 
-#ifdef FFHIP_TIMELINE
-    // phase stamps go to LDS and are copied out after the loop: a global store per stamp would sit on the same counter as the
-    // loads and turn the kernel's counted vmcnt waits into vmcnt(0) -- the instrumented kernel would not be the kernel.
-    // (Even so the timeline build runs ~35 % slower than the product; tools/dev/ablate.py times the real thing.)
-    __shared__ unsigned long long tl_lds[8][32][8];
-#define TL(k) do { if (i >= 100 && i < 132 && lane == 0) tl_lds[wave][i - 100][(k)] = __builtin_readcyclecounter(); } while (0)
-#elif defined(FFHIP_PHASES)
+#if defined(FFHIP_PHASES)
     // Where every wave's step goes, in the kernel as it runs in production (round 5; tools/dev/phases.py): the time between two stamps is ADDED to
     // a per-wave word in LDS (one ds_add_u32 of lane 0, nobody waits for it) and the sums leave the kernel once, at its end -- 256 bytes of LDS, no
     // global traffic in the loop, both workgroups of a CU still resident.  Phase k = the stretch that ENDS at TL(k): 0 loop turn-around, 1 the h waves'
@@ -525,7 +504,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
         s = unscale4(s);
         float forget, update;
-#if FFHIP_SG_O_FRONT
         // The output gate is evaluated HERE, as the fourth lane of the packed logistic gate_tile uses (round 5): four logistics in packed instructions cost what two
         // packed + one scalar evaluation cost, so this wave's instruction count stays and the back wave loses its own logistic, its four partial sums and their LDS
         // reads -- ~45 VALU instructions a tile off a SIMD whose MFMA and VALU time add (profiles/r05_coissue_probe.txt).  The same operations on the same values.
@@ -542,16 +520,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             og = L.w;
         }
         ox[wave & 1][lane] = og;
-#else
-        if (a.fast_gates) {
-            forget = logistic_hw(s.y) * c;
-            update = logistic_hw(s.x) * tanh_hw(s.z);
-        } else {
-            const ffv2 L = logistic_ref2_lean((ffv2){ s.x, s.y });
-            forget = L.y * c;
-            update = L.x * tanh_ref_lean(s.z);          // = 2 logistic(2 z) - 1, the form gate_tile evaluates
-        }
-#endif
         c = forget + update;
         if (step_t(i) >= my_tb) c = 0.0f;
         cx[wave & 1][lane] = c;
@@ -559,19 +527,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         if (lane == 0) LDSV(cxflag[wave & 1]) = i + 1;
     };
     auto gate_back = [&](int i, int gts, int gj, int my_tb) {
-#if !FFHIP_SG_O_FRONT
-        float so = sbias[gj][q].w;
-#pragma unroll
-        for (int w2 = 0; w2 < 4; w2++) so = so + ph_at(w2, gts, gj)[lane].w;
-        so = __builtin_ldexpf(so, neg_exp);
-        const float o = a.fast_gates ? logistic_hw(so) : logistic_ref_lean(so);
-#endif
         while (LDSV(cxflag[wave & 1]) != i + 1) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const float c = cx[wave & 1][lane];
-#if FFHIP_SG_O_FRONT
         const float o = ox[wave & 1][lane];
-#endif
         float h = o * (a.fast_gates ? tanh_hw(c) : tanh_ref_lean(c));
         if (step_t(i) >= my_tb) h = 0.0f;
         publish_h(i, gts, gj, h);
@@ -599,10 +558,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         };
         // Both tiles' partials are computed BEFORE the wait for the h wave's "consumed" flags -- those are raised at the end of its
         // recurrent pass, and a projection of the second tile started only then would stand between the h waves and the barrier.
-#if FFHIP_PACK_X2
-        // pieces of the NEXT step that leave behind the last MFMAs of this one, in flight across the gate phase (FFHIP_PACK_X2 >= 3): both where the registers
+        // pieces of the NEXT step that leave behind the last MFMAs of this one, in flight across the gate phase: both where the registers
         // are there (GRUmod: 124), the first one otherwise (the LSTM form spills 9 registers with both)
-        constexpr int XPRE = FFHIP_PACK_X2 >= 3 ? ((KIND == 1 || FFHIP_PACK_X2 >= 5) ? 2 : 1) : 0;
+        constexpr int XPRE = KIND == 1 ? 2 : 1;
         v4u xq[2][NS];
         auto ldq = [&](int i, int k, v4u (&dst)[NS]) {      // piece k = (tile, chunk) of x(step i)
             const int ts = (k / N < ntl) ? k / N : 0, cc = k % N;
@@ -610,15 +568,13 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #pragma unroll
             for (int s = 0; s < NS; s++) dst[s] = __builtin_amdgcn_raw_buffer_load_b128(rx, lane_off, ((chunk[cc] * NS + s) * 64) * 16, 0);
         };
-#endif
         auto project_step = [&](int i, int want) {           // x(step i) of both tiles -> px[0][kw][*]; want = the step (+1) whose partials must have been consumed (0: none)
             v4f acc[TS][NRT];
-#if FFHIP_PACK_X2
-            if constexpr (PACK && (KIND == 0 || FFHIP_PACK_X2 > 1)) {
+            if constexpr (PACK) {
                 // x(t) of the four (tile, chunk) pieces through TWO 8-register buffers, the load of piece k + 2 issued behind the MFMAs of piece k: two exposed L2
                 // round trips a step instead of four (the x waves closed every step of this form: the h waves waited 2960 of 11 640 cycles for them,
                 // profiles/r05_phases.txt).  An absent second tile re-reads the first and its products are dropped: the outstanding-load count stays static.
-                // FFHIP_PACK_X2 >= 3: pieces 0 and 1 of the NEXT step leave behind the last MFMAs of this one (in flight across the gate phase).
+                // Pieces 0 and 1 of the NEXT step leave behind the last MFMAs of this one (in flight across the gate phase).
                 if constexpr (XPRE < 1) ldq(i, 0, xq[0]);
                 if constexpr (XPRE < 2) ldq(i, 1, xq[1]);
 #pragma unroll
@@ -634,7 +590,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else
-#endif
 #pragma unroll
             for (int ts = 0; ts < TS; ts++) {
                 if (ts >= ntl) continue;
@@ -677,9 +632,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 t = *(const unsigned *)(tile_ptr(a.xin, step_t(i), 0) + (size_t)line * 128);
             touched = t;
         };
-#if FFHIP_PACK_X2
-        if constexpr (PACK && (KIND == 0 || FFHIP_PACK_X2 > 1)) { if constexpr (XPRE >= 1) ldq(0, 0, xq[0]); if constexpr (XPRE >= 2) ldq(0, 1, xq[1]); }
-#endif
+        if constexpr (PACK) { if constexpr (XPRE >= 1) ldq(0, 0, xq[0]); if constexpr (XPRE >= 2) ldq(0, 1, xq[1]); }
         project_step(0, 0);
         touch_x(1);
         sink ^= touched;
@@ -988,9 +941,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                     // They completed long ago (the poll above outlasts them) -- say so, and the sweep gets counted waits.
                     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
                     if (!recur_any() || (FFHIP_FORCE_RETRY && (i & 31) == 5)) {      // (FFHIP_FORCE_RETRY: the test build that takes the re-sweep path on purpose, below)
-#ifdef FFHIP_COUNT_FALLBACK
-                        if (lane == 0) atomicAdd(a.abort_word + 1, 1u);
-#endif
                         for (unsigned spin = 0;; spin++) {
                             if (spin > 3000000u || (spin & 255u) == 255u) {
                                 const unsigned ab = __hip_atomic_load(a.abort_word, RLX_AGENT);
@@ -1071,10 +1021,6 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         atomicAdd(a.dbg + wave * 8 + lane, (unsigned long long)tl_acc[wave][lane]);
         if (lane == 0) atomicAdd(a.dbg + 64 + wave, (unsigned long long)Tb);
     }
-#endif
-#ifdef FFHIP_TIMELINE
-    if (a.dbg && Tb >= 132)
-        for (int e = lane; e < 32 * 8; e += 64) a.dbg[(((size_t)block_index * 8 + wave) * 32 + (e >> 3)) * 16 + (e & 7)] = tl_lds[wave][e >> 3][e & 7];
 #endif
 }
 

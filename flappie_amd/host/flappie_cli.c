@@ -235,9 +235,35 @@ static const char *cli_dbg(const char *token) {
 
 /* This process, the reader children it is about to fork and the pinned staging they fill, on the CPUs of the GPU's NUMA node (eight
  * ranks of a node otherwise read their files wherever the scheduler puts them).  The node comes from sysfs -- the HIP runtime must not be up before the
- * fork --: the device-th render node of vendor 0x1002 in minor order, HIP's numbering when no *_VISIBLE_DEVICES variable re-maps it.  Left alone when the
+ * fork --: the device-th render node of vendor 0x1002 in minor order, the device number first taken through the *_VISIBLE_DEVICES variables (physical_gpu_index).  Left alone when the
  * node is unknown or none of its CPUs is in this process's set; FLAPPIE_DEBUG=no_numa_bind switches it off, sysfs_root=DIR is for the tests. */
+/* HIP device number of this process -> position among the node's GPUs in the kernel's order, through HIP_VISIBLE_DEVICES (or its synonym
+ * CUDA_VISIBLE_DEVICES) and ROCR_VISIBLE_DEVICES below it; -1 when an entry is not a plain number (a UUID) or the index is beyond the list -- the process
+ * is then left unbound: several ranks pinned to ONE socket by a wrong guess are worse off than unbound ones (shard.py physical_gpu_index) */
+static int physical_gpu_index(int device) {
+    const char *hip = getenv("HIP_VISIBLE_DEVICES");
+    const char *names[2] = { (hip && hip[0]) ? "HIP_VISIBLE_DEVICES" : "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES" };
+    for (int v = 0; v < 2; v++) {
+        const char *text = getenv(names[v]);
+        if (NULL == text || 0 == text[strspn(text, " ")]) continue;
+        const char *p = text;
+        for (int k = 0; k < device; k++) {
+            p = strchr(p, ',');
+            if (NULL == p) return -1;
+            p++;
+        }
+        p += strspn(p, " ");
+        char *end;
+        const long val = strtol(p, &end, 10);
+        if (end == p || (end[strspn(end, " ")] != ',' && end[strspn(end, " ")] != 0) || val < 0) return -1;
+        device = (int)val;
+    }
+    return device;
+}
+
 static int bind_to_gpu_numa(int device) {
+    device = physical_gpu_index(device);
+    if (device < 0) return -1;
     const char *root = cli_dbg("sysfs_root");
     char sys[256], path[512], buf[4096];
     snprintf(sys, sizeof sys, "%s", (root && root[0]) ? root : "/sys");

@@ -104,10 +104,32 @@ def numa_cpus_of_gpu(index: int, sysfs: str = "/sys") -> Tuple[int, List[int]]:
         return node, []
 
 
+def physical_gpu_index(index: int, environ=None) -> int:
+    """HIP device `index` of this process -> position among the node's GPUs as the kernel lists them, through the re-mapping variables:
+    HIP_VISIBLE_DEVICES (or its synonym CUDA_VISIBLE_DEVICES) picks from what ROCR_VISIBLE_DEVICES leaves.  -1 when an entry is not a plain number
+    (a UUID) or the index is beyond the list: the caller then leaves the process unbound -- a wrong socket is worse than none."""
+    import os
+    env = os.environ if environ is None else environ
+    for name in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        text = env.get(name, "")
+        if name == "CUDA_VISIBLE_DEVICES" and env.get("HIP_VISIBLE_DEVICES", ""):
+            continue                                  # (HIP reads its own variable first)
+        if not text.strip():
+            continue
+        items = [t.strip() for t in text.split(",")]
+        if not (0 <= index < len(items)) or not items[index].isdigit():
+            return -1
+        index = int(items[index])
+    return index
+
+
 def bind_to_gpu_numa(index: int, sysfs: str = "/sys") -> Tuple[int, int]:
     """restrict this process (and what it starts) to the CPUs it may use that sit on the GPU's NUMA node; (node, CPUs bound to), (-1, 0) = left alone
     (node unknown, or none of its CPUs is in this process's set -- a container's quota may lie elsewhere)"""
     import os
+    index = physical_gpu_index(index)
+    if index < 0:
+        return -1, 0
     node, cpus = numa_cpus_of_gpu(index, sysfs)
     if node < 0 or not cpus or not hasattr(os, "sched_setaffinity"):
         return -1, 0

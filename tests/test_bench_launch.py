@@ -106,6 +106,33 @@ def test_numa_binding_of_a_rank(tmp_path):
         assert r.returncode == 0 and "bound to" not in r.stderr
 
 
+def test_numa_binding_goes_through_the_visible_devices_lists(tmp_path):
+    """device n of a process is the n-th render node only when no *_VISIBLE_DEVICES variable re-maps it; the index is taken through the lists
+    (HIP's, or its synonym CUDA's, picks from what ROCR's leaves) and a UUID entry or a short list leaves the process unbound."""
+    sys.path.insert(0, ROOT)
+    from flappie_amd import shard
+    f = shard.physical_gpu_index
+    assert f(3, {}) == 3
+    assert f(0, {"HIP_VISIBLE_DEVICES": "5"}) == 5 and f(1, {"HIP_VISIBLE_DEVICES": "5, 2"}) == 2
+    assert f(1, {"CUDA_VISIBLE_DEVICES": "4,6"}) == 6 and f(1, {"CUDA_VISIBLE_DEVICES": "4,6", "HIP_VISIBLE_DEVICES": "7,1"}) == 1
+    assert f(1, {"HIP_VISIBLE_DEVICES": "2,0", "ROCR_VISIBLE_DEVICES": "4,5,6"}) == 4
+    assert f(1, {"HIP_VISIBLE_DEVICES": "5"}) == -1 and f(0, {"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}) == -1
+    exe = os.path.join(ROOT, "flappie_amd", "flappie")
+    if os.path.exists(exe):
+        lists = _fake_sysfs(tmp_path, [0, 0, 1, 1])
+        reads = tmp_path / "reads"
+        reads.mkdir()
+        (reads / "a.fast5").write_text("")
+        base = {k: v for k, v in os.environ.items() if not k.endswith("_VISIBLE_DEVICES")}
+        env = dict(base, FLAPPIE_DEBUG="list_only,sysfs_root=%s" % tmp_path, FLAPPIE_HIP_DEVICE="0", FLAPPIE_CLI_TIMING="1")
+        r = subprocess.run([exe, str(reads)], env=dict(env, HIP_VISIBLE_DEVICES="3"), capture_output=True, text=True)
+        assert r.returncode == 0 and "CPUs of NUMA node 1" in r.stderr, r.stderr
+        r = subprocess.run([exe, str(reads)], env=dict(env, HIP_VISIBLE_DEVICES="1,0", ROCR_VISIBLE_DEVICES="2,1"), capture_output=True, text=True)
+        assert r.returncode == 0 and "CPUs of NUMA node 0" in r.stderr, r.stderr
+        r = subprocess.run([exe, str(reads)], env=dict(env, ROCR_VISIBLE_DEVICES="GPU-0123abcd"), capture_output=True, text=True)
+        assert r.returncode == 0 and "bound to" not in r.stderr, r.stderr
+
+
 def test_bench_line_reports_the_binding(tmp_path):
     _fake_sysfs(tmp_path, [1])
     r = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"], {"FFHIP_BENCH_STUB": "1", "FFHIP_BENCH_SYSFS": str(tmp_path)})

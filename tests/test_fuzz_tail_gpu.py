@@ -89,7 +89,10 @@ def test_fuzz_tail_reads_stay_within_the_documented_bound(engine):
     # oracle's own, below, for both GPU paths.)
     for name, d_go, d_gy, nbase, nqual, npath, off1, offn, cells in rows:
         assert d_gy <= 2.0 * d_oy + 2.0e-5, (name, d_gy, d_oy)      # (the f32-MFMA cross-check path: measured 1.9x on these reads)
-        assert d_go <= d_gy + d_oy + 1.0e-6, (name, d_go)           # (triangle: nothing but rounding stands between the three)
+        # an ABSOLUTE ceiling beside the relative bound (were the oracle and the yardstick to drift together, the relative bound alone would
+        # hold nothing): on this ill-conditioned model two float32 evaluations of the reference's own algorithm sit 1.1e-4 apart, the engine measured
+        # 1.0e-4 / 2.1e-4 (default / f32-MFMA path) from the oracle; 3e-4 is the ceiling rounds 2-4 held
+        assert d_go <= 3.0e-4, (name, d_go)
         assert offn == 0
     # the default path is no further from the float32 network proper than the reference-order sums are (measured: 0.8x; the
     # f32-MFMA cross-check path sits at 1.9x on these reads -- every float32 evaluation order scatters by 1-2e-4 on this model)

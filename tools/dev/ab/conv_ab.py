@@ -1,5 +1,5 @@
-"""A/B of a convolution switch -- bit-identity of everything downstream and time.  Default: the last convolution, round-3 kernel (FFHIP_CONV_WS=0)
-against the weights-stationary one; `conv_ab.py FFHIP_CONV_SMALL_U` the thin front layers, round-3 loops (=0) against the unrolled ones."""
+"""A/B of a convolution switch -- bit-identity of everything downstream and time.  Default: the last convolution, round-3 kernel (FFHIP_DEBUG=conv_ws=0)
+against the weights-stationary one; `conv_ab.py FFHIP_DEBUG=conv_small_u` the thin front layers, round-3 loops (=0) against the unrolled ones."""
 import os, sys, subprocess, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
@@ -34,9 +34,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     res = {}
-    var = sys.argv[1] if len(sys.argv) > 1 else "FFHIP_CONV_WS"
+    var = sys.argv[1] if len(sys.argv) > 1 else "conv_ws"      # a FFHIP_DEBUG token
     for ws in ((sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("0", "1")):
-        r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **{var: ws}), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, FFHIP_DEBUG="%s=%s" % (var, ws)), capture_output=True, text=True)
         if r.returncode != 0:
             print("%s=%s failed:" % (var, ws), r.stderr[-2000:]); sys.exit(1)
         res[ws] = json.loads(r.stdout.strip().splitlines()[-1])

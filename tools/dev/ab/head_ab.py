@@ -1,4 +1,4 @@
-"""A/B of the CRF head: f32-MFMA head on the last layer's fp32 copy (FFHIP_NO_SPLIT_HEAD=1) against k_head_split -- scores vs oracle, time."""
+"""A/B of the CRF head: f32-MFMA head on the last layer's fp32 copy (FFHIP_DEBUG=no_split_head) against k_head_split -- scores vs oracle, time."""
 import os, sys, subprocess, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
@@ -36,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     res = {}
-    for tag, env in (("f32 head", {"FFHIP_NO_SPLIT_HEAD": "1"}), ("split head", {})):
+    for tag, env in (("f32 head", {"FFHIP_DEBUG": "no_split_head"}), ("split head", {})):
         r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **env), capture_output=True, text=True)
         if r.returncode != 0:
             print(tag, "failed:", r.stderr[-3000:]); sys.exit(1)

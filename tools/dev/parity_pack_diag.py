@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which read of tools/parity_pack.py's GRUmod batch (1024 reads of up to 3000 samples) is called differently from the oracle, by how much
-its scores differ, and what the other layer-kernel paths of the engine say about it (one-tile / dense forms: FFHIP_NO_PACK=1 in a second
+its scores differ, and what the other layer-kernel paths of the engine say about it (one-tile / dense forms: FFHIP_DEBUG=no_pack in a second
 process; the f32-input MFMA kernel: RUN_F32_RNN).  Development tool; run on the GPU box."""
 import multiprocessing as mp
 import os
@@ -32,7 +32,7 @@ def main():
         b.run(1.0, flags); b.finish()
         out[tag] = [(b.basecall(r), b.transitions(r).copy(), b.path(r)[0].copy()) for r in range(nread)]
         b.close()
-    print("layer kernel path:", "packed" if not os.environ.get("FFHIP_NO_PACK") else "FFHIP_NO_PACK=1 (dense / one-tile forms)")
+    print("layer kernel path:", "packed" if not "no_pack" in os.environ.get("FFHIP_DEBUG", "") else "FFHIP_DEBUG=no_pack (dense / one-tile forms)")
     for r, ref in enumerate(refs):
         d = out["default"][r]
         if d[0] != ref["basecall"]:
