@@ -244,12 +244,15 @@ def _small_hex(f: float) -> str:
     return _TRIM.sub("p", float(f).hex())
 
 
-def _write_mat(fh, name: str, m: Mat, vector: bool = False) -> None:
+def _write_mat(fh, name: str, m: Mat, vector: bool = False, row: int = 0) -> None:
+    """one tensor as cformatM / cformatV print it (misc/taiyaki_flipflop5_guppy.py:38-64): a matrix one line per row of the array it was handed -- a column of
+    the flappie matrix, or, for a convolution (row = padded feature count), one line per (filter, tap) --, a vector on one line"""
     fh.write("float __%s[] = {\n" % name)
     if vector:
         fh.write("\t" + ", ".join(_small_hex(x) for x in m.data.reshape(-1)))
     else:
-        fh.write("\t" + ",\n\t".join(", ".join(_small_hex(x) for x in col) for col in m.data))
+        lines = m.data.reshape(-1, row) if row else m.data
+        fh.write("\t" + ",\n\t".join(", ".join(_small_hex(x) for x in col) for col in lines))
     fh.write("};\n")
     fh.write("_Mat _%s = {\n\t.nr = %d,\n\t.nrq = %d,\n\t.nc = %d,\n\t.stride = %d,\n\t.data.f = __%s\n};\n"
              % (name, m.nr, m.nrq, m.nc, m.stride, name))
@@ -273,17 +276,24 @@ def tensor_names(kind: int, ident: str) -> Dict[str, str]:
 
 
 def write_mdl(path: str, model: FlipflopModel, ident: Optional[str] = None) -> None:
+    """The text the reference's dump scripts print for this model, BYTE FOR BYTE (misc/taiyaki_flipflop5_guppy.py:104-164, taiyaki_rle5.py:104-164,
+    taiyaki_flipflop_guppy.py:79-135) -- their quirks included: the lines their triple-quoted strings indent by four blanks (so the first array starts
+    four columns in, behind the #include line's newline), a convolution's array printed one (filter, tap) per line, the GRU script's `<id>_nfilter` and
+    `_conv_..._winlen` names, zero as `0x0.p+0`, no newline behind the closing #endif.  Held to the files those scripts wrote for the same numbers
+    (tests/golden/ref_writer_*.mdl, tests/golden/make_mdl_fixture.py) by tests/test_mdl_reference_writer.py."""
     ident = ident or model.ident
     names = tensor_names(model.kind, ident)
-    guard = "FLIPFLOP_%s_MODEL_H" % ident.upper()
+    guard = "%s_%s_MODEL_H" % ("RLE" if model.kind == NET_LSTM5_RLE else "FLIPFLOP", ident.upper())
     with open(path, "w") as fh:
-        fh.write("#pragma once\n#ifndef %s\n#define %s\n#include \"../util.h\"\n" % (guard, guard))
+        fh.write("#pragma once\n    #ifndef %s\n    #define %s\n    #include \"../util.h\"\n    " % (guard, guard))
         for i, c in enumerate(model.convs):
             p = names["conv%d" % (i + 1)]
-            _write_mat(fh, p + "W", c.W)
+            _write_mat(fh, p + "W", c.W, row=4 * ((c.nf + 3) // 4))
             _write_mat(fh, p + "b", c.b, vector=True)
-            fh.write("#define %sstride  %d\n#define %snfilter  %d\n#define %swinlen  %d\n"
-                     % (p, c.stride, p, c.W.nc, p, c.winlen))
+            if model.kind == NET_GRUMOD5:
+                fh.write("#define %sstride  %d\n#define %s_nfilter  %d\n    #define _%swinlen  %d\n    " % (p, c.stride, ident, c.W.nc, p, c.winlen))
+            else:
+                fh.write("#define %sstride  %d\n#define %snfilter  %d\n    #define %swinlen  %d\n    " % (p, c.stride, p, c.W.nc, p, c.winlen))
         for i, r in enumerate(model.rnns):
             p = names["rnn%d" % i]
             _write_mat(fh, p + "iW", r.iW)

@@ -11,7 +11,13 @@ the driver times.  Every read also goes through the oracle TWICE (process pools,
 so that the engine's distance from the oracle stands beside the distance BETWEEN TWO SUMMATION ORDERS OF THE REFERENCE ALGORITHM on
 the same reads: a called base that flips between those two is a near-tie of the posterior decode, not a property of the engine.
 Half the pairs are uniform (every read `tmax` samples), half ragged (1500 .. tmax, sorted as the flappie binary sorts).
-Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500] [shape=c2]
+Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500] [shape=c2] [--make-refs FILE | --refs FILE] [--gates default,fast] [--trans-reads N]
+  --make-refs FILE   no GPU: both oracle evaluations of every read, base / quality strings and a checksum of the Viterbi path only (a few MB), written to FILE --
+                     run where CPU time is free (the build container: same libff_oracle.so, same OpenBLAS binary and kernel family; the GPU box re-derives
+                     --trans-reads of them and insists on identical strings before it uses the file)
+  --refs FILE        take the oracle's strings from FILE; the transition scores are compared on the first --trans-reads reads (default 512), which
+                     the box evaluates itself
+  --gates a,b        engine passes: default = the reference's exp_ps / division replayed bit for bit, fast = FFHIP_RUN_FAST_GATES (hardware v_exp / v_rcp)
 shape: c2 = LSTM H 384 in pairs of 256-read batches (the default, the headline); h256 / c4 = LSTM / GRUmod H 256 in full 1024-read launches of the
 packed kernels (k_lstm_pack / k_grumod_pack); c5 = LSTM H 512 in 256-read batches (k_lstm_split<0,4,2>).  bench.py's models (seed 1)."""
 import multiprocessing as mp
@@ -26,7 +32,17 @@ sys.path.insert(0, ROOT)
 from flappie_amd import model as M  # noqa: E402
 
 SHAPES = {"c2": (M.NET_LSTM5, 384, 256, True), "h256": (M.NET_LSTM5, 256, 1024, False), "c4": (M.NET_GRUMOD5, 256, 1024, False), "c5": (M.NET_LSTM5, 512, 256, False)}
-SHAPE = sys.argv[3] if len(sys.argv) > 3 else "c2"
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+_opt = {}
+_argv = sys.argv[1:]
+_pos = []
+while _argv:
+    a = _argv.pop(0)
+    if a.startswith("--"):
+        _opt[a[2:]] = _argv.pop(0)
+    else:
+        _pos.append(a)
+SHAPE = _pos[2] if len(_pos) > 2 else "c2"
 KIND, H, PER_BATCH, PAIRED = SHAPES[SHAPE]
 SEED = 1
 _om = None
@@ -46,6 +62,16 @@ def _call(x):
     return dict(basecall=r["basecall"], quality=r["quality"], path=np.asarray(r["path"]), trans=np.asarray(r["trans"]))
 
 
+def _path_sum(p):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(p, dtype=np.int32).tobytes())
+
+
+def _call_small(x):
+    r = _om.basecall(x)
+    return (r["basecall"], r["quality"], _path_sum(r["path"]))
+
+
 class Tally:
     def __init__(self, what):
         self.what = what
@@ -56,8 +82,10 @@ class Tally:
         d = self.d
         d["reads"] += 1
         d["bases"] += len(ref["basecall"])
-        dt = float(np.abs(a["trans"] - ref["trans"]).max())
-        d["worst"] = max(d["worst"], dt)
+        dt = float(np.abs(a["trans"] - ref["trans"]).max()) if (a.get("trans") is not None and ref.get("trans") is not None) else float("nan")
+        if dt == dt:
+            d["worst"] = max(d["worst"], dt)
+            d["trans_reads"] = d.get("trans_reads", 0) + 1
         if a["basecall"] != ref["basecall"]:
             d["base_mismatch"] += 1
             import difflib
@@ -68,20 +96,24 @@ class Tally:
         elif a["quality"] != ref["quality"]:
             d["qual_mismatch"] += 1
             d["qual_chars_diff"] += sum(1 for x, y in zip(a["quality"], ref["quality"]) if x != y)
-        if not np.array_equal(a["path"], ref["path"]):
+        if a["psum"] != ref["psum"]:
             d["path_mismatch"] += 1
 
     def line(self):
         d = self.d
         return ("%-24s %d reads, %d bases: %d reads with another base string (%d bases apart in all = %.1f per million), %d more with another quality string "
-                "(%d characters), %d with another Viterbi path; worst |dtrans| %.2e"
+                "(%d characters), %d with another Viterbi path; worst |dtrans| %.2e over %d reads"
                 % (self.what + ":", d["reads"], d["bases"], d["base_mismatch"], d["bases_apart"], 1e6 * d["bases_apart"] / max(1, d["bases"]), d["qual_mismatch"],
-                   d["qual_chars_diff"], d["path_mismatch"], d["worst"]))
+                   d["qual_chars_diff"], d["path_mismatch"], d["worst"], d.get("trans_reads", 0)))
+
+
+def _small(r):
+    return dict(basecall=r["basecall"], quality=r["quality"], psum=_path_sum(r["path"]), trans=r["trans"])
 
 
 def main():
-    nread = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    tmax = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
+    nread = int(_pos[0]) if len(_pos) > 0 else 2048
+    tmax = int(_pos[1]) if len(_pos) > 1 else 2500
     assert nread % (2 * PER_BATCH) == 0
     t0 = time.time()
     rng = np.random.default_rng(3840)
@@ -94,54 +126,86 @@ def main():
             sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
         batches.append(sigs)
     flat = [x for sigs in batches for x in sigs]
-    ncpu = min(128, os.cpu_count() or 1)
-    with mp.Pool(ncpu, initializer=_init, initargs=(0,)) as pool:
-        ref0 = pool.map(_call, flat, chunksize=2)
-    print("oracle: %d reads, %d samples, %.0f s" % (nread, sum(x.size for x in flat), time.time() - t0), flush=True)
-    with mp.Pool(ncpu, initializer=_init, initargs=(3,)) as pool:
-        ref3 = pool.map(_call, flat, chunksize=2)
+    ncpu = int(_opt.get("procs", min(128, os.cpu_count() or 1)))
     from oracle import ffo
+    if "make-refs" in _opt:                      # ---- no GPU: strings and path checksums of every read, both evaluations
+        out = {}
+        for mode in (0, 3):
+            with mp.Pool(ncpu, initializer=_init, initargs=(mode,)) as pool:
+                res = pool.map(_call_small, flat, chunksize=2)
+            out["base%d" % mode] = np.array([r[0] for r in res])
+            out["qual%d" % mode] = np.array([r[1] for r in res])
+            out["psum%d" % mode] = np.array([r[2] for r in res], dtype=np.uint32)
+            print("mode %d: %d reads, %.0f s" % (mode, nread, time.time() - t0), flush=True)
+        np.savez_compressed(_opt["make-refs"], shape=SHAPE, nread=nread, tmax=tmax, blas=str(ffo.use_dot_mode(3)[1]), **out)
+        return
+    ntrans = nread
+    stored = None
+    if "refs" in _opt:
+        stored = np.load(_opt["refs"])
+        assert str(stored["shape"]) == SHAPE and int(stored["nread"]) == nread and int(stored["tmax"]) == tmax, "the reference file was made for another campaign"
+        ntrans = min(nread, int(_opt.get("trans-reads", 512)))
+    with mp.Pool(ncpu, initializer=_init, initargs=(0,)) as pool:
+        ref0 = [_small(r) for r in pool.map(_call, flat[:ntrans], chunksize=2)]
+    print("oracle: %d reads, %d samples, %.0f s" % (ntrans, sum(x.size for x in flat[:ntrans]), time.time() - t0), flush=True)
+    with mp.Pool(ncpu, initializer=_init, initargs=(3,)) as pool:
+        ref3 = [_small(r) for r in pool.map(_call, flat[:ntrans], chunksize=2)]
     print("oracle+blas (%s): %.0f s" % (ffo.use_dot_mode(3)[1], time.time() - t0), flush=True)
     ffo.use_dot_mode(0)
+    if stored is not None:
+        # the file's strings must be what this host computes where it computes them at all; then the rest of the reads come from the file
+        for mode, ref in ((0, ref0), (3, ref3)):
+            bad = [i for i in range(ntrans) if ref[i]["basecall"] != str(stored["base%d" % mode][i]) or ref[i]["quality"] != str(stored["qual%d" % mode][i])
+                   or ref[i]["psum"] != int(stored["psum%d" % mode][i])]
+            print("reference file against this host's oracle, mode %d: %d of %d reads differ%s" % (mode, len(bad), ntrans, (" -- " + str(bad[:8])) if bad else ""), flush=True)
+            if mode == 0:
+                assert not bad, "the stored oracle strings are not this tree's oracle"
+            for i in range(ntrans, nread):
+                ref.append(dict(basecall=str(stored["base%d" % mode][i]), quality=str(stored["qual%d" % mode][i]), psum=int(stored["psum%d" % mode][i]), trans=None))
     from flappie_amd import binding as B
     eng = B.Engine(0)
     dm = B.DeviceModel(eng, M.synthetic_model(KIND, H, seed=SEED))
-    t_eng0, t_eng3, t_00 = Tally("engine <-> oracle"), Tally("engine <-> oracle+blas"), Tally("oracle <-> oracle+blas")
-    min_kmers, paired = 10 ** 9, 0
+    t_00 = Tally("oracle <-> oracle+blas")
+    for i in range(nread):
+        t_00.add("read %d" % i, ref0[i], ref3[i])
     bs = [B.Batch(dm, PER_BATCH, tmax) for _ in range(2)]
-    for k in range(0, len(batches), 2):
-        for j in (0, 1):
-            bs[j].set_signals_ragged(batches[k + j])
-        if PAIRED:
-            bs[0].run_pair(bs[1])
-        else:
-            bs[0].run(); bs[1].run()
-        for j in (0, 1):
-            b = bs[j]
-            b.finish()
-            paired += int(b.paired())
-            assert b.rnn_path() == 3
-            for r in range(PER_BATCH):
-                i = (k + j) * PER_BATCH + r
-                a = dict(basecall=b.basecall(r), quality=b.quality(r), path=b.path(r)[0], trans=b.transitions(r))
-                tag = "batch %d read %d (%d samples)" % (k + j, r, flat[i].size)
-                t_eng0.add(tag, a, ref0[i])
-                t_eng3.add(tag, a, ref3[i])
-                t_00.add(tag, ref0[i], ref3[i])
-                s = ref0[i]["basecall"]
-                min_kmers = min(min_kmers, len({s[q:q + 5] for q in range(len(s) - 4)}))
-        print("pair %d done (%.0f s)" % (k // 2, time.time() - t0), flush=True)
+    for gates in _opt.get("gates", "default").split(","):
+        flags = {"default": 0, "fast": B.RUN_FAST_GATES}[gates]
+        t_eng0, t_eng3 = Tally("engine <-> oracle"), Tally("engine <-> oracle+blas")
+        min_kmers, paired = 10 ** 9, 0
+        t1 = time.time()
+        for k in range(0, len(batches), 2):
+            for j in (0, 1):
+                bs[j].set_signals_ragged(batches[k + j])
+            if PAIRED:
+                bs[0].run_pair(bs[1], 1.0, flags)
+            else:
+                bs[0].run(1.0, flags); bs[1].run(1.0, flags)
+            for j in (0, 1):
+                b = bs[j]
+                b.finish()
+                paired += int(b.paired())
+                assert b.rnn_path() == 3
+                for r in range(PER_BATCH):
+                    i = (k + j) * PER_BATCH + r
+                    a = dict(basecall=b.basecall(r), quality=b.quality(r), psum=_path_sum(b.path(r)[0]), trans=b.transitions(r) if i < ntrans else None)
+                    tag = "batch %d read %d (%d samples)" % (k + j, r, flat[i].size)
+                    t_eng0.add(tag, a, ref0[i])
+                    t_eng3.add(tag, a, ref3[i])
+                    s = ref0[i]["basecall"]
+                    min_kmers = min(min_kmers, len({s[q:q + 5] for q in range(len(s) - 4)}))
+        print("\n### gates: %s%s  (engine passes %.0f s)" % (gates, "" if not flags else " (FFHIP_RUN_FAST_GATES: hardware v_exp / v_rcp in the gate phase)", time.time() - t1))
+        print("campaign: shape %s (kind %d, H = %d, %d reads a batch%s), %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
+              % (SHAPE, KIND, H, PER_BATCH, ", through ffhip_batch_run_pair" if PAIRED else "", paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
+        for t in (t_eng0, t_eng3, t_00):
+            print(t.line())
+            for n in t.named[:40]:
+                print("     " + n)
+        both = set(n.split(":")[0] for n in t_eng0.named) & set(n.split(":")[0] for n in t_eng3.named)
+        print("reads the engine calls differently from BOTH evaluations of the reference algorithm: %d%s" % (len(both), (" -- " + "; ".join(sorted(both))) if both else ""), flush=True)
     for b in bs:
         b.close()
     dm.close()
-    print("campaign: shape %s (kind %d, H = %d, %d reads a batch%s), %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
-          % (SHAPE, KIND, H, PER_BATCH, ", through ffhip_batch_run_pair" if PAIRED else "", paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
-    for t in (t_eng0, t_eng3, t_00):
-        print(t.line())
-        for n in t.named:
-            print("     " + n)
-    both = set(n.split(":")[0] for n in t_eng0.named) & set(n.split(":")[0] for n in t_eng3.named)
-    print("reads the engine calls differently from BOTH evaluations of the reference algorithm: %d%s" % (len(both), (" -- " + "; ".join(sorted(both))) if both else ""))
 
 
 if __name__ == "__main__":
