@@ -64,6 +64,16 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     return e;
 }
 
+// gate arithmetic of the split layer kernels: 0 = the reference's exp_ps / division replayed bit for bit, 1 = v_exp_f32 / v_rcp_f32, 2 = those with a
+// two-word exponent and a Newton step (ffhip_math.hpp logistic_hw); run flags, or FFHIP_FAST_GATES=1|2 for a whole process
+static int gate_level(unsigned flags) {
+    if (flags & FFHIP_RUN_FAST_GATES2) return 2;
+    if (flags & FFHIP_RUN_FAST_GATES) return 1;
+    const char *e = getenv("FFHIP_FAST_GATES");
+    if (e && e[0]) return atoi(e) >= 2 ? 2 : (e[0] == '0' ? 0 : 1);
+    return 0;
+}
+
 // ---- development switches: FFHIP_DEBUG=token[,token=value ...] (ffhip_internal.hpp) ---------------------------
 namespace ffhip {
 const char *dbg(const char *token) {
@@ -1055,7 +1065,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // its launch) and the batch needs no fp32 activation buffer at all (FFHIP_NO_SPLIT_HEAD: the f32-MFMA head on the fp32 copy)
     const bool split_head = use_split && !keep && m->FFsplit != nullptr && !dbg("no_split_head");
     const bool prof = b->eng->profiling != 0;
-    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
+    const int fast_gates = gate_level(flags);
     const char *pm_env = dbg("persist_mode");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     int cur = b->run_cur;
@@ -1400,7 +1410,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     HIP_TRY(hipEventRecord(b1->pair_ev, b1->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamWaitEvent(s, b1->pair_ev, 0), FFHIP_EHIP);              // the second batch's convolutions are done before the first paired layer
     const bool prof = eng->profiling != 0;
-    const int fast_gates = ((flags & FFHIP_RUN_FAST_GATES) || getenv("FFHIP_FAST_GATES")) ? 1 : 0;
+    const int fast_gates = gate_level(flags);
     const char *pm_env = dbg("persist_mode");
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
     ffhip_batch *bb[2] = { b0, b1 };

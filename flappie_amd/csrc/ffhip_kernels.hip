@@ -454,6 +454,17 @@ k_conv_split(SampleBuf in, float *__restrict__ out, const v4u_t *__restrict__ Wp
 // weights at all.  Two workgroups a CU (<= 256 registers): one's 60 MFMAs per tile run under the other's epilogue (the 848 VALU cycles a tile of
 // reference-exact swish, split and store costs).  Workgroups of one XCD (blockIdx mod 8) share their window tiles through that XCD's L2: the
 // M blocks of a column group sit on the same XCD.  Results bit-identical to k_conv_split (same products in the same order per accumulator).
+// -DFFHIP_FORCE_SKEW=1 (tools/test_hooks/libffhip_skew.so, tests/test_resweep_gpu.py; round 6): one wave in seven, rotating with the tile, the site, the wave and the
+// workgroup, sits out ~2000 cycles in front of the counted wait, behind the barrier, behind its gather and in front of its epilogue -- the LDS-DMA gather, the DS reads of
+// the other three waves and the LDS-only barrier between them must give the release library's bits with any wave late anywhere.
+#ifndef FFHIP_FORCE_SKEW
+#define FFHIP_FORCE_SKEW 0
+#endif
+#if FFHIP_FORCE_SKEW
+#define WS_SKEW(site) do { if ((((unsigned)(nt / ngroup) * 5u + (unsigned)(site) * 3u + (unsigned)wave + blockIdx.x) % 7u) == 0u) __builtin_amdgcn_s_sleep(32); } while (0)
+#else
+#define WS_SKEW(site) do { } while (0)
+#endif
 template <int NC>
 __global__ void __launch_bounds__(256, 2)
 k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restrict__ bias, const int *__restrict__ x0a, const int *__restrict__ x0b,
@@ -520,6 +531,7 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
     while (nt < ntile) {
         // my pieces have landed: everything but the epilogue's stores, which were issued behind them and drain on their own (vector memory
         // operations of a wave retire in order on this family)
+        WS_SKEW(0);
         if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_assert(TM * kSplitNS == 4, "the counted wait above assumes four stores per epilogue");
@@ -527,6 +539,7 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        WS_SKEW(1);
         const bool two = (pass == 0) && valid(cur_b);
         int nn_a = nxt_a, nn_b = nxt_b;
         if (two) gather(nt, cur_b, buf ^ 1);
@@ -534,6 +547,7 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
             if (nt + ngroup < ntile) gather(nt + ngroup, nxt_a, buf ^ 1);
             table(nt + 2 * ngroup, nn_a, nn_b);                // (behind the gather: its wait is the next iteration's)
         }
+        WS_SKEW(2);
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const v4u_t b0 = Bt[buf][c * NSL][lane], b1 = Bt[buf][c * NSL + 1][lane];
@@ -546,6 +560,7 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
             for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_t, A[i][c][0]), __builtin_bit_cast(v8h_t, b0), acc[i], 0, 0, 0);
         }
         stored = !two;
+        WS_SKEW(3);
         if (!two) {
             // epilogue of tile nt (k_conv_split's, value for value).  (Built and measured, not kept: the epilogue one iteration late in the MFMAs'
             // own block, branch-free, for the scheduler to interleave -- it did not, 0.33 against 0.32 ms.)

@@ -247,13 +247,26 @@ __device__ __forceinline__ float tanh_ref_lean(float x) {
 // bit-compatible with exp_ps -- results move by ~1e-7 per activation, a tenth of what the summation order of a dot product
 // moves them.  The clamp keeps the reference's NaN behaviour: min/max return the finite bound for a NaN input, as
 // _mm_min_ps / _mm_max_ps do in exp_ps (sse_mathfun.h:228-229), so a NaN pre-activation gives a finite gate here too.
-__device__ __forceinline__ float logistic_hw(float x) {
+// `level` (wave-uniform): 1 = the six instructions above; 2 = the argument of v_exp_f32 carried in two words and one Newton step behind v_rcp_f32
+// (round 6).  Level 1 rounds t = -x log2(e) once, an error of |t| 2^-24 in the EXPONENT, i.e. a relative error of |x| 6e-8 in exp(-x) on top of the
+// instruction's own ulp; level 2 keeps the product's residual (one fma recovers it exactly) and the low word of log2(e) and multiplies exp2(t_hi) by
+// 1 + t_lo ln 2: exp(-x) to ~1 ulp at every |x|, the reciprocal to ~0.5 ulp -- the error budget of the reference's own cephes polynomial + division.
+__device__ __forceinline__ float logistic_hw(float x, int level = 1) {
     float v = __builtin_fminf(-x, 88.3762626647949f);
     v = __builtin_fmaxf(v, -88.3762626647949f);
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 1.44269504088896341f));
+    const float t = v * 1.44269504088896341f;
+    float e = __builtin_amdgcn_exp2f(t);
+    if (level >= 2) {
+        const float lo = __builtin_fmaf(v, 1.925963033500138e-08f, __builtin_fmaf(v, 1.44269504088896341f, -t));      // log2(e) = 0x1.715476p+0 + 1.92596e-8
+        e = __builtin_fmaf(e, lo * 0.693147180559945309f, e);
+    }
+    const float d = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(d);
+    if (level >= 2) r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return r;
 }
-__device__ __forceinline__ float tanh_hw(float x) {
-    const float y = logistic_hw(x + x);
+__device__ __forceinline__ float tanh_hw(float x, int level = 1) {
+    const float y = logistic_hw(x + x, level);
     return (y + y) - 1.0f;
 }
 

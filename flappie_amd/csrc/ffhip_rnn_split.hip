@@ -61,6 +61,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 constexpr int NS = kSplitNS;
+#ifndef FFHIP_FORCE_SKEW
+#define FFHIP_FORCE_SKEW 0       // 1: the test build that delays one wave in thirteen at every phase boundary of the step (see TL below)
+#endif
 #ifndef FFHIP_FORCE_RETRY
 #define FFHIP_FORCE_RETRY 0      // 1: every member re-sweeps h(t-1) once at every 32nd step (tools/test_hooks/libffhip_resweep.so, tests/test_resweep_gpu.py)
 #endif
@@ -350,6 +353,12 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     if (threadIdx.x < 64) tl_acc[threadIdx.x >> 3][threadIdx.x & 7] = 0u;
     unsigned tl_prev = (unsigned)__builtin_readcyclecounter();
 #define TL(k) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0) __hip_atomic_fetch_add(&tl_acc[wave][(k)], now_ - tl_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tl_prev = now_; } while (0)
+#elif FFHIP_FORCE_SKEW
+    // The test build that shakes the step's interleavings (tools/test_hooks/libffhip_skew.so, tests/test_resweep_gpu.py; round 6): at every phase boundary of every
+    // role's loop -- top of the step, behind the h waves' poll, before / behind barrier 1, behind the gate phase, behind barrier 2 -- one wave in thirteen, rotating
+    // with the step, the site, the wave and the group member, sits out ~3000 cycles (a third of a step).  Every flag protocol of the kernel (hand-off sentinels,
+    // "consumed" words, the split gate tiles' c(t) flag, LDS landing zones against partial sums) must give the release library's bits with any wave late anywhere.
+#define TL(k) do { if ((((unsigned)i * 5u + (unsigned)(k) * 3u + (unsigned)wave + (unsigned)m) % 13u) == 0u) __builtin_amdgcn_s_sleep(48); } while (0)
 #else
 #define TL(k) do { } while (0)
 #endif
@@ -415,10 +424,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             }
             const v4f s = unscale4((v4f){ s0, s1, s2, s3 });
             if (a.fast_gates) {
-                const float forget = logistic_hw(s.y) * c;
-                const float update = logistic_hw(s.x) * tanh_hw(s.z);
+                const float forget = logistic_hw(s.y, a.fast_gates) * c;
+                const float update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
                 c = forget + update;
-                h = logistic_hw(s.w) * tanh_hw(c);
+                h = logistic_hw(s.w, a.fast_gates) * tanh_hw(c, a.fast_gates);
             } else {
                 const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
                 const float tanh_g = (L.z + L.z) - 1.0f;
@@ -444,8 +453,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             sz = __builtin_ldexpf(sz, neg_exp); sr = __builtin_ldexpf(sr, neg_exp); su = __builtin_ldexpf(su, neg_exp); sx = __builtin_ldexpf(sx, neg_exp);
             const v4f b = sbias[gj][q];
             if (a.fast_gates) {
-                const float z = logistic_hw(sz + b.x), r = logistic_hw(sr + b.y);
-                const float hbar = tanh_hw(r * su + (sx + b.z));
+                const float z = logistic_hw(sz + b.x, a.fast_gates), r = logistic_hw(sr + b.y, a.fast_gates);
+                const float hbar = tanh_hw(r * su + (sx + b.z), a.fast_gates);
                 h = z * c + (1.0f - z) * hbar;
             } else {
                 const ffv2 L = logistic_ref2_lean((ffv2){ sz + b.x, sr + b.y });
@@ -464,8 +473,8 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
             if (a.fast_gates) {
-                const float z = logistic_hw(s.x + b.x), r = logistic_hw(s.y + b.y);
-                const float hbar = tanh_hw(r * s.z + (s.w + b.z));
+                const float z = logistic_hw(s.x + b.x, a.fast_gates), r = logistic_hw(s.y + b.y, a.fast_gates);
+                const float hbar = tanh_hw(r * s.z + (s.w + b.z), a.fast_gates);
                 h = z * c + (1.0f - z) * hbar;
             } else {
                 const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
@@ -481,10 +490,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
             if (a.fast_gates) {
-                const float forget = logistic_hw(s.y) * c;
-                const float update = logistic_hw(s.x) * tanh_hw(s.z);
+                const float forget = logistic_hw(s.y, a.fast_gates) * c;
+                const float update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
                 c = forget + update;
-                h = logistic_hw(s.w) * tanh_hw(c);
+                h = logistic_hw(s.w, a.fast_gates) * tanh_hw(c, a.fast_gates);
             } else {
                 const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
                 const float tanh_g = (L.z + L.z) - 1.0f;
@@ -509,9 +518,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         // reads -- ~45 VALU instructions a tile off a SIMD whose MFMA and VALU time add (profiles/r05_coissue_probe.txt).  The same operations on the same values.
         float og;
         if (a.fast_gates) {
-            forget = logistic_hw(s.y) * c;
-            update = logistic_hw(s.x) * tanh_hw(s.z);
-            og = logistic_hw(s.w);
+            forget = logistic_hw(s.y, a.fast_gates) * c;
+            update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
+            og = logistic_hw(s.w, a.fast_gates);
         } else {
             const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
             const float tanh_g = (L.z + L.z) - 1.0f;
@@ -531,7 +540,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         asm volatile("" ::: "memory");
         const float c = cx[wave & 1][lane];
         const float o = ox[wave & 1][lane];
-        float h = o * (a.fast_gates ? tanh_hw(c) : tanh_ref_lean(c));
+        float h = o * (a.fast_gates ? tanh_hw(c, a.fast_gates) : tanh_ref_lean(c));
         if (step_t(i) >= my_tb) h = 0.0f;
         publish_h(i, gts, gj, h);
     };

@@ -76,6 +76,8 @@ typedef struct {
  * the f32 run's scores, path and calls; its KEPT ACTIVATIONS are not refreshed: they stay those of the first, discarded evaluation.) */
 #define FFHIP_RUN_FAST_GATES   128u   /* split layer kernels: gate activations through the hardware exp / reciprocal (1 ulp) instead of the
                                        * instruction-for-instruction replay of the reference's exp_ps; opt-in, not bit-compatible */
+#define FFHIP_RUN_FAST_GATES2  256u   /* the same with the exponent of v_exp_f32 carried in two words and a Newton step behind v_rcp_f32: exp and the
+                                       * reciprocal to ~1 ulp at every argument (the reference's cephes replay is no closer to the true functions) */
 
 const char *ffhip_last_error(void);
 const char *ffhip_version(void);

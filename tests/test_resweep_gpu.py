@@ -5,7 +5,13 @@ for two rounds the path was wrong: the re-sweep's `buffer_load ... lds` pieces w
 zone -- the SECOND tile's -- were still queued, the two LDS write paths are not ordered, and a stale partial could replace an operand piece: one read tile wrong from
 that step on, about one launch in 10^4 (round 5: found with tools/dev/pack_repeat.py, 2 of 10 000 launches of k_grumod_pack; 199 of 200 with the path forced; profiles/r05_pack_repeat.txt).
 tools/test_hooks/libffhip_resweep.so is the release library with -DFFHIP_FORCE_RETRY=1 (every member re-sweeps once at every 32nd step): each dense / packed / paired
-form must give, bit for bit, what the release library gives."""
+form must give, bit for bit, what the release library gives.
+
+Round 6 adds the guard for the CLASS rather than the instance: tools/test_hooks/libffhip_skew.so, the release library with -DFFHIP_FORCE_SKEW=1 -- at
+every phase boundary of the layer kernels' step (top, behind the poll, before / behind barrier 1, behind the gate phase, behind barrier 2) one wave in thirteen, rotating
+with step, site, wave and group member, sits out a third of a step; in k_conv_split_ws (the other kernel that mixes LDS-DMA writes, DS reads and an LDS-only barrier) one
+wave in seven at four sites of the tile loop.  The same shapes, the same bar.  (k_head_split exchanges values between lanes of ONE wave only -- `__shfl_xor` -- and has no
+LDS: there is nothing a delayed wave could expose there.)"""
 import os
 import pickle
 import subprocess
@@ -16,6 +22,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOOK = os.environ.get("FFHIP_TEST_RESWEEP_LIB") or os.path.join(ROOT, "tools", "test_hooks", "libffhip_resweep.so")      # (the variable: to show that the test fails on a build without the fix)
+SKEW = os.path.join(ROOT, "tools", "test_hooks", "libffhip_skew.so")
 
 CHILD = r"""
 import os, pickle, sys
@@ -58,10 +65,11 @@ def _run(lib, kind, hidden, nread, T, pair, reps, out):
     return pickle.load(open(out, "rb"))
 
 
-def test_the_resweep_library_is_built_and_is_another_build_of_the_same_abi():
-    assert os.path.exists(HOOK), "tools/test_hooks/libffhip_resweep.so is missing: __graft_entry__.build() (make hooks) builds it"
+@pytest.mark.parametrize("lib", [HOOK, SKEW])
+def test_the_resweep_library_is_built_and_is_another_build_of_the_same_abi(lib):
+    assert os.path.exists(lib), "%s is missing: __graft_entry__.build() (make hooks) builds it" % os.path.relpath(lib, ROOT)
     import ctypes
-    L = ctypes.CDLL(HOOK)
+    L = ctypes.CDLL(lib)
     for sym in ("ffhip_batch_run", "ffhip_batch_run_pair", "ffhip_engine_create"):
         assert hasattr(L, sym)
 
@@ -74,6 +82,20 @@ def test_the_resweep_library_is_built_and_is_another_build_of_the_same_abi():
 def test_a_resweep_changes_nothing(tmp_path, kind, hidden, nread, T, pair):
     ref = _run(None, kind, hidden, nread, T, pair, 1, str(tmp_path / "ref.pkl"))[0]
     got = _run(HOOK, kind, hidden, nread, T, pair, 12, str(tmp_path / "got.pkl"))
+    for rep, bs in enumerate(got):
+        for k, b in enumerate(bs):
+            bad = [r for r in range(nread) if b[r] != ref[k][r]]
+            assert not bad, "launch %d, batch %d: %d reads differ (tiles %s)" % (rep, k, len(bad), sorted(set(r // 16 for r in bad))[:8])
+
+
+
+# the skewed build: the same forms + the H = 128 one-tile form; every LSTM case runs k_conv_split_ws (its last convolution) skewed as well
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,hidden,nread,T,pair", [(1, 256, 1040, 1000, False), (0, 256, 1040, 1000, False), (0, 384, 256, 1500, True), (0, 384, 256, 1500, False),
+                                                      (0, 512, 256, 1000, False), (0, 128, 96, 1000, False)])
+def test_a_late_wave_changes_nothing(tmp_path, kind, hidden, nread, T, pair):
+    ref = _run(None, kind, hidden, nread, T, pair, 1, str(tmp_path / "ref.pkl"))[0]
+    got = _run(SKEW, kind, hidden, nread, T, pair, 4, str(tmp_path / "got.pkl"))
     for rep, bs in enumerate(got):
         for k, b in enumerate(bs):
             bad = [r for r in range(nread) if b[r] != ref[k][r]]
