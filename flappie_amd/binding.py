@@ -105,6 +105,16 @@ def lib():
     L.ffhip_prep_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ffhip_prep_get_signal.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.ffhip_batch_set_prepared.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    # packed batches (several reads to a row)
+    L.ffhip_model_pack_gap.restype = C.c_size_t
+    L.ffhip_model_pack_gap.argtypes = [vp]
+    L.ffhip_model_packable.argtypes = [vp]
+    L.ffhip_pack_plan.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ffhip_batch_create_packed.restype = vp
+    L.ffhip_batch_create_packed.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int]
+    L.ffhip_batch_set_prepared_packed.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ffhip_batch_set_signals_packed.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ffhip_batch_nreads.argtypes = [vp]
     L.ffhip_quantiles.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
     L.ffhip_medmad_normalise.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ffhip_mad.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -254,10 +264,12 @@ class Prepared:
 class Batch:
     """`nread` reads of `nsample` samples (ffhip_batch)."""
 
-    def __init__(self, dmodel: DeviceModel, nread: int, nsample: int):
+    def __init__(self, dmodel: DeviceModel, nread: int, nsample: int, max_reads: int = 0):
+        """max_reads > 0: a PACKED batch -- nread rows of nsample samples that take up to max_reads reads, several to a row (set_signals_packed / set_prepared_packed)"""
         self.dmodel = dmodel
         self.nread, self.nsample = nread, nsample
-        self.h = lib().ffhip_batch_create(dmodel.engine.h, dmodel.h, nread, nsample)
+        self.h = (lib().ffhip_batch_create_packed(dmodel.engine.h, dmodel.h, nread, nsample, max_reads) if max_reads > 0
+                  else lib().ffhip_batch_create(dmodel.engine.h, dmodel.h, nread, nsample))
         if not self.h:
             raise FFHipError(lib().ffhip_last_error().decode())
         self.nblock = int(lib().ffhip_batch_nblock(self.h))
@@ -298,6 +310,31 @@ class Batch:
         assert len(reads) == self.nread
         idx = (C.c_int * self.nread)(*reads)
         _check(lib().ffhip_batch_set_prepared(self.h, prep.h, idx))
+
+    def pack_plan(self, nsamples: List[int]):
+        """first-fit-decreasing places of reads of these lengths in this batch's rows: (slot, block offset) per read, slot -1 where a read did not fit"""
+        n = len(nsamples)
+        ns = (C.c_size_t * n)(*[int(x) for x in nsamples])
+        slot, off = (C.c_int * n)(), (C.c_int * n)()
+        placed = lib().ffhip_pack_plan(self.dmodel.h, self.nread, self.nsample, n, ns, slot, off)
+        if placed < 0:
+            raise FFHipError(lib().ffhip_last_error().decode())
+        return list(slot), list(off)
+
+    def set_signals_packed(self, signals: List[np.ndarray], slots: List[int], offs: List[int]):
+        """read i stands in row slots[i] from block offs[i] on; results are then indexed by read"""
+        n = len(signals)
+        keep = [np.ascontiguousarray(x, dtype=np.float32) for x in signals]
+        ptrs = (C.POINTER(C.c_float) * n)(*[_fptr(x) for x in keep])
+        ns = (C.c_size_t * n)(*[x.size for x in keep])
+        _check(lib().ffhip_batch_set_signals_packed(self.h, n, ptrs, ns, (C.c_int * n)(*slots), (C.c_int * n)(*offs)))
+
+    def set_prepared_packed(self, prep: "Prepared", reads: List[int], slots: List[int], offs: List[int]):
+        n = len(reads)
+        _check(lib().ffhip_batch_set_prepared_packed(self.h, prep.h, n, (C.c_int * n)(*reads), (C.c_int * n)(*slots), (C.c_int * n)(*offs)))
+
+    def nreads(self) -> int:
+        return int(lib().ffhip_batch_nreads(self.h))
 
     def run(self, temperature: float = 1.0, flags: int = 0):
         _check(lib().ffhip_batch_run(self.h, temperature, flags))

@@ -259,7 +259,7 @@ __device__ __forceinline__ void fb_chain(const double *__restrict__ Er, const in
 template <int NS, int TOPO = 0>
 __global__ void __launch_bounds__(128)
 k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__restrict__ bwdbuf, int TbS, double *__restrict__ logz_out,
-         const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
+         const int *__restrict__ tbs, int flags, const int *__restrict__ wide, ReadMap map) {
     FFHIP_CHAIN_PRIO_SET();
     constexpr int Pd = FbDims<NS, TOPO>::Pd, RS = TOPO == 1 ? 10 : NS, kFbChunk = FbDims<NS, TOPO>::kChunk;
     __shared__ double ebuf[2][kFbChunk * Pd];
@@ -269,9 +269,9 @@ k_crf_fb(const double *__restrict__ E, double *__restrict__ fwdbuf, double *__re
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;
     if (Tb <= 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double *Er = E + (size_t)blockIdx.x * TbS * Pd;
-    double *F = fwdbuf + (size_t)blockIdx.x * (TbS + 1) * RS;
-    double *Bw = bwdbuf + (size_t)blockIdx.x * (TbS + 1) * RS;
+    const double *Er = E + map.row0(blockIdx.x, TbS) * Pd;
+    double *F = fwdbuf + map.row1(blockIdx.x, TbS) * RS;
+    double *Bw = bwdbuf + map.row1(blockIdx.x, TbS) * RS;
     const bool want_post = (flags & 2) != 0;
     if (wave == 0) {
         if (want_post && lane < RS) F[lane] = lane < NS ? 1.0 : 0.0;              // (run-length rows: offset C = 0 in [8])
@@ -304,10 +304,11 @@ __device__ __forceinline__ int imax16(int v) {
 template <int NS>
 __global__ void __launch_bounds__(256)
 k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__restrict__ fwdbuf, const double *__restrict__ bwdbuf, int TbS,
-          const double *__restrict__ logz, const int *__restrict__ tbs, int flags, const int *__restrict__ wide) {
+          const double *__restrict__ logz, const int *__restrict__ tbs, int flags, const int *__restrict__ wide, ReadMap map) {
     FFHIP_DECODE_PRIO_SET();
     constexpr int P = FbDims<NS>::P, Ps = P, nbase = NS / 2, off = nbase * NS;
     const int read = blockIdx.y;
+    const size_t row0 = map.row0(read, TbS), row1 = map.row1(read, TbS);
     if (wide && wide[read]) return;
     const int Tb = tbs ? tbs[read] : TbS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
@@ -327,14 +328,14 @@ k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__r
         const int blk = blockIdx.x * kPostBlocks + (round * 4 + wave) * 4 + grp;
         const bool live = blk < Tb;
         const int bc = min(blk, Tb - 1);
-        float4 *xr = (float4 *)(trans + ((size_t)read * TbS + bc) * Ps) + min(sub, P / 4 - 1);
+        float4 *xr = (float4 *)(trans + (row0 + bc) * Ps) + min(sub, P / 4 - 1);
         float4 x = *xr;
         if (flags & 1) { x.x -= sub_c; x.y -= sub_c; x.z -= sub_c; x.w -= sub_c; if (live && has) *xr = x; }
         if (!(flags & 2)) continue;
         // log of the vectors relative to their largest exponent (a common factor per block and direction cancels below); lane sub < NS
         // holds state sub of both.  value = mantissa in [0.5, 1) * 2^e; a zero (unreachable state) gives -inf like the reference's start
         const int st = min(sub, NS - 1);
-        const double va = fwdbuf[((size_t)read * (TbS + 1) + bc) * NS + st], vb = bwdbuf[((size_t)read * (TbS + 1) + bc + 1) * NS + st];
+        const double va = fwdbuf[(row1 + bc) * NS + st], vb = bwdbuf[(row1 + bc + 1) * NS + st];
         const bool pa = sub < NS && va > 0.0, pb = sub < NS && vb > 0.0;
         const int ea = pa ? __builtin_amdgcn_frexp_exp(va) : -100000, eb = pb ? __builtin_amdgcn_frexp_exp(vb) : -100000;
         const int ma = imax16(ea), mb = imax16(eb);
@@ -353,7 +354,7 @@ k_post_fb(float *__restrict__ trans, float *__restrict__ post, const double *__r
 #pragma unroll
         for (int e = 0; e < 4; e++) sum += has ? expf(v[e] - m) : 0.0f;
         const float lse = m + logf(sum16(sum));
-        if (live && has) *((float4 *)(post + ((size_t)read * TbS + blk) * Ps) + sub) = make_float4(v[0] - lse, v[1] - lse, v[2] - lse, v[3] - lse);
+        if (live && has) *((float4 *)(post + (row0 + blk) * Ps) + sub) = make_float4(v[0] - lse, v[1] - lse, v[2] - lse, v[3] - lse);
     }
 }
 
@@ -404,7 +405,7 @@ k_rle_post8(const float *__restrict__ param, float *__restrict__ post, const dou
 void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E, double *fwd, int nread, int Tb, const int *tbs) {
     launch_crf_exp(s, param, E, nread, Tb, 4, 40, tbs, nullptr, 0.0f, 8, 32);
     double *bwd = fwd + (size_t)nread * (Tb + 1) * 10;
-    hipLaunchKernelGGL((k_crf_fb<8, 1>), dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, (double *)nullptr, tbs, 2, (const int *)nullptr);
+    hipLaunchKernelGGL((k_crf_fb<8, 1>), dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, (double *)nullptr, tbs, 2, (const int *)nullptr, ReadMap());
     hipLaunchKernelGGL(k_rle_post8, dim3((Tb + kPostBlocks - 1) / kPostBlocks, nread), dim3(256), 0, s, param, post, fwd, bwd, Tb, tbs);
 }
 
@@ -497,16 +498,16 @@ void launch_rle_partition8x(hipStream_t s, const float *param, double *logz, int
 
 // flags: 1 = subtract (float)(logZ / Tb) from the scores, 2 = posterior wanted; logz: device doubles per read (required with flags & 1)
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
-                   int flags, const int *wide) {
+                   int flags, const int *wide, ReadMap map) {
     const int NS = 2 * nbase;
-    double *bwd = fwd + (size_t)nread * (Tb + 1) * NS;
+    double *bwd = fwd + (size_t)(map.nslot > 0 ? map.nslot : nread) * (Tb + 1) * NS;      // (a packed batch: the rows are its slots')
     const dim3 grid((Tb + kPostBlocks - 1) / kPostBlocks, nread);
     if (nbase == 4) {
-        hipLaunchKernelGGL(k_crf_fb<8>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide);
-        if (flags & 3) hipLaunchKernelGGL(k_post_fb<8>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
+        hipLaunchKernelGGL(k_crf_fb<8>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide, map);
+        if (flags & 3) hipLaunchKernelGGL(k_post_fb<8>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide, map);
     } else {
-        hipLaunchKernelGGL(k_crf_fb<10>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide);
-        if (flags & 3) hipLaunchKernelGGL(k_post_fb<10>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide);
+        hipLaunchKernelGGL(k_crf_fb<10>, dim3(nread), dim3(128), 0, s, E, fwd, bwd, Tb, logz, tbs, flags, wide, map);
+        if (flags & 3) hipLaunchKernelGGL(k_post_fb<10>, grid, dim3(256), 0, s, trans, post, fwd, bwd, Tb, logz, tbs, flags, wide, map);
     }
 }
 
@@ -531,17 +532,17 @@ constexpr int kVitChunk = 2048;          // blocks whose traceback words stay in
 template <int TOPO>
 __global__ void __launch_bounds__(64)
 k_viterbi8x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
-            float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
+            float *__restrict__ score_out, int TbS, const int *__restrict__ tbs, ReadMap map) {
     FFHIP_CHAIN_PRIO_SET();
     constexpr int Ps = 40, ns = 8, nbase = 4, off = 32;
     __shared__ unsigned long long tbw[kVitChunk];           // per block: first the ballot, then the 8 traceback bytes
     __shared__ unsigned careful[kVitChunk / 8 / 32];        // bit per group of 8 blocks: its words are one-hot in the lo layout
     __shared__ uint8_t path_lds[kVitChunk + 1];
     const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
-    const float *T = M + (size_t)blockIdx.x * TbS * Ps + (TOPO == 1 ? 2 * nbase : 0);      // (run-length: the transition rows of a block)
-    unsigned long long *tbg = (unsigned long long *)(tbbuf + (size_t)blockIdx.x * TbS * kMaxState);       // 16 bytes a block: room for the 8
-    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
-    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const float *T = M + map.row0(blockIdx.x, TbS) * Ps + (TOPO == 1 ? 2 * nbase : 0);      // (run-length: the transition rows of a block)
+    unsigned long long *tbg = (unsigned long long *)(tbbuf + map.row0(blockIdx.x, TbS) * kMaxState);       // 16 bytes a block: room for the 8
+    int *pth = path + map.row1(blockIdx.x, TbS);
+    float *qp = qpath + map.row1(blockIdx.x, TbS);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;
     if (Tb <= 0) return;
     const float NEG = -INFINITY;
@@ -767,7 +768,7 @@ constexpr int kVit10Chunk = 1024;
 
 __global__ void __launch_bounds__(64)
 k_viterbi10x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ qpath,
-             float *__restrict__ score_out, int TbS, const int *__restrict__ tbs) {
+             float *__restrict__ score_out, int TbS, const int *__restrict__ tbs, ReadMap map) {
     FFHIP_CHAIN_PRIO_SET();
     constexpr int NS = 10, Ps = 60, nbase = 5, off = 50, PAD = 0;
     __shared__ unsigned long long tb0[kVit10Chunk], tb1[kVit10Chunk], tb2[kVit10Chunk];    // ballots, then traceback bytes of states 0..7 | 8, 9
@@ -776,10 +777,10 @@ k_viterbi10x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__re
     __shared__ float cand[64];
     __shared__ float pvs[16];
     const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
-    const float *T = M + (size_t)blockIdx.x * TbS * Ps;
-    unsigned long long *tbg = (unsigned long long *)(tbbuf + (size_t)blockIdx.x * TbS * kMaxState);       // 16 bytes a block
-    int *pth = path + (size_t)blockIdx.x * (TbS + 1);
-    float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
+    const float *T = M + map.row0(blockIdx.x, TbS) * Ps;
+    unsigned long long *tbg = (unsigned long long *)(tbbuf + map.row0(blockIdx.x, TbS) * kMaxState);       // 16 bytes a block
+    int *pth = path + map.row1(blockIdx.x, TbS);
+    float *qp = qpath + map.row1(blockIdx.x, TbS);
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;
     if (Tb <= 0) return;
     const float NEG = -INFINITY;
@@ -979,16 +980,16 @@ k_viterbi10x(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__re
     }
 }
 
-void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs) {
-    hipLaunchKernelGGL(k_viterbi10x, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs, ReadMap map) {
+    hipLaunchKernelGGL(k_viterbi10x, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs, map);
 }
 
-void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs) {
-    hipLaunchKernelGGL(k_viterbi8x<0>, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
+void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs, ReadMap map) {
+    hipLaunchKernelGGL(k_viterbi8x<0>, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs, map);
 }
 // decode_crf_runlength for nbase = 4, stride 40 (param: shape / scale rows + 32 transition scores a block)
 void launch_rle_viterbi8x(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs) {
-    hipLaunchKernelGGL(k_viterbi8x<1>, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, tbs);
+    hipLaunchKernelGGL(k_viterbi8x<1>, dim3(nread), dim3(64), 0, s, param, tb, path, qpath, score, Tb, tbs, ReadMap());
 }
 
 }  // namespace ffhip

@@ -11,6 +11,7 @@
 #include <ctype.h>
 #include <vector>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -636,6 +637,19 @@ struct ffhip_batch {
     int *d_tbs = nullptr, *d_tbt = nullptr;
     int *rag_x0a[3] = { nullptr, nullptr, nullptr }, *rag_x0b[3] = { nullptr, nullptr, nullptr };
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
+    // Packed batch (ffhip_batch_set_*_packed): the `nread` rows of the buffers are SLOTS, each holding one or more reads one behind the other with a gap of
+    // ffhip_model_pack_gap() blocks; results are indexed by READ (0 .. nvirt - 1, the order of the set call).  hT / hTb hold the reads' lengths then.
+    int cap_reads = 0;                  // the per-read result arrays (lens, score, logZ) take this many reads (>= nread)
+    bool packed = false;
+    int nvirt = 0;
+    std::vector<int> v_slot, v_off;     // slot and first block of every read
+    int *d_vb0 = nullptr, *d_vb1 = nullptr, *d_vtb = nullptr;      // per read: first row in Tb-row / (Tb + 1)-row buffers, blocks
+    unsigned *d_live = nullptr;         // [Tb][B16]: bit r = slot 16 rt + r holds a block of a read at step t (the layer kernels' reset mask)
+    int *rag_seg[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers of a packed batch: read boundaries per row (k_conv_small `seg`)
+    size_t rag_seg_cap[3] = { 0, 0, 0 };
+    long long *d_goff = nullptr;        // destination of every read's signal (floats from sbuf[0].p + kSamplePad)
+    int4 *d_prd = nullptr;             // per read records for the device-side table / mask builders: [conv table | live mask] x cap_reads
+    Pinned h_vb0, h_vb1, h_vtb, h_prd, h_seg[3], h_goff;
     SampleBuf sbuf[3];                  // sbuf[0] = signal, sbuf[l] = output of conv l-1
     float *act[2] = { nullptr, nullptr };
     void *actS[2] = { nullptr, nullptr };      // the same two buffers in the split-operand layout (ffhip_rnn_split.hip), allocated on first use
@@ -756,11 +770,12 @@ extern "C" void ffhip_batch_destroy(ffhip_batch *b) {
     delete b;
 }
 
-extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model *m, int nread, size_t nsample) {
-    if (!eng || !m || nread <= 0 || nsample == 0 || nsample > (1u << 30)) { set_err(FFHIP_EINVAL, "bad batch arguments"); return nullptr; }
+static ffhip_batch *batch_create_impl(ffhip_engine *eng, const ffhip_model *m, int nread, size_t nsample, int cap_reads) {
+    if (!eng || !m || nread <= 0 || nsample == 0 || nsample > (1u << 30) || cap_reads < 0 || cap_reads > (1 << 22)) { set_err(FFHIP_EINVAL, "bad batch arguments"); return nullptr; }
     hipSetDevice(eng->device);
     ffhip_batch *b = new ffhip_batch();
     b->eng = eng; b->mdl = m;
+    b->cap_reads = cap_reads > nread ? cap_reads : nread;
     b->stream = eng->streams[eng->next_stream];
     eng->next_stream = (eng->next_stream + 1) % eng->nstreams;
     b->nread = nread; b->B16 = (nread + 15) / 16; b->Bp = b->B16 * 16;
@@ -798,7 +813,8 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     // b->xa (gate pre-activations, 4x the size of an activation buffer) exists only on the unfused path: allocated on first use
     if (!(b->cstate = (float *)dalloc(b, Bp * Hp * 4, true))) BFAIL();
     if (!(b->trans = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
-    if (!(b->crf_logz = (double *)dalloc(b, (size_t)nread * sizeof(double), true))) BFAIL();
+    const size_t nres = (size_t)b->cap_reads;      // per-READ results (a packed batch holds more reads than rows)
+    if (!(b->crf_logz = (double *)dalloc(b, nres * sizeof(double), true))) BFAIL();
     if (!(b->crf_e = (double *)dalloc(b, (size_t)nread * Tb * crf_exp_stride(m->P) * sizeof(double), false))) BFAIL();
     if (!(b->post = (float *)dalloc(b, (size_t)nread * Tb * Ps * 4, true))) BFAIL();
     if (!(b->fwd = (float *)dalloc(b, (size_t)2 * nread * (Tb + 1) * kFwdRowBytes, false))) BFAIL();      // forward + backward vectors
@@ -807,8 +823,8 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
     if (!(b->qpath = (float *)dalloc(b, (size_t)nread * (Tb + 1) * 4, true))) BFAIL();
     {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t o_sat = 0, o_abort = up((size_t)b->Bp * 4), o_lens = o_abort + 256, o_score = o_lens + up((size_t)nread * 4),
-                     o_bases = o_score + up((size_t)nread * 4), o_quals = o_bases + up((size_t)nread * (Tb + 1));
+        const size_t o_sat = 0, o_abort = up((size_t)b->Bp * 4), o_lens = o_abort + 256, o_score = o_lens + up(nres * 4),
+                     o_bases = o_score + up(nres * 4), o_quals = o_bases + up((size_t)nread * (Tb + 1));
         b->res_head = o_lens;
         b->res_bytes = o_quals + up((size_t)nread * (Tb + 1));
         if (!(b->res_dev = (unsigned char *)dalloc(b, b->res_bytes, true))) BFAIL();
@@ -836,10 +852,65 @@ extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model 
 #undef BFAIL
     return b;
 }
+extern "C" ffhip_batch *ffhip_batch_create(ffhip_engine *eng, const ffhip_model *m, int nread, size_t nsample) { return batch_create_impl(eng, m, nread, nsample, 0); }
+// a batch of `nslot` rows of `nsample` samples that takes up to max_reads reads, several to a row (ffhip_batch_set_prepared_packed / _signals_packed)
+extern "C" ffhip_batch *ffhip_batch_create_packed(ffhip_engine *eng, const ffhip_model *m, int nslot, size_t nsample, int max_reads) {
+    return batch_create_impl(eng, m, nslot, nsample, max_reads);
+}
+static inline int batch_nreads(const ffhip_batch *b) { return b->packed ? b->nvirt : b->nread; }
+extern "C" int ffhip_batch_nreads(const ffhip_batch *b) { return b ? batch_nreads(b) : 0; }
+// first row of a read in the buffers of Tb / Tb + 1 rows a slot
+static inline size_t read_row0(const ffhip_batch *b, int read) { return b->packed ? (size_t)b->v_slot[read] * b->Tb + b->v_off[read] : (size_t)read * b->Tb; }
+static inline size_t read_row1(const ffhip_batch *b, int read) { return b->packed ? (size_t)b->v_slot[read] * (b->Tb + 1) + b->v_off[read] : (size_t)read * (b->Tb + 1); }
+static int total_stride(const ffhip_model *m) { int st = 1; for (int l = 0; l < m->nconv; l++) st *= m->conv[l].stride; return st; }
+// does this model's default path take packed batches?  (what batch_run_impl asks of a packed batch, on the model's side)
+extern "C" int ffhip_model_packable(const ffhip_model *m) {
+    if (!m || m->kind == FFHIP_NET_LSTM5_RLE || !((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60))) return 0;
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    return (persist_supported(m->cell, m->Hp, ncu) && split_supported(m->cell, m->Hp) && m->Hp <= 384 && m->rnn[0].Wsplit != nullptr && m->conv[m->nconv - 1].Mpad == m->Hp &&
+            !dbg("no_split") && !dbg("no_fuse")) ? 1 : 0;
+}
+// Blocks that stay free behind every read of a packed slot: the widest convolution window of the model either side of a read must see the zero padding the
+// reference gives it (layers.c:216-271), in every layer's coordinates, and the dead block behind a read is the next one's zero recurrent state.
+extern "C" size_t ffhip_model_pack_gap(const ffhip_model *m) {
+    if (!m) return 0;
+    int wmax = 1;
+    for (int l = 0; l < m->nconv; l++) wmax = std::max(wmax, m->conv[l].winlen);
+    const int st = total_stride(m);
+    return (size_t)((2 * wmax + st - 1) / st + 1);
+}
+// First-fit-decreasing plan of `nread` reads into nslot rows of nsample_cap samples: slot[] / block_off[] of every read (slot -1: it did not fit); returns the number placed.
+extern "C" int ffhip_pack_plan(const ffhip_model *m, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off) {
+    if (!m || nslot <= 0 || nread < 0 || !nsample || !slot || !block_off) { set_err(FFHIP_EINVAL, "bad pack plan arguments"); return -1; }
+    const long cap = (long)ffhip_model_nblock(m, nsample_cap), gap = (long)ffhip_model_pack_gap(m);
+    std::vector<int> order(nread);
+    for (int i = 0; i < nread; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsample[x] > nsample[y]; });
+    // rows by free blocks: a multimap would do; the row count is small (<= 1024) and reads come longest first, so a scan from a moving start is short
+    std::vector<long> used(nslot, 0);
+    int placed = 0, first_open = 0;
+    for (int k = 0; k < nread; k++) {
+        const int i = order[k];
+        slot[i] = -1; block_off[i] = 0;
+        if (nsample[i] == 0 || nsample[i] > nsample_cap) continue;
+        const long nb = (long)ffhip_model_nblock(m, nsample[i]);
+        for (int r = first_open; r < nslot; r++) {
+            if (used[r] + nb + 1 <= cap) {      // (a dead block behind the last read of a row too)
+                slot[i] = r; block_off[i] = (int)used[r];
+                used[r] += nb + gap;
+                placed++;
+                break;
+            }
+        }
+        while (first_open < nslot && used[first_open] + gap + 8 >= cap) first_open++;      // (rows with no room for even a short read)
+    }
+    return placed;
+}
 
 extern "C" size_t ffhip_batch_nblock(const ffhip_batch *b) { return b ? (size_t)b->Tb : 0; }
 extern "C" size_t ffhip_batch_read_nblock(const ffhip_batch *b, int read) {
-    return (b && read >= 0 && read < b->nread) ? (size_t)b->hTb[read] : 0;
+    return (b && read >= 0 && read < batch_nreads(b)) ? (size_t)b->hTb[read] : 0;
 }
 
 // Records the reads' lengths.  All equal to the capacity: the uniform fast path (shared window tables, no
@@ -853,6 +924,7 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
         uniform = uniform && lens[r] == b->T;          // 0 = an empty slot: no work, no results
     }
     b->hT = lens;
+    b->packed = false; b->nvirt = 0;
     if (uniform) { b->ragged = false; b->hTb.assign(b->nread, b->Tb); return FFHIP_OK; }
     std::vector<int> cur(lens);
     for (int l = 0; l < m->nconv; l++) {
@@ -911,6 +983,133 @@ static int apply_lengths(ffhip_batch *b, const std::vector<int> &lens) {
     HIP_TRY(hipMemcpyAsync(b->d_tbs, tbs, (size_t)b->Bp * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipMemcpyAsync(b->d_tbt, tbt, (size_t)b->B16 * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     b->ragged = true;
+    return FFHIP_OK;
+}
+
+// Packed batch: read v (lens[v] samples) stands in row slot[v] from block off[v] on.  Builds what makes every kernel see each read as if it were alone:
+//   * the strided convolution's column -> window-start tables per ROW, every read's own table (its right edge is where the reference's quirk lives, layers.c:257-271)
+//     shifted to the read's place, kZeroCol between the reads;
+//   * the stride-1 thin layers' read boundaries per row (k_conv_small `seg`): columns outside a read are written as zeros -- the next layer's padding;
+//   * the layer kernels' live mask (bit per step and row) and the rows' extents (tbs / tbt: how many steps a read tile runs);
+//   * per read: its first row in the buffers of Tb and of Tb + 1 rows a slot, and its blocks.
+static int apply_packed(ffhip_batch *b, int nv, const std::vector<int> &lens, const int *slot, const int *off) {
+    const ffhip_model *m = b->mdl;
+    if (nv < 0 || nv > b->cap_reads) return set_err(FFHIP_EINVAL, "%d reads, the batch was created for %d", nv, b->cap_reads);
+    const int nconv = m->nconv, gap = (int)ffhip_model_pack_gap(m);
+    std::vector<int> sfrom(nconv + 1, 1);                       // sfrom[l]: samples of layer l's input per block
+    for (int l = nconv - 1; l >= 0; l--) sfrom[l] = sfrom[l + 1] * m->conv[l].stride;
+    std::vector<int> vtb(nv, 0);
+    std::vector<std::vector<int>> rows(b->nread);              // reads of every row
+    for (int v = 0; v < nv; v++) {
+        if (slot[v] < 0 || slot[v] >= b->nread || off[v] < 0 || lens[v] <= 0 || lens[v] > b->T) return set_err(FFHIP_EINVAL, "packed read %d: bad slot, offset or length", v);
+        vtb[v] = (int)ffhip_model_nblock(m, (size_t)lens[v]);
+        if (off[v] + vtb[v] + 1 > b->Tb) return set_err(FFHIP_EINVAL, "packed read %d: blocks %d .. %d do not fit a row of %d (one free block behind the last read)", v, off[v], off[v] + vtb[v], b->Tb);
+        rows[slot[v]].push_back(v);
+    }
+    for (auto &rv : rows) {
+        std::sort(rv.begin(), rv.end(), [&](int x, int y) { return off[x] < off[y]; });
+        for (size_t k = 1; k < rv.size(); k++)
+            if (off[rv[k]] < off[rv[k - 1]] + vtb[rv[k - 1]] + gap) return set_err(FFHIP_EINVAL, "packed reads %d and %d of row %d are closer than %d blocks", rv[k - 1], rv[k], slot[rv[k]], gap);
+    }
+    std::vector<int> cur(lens);
+    int nstrided = 0;
+    for (int l = 0; l < nconv; l++) {
+        const int Tmax = b->plan[l].Tout;
+        if (m->conv[l].stride == 1 && l < nconv - 1) {
+            // offsets [Bp + 1], then the boundaries (columns of this layer = samples of its input)
+            const size_t n = (size_t)b->Bp + 1 + 2 * (size_t)nv;
+            if (b->rag_seg_cap[l] < n) {
+                b->rag_seg_cap[l] = n + n / 2 + 64;
+                if (!(b->rag_seg[l] = (int *)dalloc(b, b->rag_seg_cap[l] * 4, false))) return FFHIP_ENOMEM;      // (an outgrown table stays owned until the batch goes)
+            }
+            int *sg = (int *)b->h_seg[l].get(n * 4);
+            if (!sg) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+            int at = b->Bp + 1;
+            for (int r = 0; r < b->Bp; r++) {
+                sg[r] = at;
+                if (r < b->nread)
+                    for (int v : rows[r]) {
+                        if (cur[v] < m->conv[l].winlen) return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", v, cur[v], l, m->conv[l].winlen);
+                        sg[at++] = off[v] * sfrom[l]; sg[at++] = off[v] * sfrom[l] + cur[v];
+                    }
+            }
+            sg[b->Bp] = at;
+            HIP_TRY(hipMemcpyAsync(b->rag_seg[l], sg, n * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+            continue;                                           // output length = input length
+        }
+        const size_t n = (size_t)b->Bp * Tmax;
+        if (!b->rag_x0a[l]) {
+            b->rag_x0a[l] = (int *)dalloc(b, n * 4, false);
+            b->rag_x0b[l] = (int *)dalloc(b, n * 4, false);
+            if (!b->rag_x0a[l] || !b->rag_x0b[l]) return FFHIP_ENOMEM;
+        }
+        // the table is built on the device (k_pack_conv_table: build_conv_plan column by column), kZeroCol wherever no read stands
+        if (!b->d_prd && !(b->d_prd = (int4 *)dalloc(b, (size_t)2 * b->cap_reads * sizeof(int4), false))) return FFHIP_ENOMEM;
+        if (nstrided++ > 0) HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);      // (a second strided layer: the records' host image is still being copied)
+        int4 *prd = (int4 *)b->h_prd.get((size_t)2 * b->cap_reads * sizeof(int4));
+        if (!prd) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+        const int winlen = m->conv[l].winlen, st = m->conv[l].stride, padL = (winlen - 1) / 2, ncolsL = (padL + st - 1) / st, shiftX = ncolsL * st - padL;
+        int maxcols = 0;
+        for (int v = 0; v < nv; v++) {
+            const int T = cur[v], Tout = (T + st - 1) / st;
+            if (T < winlen || T - shiftX - (winlen - 1) < 0)      // (build_conv_plan's domain check)
+                return set_err(FFHIP_EINVAL, "read %d: %d samples at convolution %d is outside the domain of the reference's convolution (winlen %d)", v, T, l, winlen);
+            if (off[v] * sfrom[l + 1] + Tout > Tmax) return set_err(FFHIP_EINVAL, "packed read %d: convolution %d runs past the row", v, l);
+            prd[v] = make_int4(slot[v], off[v] * sfrom[l + 1], off[v] * sfrom[l], T);
+            maxcols = std::max(maxcols, Tout);
+            cur[v] = Tout;
+        }
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->rag_x0a[l], kZeroCol, n, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->rag_x0b[l], kZeroCol, n, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemsetAsync(b->pabort + 2, 0, sizeof(unsigned), b->stream), FFHIP_EHIP);
+        if (nv > 0) {
+            HIP_TRY(hipMemcpyAsync(b->d_prd, prd, (size_t)nv * sizeof(int4), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+            launch_pack_conv_table(b->stream, b->d_prd, nv, maxcols, winlen, st, Tmax, b->rag_x0a[l], b->rag_x0b[l], b->pabort + 2);
+        }
+    }
+    for (int v = 0; v < nv; v++) if (cur[v] != vtb[v]) return set_err(FFHIP_EINVAL, "internal error: block count of packed read %d", v);
+    if (!b->d_tbs) {
+        b->d_tbs = (int *)dalloc(b, (size_t)b->Bp * 4, true);
+        b->d_tbt = (int *)dalloc(b, (size_t)b->B16 * 4, true);
+        if (!b->d_tbs || !b->d_tbt) return FFHIP_ENOMEM;
+    }
+    if (!b->d_live) {
+        b->d_live = (unsigned *)dalloc(b, (size_t)b->Tb * b->B16 * 4, false);
+        if (!b->d_prd && !(b->d_prd = (int4 *)dalloc(b, (size_t)2 * b->cap_reads * sizeof(int4), false))) return FFHIP_ENOMEM;
+        b->d_vb0 = (int *)dalloc(b, (size_t)b->cap_reads * 4, false);
+        b->d_vb1 = (int *)dalloc(b, (size_t)b->cap_reads * 4, false);
+        b->d_vtb = (int *)dalloc(b, (size_t)b->cap_reads * 4, false);
+        if (!b->d_live || !b->d_vb0 || !b->d_vb1 || !b->d_vtb) return FFHIP_ENOMEM;
+    }
+    int *tbs = (int *)b->h_tbs.get((size_t)b->Bp * 4), *tbt = (int *)b->h_tbt.get((size_t)b->B16 * 4);
+    int4 *prl = (int4 *)b->h_prd.get((size_t)2 * b->cap_reads * sizeof(int4));
+    if (prl) prl += b->cap_reads;                              // (second half: the first may still be waiting for its copy)
+    int *vb0 = (int *)b->h_vb0.get((size_t)std::max(1, nv) * 4), *vb1 = (int *)b->h_vb1.get((size_t)std::max(1, nv) * 4), *vt = (int *)b->h_vtb.get((size_t)std::max(1, nv) * 4);
+    if (!tbs || !tbt || !prl || !vb0 || !vb1 || !vt) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+    memset(tbs, 0, (size_t)b->Bp * 4); memset(tbt, 0, (size_t)b->B16 * 4);
+    if ((size_t)b->nread * (size_t)(b->Tb + 1) >= ((size_t)1 << 31)) return set_err(FFHIP_EINVAL, "packed batch: rows x blocks beyond 2^31");
+    int maxb = 0;
+    for (int v = 0; v < nv; v++) {
+        const int r = slot[v], rt = r / 16;
+        prl[v] = make_int4(r, off[v], vtb[v], 0);
+        maxb = std::max(maxb, vtb[v]);
+        tbs[r] = std::max(tbs[r], off[v] + vtb[v] + 1);         // (the dead block behind the row's last read is a step of the layer: the reverse layers start from it)
+        tbt[rt] = std::max(tbt[rt], tbs[r]);
+        vb0[v] = r * b->Tb + off[v]; vb1[v] = r * (b->Tb + 1) + off[v]; vt[v] = vtb[v];
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_tbs, tbs, (size_t)b->Bp * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(b->d_tbt, tbt, (size_t)b->B16 * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemsetAsync(b->d_live, 0, (size_t)b->Tb * b->B16 * 4, b->stream), FFHIP_EHIP);
+    if (nv > 0) {
+        HIP_TRY(hipMemcpyAsync(b->d_prd + b->cap_reads, prl, (size_t)nv * sizeof(int4), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        launch_pack_live(b->stream, b->d_prd + b->cap_reads, nv, maxb, b->B16, b->d_live);
+        HIP_TRY(hipMemcpyAsync(b->d_vb0, vb0, (size_t)nv * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->d_vb1, vb1, (size_t)nv * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->d_vtb, vt, (size_t)nv * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    }
+    b->hT = lens; b->hTb = vtb;
+    b->v_slot.assign(slot, slot + nv); b->v_off.assign(off, off + nv);
+    b->nvirt = nv; b->packed = true; b->ragged = true;
     return FFHIP_OK;
 }
 
@@ -975,6 +1174,13 @@ extern "C" int ffhip_batch_set_reads(ffhip_batch *b, const raw_table *reads) {
     return FFHIP_OK;
 }
 
+static int gather_tables(ffhip_batch *b) {      // device side of ffhip_batch_set_prepared(_packed)'s gather: one entry per read the batch can take
+    if (b->d_gsrc) return FFHIP_OK;
+    b->d_gsrc = (const float **)dalloc(b, (size_t)b->cap_reads * sizeof(float *), false);
+    b->d_glen = (int *)dalloc(b, (size_t)b->cap_reads * 4, false);
+    return (b->d_gsrc && b->d_glen) ? FFHIP_OK : FFHIP_ENOMEM;
+}
+
 // reads already trimmed and normalised on the device (ffhip_prep_create): device-to-device, no host copy
 extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads) {
     if (!b || !prep || !reads) return set_err(FFHIP_EINVAL, "bad prepared-read arguments");
@@ -1001,16 +1207,69 @@ extern "C" int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, 
     if (b->ragged) if (int rc = clear_signals(b)) return rc;
     SampleBuf &sb = b->sbuf[0];
     // one gather launch for the whole batch (a device-to-device copy per read is a launch per read: 512 of them cost more than the copies)
-    if (!b->d_gsrc) {
-        b->d_gsrc = (const float **)dalloc(b, (size_t)b->nread * sizeof(float *), false);
-        b->d_glen = (int *)dalloc(b, (size_t)b->nread * 4, false);
-        if (!b->d_gsrc || !b->d_glen) return FFHIP_ENOMEM;
-    }
+    if (int rc = gather_tables(b)) return rc;
     memcpy(plen, lens.data(), (size_t)b->nread * 4);
     HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src, (size_t)b->nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipMemcpyAsync(b->d_glen, plen, (size_t)b->nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
     launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, b->nread);      // (no wait here: the host images are members)
     prep_mark_used(prep, b->stream);                // ffhip_prep_destroy waits for this gather, not for the batch
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
+// ---- packed batches: reads of any lengths, several to a row (ffhip.h "packed batches")
+extern "C" int ffhip_batch_set_signals_packed(ffhip_batch *b, int nread, const float *const *signals, const size_t *nsample, const int *slot, const int *block_off) {
+    if (!b || nread < 0 || (nread > 0 && (!signals || !nsample || !slot || !block_off))) return set_err(FFHIP_EINVAL, "bad packed-signal arguments");
+    hipSetDevice(b->eng->device);
+    std::vector<int> lens(nread);
+    for (int v = 0; v < nread; v++) {
+        if (!signals[v] || nsample[v] == 0 || nsample[v] > (size_t)b->T) return set_err(FFHIP_EINVAL, "packed read %d: no signal, or longer than a row's %d samples", v, b->T);
+        lens[v] = (int)nsample[v];
+    }
+    if (int rc = apply_packed(b, nread, lens, slot, block_off)) return rc;
+    if (int rc = clear_signals(b)) return rc;
+    SampleBuf &sb = b->sbuf[0];
+    const int st = total_stride(b->mdl);
+    for (int v = 0; v < nread; v++)
+        HIP_TRY(hipMemcpyAsync((void *)(sb.p + (size_t)slot[v] * sb.rs + kSamplePad + (size_t)block_off[v] * st), signals[v], (size_t)lens[v] * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
+    b->ran = b->finished = 0;
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_batch_set_prepared_packed(ffhip_batch *b, const ffhip_prep *prep, int nread, const int *reads, const int *slot, const int *block_off) {
+    if (!b || !prep || nread < 0 || (nread > 0 && (!reads || !slot || !block_off))) return set_err(FFHIP_EINVAL, "bad packed prepared-read arguments");
+    if (rehearsal_rate() > 0) return set_err(FFHIP_EINVAL, "packed batches are not part of the host-load rehearsal");
+    hipSetDevice(b->eng->device);
+    const size_t nv = (size_t)std::max(1, nread);
+    std::vector<int> lens(nread, 0);
+    int *plen = (int *)b->h_glen.get(nv * 4);
+    const float **src = (const float **)b->h_gsrc.get(nv * sizeof(float *));
+    long long *goff = (long long *)b->h_goff.get(nv * sizeof(long long));
+    if (!plen || !src || !goff) return set_err(FFHIP_ENOMEM, "pinned host allocation failed");
+    SampleBuf &sb = b->sbuf[0];
+    const int st = total_stride(b->mdl);
+    for (int v = 0; v < nread; v++) {
+        size_t len = 0;
+        src[v] = reads[v] >= 0 ? prep_device_signal(prep, reads[v], &len) : nullptr;
+        if (!src[v] || len == 0 || len > (size_t)b->T) return set_err(FFHIP_EINVAL, "prepared read %d: rejected by trimming, or longer than a row's %d samples", reads[v], b->T);
+        lens[v] = plen[v] = (int)len;
+    }
+    if (int rc = apply_packed(b, nread, lens, slot, block_off)) return rc;
+    if (int rc = clear_signals(b)) return rc;
+    for (int v = 0; v < nread; v++) goff[v] = (long long)((size_t)slot[v] * sb.rs + (size_t)block_off[v] * st);
+    if (!b->d_goff) {      // (sized for the batch's read capacity, like the other per-read tables of a packed batch)
+        b->d_goff = (long long *)dalloc(b, (size_t)b->cap_reads * sizeof(long long), false);
+        if (!b->d_goff) return FFHIP_ENOMEM;
+    }
+    if (int rc = gather_tables(b)) return rc;
+    if (nread > 0) {
+        HIP_TRY(hipMemcpyAsync((void *)b->d_gsrc, src, (size_t)nread * sizeof(float *), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->d_glen, plen, (size_t)nread * 4, hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        HIP_TRY(hipMemcpyAsync(b->d_goff, goff, (size_t)nread * sizeof(long long), hipMemcpyHostToDevice, b->stream), FFHIP_EHIP);
+        launch_gather_rows(b->stream, b->d_gsrc, b->d_glen, sb.p + kSamplePad, sb.rs, nread, b->d_goff);
+        prep_mark_used(prep, b->stream);
+    }
     b->ran = b->finished = 0;
     return FFHIP_OK;
 }
@@ -1042,6 +1301,12 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     }
     const bool keep = (flags & FFHIP_RUN_KEEP_ACTS) != 0;
     const int *tbs = b->ragged ? b->d_tbs : nullptr, *tbt = b->ragged ? b->d_tbt : nullptr;      // ragged batch: per-read / per-tile block counts
+    // packed batch: tbs / tbt above are the ROWS' extents (what the layer kernels walk); the per-read kernels take the reads' own tables
+    const int nR = b->packed ? b->nvirt : b->nread;
+    const int *tbr = b->packed ? b->d_vtb : tbs;
+    ReadMap rmap;
+    if (b->packed) { rmap.b0 = b->d_vb0; rmap.b1 = b->d_vb1; rmap.nslot = b->nread; }
+    const unsigned *live = b->packed ? b->d_live : nullptr;
     auto keep_copy = [&](int slot, const float *src) -> int {
         if (!keep) return FFHIP_OK;
         if (!b->keep[slot] && !(b->keep[slot] = (float *)dalloc(b, (size_t)Tb * Bp * Hp * 4, false))) return FFHIP_ENOMEM;
@@ -1068,6 +1333,10 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     const int fast_gates = gate_level(flags);
     const char *pm_env = dbg("persist_mode");      // 1 = always use the write-through hand-off
     const int persist_mode = pm_env ? atoi(pm_env) : 0;
+    // A packed batch runs on the default path only: the split layer kernels know the live mask, the chain / Viterbi / assembly / trace kernels the read map
+    if (b->packed && !(use_split && conv_split && !keep && m->kind != FFHIP_NET_LSTM5_RLE && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) &&
+                       !dbg("decode_r2") && !dbg("crf_logspace") && 10.0f / temperature <= kFbRange && crf_rescale_interval(5.0f / temperature) > 0))
+        return set_err(FFHIP_EINVAL, "packed batches take the default path only (flip-flop model with 128 .. 384 hidden units, no kept activations, no f32 / stepwise / unfused flags, ordinary temperature)");
     int cur = b->run_cur;
     {
         const bool need0 = !conv_split;           // the convolution's fp32 output (every path but split layers behind a split-writing convolution)
@@ -1117,7 +1386,8 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         if (l < m->nconv - 1) {
             launch_conv_small(s, b->sbuf[l], b->sbuf[l + 1], c.taps, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, Bp, b->plan[l].Tout, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
-                              b->ragged ? b->rag_tin[l] : nullptr, (conv_f16 && l == m->nconv - 2) ? kSplitExpX : -100000, b->sat);
+                              (b->ragged && !b->packed) ? b->rag_tin[l] : nullptr, (conv_f16 && l == m->nconv - 2) ? kSplitExpX : -100000, b->sat,
+                              (b->packed && m->conv[l].stride == 1) ? b->rag_seg[l] : nullptr);
         } else if (conv_f16) {
             launch_conv_split(s, b->sbuf[l], b->act[0], c.Wsplit, c.bias, b->ragged ? b->rag_x0a[l] : b->plan[l].x0a,
                               b->ragged ? b->rag_x0b[l] : b->plan[l].x0b, B16, Tb, c.Mpad, c.winlen, m->act, b->ragged ? b->plan[l].Tout : 0,
@@ -1198,7 +1468,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
                 if (b->eng->persist_chained && (chain || !b->eng->persist_last_half)) HIP_TRY(hipStreamWaitEvent(s, b->eng->persist_done, 0), FFHIP_EHIP);      // beside another launch only if BOTH are half-chip ones
                 if (prof && rt0 == 0) hipEventRecord(b->lev[l][1], s);      // behind the wait: the layer's time is its kernels', not the other batch's
                 if (!launch_lstm_split(s, m->cell, r.Wsplit, r.bias, b->actS[cur], outS, out_f32, b->pflags, b->pabort, Tb, B16, Hp, rt0, nrt,
-                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch, beside))
+                                       backward, persist_mode, r.split_S, fast_gates, tbs, tbt, b->eng->prop.multiProcessorCount, b->split_epoch, beside, live))
                     return set_err(FFHIP_EINVAL, "split recurrent kernel: unsupported shape");
                 { HIP_TRY(hipEventRecord(b->eng->persist_done, s), FFHIP_EHIP); b->eng->persist_chained = 1; b->eng->persist_last_half = chain ? 0 : 1; }
                 b->launches[2]++;
@@ -1287,7 +1557,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             const bool want_post = !(flags & FFHIP_RUN_NO_DECODE) && !(flags & FFHIP_RUN_VITERBI_ONLY);
             if (!head_e) launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);
             mark(b, 4);       // the profile's "posterior" slot times the chain launch: partition function + normalisation + posterior together
-            launch_crf_fb(s, m->nbase, b->crf_e, b->trans, b->post, (double *)b->fwd, b->nread, Tb, b->crf_logz, tbs, want_post ? 3 : 1, nullptr);
+            launch_crf_fb(s, m->nbase, b->crf_e, b->trans, b->post, (double *)b->fwd, nR, Tb, b->crf_logz, tbr, want_post ? 3 : 1, nullptr, rmap);
             b->launches[3] += want_post ? 4 : 3;      // head, exp, chains, assembly (the subtraction alone: three)
         } else {
             if (R > 0) launch_crf_norm_linear(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, R, b->crf_logz, 1, tbs);
@@ -1317,11 +1587,11 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
             HIP_TRY(hipMemsetAsync(b->quals, 0, (size_t)b->nread * (Tb + 1), s), FFHIP_EHIP);
             b->launches[5]++;
         } else {
-            launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, b->nread, Tb, m->nbase, m->Ps, tbs);
-            launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, b->nread, Tb, m->nbase, tbs);
+            launch_viterbi(s, scores, b->tb, b->path, b->qpath, b->score, nR, Tb, m->nbase, m->Ps, tbr, rmap);
+            launch_assemble(s, b->path, b->qpath, b->bases, b->quals, b->lens, nR, Tb, m->nbase, tbr, rmap);
             b->launches[5] += 2;
             if (!(flags & FFHIP_RUN_NO_TRACE)) {
-                launch_trace(s, scores, b->trace, b->nread, Tb, m->nbase, m->Ps, 1, tbs);
+                launch_trace(s, scores, b->trace, nR, Tb, m->nbase, m->Ps, 1, tbr, rmap);
                 b->launches[5]++;
             }
         }
@@ -1393,7 +1663,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
     const ffhip_model *m = b0->mdl;
     ffhip_engine *eng = b0->eng;
     const int ncu = eng->prop.multiProcessorCount;
-    const bool pairable = b1->mdl == m && b1->eng == eng && b0->Tb == b1->Tb && b0->B16 == b1->B16 && b0->B16 <= 2 * (ncu / 32) && (((b0->B16 + 1) / 2) & 7) == 0 &&
+    const bool pairable = b1->mdl == m && b1->eng == eng && b0->Tb == b1->Tb && b0->B16 == b1->B16 && b0->packed == b1->packed && b0->B16 <= 2 * (ncu / 32) && (((b0->B16 + 1) / 2) & 7) == 0 &&
                           !(flags & (FFHIP_RUN_KEEP_ACTS | FFHIP_RUN_STEPWISE_RNN | FFHIP_RUN_F32_RNN | FFHIP_RUN_UNFUSED_RNN)) && eng->stepwise_batches == 0 &&
                           m->cell == 0 && m->Hp == 384 && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr && !dbg("no_split") &&
                           !dbg("no_fuse") && !dbg("no_pair") && persist_supported(m->cell, m->Hp, ncu);
@@ -1425,7 +1695,7 @@ extern "C" int ffhip_batch_run_pair(ffhip_batch *b0, ffhip_batch *b1, float temp
             b->split_epoch = (b->split_epoch % 0x3FFFFFFu) + 1u;
             p[k] = SplitLaunch{ r.Wsplit, r.bias, b->actS[cur], b->actS[cur ^ 1], (l == 4 && !split_head_pair) ? b->act[cur ^ 1] : nullptr, b->pflags, b->pabort,
                                 b->Tb, b->B16, 0, b->B16, (l % 2 == 0) ? 1 : 0, persist_mode, r.split_S, fast_gates,
-                                b->ragged ? b->d_tbs : nullptr, b->ragged ? b->d_tbt : nullptr, b->split_epoch };
+                                b->ragged ? b->d_tbs : nullptr, b->ragged ? b->d_tbt : nullptr, b->split_epoch, b->packed ? b->d_live : nullptr };
         }
         if (prof) hipEventRecord(b0->lev[l][1], s);
         if (eng->persist_chained) HIP_TRY(hipStreamWaitEvent(s, eng->persist_done, 0), FFHIP_EHIP);      // a paired launch fills the chip: after any other layer launch
@@ -1471,28 +1741,32 @@ static int rerun_on_f32_path(ffhip_batch *b, const std::vector<int> &reads) {
         for (int k = 0; k < n; k++) lens[k] = b->hT[reads[k0 + k]];
         if (int rc = apply_lengths(sd, lens)) return rc;
         if (int rc = clear_signals(sd)) return rc;
-        for (int k = 0; k < n; k++)
-            HIP_TRY(hipMemcpyAsync(sd->sbuf[0].p + (size_t)k * sd->sbuf[0].rs + kSamplePad, b->sbuf[0].p + (size_t)reads[k0 + k] * b->sbuf[0].rs + kSamplePad,
-                                   (size_t)lens[k] * 4, hipMemcpyDeviceToDevice, sd->stream), FFHIP_EHIP);
+        for (int k = 0; k < n; k++) {
+            const int rd = reads[k0 + k];
+            const float *from = b->packed ? b->sbuf[0].p + (size_t)b->v_slot[rd] * b->sbuf[0].rs + kSamplePad + (size_t)b->v_off[rd] * total_stride(m)
+                                          : b->sbuf[0].p + (size_t)rd * b->sbuf[0].rs + kSamplePad;
+            HIP_TRY(hipMemcpyAsync(sd->sbuf[0].p + (size_t)k * sd->sbuf[0].rs + kSamplePad, from, (size_t)lens[k] * 4, hipMemcpyDeviceToDevice, sd->stream), FFHIP_EHIP);
+        }
         sd->ran = sd->finished = 0;
         if (int rc = ffhip_batch_run(sd, b->last_temperature, (fl & ~(unsigned)FFHIP_RUN_KEEP_ACTS) | FFHIP_RUN_F32_RNN)) return rc;
         if (int rc = ffhip_batch_finish(sd)) return rc;
         hipStream_t s = b->stream;
         for (int k = 0; k < n; k++) {
-            const size_t r = (size_t)reads[k0 + k];
-            HIP_TRY(hipMemcpyAsync(b->trans + r * Tb * Ps, sd->trans + (size_t)k * Tb * Ps, Tb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            // this read's rows only (a packed batch: the rows behind them are the next read's), at its place in the batch's buffers
+            const size_t r = (size_t)reads[k0 + k], r0 = read_row0(b, (int)r), r1 = read_row1(b, (int)r), nb = (size_t)b->hTb[r], nb1 = nb + 1;
+            HIP_TRY(hipMemcpyAsync(b->trans + r0 * Ps, sd->trans + (size_t)k * Tb * Ps, nb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
             if (fl & FFHIP_RUN_NO_DECODE) continue;
-            if (!(fl & FFHIP_RUN_VITERBI_ONLY)) HIP_TRY(hipMemcpyAsync(b->post + r * Tb * Ps, sd->post + (size_t)k * Tb * Ps, Tb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
-            HIP_TRY(hipMemcpyAsync(b->path + r * L, sd->path + (size_t)k * L, L * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
-            HIP_TRY(hipMemcpyAsync(b->qpath + r * L, sd->qpath + (size_t)k * L, L * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            if (!(fl & FFHIP_RUN_VITERBI_ONLY)) HIP_TRY(hipMemcpyAsync(b->post + r0 * Ps, sd->post + (size_t)k * Tb * Ps, nb * Ps * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->path + r1, sd->path + (size_t)k * L, nb1 * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->qpath + r1, sd->qpath + (size_t)k * L, nb1 * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
             HIP_TRY(hipMemcpyAsync(b->score + r, sd->score + k, 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
-            HIP_TRY(hipMemcpyAsync(b->bases + r * L, sd->bases + (size_t)k * L, L, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
-            HIP_TRY(hipMemcpyAsync(b->quals + r * L, sd->quals + (size_t)k * L, L, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->bases + r1, sd->bases + (size_t)k * L, nb1, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            HIP_TRY(hipMemcpyAsync(b->quals + r1, sd->quals + (size_t)k * L, nb1, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
             HIP_TRY(hipMemcpyAsync(b->lens + r, sd->lens + k, 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
             if (!(fl & FFHIP_RUN_NO_TRACE) && m->kind != FFHIP_NET_LSTM5_RLE)
-                HIP_TRY(hipMemcpyAsync(b->trace + r * L * ns, sd->trace + (size_t)k * L * ns, L * ns * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
-            memcpy(b->h_bases + r * L, sd->h_bases + (size_t)k * L, L);
-            memcpy(b->h_quals + r * L, sd->h_quals + (size_t)k * L, L);
+                HIP_TRY(hipMemcpyAsync(b->trace + r1 * ns, sd->trace + (size_t)k * L * ns, nb1 * ns * 4, hipMemcpyDeviceToDevice, s), FFHIP_EHIP);
+            memcpy(b->h_bases + r1, sd->h_bases + (size_t)k * L, nb1);
+            memcpy(b->h_quals + r1, sd->h_quals + (size_t)k * L, nb1);
             b->h_lens[r] = sd->h_lens[k];
             b->h_score[r] = sd->h_score[k];
         }
@@ -1526,7 +1800,7 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
     if (b->counted) { b->counted = 0; b->eng->in_flight--; }
     HIP_TRY(hipGetLastError(), FFHIP_EHIP);
     if (*b->h_abort != 0) {
-        if ((b->last_flags & FFHIP_RUN_STEPWISE_RNN) || getenv("FFHIP_NO_FALLBACK"))
+        if ((b->last_flags & FFHIP_RUN_STEPWISE_RNN) || getenv("FFHIP_NO_FALLBACK") || b->packed)      // (a packed batch has no launch-per-step form: the caller sets its reads again, one to a row)
             return set_err(FFHIP_ETIMEOUT, "persistent recurrent kernel: an inter-workgroup wait timed out; results are invalid");
         // Not every workgroup of a persistent layer launch became resident -- something else holds part of the GPU.  The
         // launch-per-step kernels have no such requirement: run this batch again on them, and stay there for a while.
@@ -1539,11 +1813,13 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         if (rc != FFHIP_OK) return rc;
         return ffhip_batch_finish(b);
     }
+    if (b->packed && b->h_abort[2] != 0) return set_err(FFHIP_EINVAL, "packed batch: a read's convolution columns take more than two windows (not a shape of the reference's models)");
     b->finished = 1;
     b->reruns = 0;
     if (!b->is_side) {
         std::vector<int> over;
-        for (int r = 0; r < b->nread; r++) if (b->h_sat[r] && b->hT[r] > 0) over.push_back(r);
+        if (b->packed) { for (int v = 0; v < b->nvirt; v++) if (b->h_sat[b->v_slot[v]]) over.push_back(v); }      // (the flag is the row's: every read of it goes again)
+        else for (int r = 0; r < b->nread; r++) if (b->h_sat[r] && b->hT[r] > 0) over.push_back(r);
         if (!over.empty()) if (int rc = rerun_on_f32_path(b, over)) { b->finished = 0; return rc; }
     }
     return FFHIP_OK;
@@ -1553,7 +1829,7 @@ extern "C" int ffhip_batch_f32_reruns(const ffhip_batch *b) { return b ? b->reru
 extern "C" unsigned long long ffhip_engine_f32_reruns(const ffhip_engine *eng) { return eng ? eng->f32_reruns : 0; }
 
 static bool results_ok(const ffhip_batch *b, int read) {
-    if (!b || !b->finished || read < 0 || read >= b->nread) { set_err(FFHIP_EINVAL, "results not available (finish the batch, check the read index)"); return false; }
+    if (!b || !b->finished || read < 0 || read >= batch_nreads(b)) { set_err(FFHIP_EINVAL, "results not available (finish the batch, check the read index)"); return false; }
     if (b->hTb[read] == 0) { set_err(FFHIP_EINVAL, "slot %d of the batch is empty", read); return false; }
     return true;
 }
@@ -1561,11 +1837,11 @@ static bool results_ok(const ffhip_batch *b, int read) {
 extern "C" const char *ffhip_batch_basecall(const ffhip_batch *b, int read, size_t *length) {
     if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return nullptr;
     if (length) *length = (size_t)b->h_lens[read];
-    return b->h_bases + (size_t)read * (b->Tb + 1);
+    return b->h_bases + read_row1(b, read);
 }
 extern "C" const char *ffhip_batch_quality(const ffhip_batch *b, int read) {
     if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return nullptr;
-    return b->h_quals + (size_t)read * (b->Tb + 1);
+    return b->h_quals + read_row1(b, read);
 }
 extern "C" float ffhip_batch_score(const ffhip_batch *b, int read) {
     if (!results_ok(b, read) || (b->last_flags & FFHIP_RUN_NO_DECODE)) return NAN;
@@ -1581,19 +1857,19 @@ static int d2h(ffhip_batch *b, void *dst, const void *src, size_t bytes) {
 
 extern "C" int ffhip_batch_get_path(ffhip_batch *b, int read, int *path, float *qpath) {
     if (!results_ok(b, read)) return FFHIP_EINVAL;
-    const size_t L = (size_t)b->Tb + 1, n = (size_t)b->hTb[read] + 1;      // stride / this read's entries
-    if (path) if (int rc = d2h(b, path, b->path + (size_t)read * L, n * 4)) return rc;
-    if (qpath) if (int rc = d2h(b, qpath, b->qpath + (size_t)read * L, n * 4)) return rc;
+    const size_t n = (size_t)b->hTb[read] + 1;      // this read's entries
+    if (path) if (int rc = d2h(b, path, b->path + read_row1(b, read), n * 4)) return rc;
+    if (qpath) if (int rc = d2h(b, qpath, b->qpath + read_row1(b, read), n * 4)) return rc;
     return FFHIP_OK;
 }
 
 static int get_scores(ffhip_batch *b, const float *src, int read, float *out) {
     if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
     const ffhip_model *m = b->mdl;
-    const size_t Tb = b->Tb, nb = b->hTb[read];             // stride / this read's blocks
-    if (m->Ps == m->P) return d2h(b, out, src + (size_t)read * Tb * m->Ps, nb * m->P * 4);
+    const size_t nb = b->hTb[read];             // this read's blocks
+    if (m->Ps == m->P) return d2h(b, out, src + read_row0(b, read) * m->Ps, nb * m->P * 4);
     std::vector<float> tmp(nb * m->Ps);
-    if (int rc = d2h(b, tmp.data(), src + (size_t)read * Tb * m->Ps, tmp.size() * 4)) return rc;
+    if (int rc = d2h(b, tmp.data(), src + read_row0(b, read) * m->Ps, tmp.size() * 4)) return rc;
     for (size_t c = 0; c < nb; c++) memcpy(out + c * m->P, tmp.data() + c * m->Ps, (size_t)m->P * 4);
     return FFHIP_OK;
 }
@@ -1606,7 +1882,7 @@ extern "C" int ffhip_batch_transitions_to(ffhip_batch *b, int read, ffhip_mat ou
     hipSetDevice(b->eng->device);
     if (!*out.dev && !(*out.dev = pool_get(nb * m->Ps * 4))) return set_err(FFHIP_ENOMEM, "device allocation failed");
     // the batch holds read r's scores as [block][Ps]: the matrix image itself
-    HIP_TRY(hipMemcpyAsync(*out.dev, b->trans + (size_t)read * b->Tb * m->Ps, nb * m->Ps * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
+    HIP_TRY(hipMemcpyAsync(*out.dev, b->trans + read_row0(b, read) * m->Ps, nb * m->Ps * 4, hipMemcpyDeviceToDevice, b->stream), FFHIP_EHIP);
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     *out.dev_state = 2;
     return FFHIP_OK;
@@ -1618,12 +1894,12 @@ extern "C" int ffhip_batch_get_posterior(ffhip_batch *b, int read, float *out) {
 extern "C" int ffhip_batch_get_trace(ffhip_batch *b, int read, int32_t *out) {
     if (!results_ok(b, read) || !out) return FFHIP_EINVAL;
     if ((b->last_flags & (FFHIP_RUN_NO_TRACE | FFHIP_RUN_NO_DECODE)) || b->mdl->kind == FFHIP_NET_LSTM5_RLE) return set_err(FFHIP_EINVAL, "trace was not computed in this run");
-    const size_t n = ((size_t)b->Tb + 1) * b->mdl->nstate;
-    return d2h(b, out, b->trace + (size_t)read * n, ((size_t)b->hTb[read] + 1) * b->mdl->nstate * 4);
+    return d2h(b, out, b->trace + read_row1(b, read) * b->mdl->nstate, ((size_t)b->hTb[read] + 1) * b->mdl->nstate * 4);
 }
 
 extern "C" int ffhip_batch_get_activation(ffhip_batch *b, int layer, int read, float *out) {
     if (!results_ok(b, read) || !out || layer < -1 || layer > 4) return FFHIP_EINVAL;
+    if (b->packed) return set_err(FFHIP_EINVAL, "a packed batch keeps no activations");
     const ffhip_model *m = b->mdl;
     const float *src = b->keep[layer + 1];
     if (!src) {

@@ -50,6 +50,17 @@ struct SampleBuf {                 // sample-major activation buffer
 
 enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_TANH = 2 };
 
+// Packed batches (round 6; ffhip_batch_set_prepared_packed): several reads stand one behind the other in a slot (a row of the batch's buffers), so that a batch of reads
+// of any lengths costs what its samples cost.  The convolutions, the layer kernels and the CRF head work on SLOTS (window tables / a live mask say where the reads are);
+// everything per READ -- chains, Viterbi, assembly, trace -- takes the read's first row in the buffers of Tb rows a slot (b0) and of Tb + 1 rows a slot (b1).
+// Both nullptr: one read a slot, read r is row r.
+struct ReadMap {
+    const int *b0 = nullptr, *b1 = nullptr;
+    int nslot = 0;
+    __device__ __forceinline__ size_t row0(int read, int TbS) const { return b0 ? (size_t)b0[read] : (size_t)read * (size_t)TbS; }
+    __device__ __forceinline__ size_t row1(int read, int TbS) const { return b1 ? (size_t)b1[read] : (size_t)read * (size_t)(TbS + 1); }
+};
+
 // ---- kernel launchers (ffhip_kernels.hip) ----------------------------------------------------
 void launch_pack_signal(hipStream_t s, const float *src, size_t ld, SampleBuf dst, int nread);
 
@@ -58,7 +69,8 @@ void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *
                        const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp = 0,     // ldp: entries per read of a per-read window table (0 = shared)
                        const int *tin = nullptr,                                  // stride-1 layer of a ragged batch: per-read input lengths instead of a table
                        int split_exp = -100000,                                   // > -1000 (16 output features): write fp16 slices of value * 2^split_exp for launch_conv_split
-                       unsigned *sat = nullptr);                                  // per-read word set to 1 when a value leaves the split format's range (ffhip_split.hpp: clamped there; the engine re-runs such a read on the f32 path)
+                       unsigned *sat = nullptr,                                   // per-read word set to 1 when a value leaves the split format's range (ffhip_split.hpp: clamped there; the engine re-runs such a read on the f32 path)
+                       const int *seg = nullptr);                                 // stride-1 layer of a packed batch: [Bp + 1] offsets, then every row's sorted read boundaries {start, end, ...} in columns
 
 // MFMA convolution of the last conv layer: sample-major in, tile-interleaved out [Tout][B16][M/4][16][4]
 void launch_conv_mfma(hipStream_t s, SampleBuf in, float *out, const float4 *Wp, const float *bias,
@@ -95,7 +107,10 @@ int persist_blocks_per_cu(int kind, int H);
 
 // persistent LSTM layer on bf16 MFMAs over three-way split operands (ffhip_rnn_split.hip): fp32-exact products at 2.7x
 // the f32 MFMA rate.  Activations in the SPLIT layout A[t][rt][k/32][slice 0..2][lane][8 bf16] (6 bytes per value).
-void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow);
+void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow, const long long *dst_off = nullptr);
+// packed batches: the strided convolution's window table / the layer kernels' live mask from per-read records (ffhip_kernels.hip)
+void launch_pack_conv_table(hipStream_t s, const int4 *reads, int nread, int maxcols, int winlen, int stride, int Tmax, int *x0a, int *x0b, unsigned *overflow);
+void launch_pack_live(hipStream_t s, const int4 *reads, int nread, int maxblocks, int B16, unsigned *live);
 bool split_supported(int kind, int H);
 int split_launch_workgroups(int kind, int H, int nrt, int ncu, int beside);      // workgroups of one launch of nrt read tiles ...
 int split_workgroups_per_cu(int kind, int H, int nrt, int ncu, int beside);      // ... and how many of them share a CU
@@ -107,11 +122,12 @@ inline size_t split_bytes(size_t ntile, int H) { return ntile * (size_t)H * 32 *
 struct SplitLaunch {          // one batch's share of a paired layer launch
     const void *Wp; const float *bias; const void *xin; void *hout; float *hout_f32; unsigned *flags, *abort_word;
     int Tb, B16, rt0, nrt, backward, mode, scale_exp, fast_gates; const int *tbs, *tbt; unsigned epoch;
+    const unsigned *live = nullptr;      // packed batch: bit r of word [t][read tile] = slot r holds a block of a read at step t (ffhip_rnn_split.hip SplitArgs)
 };
 bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const SplitLaunch &p0, const SplitLaunch &p1);
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside);      // scale_exp: the exponent S both products carry
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside, const unsigned *live = nullptr);      // scale_exp: the exponent S both products carry; live: packed batch (SplitLaunch)
 // recurrence-only layer kernel on split operands behind launch_inproj_split (LSTM, H = 256 / 512): xa as from launch_inproj_split
 bool rnn_split_supported(int kind, int H);
 bool launch_rnn_split(hipStream_t s, const void *Wsplit, const float *xa, void *hout, float *hout_f32, unsigned *flags, unsigned *abort_word,
@@ -158,18 +174,18 @@ void launch_rle_partition8x(hipStream_t s, const float *param, double *logz, int
 void launch_rle_post8(hipStream_t s, const float *param, float *post, double *E, double *fwd, int nread, int Tb, const int *tbs);
 // ffhip_decode.hip: partition function (+ subtraction, flags & 1) and posterior (flags & 2) of 8- or 10-state reads from E in one launch; fwd = 2*nread*(Tb+1)*(2*nbase) doubles
 void launch_crf_fb(hipStream_t s, int nbase, const double *E, float *trans, float *post, double *fwd, int nread, int Tb, double *logz, const int *tbs,
-                    int flags, const int *wide);
-void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
+                    int flags, const int *wide, ReadMap map = ReadMap());
+void launch_viterbi10x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs, ReadMap map = ReadMap());
 void launch_rle_viterbi8x(hipStream_t s, const float *param, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
-void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs);
+void launch_viterbi8x(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score, int nread, int Tb, const int *tbs, ReadMap map = ReadMap());
 // Viterbi + traceback + qpath
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
-                    int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr);
+                    int nread, int Tb, int nbase, int Ps, const int *tbs = nullptr, ReadMap map = ReadMap());
 // change positions -> base / quality strings
 void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
-                     int nread, int Tb, int nbase, const int *tbs = nullptr);
+                     int nread, int Tb, int nbase, const int *tbs = nullptr, ReadMap map = ReadMap());
 // exp + trace_from_posterior
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs = nullptr);
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs = nullptr, ReadMap map = ReadMap());
 void launch_exp_inplace(hipStream_t s, float *x, size_t n);
 // run-length (runnie) head and decoders, ffhip_rle.hip: activation rows + runlengthV2 partition function + subtraction
 void launch_rle_head_finish(hipStream_t s, float *param, double *logz, int nread, int Tb, int nbase, int Ps, float temperature, const int *tbs = nullptr);

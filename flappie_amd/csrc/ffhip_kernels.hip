@@ -64,7 +64,7 @@ template <int MAXF, int KT = 0>
 __global__ void __launch_bounds__(256)
 k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const float *__restrict__ bias,
              const int *__restrict__ x0a, const int *__restrict__ x0b, int Tout, int winlen, int act, int ldp,
-             const int *__restrict__ tin, float split_scale, unsigned *__restrict__ sat) {
+             const int *__restrict__ tin, float split_scale, unsigned *__restrict__ sat, const int *__restrict__ seg) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];          // [Fout][winlen*Fin] (KT > 0: [winlen*Fin][Fout]) then bias [Fout]
     const int Fin = in.F, Fout = KT > 0 ? MAXF : out.F, K = KT > 0 ? KT : winlen * Fin;
     if (KT > 0) for (int i = threadIdx.x; i < Fout * K; i += blockDim.x) w_lds[(i % K) * MAXF + i / K] = W[i];
@@ -81,7 +81,14 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
     // tin (stride-1 layers of a ragged batch): per-read input length; the window of column c starts at c - padL
     // (layers.c:216-271 degenerates to the zero-padded "same" convolution for stride 1), zeros beyond the read
     int xs[2];
-    if (tin) { xs[0] = (c < tin[r]) ? c - (winlen - 1) / 2 : kZeroCol; xs[1] = kNoWindow; }
+    if (seg) {
+        // stride-1 layer of a PACKED batch (several reads one behind the other in this row): seg[r] .. seg[r + 1] delimit the row's sorted read boundaries
+        // {start, end, start, end, ...} behind the table's Bp + 1 offsets; column c belongs to a read iff an odd number of them is <= c
+        int lo = seg[r], hi = seg[r + 1];
+        const int first = lo;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg[mid] <= c) lo = mid + 1; else hi = mid; }
+        xs[0] = ((lo - first) & 1) ? c - (winlen - 1) / 2 : kZeroCol; xs[1] = kNoWindow;
+    } else if (tin) { xs[0] = (c < tin[r]) ? c - (winlen - 1) / 2 : kZeroCol; xs[1] = kNoWindow; }
     else { xs[0] = x0a[(size_t)r * ldp + c]; xs[1] = x0b[(size_t)r * ldp + c]; }
     if (xs[0] == kZeroCol) {                     // beyond this read's end: the next layer must see zero padding there
         float *o0 = out.p + (size_t)r * out.rs + (size_t)(kSamplePad + c) * Fout;
@@ -164,22 +171,22 @@ k_conv_small(SampleBuf in, SampleBuf out, const float *__restrict__ W, const flo
 }
 
 void launch_conv_small(hipStream_t s, SampleBuf in, SampleBuf out, const float *W, const float *bias,
-                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin, int split_exp, unsigned *sat) {
+                       const int *x0a, const int *x0b, int Bp, int Tout, int winlen, int act, int ldp, const int *tin, int split_exp, unsigned *sat, const int *seg) {
     dim3 grid((Tout + 255) / 256, Bp), block(256);
     const float split_scale = (split_exp > -1000 && out.F == 16 && kSplitNS == 2) ? split_pow2(split_exp) : 0.0f;
     const size_t lds = (size_t)(out.F * winlen * in.F + out.F) * sizeof(float);
     const char *su_env = dbg("conv_small_u");
     const bool unrolled = !(su_env && su_env[0] == '0');      // (=0: the round-3 loops, for comparison)
     if (unrolled && out.F == 4 && in.F == 1 && winlen == 5)
-        hipLaunchKernelGGL((k_conv_small<4, 5>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
+        hipLaunchKernelGGL((k_conv_small<4, 5>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat, seg);
     else if (unrolled && out.F == 16 && in.F == 4 && winlen == 5)
-        hipLaunchKernelGGL((k_conv_small<16, 20>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat);
+        hipLaunchKernelGGL((k_conv_small<16, 20>), grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat, seg);
     else if (out.F <= 4)
-        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
+        hipLaunchKernelGGL(k_conv_small<4>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat, seg);
     else if (out.F <= 16)
-        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat);
+        hipLaunchKernelGGL(k_conv_small<16>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, split_scale, sat, seg);
     else
-        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat);
+        hipLaunchKernelGGL(k_conv_small<32>, grid, block, lds, s, in, out, W, bias, x0a, x0b, Tout, winlen, act, ldp, tin, 0.0f, sat, seg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2316,14 +2323,14 @@ k_viterbi10(const float *__restrict__ M, uint8_t *__restrict__ tbbuf, int *__res
 }
 
 void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *path, float *qpath, float *score,
-                    int nread, int Tb, int nbase, int Ps, const int *tbs) {
+                    int nread, int Tb, int nbase, int Ps, const int *tbs, ReadMap map) {
     const int P = 2 * nbase * (nbase + 1);
     if (nbase == 4 && Ps == 40 && !dbg("decode_r2"))
-        launch_viterbi8x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
+        launch_viterbi8x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs, map);
     else if (nbase == 4 && Ps == 40)
         hipLaunchKernelGGL(k_viterbi8, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, tbs);
     else if (nbase == 5 && Ps == 60 && !dbg("exact_order") && !dbg("decode_r2"))
-        launch_viterbi10x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs);
+        launch_viterbi10x(s, score_mat, tb, path, qpath, score, nread, Tb, tbs, map);
     else if (nbase == 5 && !dbg("exact_order"))
         hipLaunchKernelGGL(k_viterbi10, dim3(nread), dim3(64), 0, s, score_mat, tb, path, qpath, score, Tb, Ps, tbs);
     else
@@ -2335,13 +2342,14 @@ void launch_viterbi(hipStream_t s, const float *score_mat, uint8_t *tb, int *pat
 // path[nblock] and the base of path[0] are never emitted, as in the reference.
 __global__ void __launch_bounds__(64)
 k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *__restrict__ bases,
-           char *__restrict__ quals, int *__restrict__ lens, int TbS, int nbase, const int *__restrict__ tbs) {
+           char *__restrict__ quals, int *__restrict__ lens, int TbS, int nbase, const int *__restrict__ tbs, ReadMap map) {
     FFHIP_DECODE_PRIO_SET();
     const int lane = threadIdx.x;
-    const int *pth = path + (size_t)blockIdx.x * (TbS + 1);
-    const float *qp = qpath + (size_t)blockIdx.x * (TbS + 1);
-    char *bs = bases + (size_t)blockIdx.x * (TbS + 1);
-    char *qs = quals + (size_t)blockIdx.x * (TbS + 1);
+    const size_t r1 = map.row1(blockIdx.x, TbS);
+    const int *pth = path + r1;
+    const float *qp = qpath + r1;
+    char *bs = bases + r1;
+    char *qs = quals + r1;
     const int Tb = tbs ? tbs[blockIdx.x] : TbS;          // this read's blocks; TbS is the batch's stride
     if (Tb <= 0) return;                                 // an empty slot: nothing to read, and Tb - 1 must not index
     int count = 0;
@@ -2367,8 +2375,8 @@ k_assemble(const int *__restrict__ path, const float *__restrict__ qpath, char *
 }
 
 void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *bases, char *quals, int *lens,
-                     int nread, int Tb, int nbase, const int *tbs) {
-    hipLaunchKernelGGL(k_assemble, dim3(nread), dim3(64), 0, s, path, qpath, bases, quals, lens, Tb, nbase, tbs);
+                     int nread, int Tb, int nbase, const int *tbs, ReadMap map) {
+    hipLaunchKernelGGL(k_assemble, dim3(nread), dim3(64), 0, s, path, qpath, bases, quals, lens, Tb, nbase, tbs, map);
 }
 
 // ---- trace --------------------------------------------------------------------------------------
@@ -2379,11 +2387,11 @@ void launch_assemble(hipStream_t s, const int *path, const float *qpath, char *b
 // every thread evaluates ns + 2 exponentials.  (One thread per entry, as before round 4, put ns-term and 2-term sums in the same wave: every wave walked
 // both loops at full length; same sums in the same order here, 0.31 -> 0.25 ms for a 1024-read 10-state batch beside the next batch's convolution.)
 __global__ void __launch_bounds__(256)
-k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int TbS, int nbase, int P, int Ps, int is_log, const int *__restrict__ tbs) {
+k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int TbS, int nbase, int P, int Ps, int is_log, const int *__restrict__ tbs, ReadMap map) {
     FFHIP_DECODE_PRIO_SET();
     const int ns = 2 * nbase, off = nbase * ns;
-    const float *Pp = post + (size_t)blockIdx.y * TbS * Ps;
-    int32_t *tr = trace + (size_t)blockIdx.y * (TbS + 1) * ns;
+    const float *Pp = post + map.row0(blockIdx.y, TbS) * Ps;
+    int32_t *tr = trace + map.row1(blockIdx.y, TbS) * ns;
     const int Tb = tbs ? tbs[blockIdx.y] : TbS;          // this read's blocks; TbS is the batch's stride
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (column, flip state)
     if (i >= (Tb + 1) * nbase) return;
@@ -2405,10 +2413,10 @@ k_trace(const float *__restrict__ post, int32_t *__restrict__ trace, int TbS, in
     tr[col * ns + nbase + j] = (int32_t)roundf(255.0f * flop);
 }
 
-void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs) {
+void launch_trace(hipStream_t s, const float *post, int32_t *trace, int nread, int Tb, int nbase, int Ps, int is_log, const int *tbs, ReadMap map) {
     const int P = 2 * nbase * (nbase + 1);
     const int n = (Tb + 1) * nbase;
-    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps, is_log, tbs);
+    hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256, nread), dim3(256), 0, s, post, trace, Tb, nbase, P, Ps, is_log, tbs, map);
 }
 
 // exp_activation_inplace (layers.c:56-66) on the meaningful rows
@@ -2434,14 +2442,58 @@ void launch_untile(hipStream_t s, const float *act, float *dense, int read, int 
 }
 
 // ---- rows of different lengths from anywhere on the device into the batch's signal buffer (ffhip_batch_set_prepared) ----
-__global__ void __launch_bounds__(256) k_gather_rows(const float *const *__restrict__ src, const int *__restrict__ lens, float *__restrict__ dst, size_t row_stride) {
+// (dst_off, packed batches: where read r's first sample goes, in floats from dst -- its slot's row and its place in it)
+__global__ void __launch_bounds__(256) k_gather_rows(const float *const *__restrict__ src, const int *__restrict__ lens, float *__restrict__ dst, size_t row_stride,
+                                                     const long long *__restrict__ dst_off) {
     const float *s = src[blockIdx.x];
     const int n = lens[blockIdx.x];
-    float *d = dst + (size_t)blockIdx.x * row_stride;
+    float *d = dst + (dst_off ? (size_t)dst_off[blockIdx.x] : (size_t)blockIdx.x * row_stride);
     for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i];
 }
-void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow) {
-    hipLaunchKernelGGL(k_gather_rows, dim3(nrow), dim3(256), 0, s, src, lens, dst, row_stride);
+void launch_gather_rows(hipStream_t s, const float *const *src, const int *lens, float *dst, size_t row_stride, int nrow, const long long *dst_off) {
+    hipLaunchKernelGGL(k_gather_rows, dim3(nrow), dim3(256), 0, s, src, lens, dst, row_stride, dst_off);
+}
+
+// ---- packed batches: the strided convolution's window table and the layer kernels' live mask, built on the device (a 512-row batch of 200 000-sample rows has
+// 2 x 84 MB of table: filled and uploaded by the host it cost 0.4 s a batch) ------------------------------------------------------------------------------------
+// build_conv_plan (ffhip_engine.hip: the reference's three regions, layers.c:216-271, in index space) evaluated COLUMN BY COLUMN: the candidates of column c in the
+// order the host function adds them -- left edge, the window phases w = 0, s, 2 s ..., right edge -- the first two are the column's windows, a third sets *overflow.
+// reads[v] = { row, first column of the read in its row, first input sample of the read in its row, input samples }.
+__global__ void __launch_bounds__(256) k_pack_conv_table(const int4 *__restrict__ reads, int winlen, int s, int Tmax, int *__restrict__ x0a, int *__restrict__ x0b,
+                                                         unsigned *__restrict__ overflow) {
+    const int4 rd = reads[blockIdx.y];
+    const int T = rd.w, c = blockIdx.x * 256 + threadIdx.x;
+    const int padL = (winlen - 1) / 2, padR = winlen / 2, Tout = (T + s - 1) / s;
+    if (c >= Tout) return;
+    const int ncolsL = (padL + s - 1) / s, shiftX = ncolsL * s - padL, nstepC = (winlen + s - 1) / s, nstepX = s * nstepC;
+    int a = kNoWindow, b = kNoWindow;
+    bool over = false;
+    auto add = [&](int x0) { if (a == kNoWindow) a = x0; else if (b == kNoWindow) b = x0; else over = true; };
+    if (c * s < padL) add(c * s - padL);
+    for (int w = 0; w < winlen; w += s) {
+        const int d = c - (ncolsL + w / s);
+        if (d >= 0 && d % nstepC == 0 && d / nstepC < (T - shiftX - w) / nstepX) add(shiftX + w + nstepX * (d / nstepC));
+    }
+    const int maxCol = (T - shiftX) / nstepX, rem = (T - shiftX) % nstepX;
+    const int colR = ncolsL + nstepC * (maxCol - 1) + rem / s + 1, startR = s - (padL + T - winlen) % s - 1;
+    for (int w = startR; w < padR; w += s)
+        if (colR + w / s == c) add(T - winlen + 1 + w);
+    const size_t at = (size_t)rd.x * Tmax + rd.y + c;
+    x0a[at] = (a == kNoWindow) ? kNoWindow : a + rd.z;
+    x0b[at] = (b == kNoWindow) ? kNoWindow : b + rd.z;
+    if (over) *overflow = 1u;
+}
+// live[t][read tile] |= bit of the row, for every block of every read.  reads[v] = { row, first block, blocks, - }
+__global__ void __launch_bounds__(256) k_pack_live(const int4 *__restrict__ reads, int B16, unsigned *__restrict__ live) {
+    const int4 rd = reads[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < rd.z) atomicOr(live + (size_t)(rd.y + t) * B16 + (rd.x >> 4), 1u << (rd.x & 15));
+}
+void launch_pack_conv_table(hipStream_t s, const int4 *reads, int nread, int maxcols, int winlen, int stride, int Tmax, int *x0a, int *x0b, unsigned *overflow) {
+    if (nread > 0) hipLaunchKernelGGL(k_pack_conv_table, dim3((maxcols + 255) / 256, nread), dim3(256), 0, s, reads, winlen, stride, Tmax, x0a, x0b, overflow);
+}
+void launch_pack_live(hipStream_t s, const int4 *reads, int nread, int maxblocks, int B16, unsigned *live) {
+    if (nread > 0) hipLaunchKernelGGL(k_pack_live, dim3((maxblocks + 255) / 256, nread), dim3(256), 0, s, reads, B16, live);
 }
 
 }  // namespace ffhip

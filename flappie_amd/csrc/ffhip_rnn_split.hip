@@ -83,11 +83,14 @@ struct SplitArgs {
     int fast_gates;           // FFHIP_RUN_FAST_GATES: hardware exp / reciprocal in the gate phase (ffhip_math.hpp logistic_hw)
     int split_gate;           // LSTM, N = 3, pairs: gate tiles 4 and 5 are each worked by TWO x waves on different SIMDs (front / back)
     const int *tbs, *tbt;     // ragged batch (see PersistArgs)
+    const unsigned *live;     // packed batch (several reads one behind the other in a slot, ffhip_batch_set_prepared_packed): word [t][read tile], bit r = slot r of the
+                              // tile holds a block of a read at step t; elsewhere -- the gaps between two reads, the tail of a slot -- h and c are forced to zero, which is
+                              // the next read's zero start in EITHER direction.  nullptr: one read a slot, dead beyond tbs[]
     unsigned long long *dbg;
 };
 
 struct SplitArgsOther {       // what the second batch of a paired launch brings of its own (k_lstm_split_pair)
-    const unsigned char *xin; unsigned char *hout; float *hout_f32; unsigned *flags, *abort_word; const int *tbs, *tbt; unsigned epoch; int nwg0;
+    const unsigned char *xin; unsigned char *hout; float *hout_f32; unsigned *flags, *abort_word; const int *tbs, *tbt; const unsigned *live; unsigned epoch; int nwg0;
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -190,7 +193,7 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 // tile row 4 q + c is unit 4 c + q, so that lane (q, read) of a tile's accumulator holds units q, 4 + q, 8 + q, 12 + q in its components: gate wave
 // (tile ts, component c) reads component c of the three gates and is, for the arithmetic and for the split / transpose / store of h(t), exactly
 // the 4-unit gate tile (units 4 c .. 4 c + 3) of the other forms.  The candidate's projection half travels as a fourth partial tile.
-template <int KIND, int N, int TS, bool DN, bool PACK = false>
+template <int KIND, int N, int TS, bool DN, bool PACK = false, bool LIVE = false>      // LIVE: the packed-batch forms (a.live; their own instantiations: the one-read-a-row kernels stay instruction for instruction what they were)
 __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int block_index) {
     static_assert(!DN || TS == 2, "the dense form is a pair form");
     static_assert(!PACK || (DN && N == 2), "the packed forms are dense forms at H = 256");
@@ -547,6 +550,24 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
     int my_tb = 0;
     if (gate_wave || sg_front || sg_back) my_tb = a.tbs ? a.tbs[(rtA + my_gts) * 16 + rl] : a.Tb;
     float c = 0.0f;
+    // Packed batch: this wave's gate tile is live at step i where its bit of live[t][read tile] is set.  One SCALAR load a step and gate wave, issued and waited for
+    // at the top of the step (the h waves stand in their hand-off poll there, the x waves have slack) -- a vector load would join the counted vmcnt waits of the sweep.
+    // The word becomes the bound the gate functions compare t with: everything (never dead) or nothing (dead), so that their code is the one-read-a-slot code.
+    // (the word stays in a scalar register across the matrix phase; the lane's bound is formed in the gate phase)
+    auto live_word = [&](int i) -> unsigned {
+        unsigned w = 0u;
+        if constexpr (LIVE) {
+            const unsigned *lp = a.live + ((size_t)step_t(i) * a.B16 + (rtA + my_gts));
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(lp) : "memory");
+        }
+        return w;
+    };
+    auto tb_of = [&](unsigned w) -> int {
+        if constexpr (!LIVE) return my_tb;
+        unsigned lv = (unsigned)lane;
+        asm volatile("" : "+v"(lv));
+        return ((w >> (lv & 15u)) & 1u) ? 0x7fffffff : 0;
+    };
 
     // The two roles run their own step loop (two barriers per step each), so that the register allocator sees each
     // role's live ranges alone.
@@ -649,6 +670,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
             TL(0);
+            const unsigned lw = live_word(i);
             if (i + 1 < Tb) project_step(i + 1, i + 1);
             sink ^= touched;
             touch_x(i + WARM);
@@ -658,15 +680,15 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             const int aborted = LDSV(lds_abort);      // (looked at behind the gate math: see the h waves' loop)
             if (sg_front) {
                 __builtin_amdgcn_s_setprio(3);
-                gate_front(i, my_gts, my_gj, c, my_tb);
+                gate_front(i, my_gts, my_gj, c, tb_of(lw));
                 __builtin_amdgcn_s_setprio(0);
             } else if (sg_back) {
                 __builtin_amdgcn_s_setprio(3);           // (the back half publishes the tile's h(t): as much on the step's chain as the front half; -1.3 % launch time at c2)
-                gate_back(i, my_gts, my_gj, my_tb);
+                gate_back(i, my_gts, my_gj, tb_of(lw));
                 __builtin_amdgcn_s_setprio(0);
             } else if (gate_wave) {
                 if (PACK) __builtin_amdgcn_s_setprio(3);      // every wave works a gate job: the x waves' at the h waves' priority (-1.7 %)
-                gate_tile(i, my_gts, my_gj, c, my_tb);
+                gate_tile(i, my_gts, my_gj, c, tb_of(lw));
                 if (PACK) __builtin_amdgcn_s_setprio(0);
             }
             if (aborted) return;
@@ -733,6 +755,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         raw_barrier();                                       // px(0) is in LDS before any h wave starts from it
         for (int i = 0; i < Tb; i++) {
             TL(0);
+            const unsigned lw = live_word(i);
             if (i + 1 < Tb) {
                 project(i + 1);
                 if (i + 2 < Tb) load_x(i + 2);
@@ -747,10 +770,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                                                              // compile time, so that no gate temporaries are live beside the prefetch)
                 if (sg_front) {
                     __builtin_amdgcn_s_setprio(3);           // the back wave (and with it the closing barrier) waits for this c(t)
-                    gate_front(i, my_gts, my_gj, c, my_tb);
+                    gate_front(i, my_gts, my_gj, c, tb_of(lw));
                     __builtin_amdgcn_s_setprio(0);
-                } else if (sg_back) gate_back(i, my_gts, my_gj, my_tb);
-                else if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+                } else if (sg_back) gate_back(i, my_gts, my_gj, tb_of(lw));
+                else if (gate_wave) gate_tile(i, my_gts, my_gj, c, tb_of(lw));
             }
             if (aborted) return;
             TL(4);
@@ -770,6 +793,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         raw_barrier();                                        // matches the x waves' prologue barrier
         for (int i = 0; i < Tb; i++) {
             TL(0);
+            const unsigned lw = live_word(i);
             v4f acc[TS][N];
             auto init_acc = [&]() {
 #pragma unroll
@@ -1015,7 +1039,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             // (the abort word is read here and looked at BEHIND the gate math: a read-wait-branch in front of it is ~100 cycles on the
             // chain of every step; results of an aborted launch are discarded anyway)
             const int aborted = LDSV(lds_abort);
-            if (gate_wave) gate_tile(i, my_gts, my_gj, c, my_tb);
+            if (gate_wave) gate_tile(i, my_gts, my_gj, c, tb_of(lw));
             if (aborted) return;
             TL(4);
             // close the gate phase before ph is rewritten (and before the x waves' MFMAs start next to gate VALU work)
@@ -1033,28 +1057,30 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #endif
 }
 
-template <int KIND, int N, int TS, bool DN = false>
+template <int KIND, int N, int TS, bool DN = false, bool LIVE = false>
 __global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
-k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN>(a, (int)blockIdx.x); }
+k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN, false, LIVE>(a, (int)blockIdx.x); }
 
 // the packed GRUmod form (H = 256): 128 registers, two workgroups a CU, 16 members a group
+template <bool LIVE>
 __global__ void __launch_bounds__(512, 4)
-k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true>(a, (int)blockIdx.x); }
+k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true, LIVE>(a, (int)blockIdx.x); }
+template <bool LIVE>
 __global__ void __launch_bounds__(512, 4)
-k_lstm_pack(SplitArgs a) { lstm_split_body<0, 2, 2, true, true>(a, (int)blockIdx.x); }
+k_lstm_pack(SplitArgs a) { lstm_split_body<0, 2, 2, true, true, LIVE>(a, (int)blockIdx.x); }
 
 // The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
 // others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
 // For the dense form at H = 384: 2 x 256 reads = 16 groups = two workgroups on every CU, and ONE launch whose duration is the pair's.
-template <int KIND, int N, int TS, bool DN>
+template <int KIND, int N, int TS, bool DN, bool LIVE = false>
 __global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
 k_lstm_split_pair(SplitArgs a, SplitArgsOther o) {
     int bi = (int)blockIdx.x;
     if (bi >= o.nwg0) {                                           // uniform: the second batch differs in its buffers only (same model, same shape)
         bi -= o.nwg0;
-        a.xin = o.xin; a.hout = o.hout; a.hout_f32 = o.hout_f32; a.flags = o.flags; a.abort_word = o.abort_word; a.tbs = o.tbs; a.tbt = o.tbt; a.epoch = o.epoch;
+        a.xin = o.xin; a.hout = o.hout; a.hout_f32 = o.hout_f32; a.flags = o.flags; a.abort_word = o.abort_word; a.tbs = o.tbs; a.tbt = o.tbt; a.live = o.live; a.epoch = o.epoch;
     }
-    lstm_split_body<KIND, N, TS, DN>(a, bi);
+    lstm_split_body<KIND, N, TS, DN, false, LIVE>(a, bi);
 }
 
 // ---- recurrence only, behind the projection GEMM: shapes whose two weight matrices do not fit a CU's registers ------
@@ -1575,7 +1601,7 @@ bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const Split
         a.Wp = (const v4u *)p.Wp; a.bias = p.bias; a.xin = (const unsigned char *)p.xin; a.hout = (unsigned char *)p.hout; a.hout_f32 = p.hout_f32;
         a.flags = p.flags; a.abort_word = p.abort_word;
         a.Tb = p.Tb; a.B16 = p.B16; a.H = H; a.rt0 = p.rt0; a.nrt = p.nrt; a.backward = p.backward; a.mode = p.mode;
-        a.tbs = p.tbs; a.tbt = p.tbt; a.dbg = g_split_dbg;
+        a.tbs = p.tbs; a.tbt = p.tbt; a.live = p.live; a.dbg = g_split_dbg;
         return a;
     };
     const int g0 = (p0.nrt + 1) / 2, g1 = (p1.nrt + 1) / 2;
@@ -1583,19 +1609,20 @@ bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const Split
     // the two batches share everything but their buffers: same model (weights, exponents), same capacity and tile count
     if (p0.Wp != p1.Wp || p0.bias != p1.bias || p0.Tb != p1.Tb || p0.B16 != p1.B16 || p0.rt0 != p1.rt0 || p0.nrt != p1.nrt || p0.backward != p1.backward ||
         p0.mode != p1.mode || p0.scale_exp != p1.scale_exp || p0.fast_gates != p1.fast_gates || (p0.hout_f32 == nullptr) != (p1.hout_f32 == nullptr) ||
-        (p0.tbs == nullptr) != (p1.tbs == nullptr)) return false;
+        (p0.tbs == nullptr) != (p1.tbs == nullptr) || (p0.live == nullptr) != (p1.live == nullptr)) return false;
     const SplitArgs a1 = mk(p1);
     SplitArgsOther o;
-    o.xin = a1.xin; o.hout = a1.hout; o.hout_f32 = a1.hout_f32; o.flags = a1.flags; o.abort_word = a1.abort_word; o.tbs = a1.tbs; o.tbt = a1.tbt; o.epoch = a1.epoch;
+    o.xin = a1.xin; o.hout = a1.hout; o.hout_f32 = a1.hout_f32; o.flags = a1.flags; o.abort_word = a1.abort_word; o.tbs = a1.tbs; o.tbt = a1.tbt; o.live = a1.live; o.epoch = a1.epoch;
     o.nwg0 = g0 * 32;
-    hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
+    if (p0.live) hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
+    else hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
     return true;
 #endif
 }
 
 bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bias, const void *xin, void *hout, float *hout_f32,
                        unsigned *flags, unsigned *abort_word, int Tb, int B16, int H, int rt0, int nrt, int backward, int mode,
-                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside) {
+                       int scale_exp, int fast_gates, const int *tbs, const int *tbt, int ncu, unsigned epoch, int beside, const unsigned *live) {
     SplitArgs a;
     a.epoch = epoch;
     a.acc_scale = split_pow2(scale_exp);
@@ -1605,33 +1632,35 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     a.Wp = (const v4u *)Wp; a.bias = bias; a.xin = (const unsigned char *)xin; a.hout = (unsigned char *)hout; a.hout_f32 = hout_f32;
     a.flags = flags; a.abort_word = abort_word;
     a.Tb = Tb; a.B16 = B16; a.H = H; a.rt0 = rt0; a.nrt = nrt; a.backward = backward; a.mode = mode;
-    a.tbs = tbs; a.tbt = tbt; a.dbg = g_split_dbg;
+    a.tbs = tbs; a.tbt = tbt; a.live = live; a.dbg = g_split_dbg;
     // tiles per group: 1 (two workgroups per CU, one read tile each) where that is faster, else 2 (kSplitTS)
     // ... and 2 with two workgroups per CU when the launch carries more tiles than the one-tile form can take (H <= 256)
     const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
     const int ngroup_l = (nrt + ts - 1) / ts;
 #ifndef FFHIP_SPLIT_BF16X3
-    if (split_launch_dense3(kind, H, nrt, ncu, beside)) { hipLaunchKernelGGL((k_lstm_split<0, 3, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; }
+    // (a packed batch -- a.live -- takes the LIVE instantiation of the same form)
+#define SPLIT_GO(KERNEL_T, KERNEL_F, GRID) do { if (a.live) hipLaunchKernelGGL(KERNEL_T, dim3(GRID), dim3(512), 0, s, a); else hipLaunchKernelGGL(KERNEL_F, dim3(GRID), dim3(512), 0, s, a); } while (0)
+    if (split_launch_dense3(kind, H, nrt, ncu, beside)) { SPLIT_GO((k_lstm_split<0, 3, 2, true, true>), (k_lstm_split<0, 3, 2, true>), ngroup_l * 32); return true; }
     if (split_launch_pack(kind, H, nrt, ncu)) {
         a.Wp += split_pack_offset(H);
-        if (kind == 1) hipLaunchKernelGGL(k_grumod_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL(k_lstm_pack, dim3(nrt / 2 * 16), dim3(512), 0, s, a);
+        if (kind == 1) SPLIT_GO(k_grumod_pack<true>, k_grumod_pack<false>, nrt / 2 * 16);
+        else SPLIT_GO(k_lstm_pack<true>, k_lstm_pack<false>, nrt / 2 * 16);
         return true;
     }
     if (split_launch_dense256(H, nrt, ncu)) {
-        if (kind == 0) hipLaunchKernelGGL((k_lstm_split<0, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((k_lstm_split<1, 2, 2, true>), dim3(ngroup_l * 32), dim3(512), 0, s, a);
+        if (kind == 0) SPLIT_GO((k_lstm_split<0, 2, 2, true, true>), (k_lstm_split<0, 2, 2, true>), ngroup_l * 32);
+        else SPLIT_GO((k_lstm_split<1, 2, 2, true, true>), (k_lstm_split<1, 2, 2, true>), ngroup_l * 32);
         return true;
     }
 #endif
-#define SPLIT_LAUNCH(K, NN) do { if (ts == 1) hipLaunchKernelGGL((k_lstm_split<K, NN, 1>), dim3(ngroup_l * 32), dim3(512), 0, s, a); \
-                                 else hipLaunchKernelGGL((k_lstm_split<K, NN, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); return true; } while (0)
+#define SPLIT_LAUNCH(K, NN) do { if (ts == 1) SPLIT_GO((k_lstm_split<K, NN, 1, false, true>), (k_lstm_split<K, NN, 1>), ngroup_l * 32); \
+                                 else SPLIT_GO((k_lstm_split<K, NN, 2, false, true>), (k_lstm_split<K, NN, 2>), ngroup_l * 32); return true; } while (0)
 #ifdef FFHIP_SPLIT_BF16X3
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #else
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3);
-                                      case 4: hipLaunchKernelGGL((k_lstm_split<0, 4, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a); return true; }      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves)
+                                      case 4: if (a.live) return false; hipLaunchKernelGGL((k_lstm_split<0, 4, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a); return true; }      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves)
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #endif
 #undef SPLIT_LAUNCH

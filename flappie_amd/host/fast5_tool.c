@@ -4,6 +4,8 @@
  *                      seeded noise around 500 +- 60 counts behind a 300-sample quiet stretch (what the trimming step removes),
  *                      lengths uniform in [MINLEN, MAXLEN); prints "files N samples S".  The signal of a file depends on SEED and
  *                      its index only, so several processes can fill one directory (bench.py's host-fed leg, tools/cli_throughput.py)
+ *    fast5_tool synthln DIR COUNT MEDIAN SIGMA MINLEN MAXLEN SEED [FIRST [STEP]]   the same with LOG-NORMAL lengths: exp(ln MEDIAN + SIGMA z), z ~ N(0, 1),
+ *                      clipped to [MINLEN, MAXLEN] -- a nanopore-like length mix (tools/length_mix.py)
  *    fast5_tool dump   trace.hdf5 GROUP          (prints "signal N" + values, "trace R C" + values)
  *  Layout written: /Raw/Reads/Read_1/Signal (int16) with attribute read_id (fixed string) and
  *  /UniqueGlobalKey/channel_id {digitisation, offset, range, sampling_rate} (doubles), i.e. what
@@ -33,17 +35,25 @@ static unsigned long long rng_next(unsigned long long *s) {      /* splitmix64 *
 static double rng_unit(unsigned long long *s) { return ((double)(rng_next(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
 int main(int argc, char **argv) {
-    if (argc >= 7 && 0 == strcmp(argv[1], "synth")) {
-        const long count = atol(argv[3]), minlen = atol(argv[4]), maxlen = atol(argv[5]);
-        const unsigned long long seed = strtoull(argv[6], NULL, 10);
-        const long first = argc > 7 ? atol(argv[7]) : 0, step = argc > 8 ? atol(argv[8]) : 1;
-        if (count < 0 || minlen < 1 || maxlen <= minlen || step < 1) return 1;
-        short *raw = malloc((size_t)maxlen * sizeof(short));
+    const int lognormal = argc >= 9 && 0 == strcmp(argv[1], "synthln");
+    if (lognormal || (argc >= 7 && 0 == strcmp(argv[1], "synth"))) {
+        const int o = lognormal ? 2 : 0;                          /* synthln carries MEDIAN SIGMA in front of MINLEN */
+        const double median = lognormal ? atof(argv[4]) : 0.0, sigma = lognormal ? atof(argv[5]) : 0.0;
+        const long count = atol(argv[3]), minlen = atol(argv[4 + o]), maxlen = atol(argv[5 + o]);
+        const unsigned long long seed = strtoull(argv[6 + o], NULL, 10);
+        const long first = argc > 7 + o ? atol(argv[7 + o]) : 0, step = argc > 8 + o ? atol(argv[8 + o]) : 1;
+        if (count < 0 || minlen < 1 || maxlen <= minlen || step < 1 || (lognormal && !(median >= 1.0 && sigma >= 0.0))) return 1;
+        short *raw = malloc(((size_t)maxlen + 2) * sizeof(short));
         unsigned long long total = 0;
         for (long k = 0; k < count; k++) {
             const long idx = first + k * step;
             unsigned long long st = seed * 0x100000001B3ull + (unsigned long long)idx;
-            const long n = minlen + (long)(rng_unit(&st) * (double)(maxlen - minlen));
+            long n = minlen + (long)(rng_unit(&st) * (double)(maxlen - minlen));
+            if (lognormal) {
+                const double u = rng_unit(&st), v = rng_unit(&st);
+                const double len = median * exp(sigma * sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v));
+                n = len < (double)minlen ? minlen : (len > (double)maxlen ? maxlen : (long)len);
+            }
             for (long i = 0; i < n; i += 2) {                      /* Box-Muller, two values per draw */
                 const double u = rng_unit(&st), v = rng_unit(&st);
                 const double r = sqrt(-2.0 * log(u)), a = 6.283185307179586 * v;

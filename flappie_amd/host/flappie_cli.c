@@ -316,6 +316,9 @@ static int bind_to_gpu_numa(int device) {
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 /* what the run basecalled: reads, samples of their trimmed ranges (the metric of SURVEY.md section 8d), samples read from the files */
 static unsigned long long n_called_reads, n_called_samples, n_raw_samples;
+/* what the batches cost: a batch (a launch per layer) takes as long as its longest read needs whatever the others' lengths, a read tile of 16 as long as
+ * ITS longest read holds its workgroups -- samples submitted against samples x slots paid for, at both grains (FLAPPIE_CLI_TIMING prints them) */
+static unsigned long long n_batches, n_packed_batches, n_batch_samples, n_batch_slot_samples, n_tile_slot_samples;
 static int reader_failures;              /* reader children that ended abnormally: the exit status says so */
 
 typedef struct {
@@ -348,10 +351,69 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
     return batch_cache[slot].b;
 }
 
+/* Packed batches (ffhip.h "packed batches"): reads of mixed lengths, several to a row.  One cached object per pipeline slot, `--batch` rows of the chunk's row
+ * capacity, created anew when a chunk needs longer rows. */
+static struct { ffhip_batch *b; size_t cap; int max_reads; } pack_cache[NINFLIGHT];
+static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, size_t cap, int max_reads, int slot) {
+    if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads) {
+        if (pack_cache[slot].b) ffhip_batch_destroy(pack_cache[slot].b);
+        pack_cache[slot].cap = cap + cap / 8;
+        pack_cache[slot].max_reads = max_reads;
+        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, args.batch, pack_cache[slot].cap, max_reads);
+        if (NULL == pack_cache[slot].b) { pack_cache[slot].cap = 0; return NULL; }
+    }
+    return pack_cache[slot].b;
+}
+
 /* A group of prepared reads in flight: submitted (upload + network + decode enqueued on the batch's stream), collected
  * later (flappie.c:264-316 after normalisation) -- so the host side of the next group overlaps the GPU side of this one. */
 struct chunk_ctx;
 typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_prep *prep; struct chunk_ctx *owner; } pending_batch;
+
+/* n reads in the rows of one packed batch: slot_of / off_of from ffhip_pack_plan, `cap` the row capacity it was made for */
+static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, const int *slot_of, const int *off_of,
+                                   size_t cap, int max_reads, int slot) {
+    pending_batch pb = { NULL, 1, n, malloc((n > 0 ? n : 1) * sizeof(int)), malloc((n > 0 ? n : 1) * sizeof(item *)), prep, NULL };
+    memcpy(pb.its, its, n * sizeof(item *));
+    size_t longest = 0, rows_used = 0;
+    unsigned long long samples = 0;
+    size_t *row_end = calloc(args.batch, sizeof(size_t));
+    for (int i = 0; i < n; i++) {
+        pb.idx[i] = its[i]->prepared;
+        const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
+        samples += li;
+        if (row_end) { const size_t e = (size_t)off_of[i] * 1 + ffhip_model_nblock(mdl, li); if (e > row_end[slot_of[i]]) row_end[slot_of[i]] = e; }
+    }
+    /* what the batch costs: its longest ROW (in blocks -> samples of the trimmed signal), whatever the others hold */
+    const size_t nb_cap = ffhip_model_nblock(mdl, cap);
+    const size_t spb = nb_cap ? (cap + nb_cap / 2) / nb_cap : 1;      /* samples a block (the model's stride) */
+    for (int r = 0; row_end && r < args.batch; r++) {
+        if (row_end[r] > longest) longest = row_end[r];
+        if (row_end[r]) rows_used++;
+    }
+    n_batches++; n_packed_batches++;
+    n_batch_samples += samples;
+    n_batch_slot_samples += (unsigned long long)longest * spb * (unsigned long long)(16 * ((args.batch + 15) / 16));
+    for (int r0 = 0; row_end && r0 < args.batch; r0 += 16) {
+        size_t lt = 0;
+        for (int r = r0; r < args.batch && r < r0 + 16; r++) if (row_end[r] > lt) lt = row_end[r];
+        n_tile_slot_samples += 16ull * lt * spb;
+    }
+    (void)rows_used;
+    free(row_end);
+    double t0 = now_s();
+    pb.b = acquire_packed(eng, mdl, cap, max_reads, slot);
+    t_phase[2] += now_s() - t0; t0 = now_s();
+    const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
+    int rc_sub = (NULL == pb.b) ? -1 : ffhip_batch_set_prepared_packed(pb.b, prep, n, pb.idx, slot_of, off_of);
+    t_phase[6] += now_s() - t0;
+    const double t1 = now_s();
+    if (0 == rc_sub) rc_sub = ffhip_batch_run(pb.b, args.temperature, flags);
+    t_phase[7] += now_s() - t1;
+    if (0 != rc_sub) { warnx("%s", ffhip_last_error()); pb.b = NULL; }
+    t_phase[3] += now_s() - t0;
+    return pb;
+}
 
 static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, int slot) {
     const int nmax = (n > args.batch) ? n : args.batch;
@@ -362,6 +424,14 @@ static pending_batch submit_batch(struct ffhip_engine *eng, const struct ffhip_m
     for (int i = 0; i < n; i++) {
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
         if (li > len) len = li;
+        n_batch_samples += li;
+    }
+    n_batches++;
+    n_batch_slot_samples += (unsigned long long)len * (unsigned long long)(16 * ((nmax + 15) / 16));
+    for (int i = 0; i < n; i += 16) {
+        size_t lt = 0;
+        for (int k = i; k < n && k < i + 16; k++) { const size_t lk = its[k]->res.rt.end - its[k]->res.rt.start; if (lk > lt) lt = lk; }
+        n_tile_slot_samples += 16ull * lt;
     }
     double t0 = now_s();
     int nslot = n;
@@ -610,6 +680,15 @@ static void chunk_finish(chunk_ctx *c, hid_t hdf5out) {
 /* the pipeline's state: up to NINFLIGHT - 1 batches submitted and not collected (oldest first) while the next is submitted (by default
  * one: a batch runs while the next is set up); chunks finish (are written) strictly in order */
 #define NCHUNKBUF 4
+#define PACK_ROW_MAX ((size_t)1 << 18)      /* samples a row of a packed batch holds at most (262 144: workspace of a 512-row batch ~45 GB at 384 hidden units) */
+static int rs_chunk_cap = 0;                 /* reads a chunk holds at most (= reads a packed batch must take) */
+/* packed batches: models whose default path takes them (ffhip_model_packable), ordinary temperatures, the flip-flop caller (runnie's model has no packed form);
+ * FLAPPIE_DEBUG=no_pack keeps the one-read-a-row batches */
+static int pack_allowed(const struct ffhip_model *mdl) {
+    static int v = -1;
+    if (v < 0) v = (ffhip_model_packable(mdl) && args.temperature >= 0.2f && args.temperature <= 5.0f && !cli_dbg("no_pack")) ? 1 : 0;
+    return v;
+}
 /* Reads are sorted by length inside a chunk and cut into batches there (a batch costs what its longest read costs): the more batches a chunk
  * holds, the narrower the spread of lengths inside one.  On 3500-5500-sample reads 8 instead of 4 takes 2-8 % off the GPU time of a run
  * (65 536 files: 4.07 -> 4.00 s at 384 hidden units, 2.51 -> 2.38 s at 256); 16 gains little more and delays the first and the last output. */
@@ -709,6 +788,62 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     if (c->live) errx(EXIT_FAILURE, "internal error: chunk slot still in use");
     chunk_begin(eng, c, items, n, buf);            /* the device pass runs beside the batch still in flight */
     pipe_state.nbegun++;
+    static int depth = 0;
+    if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
+    /* ---- a chunk of MIXED lengths goes in packed batches: what the one-read-a-row grouping below would pay for (rows x the group's longest read, group by
+     * group) against what the reads hold; below 0.85 the chunk's reads are placed several to a row (first fit, longest first) in as few batches of --batch rows
+     * as hold them, rows just long enough -- a batch then costs what its samples cost (nanopore-like mix: 0.07 -> 0.9+, tools/length_mix.py) */
+    int packed_chunk = 0;
+    if (c->m2 > 0 && pack_allowed(mdl)) {
+        unsigned long long real = 0, paid = 0;
+        for (int i = 0; i < c->m2; ) {
+            const size_t longest = c->group[i]->res.rt.end - c->group[i]->res.rt.start;
+            int g = 1;
+            real += longest;
+            while (i + g < c->m2 && g < args.batch && 4 * (c->group[i + g]->res.rt.end - c->group[i + g]->res.rt.start) >= 3 * longest) { real += c->group[i + g]->res.rt.end - c->group[i + g]->res.rt.start; g++; }
+            paid += (unsigned long long)longest * (unsigned long long)(4 * g < args.batch ? 16 * ((g + 15) / 16) : args.batch);
+            i += g;
+        }
+        packed_chunk = (double)real < 0.85 * (double)paid;
+    }
+    if (packed_chunk) {
+        int first = 0;                                    /* c->group[first ..) are not placed yet (longest first) */
+        size_t *ns = malloc(c->m2 * sizeof(size_t));
+        int *slot_of = malloc(c->m2 * sizeof(int)), *off_of = malloc(c->m2 * sizeof(int)), *sl2 = malloc(c->m2 * sizeof(int)), *of2 = malloc(c->m2 * sizeof(int));
+        item **sel = malloc(c->m2 * sizeof(item *)), **rest = malloc(c->m2 * sizeof(item *));
+        int nleft = c->m2;
+        memcpy(rest, c->group, c->m2 * sizeof(item *));
+        while (nleft > 0 && ns && slot_of && off_of && sl2 && of2 && sel && rest) {
+            unsigned long long total = 0;
+            for (int i = 0; i < nleft; i++) { ns[i] = rest[i]->res.rt.end - rest[i]->res.rt.start; total += ns[i]; }
+            /* rows long enough for everything left in ONE batch (5 % slack for the gaps and the fit), at least the longest read, at most PACK_ROW_MAX samples */
+            size_t cap = (size_t)((double)total / (double)args.batch * 1.05) + 64 * ffhip_model_pack_gap(mdl);
+            if (cap < ns[0] + 64) cap = ns[0] + 64;
+            if (cap > PACK_ROW_MAX && ns[0] + 64 <= PACK_ROW_MAX) cap = PACK_ROW_MAX;
+            cap = (cap + 1023) & ~(size_t)1023;
+            int placed = 0;
+            for (int tries = 0; tries < 6; tries++) {
+                placed = ffhip_pack_plan(mdl, args.batch, cap, nleft, ns, slot_of, off_of);
+                if (placed == nleft || cap >= PACK_ROW_MAX) break;
+                cap = ((size_t)((double)cap * 1.06) + 1023) & ~(size_t)1023;      /* the fit left reads over: longer rows, once more */
+            }
+            if (placed <= 0) { warnx("packed batch: no read fits a row of %zu samples", cap); break; }
+            int nsel = 0, nrest = 0;
+            for (int i = 0; i < nleft; i++) {
+                if (slot_of[i] >= 0) { sel[nsel] = rest[i]; sl2[nsel] = slot_of[i]; of2[nsel] = off_of[i]; nsel++; }
+                else rest[nrest++] = rest[i];
+            }
+            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, cap, rs_chunk_cap, pipe_state.slot);
+            cur.owner = c;
+            c->submitted++;
+            while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);
+            pipe_state.fifo[pipe_state.nfifo++] = cur;
+            pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);
+            nleft = nrest;
+            (void)first;
+        }
+        free(ns); free(slot_of); free(off_of); free(sl2); free(of2); free(sel); free(rest);
+    } else
     for (int i = 0; i < c->m2; ) {
         const size_t longest = c->group[i]->res.rt.end - c->group[i]->res.rt.start;
         int g = 1;
@@ -719,8 +854,6 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         /* default: one batch runs while the next is set up.  FLAPPIE_INFLIGHT=3 keeps two on the GPU while the third is set up: no
          * measurable gain on 4000-sample reads (80-92 against 84-87 Msamples/s, run-to-run noise), and a third batch object costs
          * long reads another 10+ GB of workspace and ~1 s of start-up */
-        static int depth = 0;
-        if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
         while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);           /* may complete and write an earlier chunk */
         pipe_state.fifo[pipe_state.nfifo++] = cur;
         pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);       /* depth in flight + the one being set up: no more batch objects than that */
@@ -954,14 +1087,21 @@ static void stop_reader_procs(void) {
     nrproc = 0;
 }
 
+/* Mixed lengths (packed batches): a read of L samples is L / stride dependent steps of every layer, whatever else the GPU holds meanwhile -- a chunk whose longest read
+ * is L should hold about --batch rows of L samples of work, or its one batch runs as long as that read with most rows empty (tools/length_mix.py: 8192 files of a
+ * log-normal mix, 33 M-sample chunks: 105 of 512 rows in use).  The chunk's sample budget therefore grows with the longest read seen while it fills, up to
+ * PACK_WINDOW_MAX samples and PACK_WINDOW_READS x the usual read count (the reader's buffers are that large).  Uniform reads never get there. */
+#define PACK_WINDOW_MAX ((size_t)224 << 20)
+#define PACK_WINDOW_READS 4
+static int g_pack_window = 0;                /* set once the model is known: pack_allowed() */
 static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *items, int *nitem) {
     /* a chunk is up to chunk_cap reads (CHUNK_BATCHES batches of the usual 4-8 k-sample reads) -- or, with long reads, what holds about as
      * many SAMPLES but at least one batch: records leave when their chunk is done, and a 1024-read chunk of 100 000-sample reads
      * would be four seconds of GPU work with nothing written (and nothing for the writer thread to overlap) */
-    const size_t sample_budget = (size_t)chunk_cap * 8192;
+    size_t sample_budget = (size_t)chunk_cap * 8192, longest = 0;
     size_t nsamp = 0;
-    int n = 0;
-    for (size_t f = first; f < fl->n && n < chunk_cap && !(n >= args.batch && nsamp >= sample_budget); f++, n++) {
+    int n = 0, read_cap = chunk_cap;
+    for (size_t f = first; f < fl->n && n < read_cap && !(n >= args.batch && nsamp >= sample_budget); f++, n++) {
         item *it = &items[n];
         memset(it, 0, sizeof(*it));
         it->filename = fl->path[f];                                   /* ownership moves to the item */
@@ -975,6 +1115,12 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
         }
         t_phase[0] += now_s() - tr0;
         if (NULL != it->res.rt.raw) nsamp += it->res.rt.n;
+        if (g_pack_window && NULL != it->res.rt.raw && it->res.rt.n > longest) {
+            longest = it->res.rt.n;
+            size_t want = (size_t)args.batch * longest;
+            if (want > PACK_WINDOW_MAX) want = PACK_WINDOW_MAX;
+            if (want > sample_budget) { sample_budget = want; read_cap = PACK_WINDOW_READS * chunk_cap; }
+        }
     }
     *nitem = n;
 }
@@ -1019,8 +1165,10 @@ int main(int argc, char *argv[]) {
     if (0 == args.batch) args.batch = (int)ffhip_model_launch_reads(mdl);
     if (args.batch <= 0) args.batch = 256;              /* (the query answered 0: no model; never an empty batch) */
     rs.chunk_cap = CHUNK_BATCHES * args.batch;
+    g_pack_window = pack_allowed(mdl);
+    rs_chunk_cap = (g_pack_window ? PACK_WINDOW_READS : 1) * rs.chunk_cap;      /* reads a chunk may hold (a packed batch takes as many) */
     for (int k = 0; k < NCHUNKBUF; k++) {
-        rs.items[k] = calloc(rs.chunk_cap, sizeof(item));
+        rs.items[k] = calloc(rs_chunk_cap, sizeof(item));
         sem_init(&rs.filled[k], 0, 0);
         sem_init(&rs.empty[k], 0, 1);
     }
@@ -1048,11 +1196,15 @@ int main(int argc, char *argv[]) {
     if (hdf5out >= 0) { pthread_mutex_lock(&hdf5_lock); H5Fclose(hdf5out); pthread_mutex_unlock(&hdf5_lock); }
     if (stdout != args.output) fclose(args.output);
     for (int k = 0; k < NINFLIGHT; k++) if (batch_cache[k].b) ffhip_batch_destroy(batch_cache[k].b);
+    for (int k = 0; k < NINFLIGHT; k++) if (pack_cache[k].b) ffhip_batch_destroy(pack_cache[k].b);
     if (getenv("FLAPPIE_CLI_TIMING")) {
         for (int k = 0; k < 8; k++) fprintf(stderr, "%-24s %8.3f s\n", phase_name[k], t_phase[k]);
         fprintf(stderr, "%-24s %8.3f s\n%-24s %8.3f s\n%-24s %8.3f s\n", "list files", t_listed - t_start, "waiting for the reader", t_wait,
                 "files listed -> done", now_s() - t_listed);
         fprintf(stderr, "basecalled: %llu reads, %llu samples (trimmed ranges), %llu raw samples\n", n_called_reads, n_called_samples, n_raw_samples);
+        if (n_batches) fprintf(stderr, "batches: %llu (%llu of them packed), %.1f reads each; padding efficiency %.3f by batch (samples / (slots x the batch's longest read, or row)), %.3f by read tile\n", n_batches, n_packed_batches,
+                               (double)n_called_reads / (double)n_batches, (double)n_batch_samples / (double)(n_batch_slot_samples ? n_batch_slot_samples : 1),
+                               (double)n_batch_samples / (double)(n_tile_slot_samples ? n_tile_slot_samples : 1));
     }
     /* reads with a sample so far out that the default path's operand format could not hold the convolution's output: none is returned
      * clamped, the engine ran them again on its f32 kernels (include/ffhip.h, ffhip_engine_f32_reruns) */

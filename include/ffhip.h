@@ -302,6 +302,24 @@ int ffhip_prep_stats(const ffhip_prep *p, int read, float *median, float *mad); 
 int ffhip_prep_get_signal(const ffhip_prep *p, int read, float *out /* end-start floats */);
 /* device-to-device and asynchronous on the batch's stream (one gather launch; the call does not wait for the GPU) */
 int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *reads /* batch nread indices into prep (-1 = empty slot); lengths <= capacity */);
+
+/* ---- packed batches: reads of ANY lengths, several to a row ---------------------------------------------------------------
+ * The reference takes reads of any length one at a time (flappie.c:245-262, 334-385).  A batch above costs what its longest read costs -- a launch per
+ * layer runs as many steps as that read has blocks whatever the others' lengths -- so a nanopore-like length mix (a long tail of 100 000-sample reads among
+ * 5000-sample ones) fills a fraction of it.  A PACKED batch is `nslot` rows of `nsample` samples; a row holds one or more reads one behind the other, each
+ * starting at a block offset of the caller's choice with at least ffhip_model_pack_gap() free blocks behind it.  Every read is still evaluated whole and
+ * exactly as if it were alone (bit for bit what the one-read-a-row batch gives): the convolutions see zero padding either side of it, the recurrent
+ * layers start from a zero state at its first block and, in the reverse layers, at its last; partition function, posterior, Viterbi, strings and trace
+ * are per read.  Results are indexed by READ, 0 .. nread - 1 in the order of the set call.  The default path only (flip-flop models with 128 .. 384 hidden units;
+ * no FFHIP_RUN_KEEP_ACTS / _F32_RNN / _STEPWISE_RNN / _UNFUSED_RNN): ffhip_batch_run says so otherwise.  ffhip_batch_run_pair takes packed batches too. */
+int ffhip_model_packable(const ffhip_model *mdl);         /* 1: this model's default path takes packed batches on this device */
+size_t ffhip_model_pack_gap(const ffhip_model *mdl);      /* free blocks a read of a packed row needs behind it */
+/* first-fit-decreasing plan: slot[i] / block_off[i] for every read (slot -1: it did not fit into nslot rows of nsample_cap samples); returns the reads placed */
+int ffhip_pack_plan(const ffhip_model *mdl, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off);
+ffhip_batch *ffhip_batch_create_packed(ffhip_engine *eng, const ffhip_model *mdl, int nslot, size_t nsample, int max_reads);
+int ffhip_batch_set_prepared_packed(ffhip_batch *b, const ffhip_prep *prep, int nread, const int *reads /* indices into prep */, const int *slot, const int *block_off);
+int ffhip_batch_set_signals_packed(ffhip_batch *b, int nread, const float *const *signals, const size_t *nsample, const int *slot, const int *block_off);
+int ffhip_batch_nreads(const ffhip_batch *b);             /* reads of the last set call (a packed batch: its reads, not its rows) */
 /* quantilef (util.c:100-139): p[] in, quantiles out */
 int ffhip_quantiles(ffhip_engine *eng, const float *x, size_t n, float *p, size_t np);
 /* difference_array / shift_scale_array / both (FFHIP_PREP_DELTA) on one host array, in place */

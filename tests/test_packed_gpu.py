@@ -1,0 +1,211 @@
+"""Packed batches (include/ffhip.h "packed batches"; round 6): reads of any lengths several to a row, each evaluated whole and exactly as if it were alone.
+
+The reference takes reads of any length one at a time (flappie.c:245-262, 334-385); a one-read-a-row batch costs what its longest read costs, and a nanopore-like
+length mix filled 7 % of it (profiles/r06_length_mix.txt).  Held here: every read of a packed batch gives, BIT FOR BIT, what the same read gives in a
+one-read-a-row batch (scores, posterior, path, strings, trace) on every form of the layer kernels that has a packed instantiation, a sample of them against the
+oracle itself, the paired launch, the planner, the argument checks, and the `flappie` binary on a directory of mixed lengths against the oracle's calls."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from flappie_amd import model as M
+from oracle import ffo
+from test_ragged_gpu import check_read
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    from flappie_amd import binding
+    return binding
+
+
+@pytest.fixture(scope="module")
+def engine(B):
+    e = B.Engine(0)
+    yield e
+    e.close()
+
+
+def _same(pb, v, ub, j):
+    return (pb.basecall(v) == ub.basecall(j) and pb.quality(v) == ub.quality(j) and pb.score(v) == ub.score(j) and pb.read_nblock(v) == ub.read_nblock(j)
+            and np.array_equal(pb.transitions(v), ub.transitions(j)) and np.array_equal(pb.posterior(v), ub.posterior(j))
+            and np.array_equal(pb.path(v)[0], ub.path(j)[0]) and np.array_equal(pb.path(v)[1][1:], ub.path(j)[1][1:]) and np.array_equal(pb.trace(v), ub.trace(j)))
+
+
+def _against_rows(B, dm, pb, sigs, order, cap, rows):
+    bad = []
+    for k0 in range(0, len(order), rows):
+        grp = order[k0:k0 + rows]
+        ub = B.Batch(dm, len(grp), cap)
+        ub.set_signals_ragged([sigs[i] for i in grp])
+        ub.run()
+        ub.finish()
+        bad += [grp[j] for j in range(len(grp)) if not _same(pb, k0 + j, ub, j)]
+        ub.close()
+    return bad
+
+
+@pytest.mark.parametrize("kind,hidden,rows,cap", [
+    (M.NET_LSTM5, 128, 16, 3000),        # one tile a group
+    (M.NET_LSTM5, 384, 48, 2500),        # three tiles: a pair + a single (the dense form needs a fuller launch: the paired test below)
+    (M.NET_GRUMOD5, 256, 32, 3000),      # 10 states, stride 2, the f32-MFMA convolution's tables
+    (M.NET_GRUMOD5, 128, 16, 2000),
+])
+def test_packed_reads_equal_one_read_a_row(B, engine, kind, hidden, rows, cap):
+    mdl = M.synthetic_model(kind, hidden, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(hidden + rows)
+    # every length mod the stride, the shortest legal read (the window), reads far shorter than a row and one that fills a row
+    lens = [19, 20, 21, 22, 23, 24, 45, 100, 101, 102, 103, 104, cap - 8, cap // 2, cap // 2 + 1] + [int(x) for x in np.clip(np.exp(np.log(cap / 6) + 0.9 * rng.standard_normal(3 * rows)), 30, cap - 50)]
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    pb = B.Batch(dm, rows, cap, max_reads=len(lens))
+    slot, off = pb.pack_plan([x.size for x in sigs])
+    order = [i for i in range(len(lens)) if slot[i] >= 0]
+    assert len(order) >= rows + 10 and max(np.bincount([slot[i] for i in order])) >= 3, "the plan should put several reads in a row"
+    gap = int(B.lib().ffhip_model_pack_gap(dm.h))
+    for r in range(rows):                                   # the plan keeps its own rule: reads of a row `gap` blocks apart, one free block behind the last
+        mine = sorted((off[i], int(B.lib().ffhip_model_nblock(dm.h, sigs[i].size))) for i in order if slot[i] == r)
+        for (o0, n0), (o1, _) in zip(mine, mine[1:]):
+            assert o1 >= o0 + n0 + gap
+        assert not mine or mine[-1][0] + mine[-1][1] + 1 <= pb.nblock
+    for flags in (0, B.RUN_VITERBI_ONLY):
+        pb.set_signals_packed([sigs[i] for i in order], [slot[i] for i in order], [off[i] for i in order])
+        pb.run(1.0, flags)
+        pb.finish()
+        assert pb.nreads() == len(order) and pb.rnn_path() == 3
+        if flags == 0:
+            assert _against_rows(B, dm, pb, sigs, order, cap, rows) == []
+    # ... and a sample against the oracle itself (the last run decoded from the scores)
+    om = ffo.OracleModel(mdl)
+    for v in list(range(0, 12)) + list(range(12, len(order), 9)):
+        check_read(pb, v, om.basecall(sigs[order[v]], viterbi_only=True), viterbi_only=True)
+    pb.close()
+    dm.close()
+
+
+def test_two_packed_batches_in_a_paired_launch(B, engine):
+    """the headline's kernel (k_lstm_split_pair, the layers of two 256-row batches as one grid) in its packed instantiation"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 384, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(11)
+    rows, cap = 256, 1500
+    pbs, sets = [], []
+    for k in range(2):
+        lens = [int(x) for x in np.clip(np.exp(np.log(300) + 0.8 * rng.standard_normal(900)), 25, cap - 50)]
+        sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+        pb = B.Batch(dm, rows, cap, max_reads=len(lens))
+        slot, off = pb.pack_plan(lens)
+        order = [i for i in range(len(lens)) if slot[i] >= 0]
+        pb.set_signals_packed([sigs[i] for i in order], [slot[i] for i in order], [off[i] for i in order])
+        pbs.append(pb)
+        sets.append((sigs, order))
+    pbs[0].run_pair(pbs[1])
+    for pb in pbs:
+        pb.finish()
+        assert pb.paired() and pb.rnn_path() == 3
+    for pb, (sigs, order) in zip(pbs, sets):
+        assert len(order) > 2 * rows
+        assert _against_rows(B, dm, pb, sigs, order, cap, rows) == []
+        pb.close()
+    dm.close()
+
+
+def test_packed_batch_argument_checks(B, engine):
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=3)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(0)
+    pb = B.Batch(dm, 16, 2000, max_reads=8)
+    a, b2 = rng.standard_normal(500).astype(np.float32), rng.standard_normal(700).astype(np.float32)
+    gap = int(B.lib().ffhip_model_pack_gap(dm.h))
+    with pytest.raises(B.FFHipError):                       # the second read starts inside the first one's gap
+        pb.set_signals_packed([a, b2], [0, 0], [0, 100 + gap - 1])
+    with pytest.raises(B.FFHipError):                       # past the row's end
+        pb.set_signals_packed([a], [0], [pb.nblock - 50])
+    with pytest.raises(B.FFHipError):                       # a row that is not there
+        pb.set_signals_packed([a], [16], [0])
+    with pytest.raises(B.FFHipError):                       # more reads than the batch was created for
+        pb.set_signals_packed([a] * 17, list(range(16)) + [0], [0] * 16 + [300])       # (a batch takes at least a read a row: 16 here)
+    pb.set_signals_packed([a, b2], [0, 0], [0, 100 + gap])
+    with pytest.raises(B.FFHipError):                       # no packed form of the kept-activation / f32 runs
+        pb.run(1.0, B.RUN_KEEP_ACTS)
+    with pytest.raises(B.FFHipError):
+        pb.run(1.0, B.RUN_F32_RNN)
+    pb.run()
+    pb.finish()
+    om = ffo.OracleModel(mdl)
+    check_read(pb, 0, om.basecall(a))
+    check_read(pb, 1, om.basecall(b2))
+    # the same object one read a row again
+    pb.set_signals_ragged([a] * 16)
+    pb.run()
+    pb.finish()
+    assert pb.nreads() == 16
+    check_read(pb, 5, om.basecall(a))
+    pb.close()
+    small = M.synthetic_model(M.NET_LSTM5, 64, seed=3)       # the f32 layer kernels have no packed form: said at run time, and by the query
+    dms = B.DeviceModel(engine, small)
+    assert B.lib().ffhip_model_packable(dms.h) == 0 and B.lib().ffhip_model_packable(dm.h) == 1
+    ps = B.Batch(dms, 16, 2000, max_reads=4)
+    ps.set_signals_packed([a], [0], [0])
+    with pytest.raises(B.FFHipError):
+        ps.run()
+    ps.close()
+    dms.close()
+    dm.close()
+
+
+def test_outlier_sample_in_a_packed_row_is_run_again_on_the_f32_path(B, engine):
+    """a value beyond the split format in one read of a row: every read of that row goes through the f32 kernels again and comes back as the oracle's call"""
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(4)
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in (900, 400, 1200, 800)]
+    sigs[1][200] = 6.0e4
+    pb = B.Batch(dm, 16, 6000, max_reads=4)
+    pb.set_signals_packed(sigs, [0, 0, 1, 0], [0, 400, 0, 800])
+    pb.run()
+    pb.finish()
+    assert pb.f32_reruns() == 3
+    om = ffo.OracleModel(mdl)
+    for v in range(4):
+        check_read(pb, v, om.basecall(sigs[v]))
+    pb.close()
+    dm.close()
+
+
+def test_cli_packs_a_directory_of_mixed_lengths(tmp_path):
+    """the `flappie` binary on single-read fast5 files of log-normal lengths: the chunk goes in packed batches (said on stderr), every record is the oracle's"""
+    from test_cli import FLAPPIE, TOOL, FAST5LIB, _oracle_calls, _parse_fastq, synth_raw, write_fast5
+    if not (os.path.exists(FLAPPIE) and os.path.exists(TOOL) and os.path.exists(FAST5LIB)):
+        pytest.skip("libhdf5 not found when the host layer was built")
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=1, ident="r941native")
+    M.write_mdl(str(tmp_path / "flipflop5_r941native.h"), mdl)
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    rng = np.random.default_rng(2)
+    raws = {}
+    lens = np.clip(np.exp(np.log(2500) + 1.0 * rng.standard_normal(70)), 700, 30000).astype(int)
+    for i, n in enumerate(lens):
+        raw = synth_raw(rng, int(n))
+        write_fast5(reads / ("read_%02d.fast5" % i), "uuid-%04d" % i, raw)
+        raws["read_%02d.fast5" % i] = ("uuid-%04d" % i, raw)
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(tmp_path), FLAPPIE_CLI_TIMING="1")
+    out = {}
+    for tag, extra in (("packed", {}), ("rows", {"FLAPPIE_DEBUG": "no_pack"})):
+        r = subprocess.run([FLAPPIE, "--model", "r941_native", "--batch", "16", str(reads)], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        pad = [ln for ln in r.stderr.splitlines() if ln.startswith("batches:")][-1]
+        npacked = int(pad.split("(")[1].split()[0])
+        assert (npacked > 0) == (tag == "packed"), pad
+        out[tag] = r.stdout
+    assert out["packed"] == out["rows"]                     # the same records in the same order, byte for byte
+    ref = _oracle_calls(mdl, raws)
+    by_uuid = {v["uuid"]: v for v in ref.values()}
+    recs = _parse_fastq(out["packed"])
+    assert sorted(x[0] for x in recs) == sorted(by_uuid)
+    for name, hdr, bases, quals in recs:
+        assert bases == by_uuid[name]["basecall"] and quals == by_uuid[name]["quality"], name
