@@ -25,6 +25,7 @@ RUN_UNFUSED_RNN = 32
 RUN_F32_RNN = 64
 RUN_FAST_GATES = 128
 RUN_FAST_GATES2 = 256
+RUN_EXACT_GATES = 512
 NGROUP = 6
 GROUP_NAMES = ("conv", "inproj", "recurrent", "head_crf", "posterior", "viterbi_assembly")
 

@@ -66,13 +66,15 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
 }
 
 // gate arithmetic of the split layer kernels: 0 = the reference's exp_ps / division replayed bit for bit, 1 = v_exp_f32 / v_rcp_f32, 2 = those with a
-// two-word exponent and a Newton step (ffhip_math.hpp logistic_hw); run flags, or FFHIP_FAST_GATES=1|2 for a whole process
+// two-word exponent and a Newton step (ffhip_math.hpp logistic_hw) -- the default since round 6 (include/ffhip.h, profiles/r06_gates_*.txt); run flags first,
+// then FFHIP_FAST_GATES=0|1|2 for a whole process
 static int gate_level(unsigned flags) {
+    if (flags & FFHIP_RUN_EXACT_GATES) return 0;
     if (flags & FFHIP_RUN_FAST_GATES2) return 2;
     if (flags & FFHIP_RUN_FAST_GATES) return 1;
     const char *e = getenv("FFHIP_FAST_GATES");
     if (e && e[0]) return atoi(e) >= 2 ? 2 : (e[0] == '0' ? 0 : 1);
-    return 0;
+    return 2;
 }
 
 // ---- development switches: FFHIP_DEBUG=token[,token=value ...] (ffhip_internal.hpp) ---------------------------
@@ -880,6 +882,24 @@ extern "C" size_t ffhip_model_pack_gap(const ffhip_model *m) {
     const int st = total_stride(m);
     return (size_t)((2 * wmax + st - 1) / st + 1);
 }
+// Rows (a multiple of 16, at most want_rows) of a packed batch of `nsample`-sample rows whose workspace takes at most 28 % of the device's memory: two such
+// objects are alive in a pipeline (one runs, one is set up) beside the prepared signals.  What a row costs is what batch_create_impl and the default path of
+// batch_run_impl allocate per block and per sample.
+extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsample) {
+    if (!m || want_rows <= 0 || nsample == 0) return 0;
+    const size_t nb = ffhip_model_nblock(m, nsample) + 1;
+    size_t per_block = (size_t)m->Ps * 8 + (size_t)crf_exp_stride(m->P) * 8 + 2 * kFwdRowBytes + kMaxState + 4 + 4 + 2 + (size_t)m->nstate * 4 + 8      // scores, E, chains, traceback, path, strings, trace, tables
+                       + 2 * (size_t)m->Hp * 2 * kSplitNS;                                                                                            // two activation buffers in the split layout
+    size_t per_sample = 0;
+    for (int l = 0; l < m->nconv; l++) per_sample += (size_t)m->conv[l].Fin * 4;       // the convolutions' inputs (sample-major; the last one's as fp16 slices: the same 4 bytes a value)
+    const double row = (double)nb * (double)per_block + (double)(nsample + 2 * kSamplePad) * (double)per_sample * (m->nconv > 1 ? 1.0 : 1.0);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return want_rows;
+    long rows = (long)((double)total_b * 0.28 / row);      // (of the device's TOTAL memory: the answer must not change while the first object is alive)
+    rows = rows / 16 * 16;
+    if (rows > want_rows) rows = want_rows;
+    return rows < 16 ? 16 : (int)rows;
+}
 // First-fit-decreasing plan of `nread` reads into nslot rows of nsample_cap samples: slot[] / block_off[] of every read (slot -1: it did not fit); returns the number placed.
 extern "C" int ffhip_pack_plan(const ffhip_model *m, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off) {
     if (!m || nslot <= 0 || nread < 0 || !nsample || !slot || !block_off) { set_err(FFHIP_EINVAL, "bad pack plan arguments"); return -1; }
@@ -1011,6 +1031,10 @@ static int apply_packed(ffhip_batch *b, int nv, const std::vector<int> &lens, co
         for (size_t k = 1; k < rv.size(); k++)
             if (off[rv[k]] < off[rv[k - 1]] + vtb[rv[k - 1]] + gap) return set_err(FFHIP_EINVAL, "packed reads %d and %d of row %d are closer than %d blocks", rv[k - 1], rv[k], slot[rv[k]], gap);
     }
+    // The set-up of a packed batch is hundreds of megabytes of fills (tables, signal rows) and a few small kernels on the batch's stream.  Beside another batch's
+    // layer launch -- which holds every CU -- a fill crawls AND keeps the next layer launch from becoming resident (kernel trace of a mixed directory: a 0.4 GB fill
+    // 170 ms long, the layer launch beside it 300 ms instead of 180): it goes behind the engine's last layer launch, beside that batch's head and decode.
+    if (b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(b->stream, b->eng->persist_done, 0), FFHIP_EHIP);
     std::vector<int> cur(lens);
     int nstrided = 0;
     for (int l = 0; l < nconv; l++) {

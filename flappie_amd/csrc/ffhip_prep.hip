@@ -372,9 +372,14 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     ok = ok && hipMemcpyAsync(d_n, n_in.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_s, s_in.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_e, e_in.data(), nread * sizeof(size_t), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (eng->persist_chained && total >= ((size_t)48 << 20)) hipStreamWaitEvent(s, eng->persist_done, 0);      // (see below: the fill and the kernel of a LARGE chunk)
     ok = ok && hipMemsetAsync(p->d_out, 0, total * 4, s) == hipSuccess;
     if (!ok) PFAIL(FFHIP_EHIP, "upload of read table failed");
     PrepArgs a{ d_raw, p->d_out, d_mad, d_off, d_n, d_s, d_e, d_so, d_eo, d_stats, trim_start, trim_end, chunk, perc, delta, shift, mode, do_trim };
+    // A LARGE chunk (the flappie binary widens its window when long reads turn up: 100 M samples and more) is tens of milliseconds of this kernel alone -- and 190 ms
+    // beside a resident layer launch of the batch in flight, which it slows down as much (kernel trace, tools/dev/mixed_trace.sh): such a chunk is prepared behind
+    // the engine's last layer launch (the wait stands in front of the output's fill above; the uploads before it are not held up: copies do not wait for compute).
+    // The usual chunks (a millisecond or two) stay where they were.
     hipLaunchKernelGGL(k_prep, dim3(nread), dim3(256), 0, s, a);
     ok = hipMemcpyAsync(p->start.data(), d_so, nread * sizeof(size_t), hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(p->end.data(), d_eo, nread * sizeof(size_t), hipMemcpyDeviceToHost, s) == hipSuccess;

@@ -353,16 +353,23 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
 
 /* Packed batches (ffhip.h "packed batches"): reads of mixed lengths, several to a row.  One cached object per pipeline slot, `--batch` rows of the chunk's row
  * capacity, created anew when a chunk needs longer rows. */
-static struct { ffhip_batch *b; size_t cap; int max_reads; } pack_cache[NINFLIGHT];
-static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, size_t cap, int max_reads, int slot) {
-    if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads) {
+static struct { ffhip_batch *b; size_t cap; int max_reads, rows; } pack_cache[NINFLIGHT];
+static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, int rows, size_t cap, int max_reads, int slot) {
+    if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads || pack_cache[slot].rows != rows) {
         if (pack_cache[slot].b) ffhip_batch_destroy(pack_cache[slot].b);
-        pack_cache[slot].cap = cap + cap / 8;
+        pack_cache[slot].cap = cap;                       /* (the caller's capacities come in steps: pack_row_cap) */
         pack_cache[slot].max_reads = max_reads;
-        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, args.batch, pack_cache[slot].cap, max_reads);
+        pack_cache[slot].rows = rows;
+        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, rows, cap, max_reads);
         if (NULL == pack_cache[slot].b) { pack_cache[slot].cap = 0; return NULL; }
     }
     return pack_cache[slot].b;
+}
+/* row capacities in steps of a quarter octave (a batch object is re-created -- seconds of hipMalloc at these sizes -- only when a chunk needs the next step) */
+static size_t pack_row_cap(size_t want) {
+    size_t c = 4096;
+    while (c < want) c = (c + c / 4 + 1023) & ~(size_t)1023;
+    return c;
 }
 
 /* A group of prepared reads in flight: submitted (upload + network + decode enqueued on the batch's stream), collected
@@ -372,12 +379,12 @@ typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_pr
 
 /* n reads in the rows of one packed batch: slot_of / off_of from ffhip_pack_plan, `cap` the row capacity it was made for */
 static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, const int *slot_of, const int *off_of,
-                                   size_t cap, int max_reads, int slot) {
+                                   int rows, size_t cap, int max_reads, int slot) {
     pending_batch pb = { NULL, 1, n, malloc((n > 0 ? n : 1) * sizeof(int)), malloc((n > 0 ? n : 1) * sizeof(item *)), prep, NULL };
     memcpy(pb.its, its, n * sizeof(item *));
     size_t longest = 0, rows_used = 0;
     unsigned long long samples = 0;
-    size_t *row_end = calloc(args.batch, sizeof(size_t));
+    size_t *row_end = calloc(rows, sizeof(size_t));
     for (int i = 0; i < n; i++) {
         pb.idx[i] = its[i]->prepared;
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
@@ -387,22 +394,22 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
     /* what the batch costs: its longest ROW (in blocks -> samples of the trimmed signal), whatever the others hold */
     const size_t nb_cap = ffhip_model_nblock(mdl, cap);
     const size_t spb = nb_cap ? (cap + nb_cap / 2) / nb_cap : 1;      /* samples a block (the model's stride) */
-    for (int r = 0; row_end && r < args.batch; r++) {
+    for (int r = 0; row_end && r < rows; r++) {
         if (row_end[r] > longest) longest = row_end[r];
         if (row_end[r]) rows_used++;
     }
     n_batches++; n_packed_batches++;
     n_batch_samples += samples;
-    n_batch_slot_samples += (unsigned long long)longest * spb * (unsigned long long)(16 * ((args.batch + 15) / 16));
-    for (int r0 = 0; row_end && r0 < args.batch; r0 += 16) {
+    n_batch_slot_samples += (unsigned long long)longest * spb * (unsigned long long)(16 * ((rows + 15) / 16));
+    for (int r0 = 0; row_end && r0 < rows; r0 += 16) {
         size_t lt = 0;
-        for (int r = r0; r < args.batch && r < r0 + 16; r++) if (row_end[r] > lt) lt = row_end[r];
+        for (int r = r0; r < rows && r < r0 + 16; r++) if (row_end[r] > lt) lt = row_end[r];
         n_tile_slot_samples += 16ull * lt * spb;
     }
     (void)rows_used;
     free(row_end);
     double t0 = now_s();
-    pb.b = acquire_packed(eng, mdl, cap, max_reads, slot);
+    pb.b = acquire_packed(eng, mdl, rows, cap, max_reads, slot);
     t_phase[2] += now_s() - t0; t0 = now_s();
     const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
     int rc_sub = (NULL == pb.b) ? -1 : ffhip_batch_set_prepared_packed(pb.b, prep, n, pb.idx, slot_of, off_of);
@@ -816,16 +823,20 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         while (nleft > 0 && ns && slot_of && off_of && sl2 && of2 && sel && rest) {
             unsigned long long total = 0;
             for (int i = 0; i < nleft; i++) { ns[i] = rest[i]->res.rt.end - rest[i]->res.rt.start; total += ns[i]; }
-            /* rows long enough for everything left in ONE batch (5 % slack for the gaps and the fit), at least the longest read, at most PACK_ROW_MAX samples */
+            /* rows long enough for everything left in ONE batch (5 % slack for the gaps and the fit), at least the longest read, at most PACK_ROW_MAX samples; as
+             * many rows (<= --batch) as the device's memory takes at that length (ffhip_pack_rows: 1024 rows of 200 000 samples at 256 hidden units would be 140 GB);
+             * what does not fit goes into the chunk's next batch */
             size_t cap = (size_t)((double)total / (double)args.batch * 1.05) + 64 * ffhip_model_pack_gap(mdl);
             if (cap < ns[0] + 64) cap = ns[0] + 64;
             if (cap > PACK_ROW_MAX && ns[0] + 64 <= PACK_ROW_MAX) cap = PACK_ROW_MAX;
-            cap = (cap + 1023) & ~(size_t)1023;
+            cap = pack_row_cap(cap);
+            int rows = ffhip_pack_rows(mdl, args.batch, cap);
             int placed = 0;
-            for (int tries = 0; tries < 6; tries++) {
-                placed = ffhip_pack_plan(mdl, args.batch, cap, nleft, ns, slot_of, off_of);
-                if (placed == nleft || cap >= PACK_ROW_MAX) break;
-                cap = ((size_t)((double)cap * 1.06) + 1023) & ~(size_t)1023;      /* the fit left reads over: longer rows, once more */
+            for (int tries = 0; tries < 3; tries++) {
+                placed = ffhip_pack_plan(mdl, rows, cap, nleft, ns, slot_of, off_of);
+                if (placed == nleft || cap >= PACK_ROW_MAX || rows < args.batch) break;
+                cap = pack_row_cap(cap + 1);                                        /* the fit left reads over: longer rows, once more */
+                rows = ffhip_pack_rows(mdl, args.batch, cap);
             }
             if (placed <= 0) { warnx("packed batch: no read fits a row of %zu samples", cap); break; }
             int nsel = 0, nrest = 0;
@@ -833,7 +844,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
                 if (slot_of[i] >= 0) { sel[nsel] = rest[i]; sl2[nsel] = slot_of[i]; of2[nsel] = off_of[i]; nsel++; }
                 else rest[nrest++] = rest[i];
             }
-            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, cap, rs_chunk_cap, pipe_state.slot);
+            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, cap, rs_chunk_cap, pipe_state.slot);
             cur.owner = c;
             c->submitted++;
             while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);

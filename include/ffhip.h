@@ -74,10 +74,15 @@ typedef struct {
 #define FFHIP_RUN_KEEP_ACTS     16u   /* keep every layer's activations for ffhip_batch_get_activation        */
 /* (A read that left the default kernels' operand range and was evaluated again on the f32 kernels -- ffhip_batch_f32_reruns() -- returns
  * the f32 run's scores, path and calls; its KEPT ACTIVATIONS are not refreshed: they stay those of the first, discarded evaluation.) */
-#define FFHIP_RUN_FAST_GATES   128u   /* split layer kernels: gate activations through the hardware exp / reciprocal (1 ulp) instead of the
-                                       * instruction-for-instruction replay of the reference's exp_ps; opt-in, not bit-compatible */
+/* Gate activations of the split layer kernels (logistic, tanh; layers.c:979-1026 through util.h:319-337, sse_mathfun.h:225-301).  Since round 6 the DEFAULT is
+ * the hardware form of FFHIP_RUN_FAST_GATES2: decided by measurement (profiles/r06_gates_*.txt: 8192 reads at the headline shape, 2048 at the two H = 256 shapes --
+ * worst |dtrans| against the oracle 2.1e-5 with either form, reads called apart from the oracle 5 against the exact form's 6, and two evaluations of the reference's
+ * own algorithm in two summation orders part on 8) and worth +4.4 % (112.6 against 107.8 Msamples/s on one box).  FFHIP_RUN_EXACT_GATES, or FFHIP_FAST_GATES=0 in
+ * the environment, brings back the operation-for-operation replay of the reference's exp_ps and division. */
+#define FFHIP_RUN_FAST_GATES   128u   /* gate activations through v_exp_f32 / v_rcp_f32 as they are (1 ulp each, the exponent rounded once) */
 #define FFHIP_RUN_FAST_GATES2  256u   /* the same with the exponent of v_exp_f32 carried in two words and a Newton step behind v_rcp_f32: exp and the
-                                       * reciprocal to ~1 ulp at every argument (the reference's cephes replay is no closer to the true functions) */
+                                       * reciprocal to ~1 ulp at every argument (the reference's cephes replay is no closer to the true functions); the default */
+#define FFHIP_RUN_EXACT_GATES  512u   /* the reference's exp_ps polynomial and its division replayed bit for bit (the default of rounds 1-5) */
 
 const char *ffhip_last_error(void);
 const char *ffhip_version(void);
@@ -316,6 +321,9 @@ int ffhip_model_packable(const ffhip_model *mdl);         /* 1: this model's def
 size_t ffhip_model_pack_gap(const ffhip_model *mdl);      /* free blocks a read of a packed row needs behind it */
 /* first-fit-decreasing plan: slot[i] / block_off[i] for every read (slot -1: it did not fit into nslot rows of nsample_cap samples); returns the reads placed */
 int ffhip_pack_plan(const ffhip_model *mdl, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off);
+/* rows (a multiple of 16, <= want_rows) of a packed batch of nsample-sample rows whose workspace fits 28 % of the device's memory (two such objects are
+ * alive in a pipeline): 512 rows of 200 000 samples are ~90 GB at 384 hidden units */
+int ffhip_pack_rows(const ffhip_model *mdl, int want_rows, size_t nsample);
 ffhip_batch *ffhip_batch_create_packed(ffhip_engine *eng, const ffhip_model *mdl, int nslot, size_t nsample, int max_reads);
 int ffhip_batch_set_prepared_packed(ffhip_batch *b, const ffhip_prep *prep, int nread, const int *reads /* indices into prep */, const int *slot, const int *block_off);
 int ffhip_batch_set_signals_packed(ffhip_batch *b, int nread, const float *const *signals, const size_t *nsample, const int *slot, const int *block_off);

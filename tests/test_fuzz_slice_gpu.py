@@ -27,7 +27,10 @@ MIN_READS = 20000
 # Later in round 4 the default path's CRF head moved to the split pipes (k_head_split) while the f32 path keeps the f32-MFMA head: one more place
 # where the two paths sum in different orders, and one more near-tie read each way: 4 base strings, 5 quality strings (the scores themselves: worst
 # 2.2e-5 as before; against the ORACLE the sampled reads show 0 mismatches on either build).
-RECORDED = dict(beyond_1e4=0, base_strings=4, quality_strings=5)      # 20 281 reads, 181 cases; worst |dtrans| 2.2e-5 (gpurun_out/r04h_tests.log, profiles/r04_fuzz_slice.txt)
+# Round 6: the default path's gate activations come from v_exp_f32 / v_rcp_f32 (two-word exponent, Newton step: include/ffhip.h FFHIP_RUN_FAST_GATES2; decided by
+# the campaigns of profiles/r06_gates_*.txt), the f32 path keeps the reference's exp_ps replay: 3 base strings, 6 quality strings, worst |dtrans| 2.16e-5 (with
+# FFHIP_RUN_EXACT_GATES on the default path: the round-5 record, 4 and 5); against the ORACLE the sampled reads show 0 mismatches either way.
+RECORDED = dict(beyond_1e4=0, base_strings=3, quality_strings=6)      # 20 281 reads, 181 cases; worst |dtrans| 2.2e-5 (profiles/r06_fuzz_slice.txt; round 4: profiles/r04_fuzz_slice.txt)
 # ... and a fixed subsample of the slice against the ORACLE (path-vs-path alone says nothing about either path): every
 # ORACLE_EVERY-th read, default path; bounds are north_star's with the recorded count of exceptions
 ORACLE_EVERY = 64

@@ -17,7 +17,7 @@ Run on the GPU box.   usage: tools/parity_h384.py [nread=2048] [tmax=2500] [shap
                      --trans-reads of them and insists on identical strings before it uses the file)
   --refs FILE        take the oracle's strings from FILE; the transition scores are compared on the first --trans-reads reads (default 512), which
                      the box evaluates itself
-  --gates a,b        engine passes: default = the reference's exp_ps / division replayed bit for bit, fast = FFHIP_RUN_FAST_GATES (hardware v_exp / v_rcp), fast2 = FFHIP_RUN_FAST_GATES2 (two-word exponent, Newton step)
+  --gates a,b        engine passes: default = the reference's exp_ps / division replayed bit for bit, fast = FFHIP_RUN_FAST_GATES (hardware v_exp / v_rcp), fast2 = FFHIP_RUN_FAST_GATES2 (two-word exponent, Newton step; the library's default since round 6), exact = default here
 shape: c2 = LSTM H 384 in pairs of 256-read batches (the default, the headline); h256 / c4 = LSTM / GRUmod H 256 in full 1024-read launches of the
 packed kernels (k_lstm_pack / k_grumod_pack); c5 = LSTM H 512 in 256-read batches (k_lstm_split<0,4,2>).  bench.py's models (seed 1)."""
 import multiprocessing as mp
@@ -170,7 +170,7 @@ def main():
         t_00.add("read %d" % i, ref0[i], ref3[i])
     bs = [B.Batch(dm, PER_BATCH, tmax) for _ in range(2)]
     for gates in _opt.get("gates", "default").split(","):
-        flags = {"default": 0, "fast": B.RUN_FAST_GATES, "fast2": B.RUN_FAST_GATES2}[gates]
+        flags = {"default": B.RUN_EXACT_GATES, "exact": B.RUN_EXACT_GATES, "fast": B.RUN_FAST_GATES, "fast2": B.RUN_FAST_GATES2}[gates]
         t_eng0, t_eng3 = Tally("engine <-> oracle"), Tally("engine <-> oracle+blas")
         min_kmers, paired = 10 ** 9, 0
         t1 = time.time()
@@ -194,7 +194,7 @@ def main():
                     t_eng3.add(tag, a, ref3[i])
                     s = ref0[i]["basecall"]
                     min_kmers = min(min_kmers, len({s[q:q + 5] for q in range(len(s) - 4)}))
-        print("\n### gates: %s%s  (engine passes %.0f s)" % (gates, {"default": " (the reference's exp_ps and division, bit for bit)", "fast": " (FFHIP_RUN_FAST_GATES: hardware v_exp / v_rcp in the gate phase)", "fast2": " (FFHIP_RUN_FAST_GATES2: v_exp with a two-word exponent, v_rcp + one Newton step)"}[gates], time.time() - t1))
+        print("\n### gates: %s%s  (engine passes %.0f s)" % (gates, {"default": " (FFHIP_RUN_EXACT_GATES: the reference's exp_ps and division, bit for bit -- the default of rounds 1-5)", "exact": " (FFHIP_RUN_EXACT_GATES: the reference's exp_ps and division, bit for bit)", "fast": " (FFHIP_RUN_FAST_GATES: hardware v_exp / v_rcp in the gate phase)", "fast2": " (FFHIP_RUN_FAST_GATES2: v_exp with a two-word exponent, v_rcp + one Newton step)"}[gates], time.time() - t1))
         print("campaign: shape %s (kind %d, H = %d, %d reads a batch%s), %d of %d batches in a paired launch; %d reads, %d samples; fewest distinct 5-mers in a read %d"
               % (SHAPE, KIND, H, PER_BATCH, ", through ffhip_batch_run_pair" if PAIRED else "", paired, len(batches), nread, sum(x.size for x in flat), min_kmers))
         for t in (t_eng0, t_eng3, t_00):
