@@ -193,8 +193,13 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 // tile row 4 q + c is unit 4 c + q, so that lane (q, read) of a tile's accumulator holds units q, 4 + q, 8 + q, 12 + q in its components: gate wave
 // (tile ts, component c) reads component c of the three gates and is, for the arithmetic and for the split / transpose / store of h(t), exactly
 // the 4-unit gate tile (units 4 c .. 4 c + 3) of the other forms.  The candidate's projection half travels as a fourth partial tile.
-template <int KIND, int N, int TS, bool DN, bool PACK = false, bool LIVE = false>      // LIVE: the packed-batch forms (a.live; their own instantiations: the one-read-a-row kernels stay instruction for instruction what they were)
+// LIVE: the packed-batch forms (a.live; their own instantiations: the one-read-a-row kernels stay instruction for instruction what they were).
+// GL: the gate level as a compile-time constant -- 2 = v_exp_f32 / v_rcp_f32 with a two-word exponent and a Newton step (the default since round 6), 0 = the reference's
+// exp_ps and division replayed bit for bit (FFHIP_RUN_EXACT_GATES).  As a run-time branch on a.fast_gates both forms sat in every kernel: 17 spilled scalar registers
+// in the paired form instead of 8, and c2 / h256 / c4 1.7 / 1.6 / 0.9 % slower (profiles/r06_gate_speed.txt).  Level 1 (the one-word exponent) runs as level 2: it was no faster.
+template <int KIND, int N, int TS, bool DN, bool PACK = false, bool LIVE = false, int GL = 2>
 __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int block_index) {
+    constexpr int fg = GL;
     static_assert(!DN || TS == 2, "the dense form is a pair form");
     static_assert(!PACK || (DN && N == 2), "the packed forms are dense forms at H = 256");
     // PACK with the LSTM (KIND 0): the same regrouping -- 16 members of 16 units, FOUR gate-major row tiles a member -- without a row to save: what
@@ -426,11 +431,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
                 s0 += pz[0]; s1 += pz[64 * 4]; s2 += pz[128 * 4]; s3 += pz[192 * 4];
             }
             const v4f s = unscale4((v4f){ s0, s1, s2, s3 });
-            if (a.fast_gates) {
-                const float forget = logistic_hw(s.y, a.fast_gates) * c;
-                const float update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
+            if (fg) {
+                const float forget = logistic_hw(s.y, fg) * c;
+                const float update = logistic_hw(s.x, fg) * tanh_hw(s.z, fg);
                 c = forget + update;
-                h = logistic_hw(s.w, a.fast_gates) * tanh_hw(c, a.fast_gates);
+                h = logistic_hw(s.w, fg) * tanh_hw(c, fg);
             } else {
                 const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
                 const float tanh_g = (L.z + L.z) - 1.0f;
@@ -455,9 +460,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             }
             sz = __builtin_ldexpf(sz, neg_exp); sr = __builtin_ldexpf(sr, neg_exp); su = __builtin_ldexpf(su, neg_exp); sx = __builtin_ldexpf(sx, neg_exp);
             const v4f b = sbias[gj][q];
-            if (a.fast_gates) {
-                const float z = logistic_hw(sz + b.x, a.fast_gates), r = logistic_hw(sr + b.y, a.fast_gates);
-                const float hbar = tanh_hw(r * su + (sx + b.z), a.fast_gates);
+            if (fg) {
+                const float z = logistic_hw(sz + b.x, fg), r = logistic_hw(sr + b.y, fg);
+                const float hbar = tanh_hw(r * su + (sx + b.z), fg);
                 h = z * c + (1.0f - z) * hbar;
             } else {
                 const ffv2 L = logistic_ref2_lean((ffv2){ sz + b.x, sr + b.y });
@@ -475,9 +480,9 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
             s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             const v4f b = sbias[gj][q];
-            if (a.fast_gates) {
-                const float z = logistic_hw(s.x + b.x, a.fast_gates), r = logistic_hw(s.y + b.y, a.fast_gates);
-                const float hbar = tanh_hw(r * s.z + (s.w + b.z), a.fast_gates);
+            if (fg) {
+                const float z = logistic_hw(s.x + b.x, fg), r = logistic_hw(s.y + b.y, fg);
+                const float hbar = tanh_hw(r * s.z + (s.w + b.z), fg);
                 h = z * c + (1.0f - z) * hbar;
             } else {
                 const ffv2 L = logistic_ref2_lean((ffv2){ s.x + b.x, s.y + b.y });
@@ -492,11 +497,11 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
             for (int w2 = 0; w2 < 4; w2++) s = s + ph_at(w2, gts, gj)[lane];
             s = unscale4(s);                               // out of the scaled space (a power of two: exact)
             // (the _lean forms give the bits of logistic_ref4 / tanh_ref with ~50 fewer instructions: ffhip_math.hpp)
-            if (a.fast_gates) {
-                const float forget = logistic_hw(s.y, a.fast_gates) * c;
-                const float update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
+            if (fg) {
+                const float forget = logistic_hw(s.y, fg) * c;
+                const float update = logistic_hw(s.x, fg) * tanh_hw(s.z, fg);
                 c = forget + update;
-                h = logistic_hw(s.w, a.fast_gates) * tanh_hw(c, a.fast_gates);
+                h = logistic_hw(s.w, fg) * tanh_hw(c, fg);
             } else {
                 const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
                 const float tanh_g = (L.z + L.z) - 1.0f;
@@ -520,10 +525,10 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         // packed + one scalar evaluation cost, so this wave's instruction count stays and the back wave loses its own logistic, its four partial sums and their LDS
         // reads -- ~45 VALU instructions a tile off a SIMD whose MFMA and VALU time add (profiles/r05_coissue_probe.txt).  The same operations on the same values.
         float og;
-        if (a.fast_gates) {
-            forget = logistic_hw(s.y, a.fast_gates) * c;
-            update = logistic_hw(s.x, a.fast_gates) * tanh_hw(s.z, a.fast_gates);
-            og = logistic_hw(s.w, a.fast_gates);
+        if (fg) {
+            forget = logistic_hw(s.y, fg) * c;
+            update = logistic_hw(s.x, fg) * tanh_hw(s.z, fg);
+            og = logistic_hw(s.w, fg);
         } else {
             const ffv4 L = logistic_ref4_lean((ffv4){ s.x, s.y, s.z + s.z, s.w });
             const float tanh_g = (L.z + L.z) - 1.0f;
@@ -543,7 +548,7 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
         asm volatile("" ::: "memory");
         const float c = cx[wave & 1][lane];
         const float o = ox[wave & 1][lane];
-        float h = o * (a.fast_gates ? tanh_hw(c, a.fast_gates) : tanh_ref_lean(c));
+        float h = o * (fg ? tanh_hw(c, fg) : tanh_ref_lean(c));
         if (step_t(i) >= my_tb) h = 0.0f;
         publish_h(i, gts, gj, h);
     };
@@ -1057,22 +1062,22 @@ __device__ __forceinline__ void lstm_split_body(const SplitArgs &a, const int bl
 #endif
 }
 
-template <int KIND, int N, int TS, bool DN = false, bool LIVE = false>
+template <int KIND, int N, int TS, bool DN = false, bool LIVE = false, int GL = 2>
 __global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
-k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN, false, LIVE>(a, (int)blockIdx.x); }
+k_lstm_split(SplitArgs a) { lstm_split_body<KIND, N, TS, DN, false, LIVE, GL>(a, (int)blockIdx.x); }
 
 // the packed GRUmod form (H = 256): 128 registers, two workgroups a CU, 16 members a group
-template <bool LIVE>
+template <bool LIVE, int GL>
 __global__ void __launch_bounds__(512, 4)
-k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true, LIVE>(a, (int)blockIdx.x); }
-template <bool LIVE>
+k_grumod_pack(SplitArgs a) { lstm_split_body<1, 2, 2, true, true, LIVE, GL>(a, (int)blockIdx.x); }
+template <bool LIVE, int GL>
 __global__ void __launch_bounds__(512, 4)
-k_lstm_pack(SplitArgs a) { lstm_split_body<0, 2, 2, true, true, LIVE>(a, (int)blockIdx.x); }
+k_lstm_pack(SplitArgs a) { lstm_split_body<0, 2, 2, true, true, LIVE, GL>(a, (int)blockIdx.x); }
 
 // The layer launches of TWO batches as one grid (ffhip_batch_run_pair): workgroups below nwg0 serve the first batch's read tiles, the
 // others the second's -- every pointer and count of a batch comes from its own argument block, nothing is shared but the weights.
 // For the dense form at H = 384: 2 x 256 reads = 16 groups = two workgroups on every CU, and ONE launch whose duration is the pair's.
-template <int KIND, int N, int TS, bool DN, bool LIVE = false>
+template <int KIND, int N, int TS, bool DN, bool LIVE = false, int GL = 2>
 __global__ void __launch_bounds__(512, (DN && N <= 2) ? 6 : ((TS == 1 || N <= 2 || DN) ? 4 : 1))
 k_lstm_split_pair(SplitArgs a, SplitArgsOther o) {
     int bi = (int)blockIdx.x;
@@ -1080,7 +1085,7 @@ k_lstm_split_pair(SplitArgs a, SplitArgsOther o) {
         bi -= o.nwg0;
         a.xin = o.xin; a.hout = o.hout; a.hout_f32 = o.hout_f32; a.flags = o.flags; a.abort_word = o.abort_word; a.tbs = o.tbs; a.tbt = o.tbt; a.live = o.live; a.epoch = o.epoch;
     }
-    lstm_split_body<KIND, N, TS, DN, false, LIVE>(a, bi);
+    lstm_split_body<KIND, N, TS, DN, false, LIVE, GL>(a, bi);
 }
 
 // ---- recurrence only, behind the projection GEMM: shapes whose two weight matrices do not fit a CU's registers ------
@@ -1614,8 +1619,9 @@ bool launch_lstm_split_pair(hipStream_t s, int kind, int H, int ncu, const Split
     SplitArgsOther o;
     o.xin = a1.xin; o.hout = a1.hout; o.hout_f32 = a1.hout_f32; o.flags = a1.flags; o.abort_word = a1.abort_word; o.tbs = a1.tbs; o.tbt = a1.tbt; o.live = a1.live; o.epoch = a1.epoch;
     o.nwg0 = g0 * 32;
-    if (p0.live) hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
-    else hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true>), dim3((g0 + g1) * 32), dim3(512), 0, s, mk(p0), o);
+    const dim3 grid((g0 + g1) * 32);
+    if (p0.live) { if (p0.fast_gates) hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, true, 2>), grid, dim3(512), 0, s, mk(p0), o); else hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, true, 0>), grid, dim3(512), 0, s, mk(p0), o); }
+    else { if (p0.fast_gates) hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, false, 2>), grid, dim3(512), 0, s, mk(p0), o); else hipLaunchKernelGGL((k_lstm_split_pair<0, 3, 2, true, false, 0>), grid, dim3(512), 0, s, mk(p0), o); }
     return true;
 #endif
 }
@@ -1638,29 +1644,39 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     const int ts = split_launch_ts(kind, H, nrt, ncu, beside);
     const int ngroup_l = (nrt + ts - 1) / ts;
 #ifndef FFHIP_SPLIT_BF16X3
-    // (a packed batch -- a.live -- takes the LIVE instantiation of the same form)
-#define SPLIT_GO(KERNEL_T, KERNEL_F, GRID) do { if (a.live) hipLaunchKernelGGL(KERNEL_T, dim3(GRID), dim3(512), 0, s, a); else hipLaunchKernelGGL(KERNEL_F, dim3(GRID), dim3(512), 0, s, a); } while (0)
-    if (split_launch_dense3(kind, H, nrt, ncu, beside)) { SPLIT_GO((k_lstm_split<0, 3, 2, true, true>), (k_lstm_split<0, 3, 2, true>), ngroup_l * 32); return true; }
+    // (a packed batch -- a.live -- takes the LIVE instantiation of the same form; the gate level picks the GL one)
+#define SPLIT_GO(KF, GRID) do { if (a.live) { if (a.fast_gates) hipLaunchKernelGGL((KF(true, 2)), dim3(GRID), dim3(512), 0, s, a); else hipLaunchKernelGGL((KF(true, 0)), dim3(GRID), dim3(512), 0, s, a); } \
+                                else { if (a.fast_gates) hipLaunchKernelGGL((KF(false, 2)), dim3(GRID), dim3(512), 0, s, a); else hipLaunchKernelGGL((KF(false, 0)), dim3(GRID), dim3(512), 0, s, a); } } while (0)
+#define K_DENSE3(L, G) k_lstm_split<0, 3, 2, true, L, G>
+#define K_GPACK(L, G) k_grumod_pack<L, G>
+#define K_LPACK(L, G) k_lstm_pack<L, G>
+#define K_D256L(L, G) k_lstm_split<0, 2, 2, true, L, G>
+#define K_D256G(L, G) k_lstm_split<1, 2, 2, true, L, G>
+    if (split_launch_dense3(kind, H, nrt, ncu, beside)) { SPLIT_GO(K_DENSE3, ngroup_l * 32); return true; }
     if (split_launch_pack(kind, H, nrt, ncu)) {
         a.Wp += split_pack_offset(H);
-        if (kind == 1) SPLIT_GO(k_grumod_pack<true>, k_grumod_pack<false>, nrt / 2 * 16);
-        else SPLIT_GO(k_lstm_pack<true>, k_lstm_pack<false>, nrt / 2 * 16);
+        if (kind == 1) SPLIT_GO(K_GPACK, nrt / 2 * 16);
+        else SPLIT_GO(K_LPACK, nrt / 2 * 16);
         return true;
     }
     if (split_launch_dense256(H, nrt, ncu)) {
-        if (kind == 0) SPLIT_GO((k_lstm_split<0, 2, 2, true, true>), (k_lstm_split<0, 2, 2, true>), ngroup_l * 32);
-        else SPLIT_GO((k_lstm_split<1, 2, 2, true, true>), (k_lstm_split<1, 2, 2, true>), ngroup_l * 32);
+        if (kind == 0) SPLIT_GO(K_D256L, ngroup_l * 32);
+        else SPLIT_GO(K_D256G, ngroup_l * 32);
         return true;
     }
 #endif
-#define SPLIT_LAUNCH(K, NN) do { if (ts == 1) SPLIT_GO((k_lstm_split<K, NN, 1, false, true>), (k_lstm_split<K, NN, 1>), ngroup_l * 32); \
-                                 else SPLIT_GO((k_lstm_split<K, NN, 2, false, true>), (k_lstm_split<K, NN, 2>), ngroup_l * 32); return true; } while (0)
+#define K_GEN(KK, NN, TT) [&]() { if (a.live) { if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<KK, NN, TT, false, true, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); else hipLaunchKernelGGL((k_lstm_split<KK, NN, TT, false, true, 0>), dim3(ngroup_l * 32), dim3(512), 0, s, a); } \
+                                  else { if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<KK, NN, TT, false, false, 2>), dim3(ngroup_l * 32), dim3(512), 0, s, a); else hipLaunchKernelGGL((k_lstm_split<KK, NN, TT, false, false, 0>), dim3(ngroup_l * 32), dim3(512), 0, s, a); } }()
+#define SPLIT_LAUNCH(K, NN) do { if (ts == 1) K_GEN(K, NN, 1); else K_GEN(K, NN, 2); return true; } while (0)
 #ifdef FFHIP_SPLIT_BF16X3
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3); }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #else
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3);
-                                      case 4: if (a.live) return false; hipLaunchKernelGGL((k_lstm_split<0, 4, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a); return true; }      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves)
+                                      case 4: if (a.live) return false;      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves; no packed form)
+                                              if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a);
+                                              else hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 0>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a);
+                                              return true; }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #endif
 #undef SPLIT_LAUNCH
