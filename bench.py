@@ -517,7 +517,8 @@ def main():
                          "= %.3f of the 16-bit MFMA peak; against the f32-input MFMA peak (%.1f) the algorithmic rate is %.3f"
                          % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS, achieved * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS,
                             PEAK_F32_MFMA_TFLOPS, achieved / PEAK_F32_MFMA_TFLOPS))
-            dtype = "f32 (products as 3 fp16 MFMA terms over 2-way split operands, f32 accumulate; gate math f32)"
+            dtype = ("f32 (products as 3 fp16 MFMA terms over 2-way split operands, f32 accumulate; gate activations f32 through v_exp_f32 / v_rcp_f32 with a two-word exponent and a Newton step"
+                     " -- FFHIP_FAST_GATES=0 replays the reference's exp_ps instead: profiles/r06_gates_c2.txt)")
         else:
             kname = ("k_lstm_fused (%s input projection + recurrence of one layer, %d dependent steps)" if fused
                      else "k_rnn_persist (%s recurrence of one layer, %d dependent steps)") % (cell, nblock)

@@ -499,7 +499,6 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
 #pragma unroll
     for (int i = 0; i < TM; i++) bv[i] = *(const v4f *)(bias + (mt0 + i) * 16 + kq * 4) * acc_scale;
     const float inv_scale = 1.0f / acc_scale;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in.p, 0, (int)0xFFFFFFFFu, 0x00020000);
     // window starts of a tile, this lane's read: both passes (x0b: the second window some columns accumulate, layers.c:257-271)
     auto table = [&](int nt, int &xa, int &xb) {
         const int t = nt < ntile ? nt : ntile - 1;
@@ -508,9 +507,12 @@ k_conv_split_ws(SampleBuf in, const v4u_t *__restrict__ Wp, const float *__restr
     };
     // gather my five pieces of (tile nt, window start x0 of this lane's read) into buffer `buf`: a tap beyond the window, or no window at
     // all, reads the leading zero pad of read 0.  Offsets come from registers only: nothing here waits for memory.
+    // (the buffer resource starts at the read TILE's first row: offsets are 32 bits, and the rows of a long-read batch -- 512 rows of 200 000 samples are 6.7 GB -- pass
+    // that as offsets from the buffer's start; sixteen rows do not)
     auto gather = [&](int nt, int x0, int buf) {
         const bool have = (x0 != kNoWindow && x0 != kZeroCol);
-        const unsigned row0 = (unsigned)(((size_t)((nt % B16) * 16 + rl) * in.rs + (size_t)(kSamplePad + (have ? x0 : 0)) * 16) * 4) + (unsigned)((kq >> 1) * 64 + (kq & 1) * 16);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(in.p + (size_t)((nt % B16) * 16) * in.rs), 0, (int)0xFFFFFFFFu, 0x00020000);
+        const unsigned row0 = (unsigned)(((size_t)rl * in.rs + (size_t)(kSamplePad + (have ? x0 : 0)) * 16) * 4) + (unsigned)((kq >> 1) * 64 + (kq & 1) * 16);
 #pragma unroll
         for (int k = 0; k < PPW; k++) {
             const int piece = wave * PPW + k, ch = piece / NSL, sl = piece % NSL;
@@ -601,7 +603,7 @@ void launch_conv_split(hipStream_t s, SampleBuf in, float *out, const void *Wp, 
     // the weights-stationary form: split output, the chip to itself, shapes it is built for (FFHIP_DEBUG=conv_ws=0: the round-3 kernel)
     const char *ws_txt = dbg("conv_ws");
     const int ws_env = ws_txt ? atoi(ws_txt) : 1;
-    if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * (size_t)(B16 * 16) < ((size_t)1 << 32)) {
+    if (!lean && out_split && kSplitNS == 2 && ws_env && act == ACT_SWISH && Mt % 8 == 0 && NC == 10 && (size_t)in.rs * 4 * 16 < ((size_t)1 << 32)) {
         // (per call, of the CURRENT device -- the caller's engine has set it: a value cached from the first call would size the groups of an engine on
         // another device of the process by the wrong chip)
         int ncu = 256;
