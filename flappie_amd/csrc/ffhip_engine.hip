@@ -870,7 +870,7 @@ extern "C" int ffhip_model_packable(const ffhip_model *m) {
     if (!m || m->kind == FFHIP_NET_LSTM5_RLE || !((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60))) return 0;
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    return (persist_supported(m->cell, m->Hp, ncu) && split_supported(m->cell, m->Hp) && m->Hp <= 384 && m->rnn[0].Wsplit != nullptr && m->conv[m->nconv - 1].Mpad == m->Hp &&
+    return (persist_supported(m->cell, m->Hp, ncu) && split_supported(m->cell, m->Hp) && m->rnn[0].Wsplit != nullptr && m->conv[m->nconv - 1].Mpad == m->Hp &&
             !dbg("no_split") && !dbg("no_fuse")) ? 1 : 0;
 }
 // Blocks that stay free behind every read of a packed slot: the widest convolution window of the model either side of a read must see the zero padding the
@@ -1360,7 +1360,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
     // A packed batch runs on the default path only: the split layer kernels know the live mask, the chain / Viterbi / assembly / trace kernels the read map
     if (b->packed && !(use_split && conv_split && !keep && m->kind != FFHIP_NET_LSTM5_RLE && ((m->nbase == 4 && m->Ps == 40) || (m->nbase == 5 && m->Ps == 60)) &&
                        !dbg("decode_r2") && !dbg("crf_logspace") && 10.0f / temperature <= kFbRange && crf_rescale_interval(5.0f / temperature) > 0))
-        return set_err(FFHIP_EINVAL, "packed batches take the default path only (flip-flop model with 128 .. 384 hidden units, no kept activations, no f32 / stepwise / unfused flags, ordinary temperature)");
+        return set_err(FFHIP_EINVAL, "packed batches take the default path only (flip-flop model with 128 .. 512 hidden units, no kept activations, no f32 / stepwise / unfused flags, ordinary temperature)");
     int cur = b->run_cur;
     {
         const bool need0 = !conv_split;           // the convolution's fp32 output (every path but split layers behind a split-writing convolution)

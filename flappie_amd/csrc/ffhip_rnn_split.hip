@@ -1673,10 +1673,10 @@ bool launch_lstm_split(hipStream_t s, int kind, const void *Wp, const float *bia
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #else
     if (kind == 0) switch (H / 128) { case 1: SPLIT_LAUNCH(0, 1); case 2: SPLIT_LAUNCH(0, 2); case 3: SPLIT_LAUNCH(0, 3);
-                                      case 4: if (a.live) return false;      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves; no packed form)
-                                              if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 2>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a);
-                                              else hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 0>), dim3((nrt + 1) / 2 * 32), dim3(512), 0, s, a);
-                                              return true; }
+                                      case 4: { const dim3 g4((nrt + 1) / 2 * 32);      // (H = 512: the pair form only -- one tile per group would need 122 registers more than a second workgroup leaves)
+                                              if (a.live) { if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, true, 2>), g4, dim3(512), 0, s, a); else hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, true, 0>), g4, dim3(512), 0, s, a); }
+                                              else { if (a.fast_gates) hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 2>), g4, dim3(512), 0, s, a); else hipLaunchKernelGGL((k_lstm_split<0, 4, 2, false, false, 0>), g4, dim3(512), 0, s, a); }
+                                              return true; } }
     if (kind == 1) switch (H / 128) { case 1: SPLIT_LAUNCH(1, 1); case 2: SPLIT_LAUNCH(1, 2); case 3: SPLIT_LAUNCH(1, 3); }
 #endif
 #undef SPLIT_LAUNCH

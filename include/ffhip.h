@@ -315,7 +315,7 @@ int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *
  * starting at a block offset of the caller's choice with at least ffhip_model_pack_gap() free blocks behind it.  Every read is still evaluated whole and
  * exactly as if it were alone (bit for bit what the one-read-a-row batch gives): the convolutions see zero padding either side of it, the recurrent
  * layers start from a zero state at its first block and, in the reverse layers, at its last; partition function, posterior, Viterbi, strings and trace
- * are per read.  Results are indexed by READ, 0 .. nread - 1 in the order of the set call.  The default path only (flip-flop models with 128 .. 384 hidden units;
+ * are per read.  Results are indexed by READ, 0 .. nread - 1 in the order of the set call.  The default path only (flip-flop models with 128 .. 512 hidden units;
  * no FFHIP_RUN_KEEP_ACTS / _F32_RNN / _STEPWISE_RNN / _UNFUSED_RNN): ffhip_batch_run says so otherwise.  ffhip_batch_run_pair takes packed batches too. */
 int ffhip_model_packable(const ffhip_model *mdl);         /* 1: this model's default path takes packed batches on this device */
 size_t ffhip_model_pack_gap(const ffhip_model *mdl);      /* free blocks a read of a packed row needs behind it */

@@ -31,35 +31,45 @@ sys.path.insert(0, %(root)r)
 from flappie_amd import binding as B
 from flappie_amd import model as M
 kind, hidden, nread, T, pair, reps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+packed = len(sys.argv) > 8 and sys.argv[8] == "1"      # the same rows as a PACKED batch (several reads to a row: the LIVE instantiations of the layer kernels)
 eng = B.Engine(0)
 dm = B.DeviceModel(eng, M.synthetic_model(kind, hidden, seed=5 + kind))
 rng = np.random.default_rng(nread + hidden)
 lens = rng.integers(T // 5, T + 1, size=nread); lens[:3] = (T, T // 5, T // 4)
 sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
+if packed:
+    lens = rng.integers(T // 8, T // 2, size=3 * nread); lens[:3] = (T - 8, T // 8, T // 4)
+    sigs = [rng.standard_normal(int(n)).astype(np.float32) for n in lens]
 res = []
 for rep in range(reps):
-    bs = [B.Batch(dm, nread, T) for _ in range(2 if pair else 1)]
+    bs = [B.Batch(dm, nread, T, max_reads=len(sigs) if packed else 0) for _ in range(2 if pair else 1)]
     for b in bs:
-        b.set_signals_ragged(sigs)
+        if packed:
+            slot, off = b.pack_plan([x.size for x in sigs])
+            keep = [i for i in range(len(sigs)) if slot[i] >= 0]
+            assert len(keep) > 2 * nread
+            b.set_signals_packed([sigs[i] for i in keep], [slot[i] for i in keep], [off[i] for i in keep])
+        else:
+            b.set_signals_ragged(sigs)
     if pair:
         bs[0].run_pair(bs[1])
     else:
         bs[0].run()
     for b in bs:
         b.finish()
-    res.append([[(b.transitions(r).tobytes(), b.basecall(r), b.quality(r)) for r in range(nread)] for b in bs])
+    res.append([[(b.transitions(r).tobytes(), b.basecall(r), b.quality(r)) for r in range(b.nreads() if packed else nread)] for b in bs])
     for b in bs:
         b.close()
 pickle.dump(res, open(out, "wb"))
 """
 
 
-def _run(lib, kind, hidden, nread, T, pair, reps, out):
+def _run(lib, kind, hidden, nread, T, pair, reps, out, packed=False):
     env = dict(os.environ)
     env.pop("FFHIP_DEBUG", None)
     if lib:
         env["FFHIP_BINDING_LIBRARY"] = lib
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(kind), str(hidden), str(nread), str(T), str(int(pair)), str(reps), out], env=env,
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(kind), str(hidden), str(nread), str(T), str(int(pair)), str(reps), out, str(int(packed))], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return pickle.load(open(out, "rb"))
@@ -100,3 +110,18 @@ def test_a_late_wave_changes_nothing(tmp_path, kind, hidden, nread, T, pair):
         for k, b in enumerate(bs):
             bad = [r for r in range(nread) if b[r] != ref[k][r]]
             assert not bad, "launch %d, batch %d: %d reads differ (tiles %s)" % (rep, k, len(bad), sorted(set(r // 16 for r in bad))[:8])
+
+
+# ... and the PACKED instantiations of the same forms (round 6: several reads to a row, the live mask; kernels of their own): the paired launch, the two packed H = 256 forms in
+# full 1024-row launches, the one-tile form -- re-swept on purpose and with late waves
+@pytest.mark.gpu
+@pytest.mark.parametrize("lib,reps", [(HOOK, 6), (SKEW, 3)])
+@pytest.mark.parametrize("kind,hidden,nread,T,pair", [(0, 384, 256, 1500, True), (0, 256, 1024, 1000, False), (1, 256, 1024, 1000, False), (0, 128, 96, 1000, False)])
+def test_packed_batches_under_a_resweep_and_with_late_waves(tmp_path, lib, reps, kind, hidden, nread, T, pair):
+    ref = _run(None, kind, hidden, nread, T, pair, 1, str(tmp_path / "ref.pkl"), packed=True)[0]
+    got = _run(lib, kind, hidden, nread, T, pair, reps, str(tmp_path / "got.pkl"), packed=True)
+    for rep, bs in enumerate(got):
+        for k, b in enumerate(bs):
+            assert len(b) == len(ref[k])
+            bad = [r for r in range(len(b)) if b[r] != ref[k][r]]
+            assert not bad, "launch %d, batch %d: %d reads differ" % (rep, k, len(bad))
