@@ -892,7 +892,7 @@ extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsamp
                        + 2 * (size_t)m->Hp * 2 * kSplitNS;                                                                                            // two activation buffers in the split layout
     size_t per_sample = 0;
     for (int l = 0; l < m->nconv; l++) per_sample += (size_t)m->conv[l].Fin * 4;       // the convolutions' inputs (sample-major; the last one's as fp16 slices: the same 4 bytes a value)
-    const double row = (double)nb * (double)per_block + (double)(nsample + 2 * kSamplePad) * (double)per_sample * (m->nconv > 1 ? 1.0 : 1.0);
+    const double row = (double)nb * (double)per_block + (double)(nsample + 2 * kSamplePad) * (double)per_sample;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return want_rows;
     long rows = (long)((double)total_b * 0.28 / row);      // (of the device's TOTAL memory: the answer must not change while the first object is alive)

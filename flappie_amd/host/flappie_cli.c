@@ -382,21 +382,20 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
                                    int rows, size_t cap, int max_reads, int slot) {
     pending_batch pb = { NULL, 1, n, malloc((n > 0 ? n : 1) * sizeof(int)), malloc((n > 0 ? n : 1) * sizeof(item *)), prep, NULL };
     memcpy(pb.its, its, n * sizeof(item *));
-    size_t longest = 0, rows_used = 0;
+    size_t longest = 0;
     unsigned long long samples = 0;
     size_t *row_end = calloc(rows, sizeof(size_t));
     for (int i = 0; i < n; i++) {
         pb.idx[i] = its[i]->prepared;
         const size_t li = its[i]->res.rt.end - its[i]->res.rt.start;
         samples += li;
-        if (row_end) { const size_t e = (size_t)off_of[i] * 1 + ffhip_model_nblock(mdl, li); if (e > row_end[slot_of[i]]) row_end[slot_of[i]] = e; }
+        if (row_end) { const size_t e = (size_t)off_of[i] + ffhip_model_nblock(mdl, li); if (e > row_end[slot_of[i]]) row_end[slot_of[i]] = e; }
     }
     /* what the batch costs: its longest ROW (in blocks -> samples of the trimmed signal), whatever the others hold */
     const size_t nb_cap = ffhip_model_nblock(mdl, cap);
     const size_t spb = nb_cap ? (cap + nb_cap / 2) / nb_cap : 1;      /* samples a block (the model's stride) */
     for (int r = 0; row_end && r < rows; r++) {
         if (row_end[r] > longest) longest = row_end[r];
-        if (row_end[r]) rows_used++;
     }
     n_batches++; n_packed_batches++;
     n_batch_samples += samples;
@@ -406,7 +405,6 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
         for (int r = r0; r < rows && r < r0 + 16; r++) if (row_end[r] > lt) lt = row_end[r];
         n_tile_slot_samples += 16ull * lt * spb;
     }
-    (void)rows_used;
     free(row_end);
     double t0 = now_s();
     pb.b = acquire_packed(eng, mdl, rows, cap, max_reads, slot);
@@ -814,7 +812,6 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         packed_chunk = (double)real < 0.85 * (double)paid;
     }
     if (packed_chunk) {
-        int first = 0;                                    /* c->group[first ..) are not placed yet (longest first) */
         size_t *ns = malloc(c->m2 * sizeof(size_t));
         int *slot_of = malloc(c->m2 * sizeof(int)), *off_of = malloc(c->m2 * sizeof(int)), *sl2 = malloc(c->m2 * sizeof(int)), *of2 = malloc(c->m2 * sizeof(int));
         item **sel = malloc(c->m2 * sizeof(item *)), **rest = malloc(c->m2 * sizeof(item *));
@@ -851,7 +848,6 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
             pipe_state.fifo[pipe_state.nfifo++] = cur;
             pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);
             nleft = nrest;
-            (void)first;
         }
         free(ns); free(slot_of); free(off_of); free(sl2); free(of2); free(sel); free(rest);
     } else

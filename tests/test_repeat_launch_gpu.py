@@ -109,3 +109,48 @@ def test_paired_headline_launches_repeat_bit_for_bit(eng):
         b.close()
     dm.close()
     assert not deviating, "%d of %d paired launches deviate from the one-tile launches: (launch, batch, reads, tiles) %s" % (len(deviating), REPS, deviating[:5])
+
+
+@pytest.mark.gpu
+def test_paired_launches_of_packed_batches_repeat_bit_for_bit(eng):
+    """the same stress on the PACKED instantiation of the headline's kernel (round 6: several reads to a row, the live mask): two packed 256-row batches as one paired
+    launch per layer, REPS times, every read against the ONE-TILE launches of the same packed rows"""
+    rows, T = 256, 1500
+    dm = B.DeviceModel(eng, M.synthetic_model(M.NET_LSTM5, 384, seed=1))
+    rng = np.random.default_rng(81)
+    bs, sets = [], []
+    for k in (0, 1):
+        lens = [int(x) for x in np.clip(np.exp(np.log(300) + 0.8 * rng.standard_normal(800)), 25, T - 50)]
+        sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+        b = B.Batch(dm, rows, T, max_reads=len(lens))
+        slot, off = b.pack_plan(lens)
+        keep = [i for i in range(len(lens)) if slot[i] >= 0]
+        bs.append(b)
+        sets.append(([sigs[i] for i in keep], [slot[i] for i in keep], [off[i] for i in keep]))
+
+    def alone():
+        out = []
+        for k in (0, 1):
+            bs[k].set_signals_packed(*sets[k])
+            bs[k].run()
+            bs[k].finish()
+            out.append(_results(bs[k], bs[k].nreads()))
+        return out
+
+    ref = _with_debug("no_dense,no_pair,split_dense=0", alone)
+    deviating = []
+    for rep in range(REPS):
+        for k in (0, 1):
+            bs[k].set_signals_packed(*sets[k])
+        bs[0].run_pair(bs[1])
+        for k in (0, 1):
+            bs[k].finish()
+            assert bs[k].paired()
+            got = _results(bs[k], bs[k].nreads())
+            bad = [r for r in range(len(got)) if got[r] != ref[k][r]]
+            if bad:
+                deviating.append((rep, k, len(bad)))
+    for b in bs:
+        b.close()
+    dm.close()
+    assert not deviating, "%d of %d paired launches of packed batches deviate from the one-tile launches: (launch, batch, reads) %s" % (len(deviating), REPS, deviating[:5])
