@@ -641,6 +641,7 @@ struct ffhip_batch {
     int *rag_tin[3] = { nullptr, nullptr, nullptr };       // stride-1 thin layers: per-read input lengths replace the table
     // Packed batch (ffhip_batch_set_*_packed): the `nread` rows of the buffers are SLOTS, each holding one or more reads one behind the other with a gap of
     // ffhip_model_pack_gap() blocks; results are indexed by READ (0 .. nvirt - 1, the order of the set call).  hT / hTb hold the reads' lengths then.
+    int res_copied = 0;                 // the result block's copy to the host is already enqueued (a packed batch: behind its decode, in ffhip_batch_run)
     int cap_reads = 0;                  // the per-read result arrays (lens, score, logZ) take this many reads (>= nread)
     bool packed = false;
     int nvirt = 0;
@@ -882,11 +883,11 @@ extern "C" size_t ffhip_model_pack_gap(const ffhip_model *m) {
     const int st = total_stride(m);
     return (size_t)((2 * wmax + st - 1) / st + 1);
 }
-// Rows (a multiple of 16, at most want_rows) of a packed batch of `nsample`-sample rows whose workspace takes at most 28 % of the device's memory: two such
-// objects are alive in a pipeline (one runs, one is set up) beside the prepared signals.  What a row costs is what batch_create_impl and the default path of
+// Rows (a multiple of 16, at most want_rows) of a packed batch of `nsample`-sample rows whose workspace takes at most 72 % / nobjects of the device's memory (512 rows of 228 352 samples at 384 hidden units: 103 GB of 288):
+// `nobjects` such objects are alive in a pipeline (two: one runs, one is set up; one: the caller collects a batch before it sets up the next) beside the prepared signals.  What a row costs is what batch_create_impl and the default path of
 // batch_run_impl allocate per block and per sample.
-extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsample) {
-    if (!m || want_rows <= 0 || nsample == 0) return 0;
+extern "C" int ffhip_pack_rows_for(const ffhip_model *m, int want_rows, size_t nsample, int nobjects) {
+    if (!m || want_rows <= 0 || nsample == 0 || nobjects < 1) return 0;
     const size_t nb = ffhip_model_nblock(m, nsample) + 1;
     size_t per_block = (size_t)m->Ps * 8 + (size_t)crf_exp_stride(m->P) * 8 + 2 * kFwdRowBytes + kMaxState + 4 + 4 + 2 + (size_t)m->nstate * 4 + 8      // scores, E, chains, traceback, path, strings, trace, tables
                        + 2 * (size_t)m->Hp * 2 * kSplitNS;                                                                                            // two activation buffers in the split layout
@@ -895,11 +896,12 @@ extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsamp
     const double row = (double)nb * (double)per_block + (double)(nsample + 2 * kSamplePad) * (double)per_sample;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return want_rows;
-    long rows = (long)((double)total_b * 0.28 / row);      // (of the device's TOTAL memory: the answer must not change while the first object is alive)
+    long rows = (long)((double)total_b * 0.72 / (double)nobjects / row);      // (of the device's TOTAL memory: the answer must not change while the first object is alive)
     rows = rows / 16 * 16;
     if (rows > want_rows) rows = want_rows;
     return rows < 16 ? 16 : (int)rows;
 }
+extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsample) { return ffhip_pack_rows_for(m, want_rows, nsample, 2); }
 // First-fit-decreasing plan of `nread` reads into nslot rows of nsample_cap samples: slot[] / block_off[] of every read (slot -1: it did not fit); returns the number placed.
 extern "C" int ffhip_pack_plan(const ffhip_model *m, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off) {
     if (!m || nslot <= 0 || nread < 0 || !nsample || !slot || !block_off) { set_err(FFHIP_EINVAL, "bad pack plan arguments"); return -1; }
@@ -1623,6 +1625,14 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         mark(b, 5);
     }
     mark(b, 6);
+    // A packed batch's strings are tens of megabytes (512 rows of 45 000 blocks: 47 MB), and ffhip_batch_finish is called when the NEXT batch's layer launches are
+    // already running: the copy's blit kernel then crawls beside them (193 ms in a kernel trace) and holds a layer launch up as long.  It goes here, behind the decode
+    // and in front of the events the next batch's layer launches wait for.
+    b->res_copied = 0;
+    if (b->packed && (phases & PH_BACK)) {
+        HIP_TRY(hipMemcpyAsync(b->res_host, b->res_dev, (flags & FFHIP_RUN_NO_DECODE) ? b->res_head : b->res_bytes, hipMemcpyDeviceToHost, s), FFHIP_EHIP);
+        b->res_copied = 1;
+    }
     HIP_TRY(hipEventRecord(b->eng->batch_done, s), FFHIP_EHIP);
     b->eng->batch_done_rec = 1;
     if (phases & PH_BACK) { HIP_TRY(hipEventRecord(b->eng->done_ring[b->eng->done_head & 3u], s), FFHIP_EHIP); b->eng->done_head++; }
@@ -1814,7 +1824,8 @@ extern "C" int ffhip_batch_finish(ffhip_batch *b) {
         return FFHIP_OK;
     }
     // one copy: [sat | abort] and, when the batch was decoded, [lens | score | bases | quals] behind them (the block of ffhip_batch_create)
-    HIP_TRY(hipMemcpyAsync(b->res_host, b->res_dev, (b->last_flags & FFHIP_RUN_NO_DECODE) ? b->res_head : b->res_bytes, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    if (!b->res_copied) HIP_TRY(hipMemcpyAsync(b->res_host, b->res_dev, (b->last_flags & FFHIP_RUN_NO_DECODE) ? b->res_head : b->res_bytes, hipMemcpyDeviceToHost, b->stream), FFHIP_EHIP);
+    b->res_copied = 0;
     (void)n; (void)L;
     HIP_TRY(hipStreamSynchronize(b->stream), FFHIP_EHIP);
     if (rehearsal_rate() > 0) {                              // (test hook above: the emulated GPU finishes this batch at rehearsal_done_at)

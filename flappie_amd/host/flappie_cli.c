@@ -354,13 +354,20 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
 /* Packed batches (ffhip.h "packed batches"): reads of mixed lengths, several to a row.  One cached object per pipeline slot, `--batch` rows of the chunk's row
  * capacity, created anew when a chunk needs longer rows. */
 static struct { ffhip_batch *b; size_t cap; int max_reads, rows; } pack_cache[NINFLIGHT];
-static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, int rows, size_t cap, int max_reads, int slot) {
-    if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads || pack_cache[slot].rows != rows) {
+static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, int rows, int rows_full, size_t cap, int max_reads, int slot) {
+    /* (an object with MORE rows or longer rows than this batch needs serves it as it is: rows without a read cost nothing, and re-creating a 90 GB object is seconds) */
+    if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads || pack_cache[slot].rows < rows) {
         if (pack_cache[slot].b) ffhip_batch_destroy(pack_cache[slot].b);
-        pack_cache[slot].cap = cap;                       /* (the caller's capacities come in steps: pack_row_cap) */
+        /* two shapes of object only, so that a slot's object is re-created when the reads get LONGER and for nothing else: a quarter of the rows for a run's first,
+         * small chunk (created in a fraction of a second, replaced by the second chunk), all the rows the memory takes otherwise; capacities in pack_row_cap's steps */
+        const int make_rows = (4 * rows <= rows_full) ? (rows_full / 4 + 15) / 16 * 16 : rows_full;
+        pack_cache[slot].cap = cap;
         pack_cache[slot].max_reads = max_reads;
-        pack_cache[slot].rows = rows;
-        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, rows, cap, max_reads);
+        pack_cache[slot].rows = make_rows;
+        const double tc0 = now_s();
+        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, make_rows, cap, max_reads);
+        if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "packed batch object (slot %d): %d rows of %zu samples, up to %d reads%s, %.2f s\n", slot, make_rows, cap, max_reads,
+                                                  pack_cache[slot].b ? "" : " -- FAILED", now_s() - tc0);
         if (NULL == pack_cache[slot].b) { pack_cache[slot].cap = 0; return NULL; }
     }
     return pack_cache[slot].b;
@@ -379,7 +386,7 @@ typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_pr
 
 /* n reads in the rows of one packed batch: slot_of / off_of from ffhip_pack_plan, `cap` the row capacity it was made for */
 static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, const int *slot_of, const int *off_of,
-                                   int rows, size_t cap, int max_reads, int slot) {
+                                   int rows, int rows_full, size_t cap, size_t cap_obj, int max_reads, int slot) {
     pending_batch pb = { NULL, 1, n, malloc((n > 0 ? n : 1) * sizeof(int)), malloc((n > 0 ? n : 1) * sizeof(item *)), prep, NULL };
     memcpy(pb.its, its, n * sizeof(item *));
     size_t longest = 0;
@@ -407,9 +414,10 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
     }
     free(row_end);
     double t0 = now_s();
-    pb.b = acquire_packed(eng, mdl, rows, cap, max_reads, slot);
+    pb.b = acquire_packed(eng, mdl, rows, rows_full, cap_obj, max_reads, slot);      /* (the object's rows come in steps; the plan was made for rows of `cap` samples) */
     t_phase[2] += now_s() - t0; t0 = now_s();
     const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
+    if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "packed batch: %d reads, %.1f Msamples in %d rows planned for %zu samples (longest row %zu)\n", n, (double)samples / 1e6, rows, cap, longest * spb);
     int rc_sub = (NULL == pb.b) ? -1 : ffhip_batch_set_prepared_packed(pb.b, prep, n, pb.idx, slot_of, off_of);
     t_phase[6] += now_s() - t0;
     const double t1 = now_s();
@@ -826,14 +834,29 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
             size_t cap = (size_t)((double)total / (double)args.batch * 1.05) + 64 * ffhip_model_pack_gap(mdl);
             if (cap < ns[0] + 64) cap = ns[0] + 64;
             if (cap > PACK_ROW_MAX && ns[0] + 64 <= PACK_ROW_MAX) cap = PACK_ROW_MAX;
-            cap = pack_row_cap(cap);
-            int rows = ffhip_pack_rows(mdl, args.batch, cap);
+            cap = (cap + 1023) & ~(size_t)1023;
+            size_t cap_obj = pack_row_cap(cap);           /* the OBJECT's rows come in steps; the PLAN fills rows of `cap` samples: a launch runs as long as its longest row */
+            /* ... and no more rows than the samples left fill (the first chunk of a run is ONE batch's worth of reads: a tenth of --batch rows of its longest read) */
+            /* Two objects of --batch rows do not fit (1024 rows of 228 352 samples at 256 hidden units: 159 GB each) but ONE does: the full launch is worth more than setting a
+             * batch up beside the one that runs (k_lstm_pack at 1024 rows 200+ Msamples/s, the forms for 512 rows 155; a packed batch's set-up is milliseconds) -- this
+             * chunk's batches go through one object, each collected before the next is set up */
+            int single = 0;
+            int rows_mem = ffhip_pack_rows_for(mdl, args.batch, cap_obj, 2);
+            if (rows_mem < args.batch && ffhip_pack_rows_for(mdl, args.batch, cap_obj, 1) >= args.batch) { single = 1; rows_mem = args.batch; }
+            if (rows_mem < args.batch && rows_mem >= args.batch / 2) rows_mem = args.batch / 2;      /* (half a launch's rows keep a form of the layer kernel that fills the chip; 7/8 of one does not) */
+            int rows = (int)(((double)total * 1.10 / (double)cap) / 16.0 + 2.0) * 16;
+            if (rows > rows_mem) rows = rows_mem;
             int placed = 0;
-            for (int tries = 0; tries < 3; tries++) {
+            for (int tries = 0; tries < 4; tries++) {
                 placed = ffhip_pack_plan(mdl, rows, cap, nleft, ns, slot_of, off_of);
-                if (placed == nleft || cap >= PACK_ROW_MAX || rows < args.batch) break;
-                cap = pack_row_cap(cap + 1);                                        /* the fit left reads over: longer rows, once more */
-                rows = ffhip_pack_rows(mdl, args.batch, cap);
+                if (placed == nleft) break;
+                if (rows < rows_mem) { rows = (rows + 32 < rows_mem) ? rows + 32 : rows_mem; continue; }      /* the fit left reads over: more rows, ... */
+                if (cap >= PACK_ROW_MAX || rows_mem < args.batch) break;
+                cap = ((size_t)((double)cap * 1.06) + 1023) & ~(size_t)1023;                                  /* ... or longer ones, once more */
+                cap_obj = pack_row_cap(cap);
+                rows_mem = ffhip_pack_rows_for(mdl, args.batch, cap_obj, single ? 1 : 2);
+                if (rows_mem < args.batch && rows_mem >= args.batch / 2) rows_mem = args.batch / 2;
+                if (rows > rows_mem) rows = rows_mem;
             }
             if (placed <= 0) { warnx("packed batch: no read fits a row of %zu samples", cap); break; }
             int nsel = 0, nrest = 0;
@@ -841,12 +864,17 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
                 if (slot_of[i] >= 0) { sel[nsel] = rest[i]; sl2[nsel] = slot_of[i]; of2[nsel] = off_of[i]; nsel++; }
                 else rest[nrest++] = rest[i];
             }
-            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, cap, rs_chunk_cap, pipe_state.slot);
+            if (single) {                                  /* one object: nothing in flight while it is set up, and no second object alive */
+                pipe_collect_all(mdl, hdf5out);
+                pipe_state.slot = 0;
+                for (int k = 1; k < NINFLIGHT; k++) if (pack_cache[k].b) { ffhip_batch_destroy(pack_cache[k].b); pack_cache[k].b = NULL; pack_cache[k].cap = 0; }
+            }
+            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, rows_mem, cap, cap_obj, rs_chunk_cap, pipe_state.slot);
             cur.owner = c;
             c->submitted++;
             while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);
             pipe_state.fifo[pipe_state.nfifo++] = cur;
-            pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);
+            pipe_state.slot = single ? 0 : (pipe_state.slot + 1) % (depth + 1);
             nleft = nrest;
         }
         free(ns); free(slot_of); free(off_of); free(sl2); free(of2); free(sel); free(rest);

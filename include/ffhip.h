@@ -321,9 +321,10 @@ int ffhip_model_packable(const ffhip_model *mdl);         /* 1: this model's def
 size_t ffhip_model_pack_gap(const ffhip_model *mdl);      /* free blocks a read of a packed row needs behind it */
 /* first-fit-decreasing plan: slot[i] / block_off[i] for every read (slot -1: it did not fit into nslot rows of nsample_cap samples); returns the reads placed */
 int ffhip_pack_plan(const ffhip_model *mdl, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off);
-/* rows (a multiple of 16, <= want_rows) of a packed batch of nsample-sample rows whose workspace fits 28 % of the device's memory (two such objects are
+/* rows (a multiple of 16, <= want_rows) of a packed batch of nsample-sample rows whose workspace fits 36 % of the device's memory (two such objects are
  * alive in a pipeline): 512 rows of 200 000 samples are ~90 GB at 384 hidden units */
 int ffhip_pack_rows(const ffhip_model *mdl, int want_rows, size_t nsample);
+int ffhip_pack_rows_for(const ffhip_model *mdl, int want_rows, size_t nsample, int nobjects);      /* the same for a pipeline of nobjects objects (72 % / nobjects each) */
 ffhip_batch *ffhip_batch_create_packed(ffhip_engine *eng, const ffhip_model *mdl, int nslot, size_t nsample, int max_reads);
 int ffhip_batch_set_prepared_packed(ffhip_batch *b, const ffhip_prep *prep, int nread, const int *reads /* indices into prep */, const int *slot, const int *block_off);
 int ffhip_batch_set_signals_packed(ffhip_batch *b, int nread, const float *const *signals, const size_t *nsample, const int *slot, const int *block_off);
