@@ -30,6 +30,7 @@
 #include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <execinfo.h>
 
 #include "../../include/decode.h"
 #include "../../include/fast5_interface.h"
@@ -353,8 +354,8 @@ static ffhip_batch *acquire_batch(struct ffhip_engine *eng, const struct ffhip_m
 
 /* Packed batches (ffhip.h "packed batches"): reads of mixed lengths, several to a row.  One cached object per pipeline slot, `--batch` rows of the chunk's row
  * capacity, created anew when a chunk needs longer rows. */
-static struct { ffhip_batch *b; size_t cap; int max_reads, rows; } pack_cache[NINFLIGHT];
-static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, int rows, int rows_full, size_t cap, int max_reads, int slot) {
+static struct { ffhip_batch *b; size_t cap; int max_reads, rows, full, single; } pack_cache[NINFLIGHT];
+static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, int rows, int rows_full, size_t cap, int max_reads, int slot, int single) {
     /* (an object with MORE rows or longer rows than this batch needs serves it as it is: rows without a read cost nothing, and re-creating a 90 GB object is seconds) */
     if (NULL == pack_cache[slot].b || pack_cache[slot].cap < cap || pack_cache[slot].max_reads < max_reads || pack_cache[slot].rows < rows) {
         if (pack_cache[slot].b) ffhip_batch_destroy(pack_cache[slot].b);
@@ -364,6 +365,8 @@ static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_
         pack_cache[slot].cap = cap;
         pack_cache[slot].max_reads = max_reads;
         pack_cache[slot].rows = make_rows;
+        pack_cache[slot].full = (make_rows == rows_full);
+        pack_cache[slot].single = single;
         const double tc0 = now_s();
         pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, make_rows, cap, max_reads);
         if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "packed batch object (slot %d): %d rows of %zu samples, up to %d reads%s, %.2f s\n", slot, make_rows, cap, max_reads,
@@ -386,7 +389,7 @@ typedef struct { ffhip_batch *b; int cached, n, *idx; item **its; const ffhip_pr
 
 /* n reads in the rows of one packed batch: slot_of / off_of from ffhip_pack_plan, `cap` the row capacity it was made for */
 static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_model *mdl, const ffhip_prep *prep, item **its, int n, const int *slot_of, const int *off_of,
-                                   int rows, int rows_full, size_t cap, size_t cap_obj, int max_reads, int slot) {
+                                   int rows, int rows_full, size_t cap, size_t cap_obj, int max_reads, int slot, int single) {
     pending_batch pb = { NULL, 1, n, malloc((n > 0 ? n : 1) * sizeof(int)), malloc((n > 0 ? n : 1) * sizeof(item *)), prep, NULL };
     memcpy(pb.its, its, n * sizeof(item *));
     size_t longest = 0;
@@ -414,7 +417,7 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
     }
     free(row_end);
     double t0 = now_s();
-    pb.b = acquire_packed(eng, mdl, rows, rows_full, cap_obj, max_reads, slot);      /* (the object's rows come in steps; the plan was made for rows of `cap` samples) */
+    pb.b = acquire_packed(eng, mdl, rows, rows_full, cap_obj, max_reads, slot, single);      /* (the object's rows come in steps; the plan was made for rows of `cap` samples) */
     t_phase[2] += now_s() - t0; t0 = now_s();
     const unsigned flags = (args.viterbi_only ? FFHIP_RUN_VITERBI_ONLY : 0u) | (args.trace ? 0u : FFHIP_RUN_NO_TRACE);
     if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "packed batch: %d reads, %.1f Msamples in %d rows planned for %zu samples (longest row %zu)\n", n, (double)samples / 1e6, rows, cap, longest * spb);
@@ -825,38 +828,51 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         item **sel = malloc(c->m2 * sizeof(item *)), **rest = malloc(c->m2 * sizeof(item *));
         int nleft = c->m2;
         memcpy(rest, c->group, c->m2 * sizeof(item *));
+        /* The SHAPE of this chunk's batch objects is fixed by the chunk as a whole -- rows long enough for its longest read and for everything in ONE batch of --batch rows
+         * (5 % slack for the gaps and the fit; at most PACK_ROW_MAX samples unless a read is longer), capacities in pack_row_cap's steps, as many rows (<= --batch) as the
+         * device's memory takes at that length (ffhip_pack_rows_for: 1024 rows of 237 568 samples at 256 hidden units are 160 GB) -- and every batch of the chunk is planned
+         * into it: what one batch does not hold goes into the next, whose reads are shorter (longest first) and fit the same object. */
+        unsigned long long total_all = 0;
+        for (int i = 0; i < nleft; i++) total_all += rest[i]->res.rt.end - rest[i]->res.rt.start;
+        const size_t longest_all = rest[0]->res.rt.end - rest[0]->res.rt.start;
+        size_t cap_all = (size_t)((double)total_all / (double)args.batch * 1.05) + 64 * ffhip_model_pack_gap(mdl);
+        if (cap_all < longest_all + 64) cap_all = longest_all + 64;
+        if (cap_all > PACK_ROW_MAX && longest_all + 64 <= PACK_ROW_MAX) cap_all = PACK_ROW_MAX;
+        size_t cap_obj = pack_row_cap(cap_all);
+        /* Two objects of --batch rows do not fit (H = 256: 1024 rows of 237 568 samples are 160 GB each) but ONE does: the full launch is worth more than setting a batch up
+         * beside the one that runs (k_lstm_pack at 1024 rows 200+ Msamples/s, the forms for 512 rows 155; a packed batch's set-up is milliseconds) -- this chunk's batches
+         * go through one object, each collected before the next is set up */
+        int single = 0;
+        int rows_mem = ffhip_pack_rows_for(mdl, args.batch, cap_obj, 2);
+        if (rows_mem < args.batch) {
+            /* (... or at least half again as many rows as two objects would have: the r941_5mC shape -- stride 2, 2.5 x the blocks a sample -- on 200 000-sample reads takes
+             * 272 rows twice or 544 once; rows are what fills the chip) */
+            const int rows_one = ffhip_pack_rows_for(mdl, args.batch, cap_obj, 1);
+            if (rows_one >= args.batch || 2 * rows_one >= 3 * rows_mem) { single = 1; rows_mem = rows_one; }
+        }
+        if (rows_mem < args.batch && rows_mem >= args.batch / 2) rows_mem = args.batch / 2;      /* (half a launch's rows keep a form of the layer kernel that fills the chip; 7/8 of one does not) */
+        /* ... unless a full-size object with rows long enough is there already: its shape stands (a shorter chunk could take more rows of shorter rows -- and pay seconds of
+         * hipMalloc for them, chunk after chunk) */
+        for (int k = 0; k < NINFLIGHT; k++)
+            if (pack_cache[k].b && pack_cache[k].full && pack_cache[k].cap >= cap_obj) { cap_obj = pack_cache[k].cap; rows_mem = pack_cache[k].rows; single = pack_cache[k].single; break; }
         while (nleft > 0 && ns && slot_of && off_of && sl2 && of2 && sel && rest) {
             unsigned long long total = 0;
             for (int i = 0; i < nleft; i++) { ns[i] = rest[i]->res.rt.end - rest[i]->res.rt.start; total += ns[i]; }
-            /* rows long enough for everything left in ONE batch (5 % slack for the gaps and the fit), at least the longest read, at most PACK_ROW_MAX samples; as
-             * many rows (<= --batch) as the device's memory takes at that length (ffhip_pack_rows: 1024 rows of 200 000 samples at 256 hidden units would be 140 GB);
-             * what does not fit goes into the chunk's next batch */
-            size_t cap = (size_t)((double)total / (double)args.batch * 1.05) + 64 * ffhip_model_pack_gap(mdl);
+            /* this batch: rows just long enough for what is left (a launch runs as long as its longest row), and no more rows than the samples left fill */
+            size_t cap = (size_t)((double)total / (double)rows_mem * 1.05) + 64 * ffhip_model_pack_gap(mdl);
             if (cap < ns[0] + 64) cap = ns[0] + 64;
-            if (cap > PACK_ROW_MAX && ns[0] + 64 <= PACK_ROW_MAX) cap = PACK_ROW_MAX;
             cap = (cap + 1023) & ~(size_t)1023;
-            size_t cap_obj = pack_row_cap(cap);           /* the OBJECT's rows come in steps; the PLAN fills rows of `cap` samples: a launch runs as long as its longest row */
-            /* ... and no more rows than the samples left fill (the first chunk of a run is ONE batch's worth of reads: a tenth of --batch rows of its longest read) */
-            /* Two objects of --batch rows do not fit (1024 rows of 228 352 samples at 256 hidden units: 159 GB each) but ONE does: the full launch is worth more than setting a
-             * batch up beside the one that runs (k_lstm_pack at 1024 rows 200+ Msamples/s, the forms for 512 rows 155; a packed batch's set-up is milliseconds) -- this
-             * chunk's batches go through one object, each collected before the next is set up */
-            int single = 0;
-            int rows_mem = ffhip_pack_rows_for(mdl, args.batch, cap_obj, 2);
-            if (rows_mem < args.batch && ffhip_pack_rows_for(mdl, args.batch, cap_obj, 1) >= args.batch) { single = 1; rows_mem = args.batch; }
-            if (rows_mem < args.batch && rows_mem >= args.batch / 2) rows_mem = args.batch / 2;      /* (half a launch's rows keep a form of the layer kernel that fills the chip; 7/8 of one does not) */
+            if (cap > cap_obj) cap = cap_obj;
             int rows = (int)(((double)total * 1.10 / (double)cap) / 16.0 + 2.0) * 16;
             if (rows > rows_mem) rows = rows_mem;
             int placed = 0;
-            for (int tries = 0; tries < 4; tries++) {
+            for (int tries = 0; tries < 6; tries++) {
                 placed = ffhip_pack_plan(mdl, rows, cap, nleft, ns, slot_of, off_of);
                 if (placed == nleft) break;
                 if (rows < rows_mem) { rows = (rows + 32 < rows_mem) ? rows + 32 : rows_mem; continue; }      /* the fit left reads over: more rows, ... */
-                if (cap >= PACK_ROW_MAX || rows_mem < args.batch) break;
-                cap = ((size_t)((double)cap * 1.06) + 1023) & ~(size_t)1023;                                  /* ... or longer ones, once more */
-                cap_obj = pack_row_cap(cap);
-                rows_mem = ffhip_pack_rows_for(mdl, args.batch, cap_obj, single ? 1 : 2);
-                if (rows_mem < args.batch && rows_mem >= args.batch / 2) rows_mem = args.batch / 2;
-                if (rows > rows_mem) rows = rows_mem;
+                if (cap >= cap_obj) break;                                                                    /* ... or longer ones, as far as the object goes */
+                cap = ((size_t)((double)cap * 1.06) + 1023) & ~(size_t)1023;
+                if (cap > cap_obj) cap = cap_obj;
             }
             if (placed <= 0) { warnx("packed batch: no read fits a row of %zu samples", cap); break; }
             int nsel = 0, nrest = 0;
@@ -869,7 +885,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
                 pipe_state.slot = 0;
                 for (int k = 1; k < NINFLIGHT; k++) if (pack_cache[k].b) { ffhip_batch_destroy(pack_cache[k].b); pack_cache[k].b = NULL; pack_cache[k].cap = 0; }
             }
-            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, rows_mem, cap, cap_obj, rs_chunk_cap, pipe_state.slot);
+            pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, rows_mem, cap, cap_obj, rs_chunk_cap, pipe_state.slot, single);
             cur.owner = c;
             c->submitted++;
             while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);
@@ -1175,8 +1191,19 @@ static void *reader_main(void *arg) {
     return NULL;
 }
 
+/* FLAPPIE_DEBUG=segv_trace: the call stack of a crash on stderr (addresses for addr2line; development) */
+static void segv_trace(int sig) {
+    void *frames[48];
+    const int n = backtrace(frames, 48);
+    static const char msg[] = "flappie: fatal signal, call stack:\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) _exit(128 + sig);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(128 + sig);
+}
+
 int main(int argc, char *argv[]) {
     argp_parse(&argp, argc, argv, 0, 0, NULL);
+    if (cli_dbg("segv_trace")) { signal(SIGSEGV, segv_trace); signal(SIGABRT, segv_trace); signal(SIGBUS, segv_trace); }
     if (NULL == args.output) args.output = stdout;
     const double t_start = now_s();
     file_list fl = { NULL, 0, 0 };
