@@ -312,6 +312,53 @@ def host_fed_leg(cfg, rank, local_rank, world, dist, nfiles=None):
     return out
 
 
+def length_mix_leg(cfg, local_rank, nfiles=None):
+    """BASELINE.json configs[2] is a DIRECTORY OF READS, and reads do not share a length: the `flappie` binary over generated single-read fast5 files of
+    log-normal lengths (median 8000 samples, sigma 1, clipped to 1000 .. 200 000: fast5_tool synthln) -- one whole run, start-up included, beside `value`, never as it.
+    The binary packs such a chunk several reads to a row (include/ffhip.h "packed batches"); its own account of what the batches paid for comes
+    back as `padding_efficiency`.  One GPU, rank 0 only (like cpu_baseline); {"skipped": why} when the binary is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    from flappie_amd import model as M
+    exe, tool = os.path.join(ROOT, "flappie_amd", "flappie"), os.path.join(ROOT, "flappie_amd", "fast5_tool")
+    if cfg["kind"] != M.NET_LSTM5 or not (os.path.exists(exe) and os.path.exists(tool)):
+        return {"skipped": "needs the flappie binary + fast5_tool (libhdf5 at build time) and an LSTM5 flip-flop model"}
+    nfiles = nfiles or int(os.environ.get("FFHIP_BENCH_LENMIX_FILES", "49152"))
+    n_short = max(256, nfiles // 3)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="ffhip_lenmix_", dir=base)
+    try:
+        os.mkdir(os.path.join(d, "reads"))
+        t0 = time.time()
+        gen = subprocess.run([tool, "synthln", os.path.join(d, "reads"), str(nfiles), "8000", "1.0", "1000", "200000", "20260930"], capture_output=True, text=True)
+        M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(cfg["kind"], cfg["hidden"], seed=1, ident=cfg["ident"]))
+        t_gen = time.time() - t0
+        readers = max(1, min(4, effective_cpus()[0]))
+        env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1")
+        runs = {}
+        for lim in (n_short, nfiles):       # a short and a long run: the rate is MARGINAL (as host_fed's): start-up and the batch objects' allocation are in both
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--readers", str(readers), "--limit", str(lim), "-o", os.path.join(d, "out.fq"), os.path.join(d, "reads")], env=env, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            called = [ln for ln in r.stderr.splitlines() if ln.startswith("basecalled:")]
+            pad = [ln for ln in r.stderr.splitlines() if ln.startswith("batches:")]
+            if gen.returncode != 0 or r.returncode != 0 or not called:
+                return {"skipped": "flappie on the mixed directory failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+            runs[lim] = (dt, int(called[-1].replace(",", " ").split()[1]), int(called[-1].split()[7]), pad[-1] if pad else "")
+        (t_s, _, raw_s, _), (t_l, reads, raw_l, pad) = runs[n_short], runs[nfiles]
+        eff = pad.split("padding efficiency ")[1].split()[0] if "padding efficiency " in pad else None
+        return {"value": round((raw_l - raw_s) / (t_l - t_s) / 1e6, 3) if t_l > t_s else None, "unit": "Msamples/s", "whole_long_run": round(raw_l / t_l / 1e6, 3),
+                "walls_s": {str(n_short): round(t_s, 3), str(nfiles): round(t_l, 3)}, "files": nfiles, "reads_called": reads, "raw_samples": raw_l,
+                "padding_efficiency": float(eff) if eff else None, "batches": pad.split(";")[0] if pad else None,
+                "note": "the flappie binary over %d generated single-read fast5 files of log-normal lengths (median 8000, sigma 1, 1000 .. 200 000 samples), --readers %d, FASTQ out: "
+                        "raw samples of files [%d, %d) / the time between a %d-file and a %d-file run (start-up and the allocation of the ~100 GB batch objects are in both -- the latter costs 0 .. 3 s an object from one "
+                        "invocation to the next, so this figure scatters: whole runs of 864.7 M samples read 83 Msamples/s in profiles/r06_length_mix.txt; `whole_long_run` has both in); padding_efficiency = samples / (rows x the batch's longest row) by the binary's own account; round 5's one-read-a-row batcher "
+                        "read 13.6 Msamples/s of this mix at 0.07 (profiles/r06_length_mix.txt); generation %.1f s (not timed)" % (nfiles, readers, n_short, nfiles, n_short, nfiles, t_gen)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,6 +374,7 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="c2 / rle: submit the batches one by one (ffhip_batch_run) instead of in pairs (ffhip_batch_run_pair)")
     ap.add_argument("--no-h2d-leg", action="store_true")
     ap.add_argument("--no-host-fed-leg", action="store_true", help="skip the per-rank run of the flappie binary over generated fast5 files")
+    ap.add_argument("--no-length-mix-leg", action="store_true", help="skip the run of the flappie binary over generated fast5 files of mixed lengths (one GPU only)")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
     ap.add_argument("--nread", type=int, default=int(os.environ.get("FFHIP_BENCH_NREAD", "0")) or None, help="override the config's reads per batch")
     args = ap.parse_args()
@@ -482,6 +530,12 @@ def main():
             hostfed = host_fed_leg(cfg, rank, local_rank, world, dist if dist_on else None)
         except Exception as e:      # a reported leg, not the benchmark: its failure must not lose the line
             hostfed = {"skipped": "host-fed leg failed: %r" % (e,)} if rank == 0 else None
+    lenmix = None
+    if world == 1 and rank == 0 and not stub and not args.no_length_mix_leg and not args.no_host_fed_leg:
+        try:
+            lenmix = length_mix_leg(cfg, local_rank)
+        except Exception as e:
+            lenmix = {"skipped": "length-mix leg failed: %r" % (e,)}
 
     if rank == 0:
         nblock = nblock_
@@ -577,6 +631,8 @@ def main():
         out["max_over_ranks_s"] = round(dt, 6)
         if hostfed is not None:
             out["host_fed"] = hostfed
+        if lenmix is not None:
+            out["length_mix"] = lenmix
         if dt_h2d is not None:
             out["h2d_inclusive"] = {"value": round(world * steps_h2d * NREAD * NSAMPLE / dt_h2d / 1e6, 4), "unit": "Msamples/s",
                                     "ms_per_step": round(dt_h2d / steps_h2d * 1e3, 4), "steps": steps_h2d,

@@ -49,7 +49,7 @@ def test_world_size_mismatch_is_an_error_message_not_an_assertion():
 
 @pytest.mark.gpu
 def test_real_line_through_the_distributed_path_with_host_fed_leg():
-    r = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline"], {"FFHIP_BENCH_FORCE_DIST": "1", "FFHIP_BENCH_HOSTFED_FILES": "1536"}, timeout=900)
+    r = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline"], {"FFHIP_BENCH_FORCE_DIST": "1", "FFHIP_BENCH_HOSTFED_FILES": "1536", "FFHIP_BENCH_LENMIX_FILES": "1024"}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r)
     assert d["n_gpus"] == 1 and d["value"] > 1.0 and "roofline" in d and len(d["per_rank_Msamples_per_s"]) == 1
@@ -57,6 +57,10 @@ def test_real_line_through_the_distributed_path_with_host_fed_leg():
     assert hf is not None
     if "skipped" not in hf:          # (needs libhdf5 at build time)
         assert hf["value"] and hf["value"] > 0.5 and len(hf["per_rank"]) == 1 and hf["files_per_rank"] == 1536
+    lm = d.get("length_mix")          # the binary on a directory of mixed read lengths (packed batches), one whole run
+    assert lm is not None
+    if "skipped" not in lm:
+        assert lm["files"] == 1024 and lm["reads_called"] == 1024 and lm["whole_long_run"] > 0.5 and lm["padding_efficiency"] > 0.5
 
 
 def _fake_sysfs(tmp_path, nodes):
