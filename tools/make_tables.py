@@ -44,14 +44,16 @@ def table(tag):
                       b["exposed_ms"], tr["recurrent_layer_hbm_bytes_per_launch"] / 1e9, tr["algorithmic_bytes_per_launch"] / 1e9, b["cpu_baseline"]["value"]))
     d = json.load(open(P("%s_bench_default.json" % tag)))
     hf = d.get("host_fed") or {}
+    lm = d.get("length_mix") or {}
     with open(P("%s_bench_default_kernel_stats.csv" % tag)) as fh:
         dk = [x for x in csv.DictReader(ln for ln in fh if not ln.startswith("#")) if any(n in x["Name"] for n in RECURRENT)]
     dk = max(dk, key=lambda x: float(x["TotalDurationNs"]))
     out.append("")
     out.append("The driver's command (`python bench.py`, `profiles/%s_bench_default.json`): **%.1f Msamples/s**, %.3f ms per step, layer launch %.3f ms by HIP events (rocprofv3 `--stats` of the same command, `%s_bench_default_kernel_stats.csv`: %.3f ms over %s calls), `roofline.frac` %.4f, "
-               "`exposed_ms` %.3f, `decode_hbm` %.0f GB/s, `h2d_inclusive` %.1f, `host_fed` %s Msamples/s (the `flappie` binary from fast5 files), `cpu_baseline` %.3f Msamples/s on %d CPUs (`%s`)."
+               "`exposed_ms` %.3f, `decode_hbm` %.0f GB/s, `h2d_inclusive` %.1f, `host_fed` %s Msamples/s (the `flappie` binary from fast5 files of 3500-5500 samples), `length_mix` %s (the same binary on log-normal read lengths, 1000 … 200 000 samples: marginal rate, the binary's padding efficiency), `cpu_baseline` %.3f Msamples/s on %d CPUs (`%s`)."
                % (tag, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], tag, float(dk["AverageNs"]) / 1e6, dk["Calls"], d["roofline"]["frac"], d["exposed_ms"], d["decode_hbm"]["achieved"],
-                  (d.get("h2d_inclusive") or {}).get("value", float("nan")), ("%.1f" % hf["value"]) if hf.get("value") else "-", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["kind"]))
+                  (d.get("h2d_inclusive") or {}).get("value", float("nan")), ("%.1f" % hf["value"]) if hf.get("value") else "-",
+                  ("%.1f Msamples/s at %.2f" % (lm["value"], lm["padding_efficiency"])) if lm.get("value") else "-", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["kind"]))
     out.append("Records: `profiles/%s_{c2,h256,c4,c5,rle}_{bench.json, kernel_stats.csv, sq_pmc.csv, hbm_traffic_pmc.csv, traffic.json}` (`tools/profile_all.sh`, one box, the final tree); "
                "the boxes of the pool differ by a few per cent (the layer launches run at the socket's power cap), so do other runs of these commands." % tag)
     return "\n".join(out)
