@@ -346,11 +346,20 @@ def length_mix_leg(cfg, local_rank, nfiles=None):
             if gen.returncode != 0 or r.returncode != 0 or not called:
                 return {"skipped": "flappie on the mixed directory failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
             runs[lim] = (dt, int(called[-1].replace(",", " ").split()[1]), int(called[-1].split()[7]), pad[-1] if pad else "")
+            phases = {}
+            for ln in r.stderr.splitlines():      # the binary's own wall-clock split (FLAPPIE_CLI_TIMING) of the last run
+                m = ln.rsplit(None, 2)
+                if len(m) == 3 and m[2] == "s" and not ln.startswith("packed"):
+                    try:
+                        phases[m[0].strip()] = float(m[1])
+                    except ValueError:
+                        pass
+            objects = [ln for ln in r.stderr.splitlines() if ln.startswith("packed batch object")]
         (t_s, _, raw_s, _), (t_l, reads, raw_l, pad) = runs[n_short], runs[nfiles]
         eff = pad.split("padding efficiency ")[1].split()[0] if "padding efficiency " in pad else None
         return {"value": round((raw_l - raw_s) / (t_l - t_s) / 1e6, 3) if t_l > t_s else None, "unit": "Msamples/s", "whole_long_run": round(raw_l / t_l / 1e6, 3),
                 "walls_s": {str(n_short): round(t_s, 3), str(nfiles): round(t_l, 3)}, "files": nfiles, "reads_called": reads, "raw_samples": raw_l,
-                "padding_efficiency": float(eff) if eff else None, "batches": pad.split(";")[0] if pad else None,
+                "padding_efficiency": float(eff) if eff else None, "batches": pad.split(";")[0] if pad else None, "long_run_phases_s": phases, "long_run_batch_objects": objects,
                 "note": "the flappie binary over %d generated single-read fast5 files of log-normal lengths (median 8000, sigma 1, 1000 .. 200 000 samples), --readers %d, FASTQ out: "
                         "raw samples of files [%d, %d) / the time between a %d-file and a %d-file run (start-up and the allocation of the ~100 GB batch objects are in both -- the latter costs 0 .. 3 s an object from one "
                         "invocation to the next, so this figure scatters: whole runs of 864.7 M samples read 83 Msamples/s in profiles/r06_length_mix.txt; `whole_long_run` has both in); padding_efficiency = samples / (rows x the batch's longest row) by the binary's own account; round 5's one-read-a-row batcher "
