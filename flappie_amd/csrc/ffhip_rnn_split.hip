@@ -30,8 +30,9 @@
 //     waves 4-7 ("h waves", high priority) hold the recurrent weights and START their accumulators from the projection
 //     partials of their K quarter (LDS), wait for h(t-1), add sW h(t-1), and leave the gate pre-activations in LDS;
 //   * after one LDS-only barrier six waves (the h waves and x waves 0, 1) do the gate math of one 16 x 16 tile each
-//     (4 gates of one unit of one read per lane, cell state in a register; ffhip_math.hpp *_lean forms, bit-identical
-//     to the reference-order arithmetic), split h(t) and store it; a second barrier closes the gate phase, so that no
+//     (4 gates of one unit of one read per lane, cell state in a register; the gate level GL is a template parameter: 2 = ffhip_math.hpp
+//     logistic_hw, v_exp_f32 with a two-word exponent + v_rcp_f32 with a Newton step, the default since round 6 -- DESIGN.md section 3 --, 0 = the
+//     *_lean forms, bit-identical to the reference-order arithmetic), split h(t) and store it; a second barrier closes the gate phase, so that no
 //     MFMA stream starts next to a gate wave on its SIMD: v_mfma_f32_16x16x32_f16 holds the SIMD's VALU issue port for its four
 //     passes, a gate wave beside a back-to-back stream makes NO progress (tools/dev/coissue_probe.cpp, profiles/r05_coissue_probe.txt;
 //     round 2's "0.92-0.95 beside a dense stream" came from a stream with a loop branch behind every three MFMAs and is withdrawn,
