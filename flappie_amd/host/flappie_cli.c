@@ -368,7 +368,7 @@ static ffhip_batch *acquire_packed(struct ffhip_engine *eng, const struct ffhip_
         pack_cache[slot].full = (make_rows == rows_full);
         pack_cache[slot].single = single;
         const double tc0 = now_s();
-        pack_cache[slot].b = ffhip_batch_create_packed(eng, mdl, make_rows, cap, max_reads);
+        pack_cache[slot].b = cli_dbg("pack_fail") ? NULL : ffhip_batch_create_packed(eng, mdl, make_rows, cap, max_reads);      /* (pack_fail: tests -- as if the device had no memory for it) */
         if (getenv("FLAPPIE_CLI_TIMING")) fprintf(stderr, "packed batch object (slot %d): %d rows of %zu samples, up to %d reads%s, %.2f s\n", slot, make_rows, cap, max_reads,
                                                   pack_cache[slot].b ? "" : " -- FAILED", now_s() - tc0);
         if (NULL == pack_cache[slot].b) { pack_cache[slot].cap = 0; return NULL; }
@@ -794,6 +794,11 @@ static void pipe_collect_all(const struct ffhip_model *mdl, hid_t hdf5out) {
     while (pipe_state.nfifo) pipe_collect_oldest(mdl, hdf5out);
 }
 
+/* reads sorted by trimmed length, longest first, in one-read-a-row batches: a batch takes up to --batch consecutive ones as long as the shortest is at least 3/4 of the
+ * longest (a read tile of 16 costs what its longest read costs) */
+static void run_groups(struct ffhip_engine *eng, const struct ffhip_model *mdl, struct chunk_ctx *c, item **group, int m2, hid_t hdf5out, int depth);
+static int pack_failed = 0;                  /* a packed batch object could not be created (memory): the rest of the run goes one read a row */
+
 static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out) {
     chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
     if (writer.started == 1) {                        /* the slot's previous chunk may still be with the writer */
@@ -810,7 +815,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
      * group) against what the reads hold; below 0.85 the chunk's reads are placed several to a row (first fit, longest first) in as few batches of --batch rows
      * as hold them, rows just long enough -- a batch then costs what its samples cost (nanopore-like mix: 0.07 -> 0.9+, tools/length_mix.py) */
     int packed_chunk = 0;
-    if (c->m2 > 0 && pack_allowed(mdl)) {
+    if (c->m2 > 0 && pack_allowed(mdl) && !pack_failed) {
         unsigned long long real = 0, paid = 0;
         for (int i = 0; i < c->m2; ) {
             const size_t longest = c->group[i]->res.rt.end - c->group[i]->res.rt.start;
@@ -886,6 +891,19 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
                 for (int k = 1; k < NINFLIGHT; k++) if (pack_cache[k].b) { ffhip_batch_destroy(pack_cache[k].b); pack_cache[k].b = NULL; pack_cache[k].cap = 0; }
             }
             pending_batch cur = submit_packed(eng, mdl, c->prep, sel, nsel, sl2, of2, rows, rows_mem, cap, cap_obj, rs_chunk_cap, pipe_state.slot, single);
+            if (NULL == cur.b && NULL == pack_cache[pipe_state.slot].b) {
+                /* the object could not be created (device memory): no read is dropped for that -- this batch's reads and the chunk's remaining ones go one read a row,
+                 * and so does the rest of the run */
+                warnx("packed batches are off for the rest of this run (no memory for %d rows of %zu samples)", rows_mem, cap_obj);
+                pack_failed = 1;
+                free(cur.idx); free(cur.its);
+                pipe_collect_all(mdl, hdf5out);                /* (nothing in flight any more: the packed objects that were made give their memory back) */
+                for (int k = 0; k < NINFLIGHT; k++) if (pack_cache[k].b) { ffhip_batch_destroy(pack_cache[k].b); pack_cache[k].b = NULL; pack_cache[k].cap = 0; }
+                memcpy(sel + nsel, rest, nrest * sizeof(item *));
+                qsort(sel, nsel + nrest, sizeof(item *), by_length_desc);
+                run_groups(eng, mdl, c, sel, nsel + nrest, hdf5out, depth);
+                break;
+            }
             cur.owner = c;
             c->submitted++;
             while (pipe_state.nfifo >= depth) pipe_collect_oldest(mdl, hdf5out);
@@ -894,12 +912,21 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
             nleft = nrest;
         }
         free(ns); free(slot_of); free(off_of); free(sl2); free(of2); free(sel); free(rest);
-    } else
-    for (int i = 0; i < c->m2; ) {
-        const size_t longest = c->group[i]->res.rt.end - c->group[i]->res.rt.start;
+    } else run_groups(eng, mdl, c, c->group, c->m2, hdf5out, depth);
+    c->all_submitted = 1;
+    /* A chunk without a single batch (every read failed) collects nothing on its own account: the batch still in flight belongs
+     * to an OLDER chunk, whose reader buffer is only released when it is written -- two such chunks in a row and the reader
+     * thread would wait for that buffer while this thread waits for the reader (ADVICE r2).  Collect it now. */
+    if (0 == c->m2) pipe_collect_all(mdl, hdf5out);
+    pipe_finish_ready(hdf5out);
+}
+
+static void run_groups(struct ffhip_engine *eng, const struct ffhip_model *mdl, struct chunk_ctx *c, item **group, int m2, hid_t hdf5out, int depth) {
+    for (int i = 0; i < m2; ) {
+        const size_t longest = group[i]->res.rt.end - group[i]->res.rt.start;
         int g = 1;
-        while (i + g < c->m2 && g < args.batch && 4 * (c->group[i + g]->res.rt.end - c->group[i + g]->res.rt.start) >= 3 * longest) g++;
-        pending_batch cur = submit_batch(eng, mdl, c->prep, c->group + i, g, pipe_state.slot);
+        while (i + g < m2 && g < args.batch && 4 * (group[i + g]->res.rt.end - group[i + g]->res.rt.start) >= 3 * longest) g++;
+        pending_batch cur = submit_batch(eng, mdl, c->prep, group + i, g, pipe_state.slot);
         cur.owner = c;
         c->submitted++;
         /* default: one batch runs while the next is set up.  FLAPPIE_INFLIGHT=3 keeps two on the GPU while the third is set up: no
@@ -910,12 +937,6 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
         pipe_state.slot = (pipe_state.slot + 1) % (depth + 1);       /* depth in flight + the one being set up: no more batch objects than that */
         i += g;
     }
-    c->all_submitted = 1;
-    /* A chunk without a single batch (every read failed) collects nothing on its own account: the batch still in flight belongs
-     * to an OLDER chunk, whose reader buffer is only released when it is written -- two such chunks in a row and the reader
-     * thread would wait for that buffer while this thread waits for the reader (ADVICE r2).  Collect it now. */
-    if (0 == c->m2) pipe_collect_all(mdl, hdf5out);
-    pipe_finish_ready(hdf5out);
 }
 
 /* Without the reader thread (FLAPPIE_DEBUG=no_reader_thread) this thread fills the reader buffers itself: buffer k may only be

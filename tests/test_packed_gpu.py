@@ -203,14 +203,17 @@ def test_cli_packs_a_directory_of_mixed_lengths(tmp_path):
         raws["read_%02d.fast5" % i] = ("uuid-%04d" % i, raw)
     env = dict(os.environ, FLAPPIE_MODEL_DIR=str(tmp_path), FLAPPIE_CLI_TIMING="1")
     out = {}
-    for tag, extra in (("packed", {}), ("rows", {"FLAPPIE_DEBUG": "no_pack"})):
+    # packed; one read a row; and a run whose packed batch object cannot be created (as if the device were out of memory): no read is lost, the run goes on one read a row
+    for tag, extra in (("packed", {}), ("rows", {"FLAPPIE_DEBUG": "no_pack"}), ("fallback", {"FLAPPIE_DEBUG": "pack_fail"})):
         r = subprocess.run([FLAPPIE, "--model", "r941_native", "--batch", "16", str(reads)], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         pad = [ln for ln in r.stderr.splitlines() if ln.startswith("batches:")][-1]
         npacked = int(pad.split("(")[1].split()[0])
-        assert (npacked > 0) == (tag == "packed"), pad
+        if tag != "fallback":                               # (the fall-back run counts the one attempt that failed)
+            assert (npacked > 0) == (tag == "packed"), pad
+        assert ("packed batches are off for the rest of this run" in r.stderr) == (tag == "fallback")
         out[tag] = r.stdout
-    assert out["packed"] == out["rows"]                     # the same records in the same order, byte for byte
+    assert out["packed"] == out["rows"] == out["fallback"]   # the same records in the same order, byte for byte
     ref = _oracle_calls(mdl, raws)
     by_uuid = {v["uuid"]: v for v in ref.values()}
     recs = _parse_fastq(out["packed"])
