@@ -154,3 +154,38 @@ def test_paired_launches_of_packed_batches_repeat_bit_for_bit(eng):
         b.close()
     dm.close()
     assert not deviating, "%d of %d paired launches of packed batches deviate from the one-tile launches: (launch, batch, reads) %s" % (len(deviating), REPS, deviating[:5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [M.NET_GRUMOD5, M.NET_LSTM5])
+def test_full_packed_h256_launches_of_packed_batches_repeat_bit_for_bit(eng, kind):
+    """... and on the PACKED-BATCH instantiations of the two H = 256 forms (k_grumod_pack<true, 2>, k_lstm_pack<true, 2>): a full 1024-row launch whose rows hold
+    several reads each, REPS times, against the one-tile launches of the same rows"""
+    rows, T = 1024, 1000
+    dm = B.DeviceModel(eng, M.synthetic_model(kind, 256, seed=5 + kind))
+    rng = np.random.default_rng(91 + kind)
+    lens = [int(x) for x in np.clip(np.exp(np.log(220) + 0.7 * rng.standard_normal(3200)), 25, T - 50)]
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    b = B.Batch(dm, rows, T, max_reads=len(lens))
+    slot, off = b.pack_plan(lens)
+    keep = [i for i in range(len(lens)) if slot[i] >= 0]
+    args_ = ([sigs[i] for i in keep], [slot[i] for i in keep], [off[i] for i in keep])
+    assert len(keep) > 2 * rows and len(set(slot[i] for i in keep)) > 900        # (nearly) every row in use; the batch has 64 read tiles either way: the launch is a full one of the packed form
+
+    def once():
+        b.set_signals_packed(*args_)
+        b.run()
+        b.finish()
+        return _results(b, b.nreads())
+
+    ref = _with_debug("no_dense,no_pack", once)
+    deviating = []
+    for rep in range(REPS):
+        got = once()
+        assert b.rnn_path() == 3
+        bad = [r for r in range(len(got)) if got[r] != ref[r]]
+        if bad:
+            deviating.append((rep, len(bad)))
+    b.close()
+    dm.close()
+    assert not deviating, "%d of %d launches deviate from the one-tile launches: (launch, reads) %s" % (len(deviating), REPS, deviating[:5])
