@@ -66,7 +66,6 @@ keep = [i for i in range(len(lens)) if slot[i] >= 0]
 for pb in pbs:
     pb.set_signals_packed([sigs[i] for i in keep], [slot[i] for i in keep], [off[i] for i in keep])
 real = sum(lens[i] for i in keep)
-stride = cap // pbs[0].nblock if pbs[0].nblock else 5
 row_end = {}
 for i in keep:
     row_end[slot[i]] = max(row_end.get(slot[i], 0), off[i] * round(cap / pbs[0].nblock) + lens[i])
