@@ -46,6 +46,9 @@ try:
         if name == "mixed":
             env.update(extra)
         res = {}
+        # (a first short run is thrown away: device memory that another process has just given back costs seconds to allocate again -- 2 x 100 GB for the packed batch
+        # objects --, memory untouched since the box came up does not; the timed runs then all start from the same state)
+        subprocess.run([exe, "--readers", readers, "--limit", str(n // 2), "-o", os.path.join(d, "out.fq"), os.path.join(d, name)], env=env, capture_output=True, text=True)
         for rep in range(2):
             for lim in (n // 2, n):
                 t0 = time.perf_counter()
