@@ -337,9 +337,9 @@ def length_mix_leg(cfg, local_rank, nfiles=None):
         readers = max(1, min(4, effective_cpus()[0]))
         env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1")
         runs = {}
-        # a short and a long run: the rate is MARGINAL (as host_fed's): start-up and the batch objects' allocation are in both.  A first short run is thrown away: device memory
-        # that another process has just given back costs seconds to allocate again (2 x 100 GB here), memory untouched since the box came up does not -- both timed runs
-        # then start from the same state
+        # a short and a long run: the rate is MARGINAL (as host_fed's): start-up and the batch objects' allocation are in both.  A first short run is thrown away: what the allocation
+        # of the 2 x 100 GB batch objects costs depends on what the box's memory has been through (0 .. 5 s; the first process to touch it pays most:
+        # profiles/r06_length_mix.txt) -- both timed runs then start from the same state
         for k, lim in enumerate((n_short, n_short, nfiles)):
             t0 = time.perf_counter()
             r = subprocess.run([exe, "--readers", str(readers), "--limit", str(lim), "-o", os.path.join(d, "out.fq"), os.path.join(d, "reads")], env=env, capture_output=True, text=True)

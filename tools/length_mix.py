@@ -46,8 +46,8 @@ try:
         if name == "mixed":
             env.update(extra)
         res = {}
-        # (a first short run is thrown away: device memory that another process has just given back costs seconds to allocate again -- 2 x 100 GB for the packed batch
-        # objects --, memory untouched since the box came up does not; the timed runs then all start from the same state)
+        # (a first short run is thrown away: what the allocation of the 2 x 100 GB packed batch objects costs depends on what the box's memory has been through -- 0 .. 5 s,
+        # the first process to touch it pays most --; the timed runs then all start from the same state)
         subprocess.run([exe, "--readers", readers, "--limit", str(n // 2), "-o", os.path.join(d, "out.fq"), os.path.join(d, name)], env=env, capture_output=True, text=True)
         for rep in range(2):
             for lim in (n // 2, n):
