@@ -24,7 +24,10 @@ static void dattr(hid_t g, const char *name, double v) {
     H5Aclose(a); H5Sclose(s);
 }
 
-static int write_read(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n);
+static int write_read_x(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n, unsigned flags, hsize_t chunk);
+static int write_read(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n) {
+    return write_read_x(path, read_id, digitisation, offset, range, rate, raw, n, 0, 0);
+}
 
 static unsigned long long rng_next(unsigned long long *s) {      /* splitmix64 */
     unsigned long long z = (*s += 0x9E3779B97F4A7C15ull);
@@ -74,7 +77,7 @@ int main(int argc, char **argv) {
         printf("files %ld samples %llu\n", count, total);
         return 0;
     }
-    if (argc >= 9 && 0 == strcmp(argv[1], "write")) {
+    if (argc >= 9 && (0 == strcmp(argv[1], "write") || 0 == strcmp(argv[1], "writex"))) {
         FILE *fh = fopen(argv[8], "rb");
         if (!fh) return 2;
         fseek(fh, 0, SEEK_END); long bytes = ftell(fh); fseek(fh, 0, SEEK_SET);
@@ -82,7 +85,9 @@ int main(int argc, char **argv) {
         short *raw = malloc(bytes);
         if (fread(raw, 2, n, fh) != n) return 2;
         fclose(fh);
-        const int rc = write_read(argv[2], argv[3], atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7]), raw, n);
+        const unsigned flags = (0 == strcmp(argv[1], "writex") && argc > 9) ? (unsigned)strtoul(argv[9], NULL, 0) : 0;
+        const hsize_t chunk = (0 == strcmp(argv[1], "writex") && argc > 10) ? (hsize_t)atol(argv[10]) : 0;
+        const int rc = write_read_x(argv[2], argv[3], atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7]), raw, n, flags, chunk);
         free(raw);
         return rc;
     }
@@ -114,25 +119,78 @@ int main(int argc, char **argv) {
     return 1;
 }
 
-static int write_read(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n) {
-    hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+/* FLAGS of `writex` (the layouts a single-read file can come in; tests/test_fast5_raw.py): 1 chunked Signal (CHUNK elements), 2 deflate, 4 shuffle, 8 fletcher32,
+ * 16 read_id as a variable-length string, 32 the latest file format (superblock 3, version-2 object headers, link messages), 64 thirty more attributes on
+ * the read group and on channel_id (continuation blocks; with 32: dense attribute storage), 128 two more read groups (Read_7, Read_12: name order),
+ * 256 channel_id's numbers as float32 / int32 / int64 instead of doubles, 512 forty more groups beside /Raw/Reads/Read_1 (several symbol nodes) */
+static void xattr(hid_t g, const char *name, hid_t ftype, hid_t mtype, const void *v) {
+    hid_t s = H5Screate(H5S_SCALAR);
+    hid_t a = H5Acreate(g, name, ftype, s, H5P_DEFAULT, H5P_DEFAULT);
+    H5Awrite(a, mtype, v);
+    H5Aclose(a); H5Sclose(s);
+}
+
+static int write_read_x(const char *path, const char *read_id, double digitisation, double offset, double range, double rate, const short *raw, hsize_t n, unsigned flags, hsize_t chunk) {
+    hid_t fapl = H5P_DEFAULT;
+    if (flags & 32) { fapl = H5Pcreate(H5P_FILE_ACCESS); H5Pset_libver_bounds(fapl, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST); }
+    hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
     if (f < 0) return 2;
     hid_t g1 = H5Gcreate(f, "/Raw", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     hid_t g2 = H5Gcreate(f, "/Raw/Reads", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    hid_t g3 = H5Gcreate(f, "/Raw/Reads/Read_1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, strlen(read_id) + 1);
+    if (flags & 128) {
+        hid_t o1 = H5Gcreate(f, "/Raw/Reads/Read_7", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT); H5Gclose(o1);
+        o1 = H5Gcreate(f, "/Raw/Reads/Read_12", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT); H5Gclose(o1);
+    }
+    hid_t g3 = H5Gcreate(f, (flags & 128) ? "/Raw/Reads/Read_100" : "/Raw/Reads/Read_1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (flags & 512)
+        for (int k = 0; k < 40; k++) {
+            char nm[64]; snprintf(nm, sizeof(nm), "/Raw/Reads/Z_%02d", k);
+            hid_t o1 = H5Gcreate(f, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT); H5Gclose(o1);
+        }
     hid_t ss = H5Screate(H5S_SCALAR);
-    hid_t a = H5Acreate(g3, "read_id", st, ss, H5P_DEFAULT, H5P_DEFAULT);
-    H5Awrite(a, st, read_id);
-    H5Aclose(a); H5Sclose(ss); H5Tclose(st);
+    if (flags & 64)
+        for (int k = 0; k < 30; k++) { char nm[64]; double v = k; snprintf(nm, sizeof(nm), "extra_%02d", k); xattr(g3, nm, H5T_IEEE_F64LE, H5T_NATIVE_DOUBLE, &v); }
+    if (flags & 16) {
+        hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, H5T_VARIABLE);
+        hid_t a = H5Acreate(g3, "read_id", st, ss, H5P_DEFAULT, H5P_DEFAULT);
+        H5Awrite(a, st, &read_id);
+        H5Aclose(a); H5Tclose(st);
+    } else {
+        hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, strlen(read_id) + 1);
+        hid_t a = H5Acreate(g3, "read_id", st, ss, H5P_DEFAULT, H5P_DEFAULT);
+        H5Awrite(a, st, read_id);
+        H5Aclose(a); H5Tclose(st);
+    }
+    H5Sclose(ss);
     hid_t sp = H5Screate_simple(1, &n, NULL);
-    hid_t d = H5Dcreate(g3, "Signal", H5T_STD_I16LE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t dcpl = H5P_DEFAULT;
+    if (flags & 15) {
+        dcpl = H5Pcreate(H5P_DATASET_CREATE);
+        hsize_t ch = (chunk > 0 && chunk < n) ? chunk : (n > 0 ? n : 1);     /* a chunk of a fixed-size dataset is at most the dataset */
+        H5Pset_chunk(dcpl, 1, &ch);
+        if (flags & 4) H5Pset_shuffle(dcpl);
+        if (flags & 2) H5Pset_deflate(dcpl, 1);
+        if (flags & 8) H5Pset_fletcher32(dcpl);
+    }
+    hid_t d = H5Dcreate(g3, "Signal", H5T_STD_I16LE, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+    if (d < 0) return 3;
     H5Dwrite(d, H5T_NATIVE_SHORT, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw);
     H5Dclose(d); H5Sclose(sp);
+    if (dcpl != H5P_DEFAULT) H5Pclose(dcpl);
     hid_t u1 = H5Gcreate(f, "/UniqueGlobalKey", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     hid_t u2 = H5Gcreate(f, "/UniqueGlobalKey/channel_id", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    dattr(u2, "digitisation", digitisation); dattr(u2, "offset", offset);
-    dattr(u2, "range", range); dattr(u2, "sampling_rate", rate);
+    if (flags & 64)
+        for (int k = 0; k < 30; k++) { char nm[64]; double v = k; snprintf(nm, sizeof(nm), "aaa_%02d", k); xattr(u2, nm, H5T_IEEE_F64LE, H5T_NATIVE_DOUBLE, &v); }
+    if (flags & 256) {
+        const float dg = (float)digitisation; const int of = (int)offset; const long long rg = (long long)range;
+        xattr(u2, "digitisation", H5T_IEEE_F32LE, H5T_NATIVE_FLOAT, &dg);
+        xattr(u2, "offset", H5T_STD_I32LE, H5T_NATIVE_INT, &of);
+        xattr(u2, "range", H5T_STD_I64LE, H5T_NATIVE_LLONG, &rg);
+    } else {
+        dattr(u2, "digitisation", digitisation); dattr(u2, "offset", offset); dattr(u2, "range", range);
+    }
+    dattr(u2, "sampling_rate", rate);
     H5Gclose(u2); H5Gclose(u1); H5Gclose(g3); H5Gclose(g2); H5Gclose(g1); H5Fclose(f);
+    if (fapl != H5P_DEFAULT) H5Pclose(fapl);
     return 0;
 }

@@ -15,6 +15,9 @@ extern "C" {
 /* fast5_interface.c:231-318: /Raw/Reads/<first entry>/Signal + its `read_id`, optionally scaled to pA with
  * /UniqueGlobalKey/channel_id {digitisation, offset, range}.  raw == NULL on failure. */
 raw_table read_raw(const char *filename, bool scale_to_pA);
+/* the same through libhdf5 only: read_raw tries host/fast5_raw.c first (a single-read file walked in memory, no libhdf5 call) and comes here for every file
+ * that reader does not know (not in the reference's header) */
+raw_table read_raw_hdf5(const char *filename, bool scale_to_pA);
 /* fast5_interface.c:59-74: -1 if filename is NULL; opens an existing file read-write, else creates it */
 hid_t open_or_create_hdf5(const char *filename);
 /* fast5_interface.c:321-349: group `readname` with `signal` (f32, trimmed normalised signal) and `trace`
