@@ -27,6 +27,7 @@ HOOKS = os.path.join(ROOT, "tools", "test_hooks")          # `make -C flappie_am
 if not os.path.exists(os.path.join(HOOKS, "libffhip.so")):
     sys.exit("tools/test_hooks/libffhip.so is missing: make -C flappie_amd/csrc hooks")
 NSHARD = 8
+LAST_THROTTLE = (0, 0.0)
 NOGPU = True          # emulated processes keep off the physical GPU altogether (--emu-on-gpu: their signal preparation and copies run on it)
 
 
@@ -36,10 +37,20 @@ def cpu_times():
     return sum(v), v[3] + v[4]          # total, idle + iowait
 
 
+def throttled():
+    """(periods in which this container's CPU quota ran out, seconds its threads then stood still) so far -- cgroup v2 cpu.stat, (0, 0.0) where there is none"""
+    try:
+        kv = dict(ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0)) / 1e6
+    except (OSError, ValueError):
+        return 0, 0.0
+
+
 def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
     """start one flappie per shard in `procs` at once; returns {shard: (wall, reads, raw samples, fallbacks)} and the host's CPU use"""
     env0 = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE="0", FLAPPIE_CLI_TIMING="1")
     c0 = cpu_times()
+    th0 = throttled()
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     ps = {}
     t0 = time.perf_counter()
@@ -50,6 +61,9 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
             env["LD_LIBRARY_PATH"] = HOOKS + os.pathsep + env.get("LD_LIBRARY_PATH", "")      # the -DFFHIP_TEST_HOOKS library: the release one has no such hook
             if NOGPU:
                 env["FFHIP_DEBUG_HOST_REHEARSAL_NOGPU"] = "1"
+            # the rehearsal hook knows the one-read-a-row batches only (ffhip_batch_set_prepared_packed refuses under it, and a refused packed batch makes the
+            # binary create its packed objects on the ONE physical GPU first: eight processes queue there, round 6's first rehearsal)
+            env["FLAPPIE_DEBUG"] = ",".join(x for x in (env.get("FLAPPIE_DEBUG", ""), "no_pack") if x)
         cmd = [EXE, "--readers", str(readers), "--shard", "%d/%d" % (g, NSHARD)] + (["--shard-by-size"] if by_size else []) + ["--limit", str(n), "-o", os.path.join(d, "out.%d.fq" % g), os.path.join(d, "reads")]
         ps[g] = (subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), time.perf_counter())
     out = {}
@@ -63,6 +77,9 @@ def run_set(d, n, readers, procs, gpu_rate, by_size, real=(0,)):
     ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     busy = 1.0 - (c1[1] - c0[1]) / max(1, c1[0] - c0[0])
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)       # this set's own processes (readers included), not the host's other tenants
+    th1 = throttled()
+    global LAST_THROTTLE
+    LAST_THROTTLE = (th1[0] - th0[0], th1[1] - th0[1])
     return out, busy, time.perf_counter() - t0, cpu_s
 
 
@@ -124,8 +141,9 @@ def main():
                     print("%-6s process %d (%s): marginal %.1f Msamples/s (%d raw samples in %.3f s; long run %.2f s, short %.2f s)%s%s"
                           % (label, g, "real GPU" if g in real else "emulated GPU", raw / dt / 1e6 if dt > 0 else float("nan"), raw, dt, l_out[g][0], s_out[g][0],
                              "" if ok else "  ** run failed or incomplete **", ("  [%d fall-backs to the step kernels]" % l_out[g][3]) if l_out[g][3] else ""))
+                print("%-6s the container's CPU quota ran out in %d scheduler periods of the last run (its threads stood still for %.2f thread-seconds in all)" % ((label,) + LAST_THROTTLE))
                 if a.phases:
-                    g = procs[-1]
+                    g = procs[0] if real else procs[-1]
                     print("       phases of process %d in the long run (FLAPPIE_CLI_TIMING): %s" % (g, "; ".join(" ".join(ln.split()) for ln in l_out[g][5])))
                 print("%-6s CPU time of these processes (readers included): %.2f s in the long run over %.2f s wall = %.1f CPUs; marginal %.3f CPU-s per million raw samples  "
                       "[whole host, other tenants included: %.1f %% of %d hardware threads busy]" % (label, l_cpu, wall, l_cpu / wall, (l_cpu - s_cpu) / max(1.0, d_raw / 1e6), 100 * busy, nhw))
