@@ -71,7 +71,7 @@ static struct argp_option options[] = {
     {"no-uuid", 15, 0, OPTION_ALIAS, "Output read file"},
     {"batch", 16, "nreads", 0, "Reads per GPU batch (default: what one layer launch takes -- 1024 at up to 256 hidden units, 512 up to 384, else 256)"},
     {"shard", 18, "g/n", 0, "Call only files g, g+n, g+2n, ... of the sorted input list (one process per GPU: tools/flappie_multi_gpu.sh)"},
-    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 4: one keeps up with ~50 Msamples/s, more only cost CPU; 0 reads in this process)"},
+    {"readers", 17, "n", 0, "fast5 reader processes feeding the GPU (default 4: one keeps up with ~50 Msamples/s of files that need libhdf5 and > 200 of those host/fast5_raw.c reads; more only cost CPU; 0 reads in this process)"},
     {"shard-by-size", 19, 0, 0, "With --shard: deal the files to the n shards by size (largest first, each to the lightest shard) instead of by index"},
     {0}
 };
@@ -1039,7 +1039,7 @@ typedef struct {
 } reader_state;
 
 /* ---- reader PROCESSES.  Opening and reading a single-read fast5 costs ~0.1-0.15 ms of CPU in libhdf5 (~6800 files/s on one
- * core), this libhdf5 is not thread-safe, and one MI355X consumes 15-20 000 reads of 4000 samples per second: one reader
+ * core; since round 6 read_raw walks the files it knows itself, host/fast5_raw.c: ~10 us, and libhdf5 is the fall-back), this libhdf5 is not thread-safe, and one MI355X consumes 15-20 000 reads of 4000 samples per second: one reader
  * thread caps the binary at less than half of what the kernels deliver.  So the files are read by `--readers` child
  * processes, forked BEFORE the HIP runtime starts (a fork of a process with a live GPU context is not supported): child k
  * reads files k, k + R, k + 2R ... in order (read_raw, fast5_interface.c:231-318, with the pA scaling of flappie.c:248) and
