@@ -412,6 +412,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # More than one rank: a host thread that waits for its GPU sleeps on the interrupt instead of spinning (FFHIP_DEBUG=blocking_sync, ffhip_engine_create:
+    # hipDeviceScheduleBlockingSync).  One rank spins 2.1-2.4 CPUs away, a blocking one 1.6, at the same Msamples/s (profiles/r06_blocking_sync.txt) -- eight
+    # spinning ranks would sit on the 16 CPUs a container of this pool is granted.  FFHIP_BENCH_SPIN=1 keeps HIP's default; the line says which (`host_wait`).
+    if world > 1 and not os.environ.get("FFHIP_BENCH_SPIN") and "blocking_sync" not in os.environ.get("FFHIP_DEBUG", ""):
+        os.environ["FFHIP_DEBUG"] = ",".join(x for x in (os.environ.get("FFHIP_DEBUG", ""), "blocking_sync") if x)
     # this rank, the flappie process of its host-fed leg and that one's reader children on the CPUs of the GPU's NUMA node (flappie_amd/shard.py;
     # FFHIP_BENCH_SYSFS: a fake sysfs tree for the CPU tests; FFHIP_BENCH_NO_NUMA_BIND=1: off)
     from flappie_amd import shard as _shard
@@ -639,6 +644,7 @@ def main():
                            "peak": 8000.0, "unit": "GB/s", "bytes_per_block": bytes_per_block, "ms": round(dec_ms, 4)},
         }
         out["per_rank_Msamples_per_s"] = per_rank
+        out["host_wait"] = "blocking (hipDeviceScheduleBlockingSync)" if "blocking_sync" in os.environ.get("FFHIP_DEBUG", "") else "spin (HIP's default)"
         out["host_binding"] = {"rank0_numa_node": numa_bound[0], "rank0_cpus": numa_bound[1] or len(os.sched_getaffinity(0)),
                                "note": "every rank binds itself (and the flappie process + reader children of its host-fed leg) to the CPUs of its GPU's NUMA node "
                                        "that it may use; node -1 = not known or outside this container's CPU set: left alone"}

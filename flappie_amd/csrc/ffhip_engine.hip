@@ -49,6 +49,9 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     ffhip_engine *e = new ffhip_engine();
     e->device = device;
     HIP_TRY(hipSetDevice(device), (delete e, nullptr));
+    // how a host thread waits for the device: HIP's default spins (a CPU per waiting thread -- eight ranks of a node, a CPU each); FFHIP_DEBUG=blocking_sync
+    // sleeps on the interrupt instead (bench.py asks for it when it runs more than one rank; profiles/r06_blocking_sync.txt)
+    if (dbg("blocking_sync")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     HIP_TRY(hipGetDeviceProperties(&e->prop, device), (delete e, nullptr));
     if (strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) {
         set_err(FFHIP_ENODEV, "device %d is %s; this library is built for gfx950 only", device, e->prop.gcnArchName);
