@@ -119,15 +119,16 @@ static const h5msg *find_msg(const h5obj *o, unsigned type) {
 /* visit(name, address) for every link of a group; want == NULL: keep the smallest name in strcmp order (index 0 of H5_INDEX_NAME, increasing) */
 typedef struct { const char *want; char best[256]; uint64_t addr; int found; } pick;
 
-static void offer(pick *pk, const char *name, size_t len, uint64_t addr) {
-    if (len >= sizeof(pk->best)) return;
+static int offer(pick *pk, const char *name, size_t len, uint64_t addr) {
+    if (len >= sizeof(pk->best)) return 0;                                       /* a name this long: not compared here */
     if (NULL != pk->want) {
         if (strlen(pk->want) == len && 0 == memcmp(pk->want, name, len)) { pk->addr = addr; pk->found = 1; }
-        return;
+        return 1;
     }
     char tmp[256];
     memcpy(tmp, name, len); tmp[len] = 0;
     if (!pk->found || strcmp(tmp, pk->best) < 0) { memcpy(pk->best, tmp, len + 1); pk->addr = addr; pk->found = 1; }
+    return 1;
 }
 
 static int walk_group_btree(const h5file *f, uint64_t addr, const unsigned char *heap, size_t heap_len, pick *pk, int depth) {
@@ -150,7 +151,7 @@ static int walk_group_btree(const h5file *f, uint64_t addr, const unsigned char 
             if (noff >= heap_len) return 0;
             const void *z = memchr(heap + noff, 0, heap_len - (size_t)noff);
             if (NULL == z) return 0;
-            offer(pk, (const char *)heap + noff, (size_t)((const unsigned char *)z - (heap + noff)), oaddr);
+            if (!offer(pk, (const char *)heap + noff, (size_t)((const unsigned char *)z - (heap + noff)), oaddr)) return 0;
         }
     }
     return 1;
@@ -199,7 +200,7 @@ static int group_lookup(const h5file *f, uint64_t gaddr, pick *pk) {
         off += (size_t)nlen;
         if (0 != ltype) return 0;                                                /* soft / external links: libhdf5 resolves those */
         if (off + 8 > sz) return 0;
-        offer(pk, name, (size_t)nlen, le(d + off, 8));
+        if (!offer(pk, name, (size_t)nlen, le(d + off, 8))) return 0;
         seen = 1;
     }
     return seen;
