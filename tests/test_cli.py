@@ -424,6 +424,36 @@ def test_reader_processes_and_multi_gpu_script(cli_inputs, tmp_path):
 
 @needs_hdf5
 @pytest.mark.gpu
+def test_fast5_layouts_through_the_binary(cli_inputs, tmp_path):
+    """single-read files in the layouts a fast5 comes in (contiguous / chunked + deflate + shuffle Signal, fixed and variable-length read_id, old and
+    latest file format, more read groups, float32 / integer channel attributes, dense attribute storage = a file the libhdf5-free reader refuses) through
+    the binary: the default (host/fast5_raw.c first, libhdf5 for what it refuses) gives the bytes FLAPPIE_DEBUG=hdf5_read (libhdf5 for every file) gives,
+    with reader processes and in-process (fast5_interface.c:231-318)."""
+    d, mdl, reads, raws = cli_inputs
+    env = dict(os.environ, FLAPPIE_MODEL_DIR=str(d))
+    big = tmp_path / "reads"
+    big.mkdir()
+    rng = np.random.default_rng(41)
+    layouts = [(0, 0), (7, 1000), (3, 512), (16, 0), (19, 700), (32, 0), (32 | 16, 0), (128, 0), (256, 0), (64, 0), (32 | 64, 0), (512, 0), (1 | 2 | 4 | 8, 333)]
+    for i in range(39):
+        flags, chunk = layouts[i % len(layouts)]
+        raw = synth_raw(rng, int(rng.integers(1500, 4200)))
+        tmp = str(big / "x.i16")
+        np.asarray(raw, dtype="<i2").tofile(tmp)
+        subprocess.run([TOOL, "writex", str(big / ("read_%03d.fast5" % i)), "uuid-%04d" % i, "8192.0", "10.0", "1400.0", "4000.0", tmp, str(flags), str(chunk)], check=True)
+        os.unlink(tmp)
+    outs = {}
+    for tag, extra, e2 in (("fast", ["--readers", "3"], {}), ("hdf5", ["--readers", "3"], {"FLAPPIE_DEBUG": "hdf5_read"}), ("fast_inproc", ["--readers", "0"], {})):
+        r = subprocess.run([FLAPPIE, "--batch", "8"] + extra + [str(big)], env=dict(env, **e2), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = r.stdout
+    recs = _parse_fastq(outs["fast"])
+    assert len(recs) == 39 and all(x[0].startswith("uuid-") for x in recs)          # the read_id attribute is the record's name (flappie.c:284-292 with --uuid, the default)
+    assert outs["fast"] == outs["hdf5"] == outs["fast_inproc"]
+
+
+@needs_hdf5
+@pytest.mark.gpu
 def test_batch_pipeline_across_chunks(cli_inputs, tmp_path):
     """the binary works in chunks of 4 x --batch reads and keeps its batch pipeline going across them (the first batch of a chunk
     is submitted before the last batch of the previous chunk is collected, a chunk is written while the next one runs): 150 reads
