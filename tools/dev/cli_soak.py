@@ -19,10 +19,11 @@ for hidden in (256, 384):
         subprocess.run([tool, "write", os.path.join(reads, "read_%05d.fast5" % i), "uuid-%05d" % i, "8192", "10", "1400", "4000", tmp], check=True)
     env = dict(os.environ, FLAPPIE_MODEL_DIR=d)
     sums = {}
-    for tag, extra in (("default", []), ("batch 64, 3 readers", ["--batch", "64", "--readers", "3"]), ("batch 200, 12 readers", ["--batch", "200", "--readers", "12"]),
-                       ("batch 1024", ["--batch", "1024"])):
+    # (round 6: the files through libhdf5 only, and every chunk in one-read-a-row batches, must give the same bytes as the defaults -- host/fast5_raw.c, packed batches)
+    for tag, extra, dbg in (("default", [], ""), ("batch 64, 3 readers", ["--batch", "64", "--readers", "3"], ""), ("batch 200, 12 readers", ["--batch", "200", "--readers", "12"], ""),
+                            ("batch 1024", ["--batch", "1024"], ""), ("libhdf5 reader", [], "hdf5_read"), ("one read a row", [], "no_pack"), ("in-process reader", ["--readers", "0"], "")):
         t0 = time.time()
-        r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie")] + extra + [reads], env=env, capture_output=True)
+        r = subprocess.run([os.path.join(ROOT, "flappie_amd", "flappie")] + extra + [reads], env=dict(env, FLAPPIE_DEBUG=dbg) if dbg else env, capture_output=True)
         assert r.returncode == 0, r.stderr[-500:]
         sums[tag] = hashlib.md5(r.stdout).hexdigest()
         print("H %d  %-24s %d records  md5 %s  %.1f s" % (hidden, tag, r.stdout.count(b"\n@uuid") + r.stdout.startswith(b"@uuid"), sums[tag], time.time() - t0), flush=True)
