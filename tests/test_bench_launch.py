@@ -40,6 +40,8 @@ def test_self_launch_with_a_stub_engine(n):
     assert abs(d["value"] - samples / d["max_over_ranks_s"] / 1e6) <= 1e-3 * d["value"]          # whole job / slowest rank
     assert d["value"] <= sum(d["per_rank_Msamples_per_s"]) * (1 + 1e-6)                            # MAX over ranks, not a sum of rates
     assert abs(d["ms_per_step"] - d["max_over_ranks_s"] / 6 * 1e3) < 1e-3
+    # more than one rank: the ranks' host threads wait for their GPUs blocking, not spinning (profiles/r06_blocking_sync.txt), and the line says so
+    assert d["host_wait"].startswith("blocking" if n > 1 else "spin")
 
 
 def test_world_size_mismatch_is_an_error_message_not_an_assertion():
