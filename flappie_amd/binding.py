@@ -313,7 +313,7 @@ class Batch:
         _check(lib().ffhip_batch_set_prepared(self.h, prep.h, idx))
 
     def pack_plan(self, nsamples: List[int]):
-        """first-fit-decreasing places of reads of these lengths in this batch's rows: (slot, block offset) per read, slot -1 where a read did not fit"""
+        """places (ffhip_pack_plan: longest first, each into the emptiest row) of reads of these lengths in this batch's rows: (slot, block offset) per read, slot -1 where a read did not fit"""
         n = len(nsamples)
         ns = (C.c_size_t * n)(*[int(x) for x in nsamples])
         slot, off = (C.c_int * n)(), (C.c_int * n)()

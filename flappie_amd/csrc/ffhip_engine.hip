@@ -9,6 +9,7 @@
 #include <math.h>
 #include <time.h>
 #include <ctype.h>
+#include <queue>
 #include <vector>
 #include <map>
 #include <algorithm>
@@ -905,30 +906,54 @@ extern "C" int ffhip_pack_rows_for(const ffhip_model *m, int want_rows, size_t n
     return rows < 16 ? 16 : (int)rows;
 }
 extern "C" int ffhip_pack_rows(const ffhip_model *m, int want_rows, size_t nsample) { return ffhip_pack_rows_for(m, want_rows, nsample, 2); }
-// First-fit-decreasing plan of `nread` reads into nslot rows of nsample_cap samples: slot[] / block_off[] of every read (slot -1: it did not fit); returns the number placed.
+// Plan of `nread` reads into nslot rows of nsample_cap samples: slot[] / block_off[] of every read (slot -1: it did not fit); returns the number placed.
+// Longest read first, each into the row that holds LEAST so far (round 6, third session; rounds before: into the first row it fits).  A launch runs as long as its longest
+// row, whatever the others hold: first fit fills row after row to the brim -- the longest row IS the capacity, and the slack the caller plans with (5 %) is paid as empty
+// steps of every layer -- while the least-loaded rule ends with all rows within a short read of the mean (the classic longest-processing-time bound), so the launch
+// lasts total / rows.  A read that does not fit the emptiest row fits none.  FFHIP_DEBUG=pack_first_fit: the old rule.
 extern "C" int ffhip_pack_plan(const ffhip_model *m, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off) {
     if (!m || nslot <= 0 || nread < 0 || !nsample || !slot || !block_off) { set_err(FFHIP_EINVAL, "bad pack plan arguments"); return -1; }
     const long cap = (long)ffhip_model_nblock(m, nsample_cap), gap = (long)ffhip_model_pack_gap(m);
     std::vector<int> order(nread);
     for (int i = 0; i < nread; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsample[x] > nsample[y]; });
-    // rows by free blocks: a multimap would do; the row count is small (<= 1024) and reads come longest first, so a scan from a moving start is short
     std::vector<long> used(nslot, 0);
-    int placed = 0, first_open = 0;
+    int placed = 0;
+    if (dbg("pack_first_fit")) {
+        // rows by free blocks: the row count is small (<= 1024) and reads come longest first, so a scan from a moving start is short
+        int first_open = 0;
+        for (int k = 0; k < nread; k++) {
+            const int i = order[k];
+            slot[i] = -1; block_off[i] = 0;
+            if (nsample[i] == 0 || nsample[i] > nsample_cap) continue;
+            const long nb = (long)ffhip_model_nblock(m, nsample[i]);
+            for (int r = first_open; r < nslot; r++) {
+                if (used[r] + nb + 1 <= cap) {      // (a dead block behind the last read of a row too)
+                    slot[i] = r; block_off[i] = (int)used[r];
+                    used[r] += nb + gap;
+                    placed++;
+                    break;
+                }
+            }
+            while (first_open < nslot && used[first_open] + gap + 8 >= cap) first_open++;      // (rows with no room for even a short read)
+        }
+        return placed;
+    }
+    // a min-heap of (blocks in use, row): ties go to the lower row, so a plan is a function of its arguments
+    typedef std::pair<long, int> Row;
+    std::priority_queue<Row, std::vector<Row>, std::greater<Row>> rows;
+    for (int r = 0; r < nslot; r++) rows.push(Row(0, r));
     for (int k = 0; k < nread; k++) {
         const int i = order[k];
         slot[i] = -1; block_off[i] = 0;
         if (nsample[i] == 0 || nsample[i] > nsample_cap) continue;
         const long nb = (long)ffhip_model_nblock(m, nsample[i]);
-        for (int r = first_open; r < nslot; r++) {
-            if (used[r] + nb + 1 <= cap) {      // (a dead block behind the last read of a row too)
-                slot[i] = r; block_off[i] = (int)used[r];
-                used[r] += nb + gap;
-                placed++;
-                break;
-            }
-        }
-        while (first_open < nslot && used[first_open] + gap + 8 >= cap) first_open++;      // (rows with no room for even a short read)
+        const Row top = rows.top();
+        if (top.first + nb + 1 > cap) continue;      // (a dead block behind the last read of a row too) -- not in the emptiest row: in none
+        rows.pop();
+        slot[i] = top.second; block_off[i] = (int)top.first;
+        rows.push(Row(top.first + nb + gap, top.second));
+        placed++;
     }
     return placed;
 }

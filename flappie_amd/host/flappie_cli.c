@@ -812,7 +812,7 @@ static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, 
     static int depth = 0;
     if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
     /* ---- a chunk of MIXED lengths goes in packed batches: what the one-read-a-row grouping below would pay for (rows x the group's longest read, group by
-     * group) against what the reads hold; below 0.85 the chunk's reads are placed several to a row (first fit, longest first) in as few batches of --batch rows
+     * group) against what the reads hold; below 0.85 the chunk's reads are placed several to a row (ffhip_pack_plan: longest first, each into the emptiest row) in as few batches of --batch rows
      * as hold them, rows just long enough -- a batch then costs what its samples cost (nanopore-like mix: 0.07 -> 0.9+, tools/length_mix.py) */
     int packed_chunk = 0;
     if (c->m2 > 0 && pack_allowed(mdl) && !pack_failed) {

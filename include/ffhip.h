@@ -319,7 +319,9 @@ int ffhip_batch_set_prepared(ffhip_batch *b, const ffhip_prep *prep, const int *
  * no FFHIP_RUN_KEEP_ACTS / _F32_RNN / _STEPWISE_RNN / _UNFUSED_RNN): ffhip_batch_run says so otherwise.  ffhip_batch_run_pair takes packed batches too. */
 int ffhip_model_packable(const ffhip_model *mdl);         /* 1: this model's default path takes packed batches on this device */
 size_t ffhip_model_pack_gap(const ffhip_model *mdl);      /* free blocks a read of a packed row needs behind it */
-/* first-fit-decreasing plan: slot[i] / block_off[i] for every read (slot -1: it did not fit into nslot rows of nsample_cap samples); returns the reads placed */
+/* plan of a packed batch: slot[i] / block_off[i] for every read (slot -1: it did not fit into nslot rows of nsample_cap samples); returns the reads placed.  Longest read first,
+ * each into the row that holds least so far: a launch runs as long as its longest row, and this rule leaves all rows within a short read of total / nslot (first fit -- the
+ * rule before round 6's third session, FFHIP_DEBUG=pack_first_fit -- fills row after row to nsample_cap: profiles/r06_pack_bench.txt, fill 0.93 -> 0.98) */
 int ffhip_pack_plan(const ffhip_model *mdl, int nslot, size_t nsample_cap, int nread, const size_t *nsample, int *slot, int *block_off);
 /* rows (a multiple of 16, <= want_rows) of a packed batch of nsample-sample rows whose workspace fits 36 % of the device's memory (two such objects are
  * alive in a pipeline): 512 rows of 200 000 samples are ~90 GB at 384 hidden units */

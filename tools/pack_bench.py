@@ -3,7 +3,7 @@
 several to a row -- beside the same rows filled with equal reads one to a row (include/ffhip.h "packed batches"; the binary's side of it: tools/length_mix.py).
 
 A window of log-normal read lengths (median 8000, sigma 1, clipped to 1000 .. `longest`) is planned into `rows` rows of max(longest, total / rows) samples
-(ffhip_pack_plan, first fit, longest first) -- the flappie binary's policy --, two batch objects in flight, K steps each; reported: Msamples/s of REAL samples, the
+(ffhip_pack_plan: longest first, each into the emptiest row; FFHIP_DEBUG=pack_first_fit: the rule before round 6's third session) -- the flappie binary's policy --, two batch objects in flight, K steps each; reported: Msamples/s of REAL samples, the
 fill of the rows (samples / (rows x the longest row)), the HIP-event time of the layer launches per step.  The uniform leg is `rows` reads of the row length.
 Run on the GPU box.   usage: tools/pack_bench.py [hidden=384] [rows=512] [longest=60000] [steps=6]"""
 import os
