@@ -410,6 +410,9 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
     n_batches++; n_packed_batches++;
     n_batch_samples += samples;
     n_batch_slot_samples += (unsigned long long)longest * spb * (unsigned long long)(16 * ((rows + 15) / 16));
+    if (cli_dbg("pack_log"))             /* development: what every packed batch holds and pays for */
+        fprintf(stderr, "packed batch %llu: %d reads, %llu samples in %d rows planned for %zu samples (object: %d rows of %zu), longest row %zu samples, longest read %zu: fill %.3f\n", n_packed_batches, n, samples,
+                rows, cap, rows_full, cap_obj, longest * spb, (size_t)(its[0]->res.rt.end - its[0]->res.rt.start), (double)samples / ((double)(longest * spb) * (double)(16 * ((rows + 15) / 16))));
     for (int r0 = 0; row_end && r0 < rows; r0 += 16) {
         size_t lt = 0;
         for (int r = r0; r < rows && r < r0 + 16; r++) if (row_end[r] > lt) lt = row_end[r];
@@ -1189,7 +1192,10 @@ static void read_chunk(const file_list *fl, size_t first, int chunk_cap, item *i
         if (NULL != it->res.rt.raw) nsamp += it->res.rt.n;
         if (g_pack_window && NULL != it->res.rt.raw && it->res.rt.n > longest) {
             longest = it->res.rt.n;
-            size_t want = (size_t)args.batch * longest;
+            /* (... and a twentieth more: these are RAW samples, the rows hold trimmed ones, and rows that average a little MORE than the longest read let the planner --
+             * every read into the emptiest row -- end with all rows alike; at exactly --batch x longest the trimming left the rows 2.7 % under a row that holds the
+             * longest read alone, and that row is what the launch lasts: fill 0.973 -> 0.99, tools/dev/pack_log.sh) */
+            size_t want = (size_t)args.batch * longest + (size_t)args.batch * longest / 20;
             if (want > PACK_WINDOW_MAX) want = PACK_WINDOW_MAX;
             if (want > sample_budget) { sample_budget = want; read_cap = PACK_WINDOW_READS * chunk_cap; }
         }
