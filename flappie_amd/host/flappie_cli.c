@@ -315,6 +315,7 @@ static int bind_to_gpu_numa(int device) {
 }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static double t_program_start;          /* main's first statement (FLAPPIE_DEBUG=pack_log's time stamps) */
 /* what the run basecalled: reads, samples of their trimmed ranges (the metric of SURVEY.md section 8d), samples read from the files */
 static unsigned long long n_called_reads, n_called_samples, n_raw_samples;
 /* what the batches cost: a batch (a launch per layer) takes as long as its longest read needs whatever the others' lengths, a read tile of 16 as long as
@@ -411,7 +412,7 @@ static pending_batch submit_packed(struct ffhip_engine *eng, const struct ffhip_
     n_batch_samples += samples;
     n_batch_slot_samples += (unsigned long long)longest * spb * (unsigned long long)(16 * ((rows + 15) / 16));
     if (cli_dbg("pack_log"))             /* development: what every packed batch holds and pays for */
-        fprintf(stderr, "packed batch %llu: %d reads, %llu samples in %d rows planned for %zu samples (object: %d rows of %zu), longest row %zu samples, longest read %zu: fill %.3f\n", n_packed_batches, n, samples,
+        fprintf(stderr, "packed batch %llu (submitted at %.3f s): %d reads, %llu samples in %d rows planned for %zu samples (object: %d rows of %zu), longest row %zu samples, longest read %zu: fill %.3f\n", n_packed_batches, now_s() - t_program_start, n, samples,
                 rows, cap, rows_full, cap_obj, longest * spb, (size_t)(its[0]->res.rt.end - its[0]->res.rt.start), (double)samples / ((double)(longest * spb) * (double)(16 * ((rows + 15) / 16))));
     for (int r0 = 0; row_end && r0 < rows; r0 += 16) {
         size_t lt = 0;
@@ -1229,6 +1230,7 @@ static void segv_trace(int sig) {
 }
 
 int main(int argc, char *argv[]) {
+    t_program_start = now_s();
     argp_parse(&argp, argc, argv, 0, 0, NULL);
     if (cli_dbg("segv_trace")) { signal(SIGSEGV, segv_trace); signal(SIGABRT, segv_trace); signal(SIGBUS, segv_trace); }
     if (NULL == args.output) args.output = stdout;

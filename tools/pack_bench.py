@@ -53,8 +53,8 @@ def timed(batches, label, real_samples, row_samples):
     eng.synchronize()
     dt = time.perf_counter() - t0
     layer_ms = float(np.mean([b.profile()["recurrent"]["ms"] for b in batches]))
-    print("%-8s %d steps in %.3f s: %.1f Msamples/s of real samples; rows %d x %d samples, fill %.3f; layer launches %.1f ms a step (%.2f us a block-step); rnn path %d"
-          % (label, steps, dt, steps * real_samples / dt / 1e6, rows, cap, real_samples / row_samples, layer_ms, 1e3 * layer_ms / 5 / batches[0].nblock, batches[0].rnn_path()), flush=True)
+    print("%-8s %d steps in %.3f s: %.1f Msamples/s of real samples; rows %d x %d samples, fill %.3f; layer launches %.1f ms a step (%.2f us a block-step of the longest row); rnn path %d"
+          % (label, steps, dt, steps * real_samples / dt / 1e6, rows, cap, real_samples / row_samples, layer_ms, 1e3 * layer_ms / 5 / (row_samples / rows / (cap / batches[0].nblock)), batches[0].rnn_path()), flush=True)      # (a layer launch runs the longest ROW's blocks, not the capacity's: the packed leg's figure divided by the capacity until round 6's third session and read ~4 % low)
     eng.set_profiling(False)
     return steps * real_samples / dt / 1e6
 
