@@ -256,6 +256,11 @@ struct ffhip_prep {
     mutable hipEvent_t used = nullptr;   // recorded behind the last asynchronous read of d_out (ffhip_batch_set_prepared's gather)
     std::vector<size_t> off, start, end;
     std::vector<float> stats;
+    // ffhip_prep_begin: enqueued and not yet waited for (the tables the uploads read live here until then; `start` / `end` / `stats` are being written)
+    bool pending = false;
+    std::vector<size_t> n_in, s_in, e_in;
+    // pinned landing place of the ranges and statistics, in the engine's staging buffer (a copy into pageable memory is not asynchronous: the call would wait for the kernel)
+    void *h_res = nullptr;
 };
 
 // ---- buffers kept by the engine (ffhip_host.hpp): no hipMalloc / hipFree -- i.e. no device-wide synchronisation -- per chunk ----
@@ -307,6 +312,7 @@ void ffhip::prep_mark_used(const ffhip_prep *p, hipStream_t s) {
 
 extern "C" void ffhip_prep_destroy(ffhip_prep *p) {
     if (!p) return;
+    if (p->pending) { hipStreamSynchronize(p->eng->prep_stream); p->pending = false; }
     if (p->used) { hipEventSynchronize(p->used); hipEventDestroy(p->used); }
     if (p->d_out) {
         // back to the engine's pool (at most four buffers wait there; the smallest goes when a fifth arrives)
@@ -323,7 +329,7 @@ extern "C" void ffhip_prep_destroy(ffhip_prep *p) {
 }
 
 static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
-                            size_t chunk, float perc, int mode, float delta, int do_trim, float shift = 0.0f) {
+                            size_t chunk, float perc, int mode, float delta, int do_trim, float shift = 0.0f, bool wait = true) {
     if (!eng || !reads || nread <= 0) { set_err(FFHIP_EINVAL, "bad signal-preparation arguments"); return nullptr; }
     if (mode < FFHIP_PREP_MEDMAD || mode > FFHIP_PREP_SHIFT_SCALE) { set_err(FFHIP_EINVAL, "unknown preparation mode %d", mode); return nullptr; }
     if (do_trim && (chunk < 2 || chunk > (size_t)kMaxChunk || !(perc >= 0.0f && perc <= 1.0f))) {
@@ -337,7 +343,8 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     p->eng = eng;
     p->nread = nread;
     p->off.resize(nread); p->start.resize(nread); p->end.resize(nread); p->stats.assign((size_t)2 * nread, 0.0f);
-    std::vector<size_t> n_in(nread), s_in(nread), e_in(nread);
+    std::vector<size_t> &n_in = p->n_in, &s_in = p->s_in, &e_in = p->e_in;
+    n_in.resize(nread); s_in.resize(nread); e_in.resize(nread);
     size_t total = 0;
     for (int r = 0; r < nread; r++) {
         const raw_table &rt = reads[r];
@@ -352,7 +359,9 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     float *d_raw = (float *)prep_scratch(eng, 0, total * 4), *d_mad = (float *)prep_scratch(eng, 1, total * 4);
     size_t *d_sz = (size_t *)prep_scratch(eng, 2, (size_t)6 * nread * sizeof(size_t));
     float *d_stats = (float *)prep_scratch(eng, 3, (size_t)2 * nread * 4);
-    float *pin = (float *)prep_pinned(eng, total * 4);
+    // (behind the raw samples: the landing place of ffhip_prep_begin's results -- ranges [2 nread] size_t, statistics [2 nread] float -- in the same pinned buffer)
+    const size_t res_off = (total * 4 + 63) & ~(size_t)63, res_bytes = (size_t)2 * nread * sizeof(size_t) + (size_t)2 * nread * 4;
+    float *pin = (float *)prep_pinned(eng, res_off + res_bytes);
 #define PFAIL(code, msg) do { set_err(code, msg); ffhip_prep_destroy(p); return nullptr; } while (0)
     if (!d_raw || !d_mad || !d_sz || !d_stats || !pin || !(p->d_out = prep_pool_take(eng, total * 4, &p->d_out_cap))) PFAIL(FFHIP_ENOMEM, "device allocation failed");
     // one packed upload for the chunk: the reads are gathered in pinned memory first (a copy per read from pageable memory costs
@@ -381,6 +390,16 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     // the engine's last layer launch (the wait stands in front of the output's fill above; the uploads before it are not held up: copies do not wait for compute).
     // The usual chunks (a millisecond or two) stay where they were.
     hipLaunchKernelGGL(k_prep, dim3(nread), dim3(256), 0, s, a);
+    if (!wait) {
+        // ffhip_prep_begin: the results land in pinned memory (ffhip_prep_finish waits and takes them from there); d_so and d_eo stand one behind the other
+        const size_t nb = (size_t)2 * nread * sizeof(size_t);
+        p->h_res = (char *)pin + res_off;
+        ok = hipMemcpyAsync(p->h_res, d_so, nb, hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync((char *)p->h_res + nb, d_stats, (size_t)2 * nread * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (!ok) PFAIL(FFHIP_EHIP, "signal-preparation kernel failed");
+        p->pending = true;
+        return p;
+    }
     ok = hipMemcpyAsync(p->start.data(), d_so, nread * sizeof(size_t), hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(p->end.data(), d_eo, nread * sizeof(size_t), hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(p->stats.data(), d_stats, (size_t)2 * nread * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
@@ -388,6 +407,30 @@ static ffhip_prep *prep_run(ffhip_engine *eng, const raw_table *reads, int nread
     if (!ok) PFAIL(FFHIP_EHIP, "signal-preparation kernel failed");
 #undef PFAIL
     return p;
+}
+
+// The two halves of ffhip_prep_create (round 6): begin enqueues the uploads, the kernel and the copies of the ranges on the engine's preparation stream and returns;
+// finish waits for them.  A caller with a pipeline of chunks begins chunk k + 1 before it submits chunk k's batches: the preparation -- one workgroup a read, as long as
+// its longest read's selection passes -- then runs BESIDE those batches' convolutions instead of in front of the next ones' (profiles/r06_pack_trace.txt).
+// ONE preparation may be pending at a time (the engine's staging buffers are shared); ranges, statistics and signals are there after finish.
+extern "C" ffhip_prep *ffhip_prep_begin(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
+                                        size_t varseg_chunk, float varseg_thresh, int mode, float delta) {
+    return prep_run(eng, reads, nread, trim_start, trim_end, varseg_chunk, varseg_thresh, mode, delta, 1, 0.0f, false);
+}
+extern "C" int ffhip_prep_finish(ffhip_prep *p) {
+    if (!p) return set_err(FFHIP_EINVAL, "no preparation");
+    if (!p->pending) return FFHIP_OK;
+    hipSetDevice(p->eng->device);
+    p->pending = false;
+    if (hipStreamSynchronize(p->eng->prep_stream) != hipSuccess || hipGetLastError() != hipSuccess) return set_err(FFHIP_EHIP, "signal-preparation kernel failed");
+    if (p->h_res) {
+        const size_t *r = (const size_t *)p->h_res;
+        const float *st = (const float *)((const char *)p->h_res + (size_t)2 * p->nread * sizeof(size_t));
+        for (int i = 0; i < p->nread; i++) { p->start[i] = r[i]; p->end[i] = r[p->nread + i]; }
+        for (size_t i = 0; i < (size_t)2 * p->nread; i++) p->stats[i] = st[i];
+        p->h_res = nullptr;
+    }
+    return FFHIP_OK;
 }
 
 extern "C" ffhip_prep *ffhip_prep_create(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,

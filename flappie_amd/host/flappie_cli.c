@@ -593,7 +593,11 @@ static int by_length_desc(const void *x, const void *y) {
     return (la < lb) - (la > lb);
 }
 
-static void chunk_begin(struct ffhip_engine *eng, chunk_ctx *c, item *items, int n, int buf) {
+/* The chunk's device pass in two halves (round 6, third session): begin enqueues it (wait = 0: ffhip_prep_begin returns at once), finish waits for it, takes the
+ * ranges and sorts the reads.  pipe_chunk begins chunk k + 1 before it submits chunk k's batches when that chunk is a large one: its preparation -- one workgroup a
+ * read, as long as the longest read's selection passes last, and held behind the engine's last layer launch -- then runs beside chunk k's convolutions instead of in
+ * front of chunk k + 1's (profiles/r06_pack_trace.txt). */
+static void chunk_begin(struct ffhip_engine *eng, chunk_ctx *c, item *items, int n, int buf, int wait) {
     memset(c, 0, sizeof(*c));
     c->items = items; c->n = n; c->buf = buf; c->live = 1;
     c->group = calloc(n > 0 ? n : 1, sizeof(item *));
@@ -604,10 +608,18 @@ static void chunk_begin(struct ffhip_engine *eng, chunk_ctx *c, item *items, int
         if (NULL != items[i].res.rt.raw) { c->rts[m] = items[i].res.rt; items[i].prepared = m++; }
     }
     double tp0 = now_s();
-    c->prep = (m > 0) ? ffhip_prep_create(eng, c->rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
-                                          (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
+    c->prep = (m > 0) ? (wait ? ffhip_prep_create : ffhip_prep_begin)(eng, c->rts, m, args.trim_start, args.trim_end, args.varseg_chunk, args.varseg_thresh,
+                                                                         (args.delta == 0.0f) ? FFHIP_PREP_MEDMAD : FFHIP_PREP_DELTA, args.delta) : NULL;
     t_phase[1] += now_s() - tp0;
     if (m > 0 && NULL == c->prep) warnx("%s", ffhip_last_error());
+}
+
+static void chunk_begin_finish(chunk_ctx *c) {
+    item *items = c->items;
+    const int n = c->n;
+    double tp0 = now_s();
+    if (NULL != c->prep && 0 != ffhip_prep_finish(c->prep)) { warnx("%s", ffhip_last_error()); ffhip_prep_destroy(c->prep); c->prep = NULL; }
+    t_phase[1] += now_s() - tp0;
     for (int i = 0; i < n; i++) {
         if (items[i].prepared < 0) continue;
         size_t st = 0, en = 0;
@@ -803,16 +815,40 @@ static void pipe_collect_all(const struct ffhip_model *mdl, hid_t hdf5out) {
 static void run_groups(struct ffhip_engine *eng, const struct ffhip_model *mdl, struct chunk_ctx *c, item **group, int m2, hid_t hdf5out, int depth);
 static int pack_failed = 0;                  /* a packed batch object could not be created (memory): the rest of the run goes one read a row */
 
-static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out) {
+/* the context of the next chunk to begin (chunk sequence number nbegun): its slot's previous chunk may still be with the writer */
+static chunk_ctx *chunk_slot(void) {
     chunk_ctx *c = &pipe_state.ctx[pipe_state.nbegun % NCHUNKBUF];
-    if (writer.started == 1) {                        /* the slot's previous chunk may still be with the writer */
+    if (writer.started == 1) {
         pthread_mutex_lock(&writer.mu);
         while (__atomic_load_n(&c->live, __ATOMIC_ACQUIRE)) pthread_cond_wait(&writer.cv, &writer.mu);
         pthread_mutex_unlock(&writer.mu);
     }
     if (c->live) errx(EXIT_FAILURE, "internal error: chunk slot still in use");
-    chunk_begin(eng, c, items, n, buf);            /* the device pass runs beside the batch still in flight */
-    pipe_state.nbegun++;
+    return c;
+}
+static chunk_ctx *chunk_ahead = NULL;        /* the chunk whose device pass was begun while its predecessor was handled (its items are the next pipe_chunk's) */
+
+/* look_ahead (may be NULL): asked AFTER this chunk's own device pass has been waited for -- i.e. when the batch in flight has just ended -- whether the chunk that follows is in
+ * the reader's buffers already and is a large one; its device pass is then begun here, in front of this chunk's batches, and runs beside their convolutions */
+typedef int (*look_ahead_fn)(item **items, int *n, int *buf);
+static void pipe_chunk(struct ffhip_engine *eng, const struct ffhip_model *mdl, item *items, int n, int buf, hid_t hdf5out, look_ahead_fn look_ahead) {
+    chunk_ctx *c = chunk_ahead;
+    if (NULL != c) {
+        if (c->items != items || c->n != n) errx(EXIT_FAILURE, "internal error: the chunk prepared ahead is not the one that follows");
+        chunk_ahead = NULL;
+    } else {
+        c = chunk_slot();
+        chunk_begin(eng, c, items, n, buf, 1);     /* the device pass runs beside the batch still in flight */
+        pipe_state.nbegun++;
+    }
+    chunk_begin_finish(c);
+    item *next_items = NULL;
+    int next_n = 0, next_buf = 0;
+    if (NULL != look_ahead && look_ahead(&next_items, &next_n, &next_buf)) {
+        chunk_ahead = chunk_slot();
+        chunk_begin(eng, chunk_ahead, next_items, next_n, next_buf, 0);
+        pipe_state.nbegun++;
+    }
     static int depth = 0;
     if (0 == depth) { const char *e = getenv("FLAPPIE_INFLIGHT"); depth = (e && atoi(e) == 3) ? NINFLIGHT - 1 : 1; }
     /* ---- a chunk of MIXED lengths goes in packed batches: what the one-read-a-row grouping below would pay for (rows x the group's longest read, group by
@@ -1219,6 +1255,26 @@ static void *reader_main(void *arg) {
     return NULL;
 }
 
+/* pipe_chunk's look-ahead over the reader thread's buffers: buffer kn holds the next chunk if its `filled` can be taken now (the main loop then skips its own wait for it) */
+static struct { reader_state *rs; int on, kn, more, taken; } la;
+static int look_ahead_reader(item **items, int *n, int *buf) {
+    if (!la.on || !la.more || la.taken) return 0;
+    if (0 != sem_trywait(&la.rs->filled[la.kn])) {
+        if (cli_dbg("pack_log")) fprintf(stderr, "look-ahead at %.3f s: the reader has not filled buffer %d yet\n", now_s() - t_program_start, la.kn);
+        return 0;
+    }
+    la.taken = 1;
+    if (cli_dbg("pack_log")) fprintf(stderr, "look-ahead at %.3f s: buffer %d is there (%d reads)\n", now_s() - t_program_start, la.kn, la.rs->nitem[la.kn]);
+    unsigned long long raw = 0;
+    for (int i = 0; i < la.rs->nitem[la.kn]; i++) if (NULL != la.rs->items[la.kn][i].res.rt.raw) raw += la.rs->items[la.kn][i].res.rt.n;
+    unsigned long long least = 48ull << 20;      /* the usual chunks: their device pass is a millisecond beside the batch in flight as it is */
+    const char *lm = cli_dbg("prep_ahead_min");  /* tests: FLAPPIE_DEBUG=prep_ahead_min=0 takes this path with chunks of any size */
+    if (NULL != lm) least = strtoull(lm, NULL, 10);
+    if (raw < least) return 0;
+    *items = la.rs->items[la.kn]; *n = la.rs->nitem[la.kn]; *buf = la.kn;
+    return 1;
+}
+
 /* FLAPPIE_DEBUG=segv_trace: the call stack of a crash on stderr (addresses for addr2line; development) */
 static void segv_trace(int sig) {
     void *frames[48];
@@ -1269,14 +1325,18 @@ int main(int argc, char *argv[]) {
     size_t done = 0;
     double t_wait = 0.0;
     if (threaded) { pipe_state.released = release_buffer; pipe_state.released_arg = &rs; }
+    /* A LARGE chunk that follows (the window of a directory of long reads: 48 M raw samples and more, what ffhip_prep_create holds behind the engine's last layer launch) has its
+     * device pass begun before this chunk's batches are submitted, if the reader has it ready by then (FLAPPIE_DEBUG=no_prep_ahead: never) */
+    la.rs = &rs; la.on = threaded && !cli_dbg("no_prep_ahead"); la.taken = 0;
     for (int k = 0; done < fl.n; k = (k + 1) % NCHUNKBUF) {
         const double tw0 = now_s();
-        /* buffer k was released when the chunk three back was written: at most two chunks are unfinished at a time */
-        if (threaded) sem_wait(&rs.filled[k]);
+        /* buffer k was released when the chunk three back was written: at most two chunks are unfinished at a time (three with a chunk prepared ahead) */
+        if (threaded) { if (!la.taken) sem_wait(&rs.filled[k]); }
         else { pipe_wait_slot_written(); read_chunk(&fl, done, done == 0 ? rs.chunk_cap / CHUNK_BATCHES : rs.chunk_cap, rs.items[k], &rs.nitem[k]); }
         t_wait += now_s() - tw0;
         const int nk = rs.nitem[k];              /* (the reader may refill the buffer as soon as the chunk is written) */
-        pipe_chunk(eng, mdl, rs.items[k], nk, k, hdf5out);
+        la.taken = 0; la.kn = (k + 1) % NCHUNKBUF; la.more = done + (size_t)nk < fl.n;
+        pipe_chunk(eng, mdl, rs.items[k], nk, k, hdf5out, look_ahead_reader);
         done += nk;
     }
     pipe_drain(mdl, hdf5out);

@@ -300,6 +300,11 @@ typedef struct ffhip_prep ffhip_prep;
 #define FFHIP_PREP_SHIFT_SCALE 4   /* shift_scale_array (util.c:214-223), ffhip_array_transform only */
 ffhip_prep *ffhip_prep_create(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
                               size_t varseg_chunk, float varseg_thresh, int mode, float delta);
+/* the same in two halves: begin enqueues (uploads, kernel, the ranges' copies) and returns, finish waits -- a pipeline begins chunk k + 1 before it submits chunk k's
+ * batches, and the preparation runs beside their convolutions.  One preparation may be pending at a time; ranges, statistics and signals are valid after finish. */
+ffhip_prep *ffhip_prep_begin(ffhip_engine *eng, const raw_table *reads, int nread, size_t trim_start, size_t trim_end,
+                             size_t varseg_chunk, float varseg_thresh, int mode, float delta);
+int ffhip_prep_finish(ffhip_prep *p);
 void ffhip_prep_destroy(ffhip_prep *p);      /* waits for the copies ffhip_batch_set_prepared enqueued from it, not for the batches */
 /* start >= end: the read was rejected (trim_and_segment_raw would have returned a NULL table) */
 int ffhip_prep_range(const ffhip_prep *p, int read, size_t *start, size_t *end);

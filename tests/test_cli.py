@@ -475,6 +475,14 @@ def test_batch_pipeline_across_chunks(cli_inputs, tmp_path):
         outs[tag] = r.stdout
     assert len(_parse_fastq(outs["chunks"])) == 150
     assert outs["chunks"] == outs["one"] == outs["main"]
+    # the next chunk's device pass begun AHEAD (ffhip_prep_begin / ffhip_prep_finish: the path a directory of long reads takes; prep_ahead_min=0 takes it with these small
+    # chunks too) gives the same bytes, and the path was taken
+    r = subprocess.run([FLAPPIE, "--no-uuid", "--batch", "8", "--readers", "3", str(big)], env=dict(env, FLAPPIE_DEBUG="prep_ahead_min=0,pack_log"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == outs["chunks"]
+    assert r.stderr.count("is there (") >= 1, r.stderr[-2000:]
+    r = subprocess.run([FLAPPIE, "--no-uuid", "--batch", "8", "--readers", "3", str(big)], env=dict(env, FLAPPIE_DEBUG="no_prep_ahead"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout == outs["chunks"]
     for name in ("read_000.fast5", "read_077.fast5", "read_149.fast5"):
         sa, ta = dump_trace(tmp_path / "chunks.hdf5", name)
         sb, tb = dump_trace(tmp_path / "one.hdf5", name)
