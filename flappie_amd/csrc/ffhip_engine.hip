@@ -63,6 +63,7 @@ extern "C" ffhip_engine *ffhip_engine_create(int device) {
     for (int i = 0; i < e->nstreams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming), (delete e, nullptr));
+    HIP_TRY(hipEventCreateWithFlags(&e->head_done, hipEventDisableTiming), (delete e, nullptr));
     HIP_TRY(hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming), (delete e, nullptr));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreateWithFlags(&e->done_ring[i], hipEventDisableTiming), (delete e, nullptr));
     ffhip::pool_engine_born(device);
@@ -310,6 +311,7 @@ extern "C" void ffhip_engine_destroy(ffhip_engine *e) {
     for (int i = 0; i < 4; i++) if (e->prep_scratch[i]) hipFree(e->prep_scratch[i]);
     for (auto &b : e->prep_pool) hipFree(b.first);
     if (e->persist_done) hipEventDestroy(e->persist_done);
+    if (e->head_done) hipEventDestroy(e->head_done);
     if (e->batch_done) hipEventDestroy(e->batch_done);
     for (int i = 0; i < 4; i++) if (e->done_ring[i]) hipEventDestroy(e->done_ring[i]);
     delete e;
@@ -1065,6 +1067,10 @@ static int apply_packed(ffhip_batch *b, int nv, const std::vector<int> &lens, co
     // layer launch -- which holds every CU -- a fill crawls AND keeps the next layer launch from becoming resident (kernel trace of a mixed directory: a 0.4 GB fill
     // 170 ms long, the layer launch beside it 300 ms instead of 180): it goes behind the engine's last layer launch, beside that batch's head and decode.
     if (b->eng->persist_chained) HIP_TRY(hipStreamWaitEvent(b->stream, b->eng->persist_done, 0), FFHIP_EHIP);
+    // ... and behind the CRF head of the packed batch that ran last (round 6, third session): the head is a throughput kernel (12 ms alone for a 100 M-sample batch) that k_conv_split_ws
+    // beside it stretches to 47 ms, and the chains wait for it -- with the head first they run under the convolutions instead of behind them (profiles/r06_pack_trace.txt).
+    // FFHIP_DEBUG=no_pack_behind_head: both start with the gap.
+    if (b->eng->head_done_rec && !dbg("no_pack_behind_head")) HIP_TRY(hipStreamWaitEvent(b->stream, b->eng->head_done, 0), FFHIP_EHIP);
     std::vector<int> cur(lens);
     int nstrided = 0;
     for (int l = 0; l < nconv; l++) {
@@ -1607,6 +1613,7 @@ static int batch_run_impl(ffhip_batch *b, float temperature, unsigned flags, int
         const bool head_e = split_head && post_done && head_split_writes_E(m->P);
         if (split_head) launch_head_split(s, b->actS[cur], b->trans, m->FFsplit, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 32, temperature / 5.0f, m->FF_split_S, 0, head_e ? b->crf_e : nullptr);
         else launch_head(s, b->act[cur], b->trans, m->FFp, m->FFb, Tb, B16, b->nread, m->P, m->Ps, Hp / 16, temperature / 5.0f);
+        if (b->packed) { HIP_TRY(hipEventRecord(b->eng->head_done, s), FFHIP_EHIP); b->eng->head_done_rec = 1; }      // (the next packed batch's set-up and convolutions start behind it: apply_packed)
         if (post_done) {
             const bool want_post = !(flags & FFHIP_RUN_NO_DECODE) && !(flags & FFHIP_RUN_VITERBI_ONLY);
             if (!head_e) launch_crf_exp(s, b->trans, b->crf_e, b->nread, Tb, m->nbase, m->Ps, tbs, nullptr, 0.0f);

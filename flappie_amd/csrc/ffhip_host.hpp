@@ -18,6 +18,7 @@ struct ffhip_engine {
     // Two batches (streams) may run such kernels at the same time only if both fit; otherwise the
     // launches are chained through this event.
     hipEvent_t persist_done = nullptr;
+    hipEvent_t head_done = nullptr; int head_done_rec = 0;      // behind the CRF head of the last batch run: a packed batch's set-up waits for it (ffhip_engine.hip apply_packed)
     int persist_chained = 0;
     hipEvent_t batch_done = nullptr;     // end of the last submitted batch (any stream): see batch_run_impl, "whole batches one after the other"
     int batch_done_rec = 0;

@@ -7,6 +7,7 @@ python -c "
 import sys; sys.path.insert(0,'.')
 from flappie_amd import model as M
 M.write_mdl('$d/flipflop5_r941native.h', M.synthetic_model(M.NET_LSTM5, 384, seed=1, ident='r941native'))"
+rm -rf gpurun_out/prof_packtrace
 FLAPPIE_MODEL_DIR=$d rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_packtrace -- flappie_amd/flappie --readers 4 -o $d/out.fq $d/reads > /dev/null 2>&1
 rm -rf $d
 f=$(find gpurun_out/prof_packtrace -name "*kernel_trace.csv" | head -1)
