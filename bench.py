@@ -335,7 +335,8 @@ def length_mix_leg(cfg, local_rank, nfiles=None):
         M.write_mdl(os.path.join(d, "flipflop5_r941native.h"), M.synthetic_model(cfg["kind"], cfg["hidden"], seed=1, ident=cfg["ident"]))
         t_gen = time.time() - t0
         readers = max(1, min(4, effective_cpus()[0]))
-        env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1")
+        env = dict(os.environ, FLAPPIE_MODEL_DIR=d, FLAPPIE_HIP_DEVICE=str(local_rank), FLAPPIE_CLI_TIMING="1",
+                   FLAPPIE_DEBUG=",".join(x for x in (os.environ.get("FLAPPIE_DEBUG", ""), "pack_log") if x))      # (pack_log: a line a packed batch with the time it was submitted)
         runs = {}
         # a short and a long run: the rate is MARGINAL (as host_fed's): start-up and the batch objects' allocation are in both.  A first short run is thrown away: what the allocation
         # of the 2 x 100 GB batch objects costs depends on what the box's memory has been through (0 .. 5 s; the first process to touch it pays most:
@@ -362,10 +363,21 @@ def length_mix_leg(cfg, local_rank, nfiles=None):
             objects = [ln for ln in r.stderr.splitlines() if ln.startswith("packed batch object")]
         (t_s, _, raw_s, _), (t_l, reads, raw_l, pad) = runs[n_short], runs[nfiles]
         eff = pad.split("padding efficiency ")[1].split()[0] if "padding efficiency " in pad else None
-        return {"value": round((raw_l - raw_s) / (t_l - t_s) / 1e6, 3) if t_l > t_s else None, "unit": "Msamples/s", "whole_long_run": round(raw_l / t_l / 1e6, 3),
+        # The steady state by the long run's own account: the binary says when it submitted every packed batch and how many (trimmed) samples it holds; from the third batch
+        # on -- both batch objects exist by then: their allocation costs 0 .. 5 s from one invocation to the next (profiles/r06_alloc_probe.txt) and makes the difference of two
+        # walls scatter by tens of per cent -- the samples of batches 3 .. n - 1 over the time between the third and the last submission.  `marginal_walls` is that difference.
+        import re
+        sub = [(int(m.group(1)), float(m.group(2)), int(m.group(3))) for m in re.finditer(r"^packed batch (\d+) \(submitted at ([0-9.]+) s\): \d+ reads, (\d+) samples", r.stderr, re.M)]
+        steady = None
+        if len(sub) >= 5 and sub[-1][1] > sub[2][1]:
+            steady = sum(x[2] for x in sub[2:-1]) / (sub[-1][1] - sub[2][1]) / 1e6
+        marginal = (raw_l - raw_s) / (t_l - t_s) / 1e6 if t_l > t_s else None
+        return {"value": round(steady if steady is not None else marginal, 3) if (steady or marginal) else None, "unit": "Msamples/s",
+                "basis": "steady state: trimmed samples of the long run's packed batches 3 .. n-1 / the time between the third and the last submission (the binary's own time stamps)" if steady is not None else "marginal rate of the two walls",
+                "marginal_walls": round(marginal, 3) if marginal else None, "packed_batches_long_run": len(sub), "whole_long_run": round(raw_l / t_l / 1e6, 3),
                 "walls_s": {str(n_short): round(t_s, 3), str(nfiles): round(t_l, 3)}, "files": nfiles, "reads_called": reads, "raw_samples": raw_l,
                 "padding_efficiency": float(eff) if eff else None, "batches": pad.split(";")[0] if pad else None, "long_run_phases_s": phases, "long_run_batch_objects": objects,
-                "note": "the flappie binary over %d generated single-read fast5 files of log-normal lengths (median 8000, sigma 1, 1000 .. 200 000 samples), --readers %d, FASTQ out: "
+                "note": "the flappie binary over %d generated single-read fast5 files of log-normal lengths (median 8000, sigma 1, 1000 .. 200 000 samples), --readers %d, FASTQ out; `value`: see `basis`; `marginal_walls`: "
                         "raw samples of files [%d, %d) / the time between a %d-file and a %d-file run (start-up and the allocation of the ~100 GB batch objects are in both -- the latter costs 0 .. 3 s an object from one "
                         "invocation to the next, so this figure scatters: whole runs of 864.7 M samples read 83 Msamples/s in profiles/r06_length_mix.txt; `whole_long_run` has both in); padding_efficiency = samples / (rows x the batch's longest row) by the binary's own account; round 5's one-read-a-row batcher "
                         "read 13.6 Msamples/s of this mix at 0.07 (profiles/r06_length_mix.txt); generation %.1f s (not timed)" % (nfiles, readers, n_short, nfiles, n_short, nfiles, t_gen)}

@@ -50,7 +50,7 @@ def table(tag):
     dk = max(dk, key=lambda x: float(x["TotalDurationNs"]))
     out.append("")
     out.append("The driver's command (`python bench.py`, `profiles/%s_bench_default.json`): **%.1f Msamples/s**, %.3f ms per step, layer launch %.3f ms by HIP events (rocprofv3 `--stats` of the same command, `%s_bench_default_kernel_stats.csv`: %.3f ms over %s calls), `roofline.frac` %.4f, "
-               "`exposed_ms` %.3f, `decode_hbm` %.0f GB/s, `h2d_inclusive` %.1f, `host_fed` %s Msamples/s (the `flappie` binary from fast5 files of 3500-5500 samples), `length_mix` %s (the same binary on log-normal read lengths, 1000 … 200 000 samples: marginal rate, the binary's padding efficiency), `cpu_baseline` %.3f Msamples/s on %d CPUs (`%s`)."
+               "`exposed_ms` %.3f, `decode_hbm` %.0f GB/s, `h2d_inclusive` %.1f, `host_fed` %s Msamples/s (the `flappie` binary from fast5 files of 3500-5500 samples), `length_mix` %s (the same binary on log-normal read lengths, 1000 … 200 000 samples: its steady state by its own time stamps, its padding efficiency), `cpu_baseline` %.3f Msamples/s on %d CPUs (`%s`)."
                % (tag, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], tag, float(dk["AverageNs"]) / 1e6, dk["Calls"], d["roofline"]["frac"], d["exposed_ms"], d["decode_hbm"]["achieved"],
                   (d.get("h2d_inclusive") or {}).get("value", float("nan")), ("%.1f" % hf["value"]) if hf.get("value") else "-",
                   ("%.1f Msamples/s at %.2f" % (lm["value"], lm["padding_efficiency"])) if lm.get("value") else "-", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["kind"]))
