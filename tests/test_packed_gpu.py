@@ -122,6 +122,41 @@ def test_two_packed_batches_in_a_paired_launch(B, engine):
     dm.close()
 
 
+def test_planner_ends_with_rows_alike(B, engine, monkeypatch):
+    """ffhip_pack_plan: longest read first, each into the row that holds least so far.  A launch runs as long as its longest row, so what the plan is judged by is that row:
+    within a short read of the mean for a nanopore-like mix (first fit -- the rule of the first two sessions, FFHIP_DEBUG=pack_first_fit -- fills row after row to the capacity
+    it was given); every read placed, the gaps kept, a plan a function of its arguments."""
+    mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=1)
+    dm = B.DeviceModel(engine, mdl)
+    rng = np.random.default_rng(7)
+    rows, cap = 64, 90000
+    lens = [int(x) for x in np.clip(np.exp(np.log(2500) + 1.0 * rng.standard_normal(1200)), 200, 50000)]
+    total = sum(lens)
+    assert total < 0.9 * rows * cap
+    pb = B.Batch(dm, rows, cap, max_reads=len(lens))
+    gap = int(B.lib().ffhip_model_pack_gap(dm.h))
+
+    def row_ends(slot, off):
+        ends = np.zeros(rows, dtype=np.int64)
+        for i, n in enumerate(lens):
+            assert slot[i] >= 0
+            ends[slot[i]] = max(ends[slot[i]], off[i] + int(B.lib().ffhip_model_nblock(dm.h, n)))
+        return ends
+    slot, off = pb.pack_plan(lens)
+    again = pb.pack_plan(lens)
+    assert list(slot) == list(again[0]) and list(off) == list(again[1])
+    ends = row_ends(slot, off)
+    mean = (total / 5 + len(lens) * gap) / rows                       # blocks a row would hold if all were alike (stride 5)
+    assert ends.max() <= mean + 250 and ends.max() - ends.min() <= 600, (ends.max(), ends.min(), mean)
+    monkeypatch.setenv("FFHIP_DEBUG", "pack_first_fit")
+    slot_ff, off_ff = pb.pack_plan(lens)
+    monkeypatch.delenv("FFHIP_DEBUG")
+    ends_ff = row_ends(slot_ff, off_ff)
+    assert ends_ff.max() > 1.08 * ends.max()                          # the old rule's longest row IS the capacity
+    pb.close()
+    dm.close()
+
+
 def test_packed_batch_argument_checks(B, engine):
     mdl = M.synthetic_model(M.NET_LSTM5, 128, seed=3)
     dm = B.DeviceModel(engine, mdl)
