@@ -101,6 +101,9 @@ def lib():
     L.ffhip_batch_set_signals_ragged.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
     L.ffhip_prep_create.restype = vp
     L.ffhip_prep_create.argtypes = [vp, C.POINTER(CRawTable), C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_float]
+    L.ffhip_prep_begin.restype = vp
+    L.ffhip_prep_begin.argtypes = L.ffhip_prep_create.argtypes
+    L.ffhip_prep_finish.argtypes = [vp]
     L.ffhip_prep_destroy.argtypes = [vp]
     L.ffhip_prep_range.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ffhip_prep_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -229,16 +232,21 @@ class Prepared:
     """Raw reads trimmed and normalised on the device (ffhip_prep): trim_and_segment_raw + medmad_normalise_array."""
 
     def __init__(self, engine: "Engine", raws: List[np.ndarray], trim_start: int = 200, trim_end: int = 10,
-                 varseg_chunk: int = 100, varseg_thresh: float = 0.0, mode: int = PREP_MEDMAD, delta: float = 0.0):
+                 varseg_chunk: int = 100, varseg_thresh: float = 0.0, mode: int = PREP_MEDMAD, delta: float = 0.0, begin_only: bool = False):
+        """begin_only: ffhip_prep_begin (the work is enqueued, the call returns); `finish()` then waits -- ranges, statistics and signals are there after it"""
         self.engine = engine
         self.n = len(raws)
         arr = (CRawTable * self.n)()
         keep = [np.ascontiguousarray(r, dtype=np.float32) for r in raws]
         for i, r in enumerate(keep):
             arr[i] = CRawTable(None, r.size, 0, r.size, _fptr(r))
-        self.h = lib().ffhip_prep_create(engine.h, arr, self.n, trim_start, trim_end, varseg_chunk, varseg_thresh, mode, delta)
+        fn = lib().ffhip_prep_begin if begin_only else lib().ffhip_prep_create
+        self.h = fn(engine.h, arr, self.n, trim_start, trim_end, varseg_chunk, varseg_thresh, mode, delta)
         if not self.h:
             raise FFHipError(lib().ffhip_last_error().decode())
+
+    def finish(self):
+        _check(lib().ffhip_prep_finish(self.h))
 
     def range(self, i: int):
         s, e = C.c_size_t(0), C.c_size_t(0)

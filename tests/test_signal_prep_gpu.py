@@ -171,3 +171,24 @@ def test_prepared_reads_feed_batches_device_to_device(B, engine):
         b.close()
     p.close()
     dm.close()
+
+
+def test_begin_and_finish_equal_create(B, engine):
+    """ffhip_prep_begin + ffhip_prep_finish (the two halves a pipeline uses to prepare a chunk ahead) give what ffhip_prep_create gives: ranges, statistics, signals bit for bit;
+    a second finish is a no-op, and a preparation begun and never finished is waited for by its destruction"""
+    rng = np.random.default_rng(21)
+    raws = [(500 + 60 * rng.standard_normal(n)).astype(np.float32) for n in (1500, 4000, 4013, 777, 20000, 2600)]
+    for r in raws:
+        r[:300] = (520 + 4 * rng.standard_normal(300)).astype(np.float32)
+    a = B.Prepared(engine, raws)
+    b = B.Prepared(engine, raws, begin_only=True)
+    b.finish()
+    b.finish()
+    for i in range(len(raws)):
+        assert a.range(i) == b.range(i) and a.stats(i) == b.stats(i)
+        assert np.array_equal(a.signal(i), b.signal(i))
+    c = B.Prepared(engine, raws, begin_only=True)
+    c.close()
+    a.close()
+    b.close()
+
